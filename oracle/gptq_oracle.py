@@ -1,0 +1,258 @@
+"""CPU ORACLE for the GPTQ/AWQ int4/int8 grouped dequant-matmul path  --  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this module, and
+only as the checker / reported baseline.  The product (gptqmodel_amd/) never imports it and fails
+loudly when the HIP library is missing.
+
+It is an independent numpy restatement of the reference algorithm (ModelCloud/GPTQModel), each function
+citing the reference file:line it follows (paths relative to /root/reference/):
+
+  GPTQ  gptqmodel/nn_modules/qlinear/torch.py          TorchLinear  (BACKEND.TORCH / GPTQ_TORCH)
+        gptqmodel/nn_modules/qlinear/__init__.py       buffer contract, generic dequant
+        gptqmodel/utils/model.py:750-844               v1 -> v2 qzeros conversion
+  AWQ   gptqmodel/nn_modules/qlinear/torch_awq.py      AwqTorchLinear (BACKEND.TORCH_AWQ)
+        gptqmodel/quantization/awq/utils/packing_utils.py
+
+PARITY PIN (see DESIGN.md "Oracle"): checked against
+  * tests/golden/q4_kat_1024.npz   -- the reference's own known-answer vector tests/q4_reference.py
+    (recipe tests/test_q4_exllama_v2.py:65-88), and
+  * tests/golden/ref_*.npz         -- outputs of the real reference TorchLinear / AwqTorchLinear run in
+    the build container by oracle/make_golden.py (dequant stage bit-exact, forward within 1 output ulp).
+
+Rounding contract restated:
+  W[k,n]  = round_to(scales.dtype)( float(scales[g,n]) * (code[k,n] - zero[g,n]) )   one rounding
+  W'      = round_to(x.dtype)(W)                  (second rounding only when scales fp16 and x bf16)
+  y[m,n]  = round_to(x.dtype)( sum_k float(x[m,k]) * float(W'[k,n]) )  (+ bias, rounded again)
+The contraction itself is aten matmul in the reference (accumulation order unpinned); the oracle
+accumulates in fp32 (numpy sgemm) -- parity for that stage is "within tolerance", see tests.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+AWQ_ORDER = (0, 2, 4, 6, 1, 3, 5, 7)          # packing_utils.py:9
+AWQ_REVERSE_ORDER = (0, 4, 1, 5, 2, 6, 3, 7)  # packing_utils.py:10
+
+FP16 = "fp16"
+BF16 = "bf16"
+
+
+# ----------------------------------------------------------------------------------------------
+# bf16 helpers (numpy has no bfloat16): bf16 values are carried as float32 arrays that are exactly
+# representable in bf16; `round_bf16` is round-to-nearest-even like torch's .to(torch.bfloat16).
+# ----------------------------------------------------------------------------------------------
+def round_bf16(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    rounding = ((u >> 16) & 1) + 0x7FFF
+    r = (((u + rounding) >> 16) << 16).astype(np.uint32)
+    out = r.view(np.float32).copy()
+    nan = np.isnan(x)
+    if nan.any():
+        out[nan] = np.nan
+    return out
+
+
+def bf16_bits(x: np.ndarray) -> np.ndarray:
+    """float32 array (already bf16-representable) -> uint16 bit patterns."""
+    return (np.ascontiguousarray(x, dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16)
+
+
+def bf16_from_bits(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def round_to(x: np.ndarray, dtype: str) -> np.ndarray:
+    """Round an fp32 array to `dtype` and return it as float32 (exactly representable)."""
+    if dtype == FP16:
+        return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
+    if dtype == BF16:
+        return round_bf16(x)
+    raise ValueError(dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# GPTQ
+# ----------------------------------------------------------------------------------------------
+def unpack_rows(qweight: np.ndarray, bits: int) -> np.ndarray:
+    """qweight int32 [K/pf, N] -> codes uint8 [K, N]; code(8r+j, n) = (word >> bits*j) & maxq.
+    Follows torch.py:706-714 (`_right_shift_unpack` of qweight.unsqueeze(1) by wf[1,pf,1], & maxq)
+    and the layout contract qlinear/__init__.py:827-865."""
+    assert bits in (2, 4, 8)
+    pf = 32 // bits
+    w = np.ascontiguousarray(qweight).view(np.uint32)
+    shifts = (np.arange(pf, dtype=np.uint32) * bits)[None, :, None]
+    codes = (w[:, None, :] >> shifts) & np.uint32((1 << bits) - 1)
+    return codes.reshape(w.shape[0] * pf, w.shape[1]).astype(np.uint8)
+
+
+def unpack_cols(qzeros: np.ndarray, bits: int) -> np.ndarray:
+    """qzeros int32 [G, N/pf] -> zeros uint8 [G, N]; zero(g, pf*c+j) = (word >> bits*j) & maxq.
+    Follows torch.py:465-478 (`_stream_decode_qzeros`)."""
+    assert bits in (2, 4, 8)
+    pf = 32 // bits
+    w = np.ascontiguousarray(qzeros).view(np.uint32)
+    shifts = (np.arange(pf, dtype=np.uint32) * bits)[None, None, :]
+    z = (w[:, :, None] >> shifts) & np.uint32((1 << bits) - 1)
+    return z.reshape(w.shape[0], w.shape[1] * pf).astype(np.uint8)
+
+
+def convert_v1_to_v2_qzeros(qzeros: np.ndarray, bits: int) -> np.ndarray:
+    """GPTQ v1 checkpoints store zero-1; the loader adds 0x11111111 (4-bit) / 0x01010101 (8-bit) per
+    int32 word with wraparound.  utils/model.py:814-831."""
+    add = {2: 0x55555555, 4: 0x11111111, 8: 0x01010101}[bits]
+    return (np.ascontiguousarray(qzeros).view(np.uint32) + np.uint32(add)).view(np.int32)
+
+
+def normalize_g_idx(g_idx: np.ndarray, groups: int) -> np.ndarray:
+    """Negative g_idx wraps by +G like python/torch indexing does in `scales[g_idx]` (torch.py:717)."""
+    g = np.asarray(g_idx).astype(np.int64)
+    g = np.where(g < 0, g + groups, g)
+    if g.min() < 0 or g.max() >= groups:
+        raise IndexError("g_idx out of range")  # torch raises IndexError too
+    return g
+
+
+def dequant_gptq(qweight, qzeros, scales_f32, g_idx, bits: int, scale_dtype: str = FP16) -> np.ndarray:
+    """[K,N] weights as float32 holding values exactly representable in `scale_dtype`.
+    W = scales[g_idx] * (code - zeros[g_idx])   torch.py:716-717  == qlinear/__init__.py:1001-1003.
+    (code - zero) is an int8/int16 subtraction (exact), the product of an fp16|bf16 scale and an integer
+    |.|<=255 is exact in fp32, so rounding the fp32 product once reproduces torch's fp16/bf16 multiply."""
+    codes = unpack_rows(qweight, bits).astype(np.int32)
+    zeros = unpack_cols(qzeros, bits).astype(np.int32)
+    scales_f32 = np.asarray(scales_f32, dtype=np.float32)
+    g = normalize_g_idx(g_idx, scales_f32.shape[0])
+    w = scales_f32[g] * (codes - zeros[g]).astype(np.float32)
+    return round_to(w, scale_dtype)
+
+
+def matmul_round(x_f32: np.ndarray, w_f32: np.ndarray, bias_f32, act_dtype: str) -> np.ndarray:
+    """out = round(x @ W) (+ bias, rounded again: `out.add_(bias)` on a tensor of x.dtype, torch.py:337-342)."""
+    acc = np.asarray(x_f32, np.float32) @ np.asarray(w_f32, np.float32)
+    out = round_to(acc, act_dtype)
+    if bias_f32 is not None:
+        out = round_to(out + np.asarray(bias_f32, np.float32)[None, :], act_dtype)
+    return out
+
+
+def forward_gptq(x_f32, qweight, qzeros, scales_f32, g_idx, bits: int, bias_f32=None,
+                 act_dtype: str = FP16, scale_dtype: str = FP16) -> np.ndarray:
+    """TorchLinear._forward_eager (torch.py:326-347): dequantize, cast weights to x.dtype, matmul, bias."""
+    w = dequant_gptq(qweight, qzeros, scales_f32, g_idx, bits, scale_dtype)
+    if act_dtype != scale_dtype:
+        w = round_to(w, act_dtype)  # torch.py:331-335  weights.to(dtype=x.dtype)
+    x2 = np.asarray(x_f32, np.float32).reshape(-1, x_f32.shape[-1])
+    out = matmul_round(x2, w, bias_f32, act_dtype)
+    return out.reshape(x_f32.shape[:-1] + (w.shape[1],))
+
+
+# ----------------------------------------------------------------------------------------------
+# AWQ (FORMAT.GEMM)
+# ----------------------------------------------------------------------------------------------
+def unpack_awq_cols(q: np.ndarray, bits: int = 4) -> np.ndarray:
+    """[R, N/8] int32 -> uint8 [R, N] in LOGICAL column order.
+    packing_utils.py:13-27 (`_unpack_columnwise`: slot 8c+i = nibble i) followed by
+    packing_utils.py:43-57 (`reverse_awq_order`: logical col 8c+j = slot 8c+REV[j]) and the & 0xF of :113-114."""
+    assert bits == 4
+    w = np.ascontiguousarray(q).view(np.uint32)
+    shifts = (np.arange(8, dtype=np.uint32) * 4)[None, None, :]
+    slots = ((w[:, :, None] >> shifts) & np.uint32(0xF)).astype(np.uint8)  # [R, N/8, 8] nibble i
+    logical = slots[:, :, list(AWQ_REVERSE_ORDER)]
+    return logical.reshape(w.shape[0], w.shape[1] * 8)
+
+
+def dequant_awq(qweight, qzeros, scales_f32, group_size: int, compute_dtype: str = FP16) -> np.ndarray:
+    """packing_utils.py:106-121 `dequantize_gemm`: (iweight - izeros.repeat(g)) * scales.repeat(g).
+    scales are first cast to the compute dtype (torch_awq.py:149-155), the product is rounded once."""
+    codes = unpack_awq_cols(qweight).astype(np.int32)
+    zeros = unpack_awq_cols(qzeros).astype(np.int32)
+    s = round_to(np.asarray(scales_f32, np.float32), compute_dtype)
+    k = codes.shape[0]
+    if group_size == -1:
+        group_size = k
+    g = np.arange(k) // group_size
+    w = (codes - zeros[g]).astype(np.float32) * s[g]
+    return round_to(w, compute_dtype)
+
+
+def forward_awq(x_f32, qweight, qzeros, scales_f32, group_size: int, bias_f32=None,
+                act_dtype: str = FP16) -> np.ndarray:
+    """AwqTorchLinear.forward (torch_awq.py:157-195): out-of-place bias add in compute dtype."""
+    w = dequant_awq(qweight, qzeros, scales_f32, group_size, act_dtype)
+    x2 = np.asarray(x_f32, np.float32).reshape(-1, x_f32.shape[-1])
+    bias = None if bias_f32 is None else round_to(np.asarray(bias_f32, np.float32), act_dtype)
+    out = matmul_round(x2, w, bias, act_dtype)
+    return out.reshape(x_f32.shape[:-1] + (w.shape[1],))
+
+
+def awq_to_gptq_layout(qweight, qzeros, bits: int = 4):
+    """packing_utils.py:90-103 `unpack_reorder_pack`: AWQ [K,N/8] interleaved -> K-packed sequential
+    qweight [K/8,N] + N-packed sequential qzeros [G,N/8] (zeros as-is, no +-1).  Checker for the
+    device repack kernel."""
+    codes = unpack_awq_cols(qweight)
+    zeros = unpack_awq_cols(qzeros)
+    return pack_rows(codes, bits), pack_cols(zeros, bits)
+
+
+# ----------------------------------------------------------------------------------------------
+# packers for synthetic fixtures (inverse of the unpackers above; contract of
+# qlinear/__init__.py:1197-1323 python pack path -- only the bit layout, no quantisation)
+# ----------------------------------------------------------------------------------------------
+def pack_rows(codes: np.ndarray, bits: int) -> np.ndarray:
+    pf = 32 // bits
+    k, n = codes.shape
+    assert k % pf == 0
+    c = codes.astype(np.uint32).reshape(k // pf, pf, n)
+    shifts = (np.arange(pf, dtype=np.uint32) * bits)[None, :, None]
+    return np.bitwise_or.reduce(c << shifts, axis=1).astype(np.uint32).view(np.int32)
+
+
+def pack_cols(zeros: np.ndarray, bits: int) -> np.ndarray:
+    pf = 32 // bits
+    g, n = zeros.shape
+    assert n % pf == 0
+    z = zeros.astype(np.uint32).reshape(g, n // pf, pf)
+    shifts = (np.arange(pf, dtype=np.uint32) * bits)[None, None, :]
+    return np.bitwise_or.reduce(z << shifts, axis=2).astype(np.uint32).view(np.int32)
+
+
+def pack_awq_cols(vals: np.ndarray) -> np.ndarray:
+    """[R,N] logical uint8 -> AWQ int32 [R,N/8]: nibble i of word c holds column 8c+AWQ_ORDER[i]
+    (torch_awq.py:134-139)."""
+    r, n = vals.shape
+    v = vals.astype(np.uint32).reshape(r, n // 8, 8)[:, :, list(AWQ_ORDER)]
+    shifts = (np.arange(8, dtype=np.uint32) * 4)[None, None, :]
+    return np.bitwise_or.reduce(v << shifts, axis=2).astype(np.uint32).view(np.int32)
+
+
+def act_order_perm(g_idx: np.ndarray) -> np.ndarray:
+    """Stable argsort of g_idx: the row order in which the backend stores act-order weights
+    (semantics of torch_fused.py:121-151 / utils/marlin.py:368-372)."""
+    return np.argsort(np.asarray(g_idx).astype(np.int64), kind="stable").astype(np.int32)
+
+
+# ----------------------------------------------------------------------------------------------
+# torch-CPU restatement: the same op sequence as BACKEND.TORCH, multi-threaded aten, used ONLY as the
+# timed `cpu_baseline` ("port") in bench.py and cross-checked against the numpy oracle in tests.
+# ----------------------------------------------------------------------------------------------
+def torch_cpu_forward_gptq(x, qweight, qzeros, scales, g_idx, bits: int, bias=None):
+    """x [M,K] fp16|bf16 CPU tensor; packed tensors as in the checkpoint (v2 zeros).
+    Same aten op sequence as torch.py:700-717 + 326-347: shift-unpack to int8, mask, gather by g_idx,
+    (w - z) * s in scales dtype, cast, matmul, bias."""
+    import torch
+    pf = 32 // bits
+    maxq = (1 << bits) - 1
+    ddt = torch.int16 if bits == 8 else torch.int8
+    sh = torch.arange(0, 32, bits, dtype=torch.int32)
+    z = torch.bitwise_and(torch.bitwise_right_shift(qzeros.unsqueeze(2).expand(-1, -1, pf), sh.view(1, 1, pf)).to(ddt), maxq)
+    z = z.reshape(scales.shape)
+    w = torch.bitwise_and(torch.bitwise_right_shift(qweight.unsqueeze(1).expand(-1, pf, -1), sh.view(1, pf, 1)).to(ddt), maxq)
+    w = w.reshape(w.shape[0] * pf, w.shape[2])
+    g = g_idx.long()
+    weights = scales[g] * (w - z[g])
+    if weights.dtype != x.dtype:
+        weights = weights.to(x.dtype)
+    out = torch.matmul(x, weights)
+    if bias is not None:
+        out.add_(bias.to(out.dtype))
+    return out
