@@ -1,0 +1,82 @@
+"""ctypes binding of libgptqhip.so (C ABI in include/gptqhip.h).
+
+The library is built in-tree (gptqmodel_amd/csrc/libgptqhip.so) so that it travels with the source
+snapshot.  There is NO fallback: if the shared object is missing or fails to load, `load()` raises --
+the product path must fail loudly rather than silently run something else.
+
+Precedent for a ctypes C-ABI kernel plugin inside the reference: `_GGMLBridge`
+(gptqmodel/nn_modules/qlinear/gguf_cpp.py:88).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC_DIR, "libgptqhip.so")
+ABI_VERSION = 1
+
+# every symbol include/gptqhip.h declares: name -> (restype, argtypes)
+_c = ctypes
+_vp, _i, _sz = _c.c_void_p, _c.c_int, _c.c_size_t
+SIGNATURES = {
+    "gptqhip_abi_version": (_i, []),
+    "gptqhip_last_error": (_c.c_char_p, []),
+    "gptqhip_device_info": (_i, [_i, _c.POINTER(_i), _c.POINTER(_sz), _c.c_char_p, _i]),
+    "gptqhip_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "gptqhip_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "gptqhip_dequant": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "gptqhip_repack_awq": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "gptqhip_repack_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "gptqhip_gather_cols": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "gptqhip_set_tuning": (_i, [_i, _i]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libgptqhip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j8"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"building libgptqhip.so failed (exit {res.returncode}):\n{res.stderr[-4000:]}")
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once per process (a lock, like the reference's loader lock gptqmodel/extension.py:121)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libgptqhip.so not found at {LIB_PATH}; run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C gptqmodel_amd/csrc`.  There is no CPU/PyTorch fallback for the HIP backend."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        got = lib.gptqhip_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"libgptqhip.so ABI version {got} != expected {ABI_VERSION}; rebuild it")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().gptqhip_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,249 @@
+// C ABI of libgptqhip.so (declared in include/gptqhip.h): argument validation, workspace carving,
+// kernel selection.  No torch types, no global mutable state besides the thread-local error string and
+// the process-wide tuning overrides used by benchmarks.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gptqhip.h"
+#include "gptqhip_device.h"
+#include "gptqhip_host.h"
+
+namespace gptqhip {
+
+static thread_local char g_err[512] = "";
+static int g_force_split = 0;
+static int g_force_kernel = 0;
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return GPTQHIP_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return GPTQHIP_EHIP;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+constexpr int kSkinnyMaxM = 64;
+constexpr bool kHaveTiled = false;
+
+struct WorkspaceLayout {
+    size_t counters_off, counters_bytes;
+    size_t gather_off, gather_bytes;
+    size_t slabs_off, slabs_bytes;
+    size_t total;
+};
+
+static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int has_perm) {
+    WorkspaceLayout L;
+    const int strips = (N + 63) / 64;
+    L.counters_off = 0;
+    L.counters_bytes = align_up((size_t)strips * sizeof(int), 256);
+    L.gather_off = L.counters_off + L.counters_bytes;
+    L.gather_bytes = has_perm ? align_up((size_t)M * K * 2, 256) : 0;
+    L.slabs_off = L.gather_off + L.gather_bytes;
+    const int mchunk = M < kSkinnyMaxM ? M : kSkinnyMaxM;
+    // worst case over the split heuristics: the skinny plan for one row-chunk
+    size_t floats = 0;
+    for (int gs : {group_size, 128, 32}) {
+        if (gs <= 0 || K % gs != 0) continue;
+        const SkinnyPlan pl = plan_skinny(mchunk, K, N, gs, g_force_split);
+        if (pl.slab_floats > floats) floats = pl.slab_floats;
+    }
+    L.slabs_bytes = align_up(floats * sizeof(float), 256);
+    L.total = L.slabs_off + L.slabs_bytes;
+    return L;
+}
+
+}  // namespace gptqhip
+
+using namespace gptqhip;
+
+extern "C" {
+
+int gptqhip_abi_version(void) { return GPTQHIP_ABI_VERSION; }
+
+const char* gptqhip_last_error(void) { return g_err; }
+
+int gptqhip_set_tuning(int force_split_k, int force_kernel) {
+    g_force_split = force_split_k;
+    g_force_kernel = force_kernel;
+    return GPTQHIP_OK;
+}
+
+int gptqhip_device_info(int device, int* cu_count, size_t* hbm_bytes, char* arch, int arch_len) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+        set_error("gptqhip_device_info: no HIP device %d (count %d)", device, n);
+        return GPTQHIP_ENODEV;
+    }
+    hipDeviceProp_t prop;
+    int rc = check_hip(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+    if (rc) return rc;
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    if (arch && arch_len > 0) {
+        strncpy(arch, prop.gcnArchName, (size_t)arch_len - 1);
+        arch[arch_len - 1] = 0;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("gptqhip: device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+        return GPTQHIP_ENODEV;
+    }
+    return GPTQHIP_OK;
+}
+
+size_t gptqhip_workspace_bytes(int M, int K, int N, int has_perm) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    return layout_workspace(M, K, N, 0, has_perm).total;
+}
+
+static int validate_common(const char* fn, int K, int N, int group_size, int bits) {
+    if (bits != 4 && bits != 8) {
+        set_error("%s: bits=%d unsupported (4 or 8)", fn, bits);
+        return GPTQHIP_EINVAL;
+    }
+    if (K <= 0 || N <= 0 || K % 32 != 0 || N % 8 != 0) {
+        set_error("%s: K=%d must be a positive multiple of 32 and N=%d of 8", fn, K, N);
+        return GPTQHIP_EINVAL;
+    }
+    if (group_size <= 0 || group_size % 32 != 0 || K % group_size != 0) {
+        set_error("%s: group_size=%d must be a multiple of 32 dividing K=%d", fn, group_size, K);
+        return GPTQHIP_EINVAL;
+    }
+    return GPTQHIP_OK;
+}
+
+int gptqhip_gemm(const void* x, const int32_t* qweight, const int32_t* qzeros, const void* scales,
+                 const int32_t* perm, const void* bias, void* out, void* workspace, size_t workspace_bytes, int M,
+                 int K, int N, int group_size, int bits, int act_dtype, int scale_dtype, gptqhip_stream_t stream_) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (M == 0) return GPTQHIP_OK;  // empty batch: nothing to do (reference returns an empty tensor)
+    if (!x || !qweight || !qzeros || !scales || !out) {
+        set_error("gptqhip_gemm: null tensor pointer");
+        return GPTQHIP_EINVAL;
+    }
+    if (M < 0) {
+        set_error("gptqhip_gemm: M=%d", M);
+        return GPTQHIP_EINVAL;
+    }
+    int rc = validate_common("gptqhip_gemm", K, N, group_size, bits);
+    if (rc) return rc;
+    if ((act_dtype != GPTQHIP_FP16 && act_dtype != GPTQHIP_BF16) ||
+        (scale_dtype != GPTQHIP_FP16 && scale_dtype != GPTQHIP_BF16)) {
+        set_error("gptqhip_gemm: dtype tags must be GPTQHIP_FP16/BF16");
+        return GPTQHIP_EINVAL;
+    }
+    const WorkspaceLayout L = layout_workspace(M, K, N, group_size, perm != nullptr);
+    if (!workspace || workspace_bytes < L.total) {
+        set_error("gptqhip_gemm: workspace %zu bytes < required %zu", workspace_bytes, L.total);
+        return GPTQHIP_ENOMEM;
+    }
+    char* ws = reinterpret_cast<char*>(workspace);
+    int* counters = reinterpret_cast<int*>(ws + L.counters_off);
+    float* slabs = reinterpret_cast<float*>(ws + L.slabs_off);
+
+    const void* xin = x;
+    if (perm) {
+        void* gbuf = ws + L.gather_off;
+        rc = launch_gather_cols(x, perm, gbuf, M, K, stream);
+        if (rc) return rc;
+        xin = gbuf;
+    }
+
+    GemmArgs a;
+    a.qweight = qweight;
+    a.qzeros = qzeros;
+    a.scales = scales;
+    a.bias = bias;
+    a.K = K;
+    a.N = N;
+    a.group_size = group_size;
+    a.bits = bits;
+    a.act_dtype = act_dtype;
+    a.scale_dtype = scale_dtype;
+
+    const bool use_tiled = kHaveTiled && ((g_force_kernel == 2) || (g_force_kernel == 0 && M > kSkinnyMaxM));
+    if (use_tiled && bits == 4) {
+        a.x = xin;
+        a.out = out;
+        a.M = M;
+        const TiledPlan tp = plan_tiled(M, K, N, group_size);
+        return launch_tiled(a, tp, slabs, counters, stream);
+    }
+    // skinny kernel, 64 rows at a time
+    for (int m0 = 0; m0 < M; m0 += kSkinnyMaxM) {
+        const int mc = (M - m0) < kSkinnyMaxM ? (M - m0) : kSkinnyMaxM;
+        a.x = reinterpret_cast<const char*>(xin) + (size_t)m0 * K * 2;
+        a.out = reinterpret_cast<char*>(out) + (size_t)m0 * N * 2;
+        a.M = mc;
+        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split);
+        rc = launch_skinny(a, pl, slabs, counters, stream);
+        if (rc) return rc;
+    }
+    return GPTQHIP_OK;
+}
+
+int gptqhip_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* g_idx,
+                    void* out, int K, int N, int group_size, int bits, int scale_dtype, int out_dtype,
+                    gptqhip_stream_t stream) {
+    if (!qweight || !qzeros || !scales || !out) {
+        set_error("gptqhip_dequant: null tensor pointer");
+        return GPTQHIP_EINVAL;
+    }
+    if (bits != 4 && bits != 8) {
+        set_error("gptqhip_dequant: bits=%d unsupported", bits);
+        return GPTQHIP_EINVAL;
+    }
+    const int pf = 32 / bits;
+    if (K <= 0 || N <= 0 || K % pf != 0 || N % pf != 0 || group_size <= 0 || K % group_size != 0) {
+        set_error("gptqhip_dequant: bad shape K=%d N=%d group_size=%d", K, N, group_size);
+        return GPTQHIP_EINVAL;
+    }
+    return launch_dequant(qweight, qzeros, scales, g_idx, out, K, N, group_size, bits, scale_dtype, out_dtype,
+                          reinterpret_cast<hipStream_t>(stream));
+}
+
+int gptqhip_repack_awq(const int32_t* qweight_awq, const int32_t* qzeros_awq, int32_t* qweight_out,
+                       int32_t* qzeros_out, int K, int N, int G, gptqhip_stream_t stream) {
+    if (!qweight_awq || !qzeros_awq || !qweight_out || !qzeros_out) {
+        set_error("gptqhip_repack_awq: null tensor pointer");
+        return GPTQHIP_EINVAL;
+    }
+    if (K <= 0 || N <= 0 || G <= 0 || K % 8 != 0 || N % 8 != 0) {
+        set_error("gptqhip_repack_awq: bad shape K=%d N=%d G=%d", K, N, G);
+        return GPTQHIP_EINVAL;
+    }
+    return launch_repack_awq(qweight_awq, qzeros_awq, qweight_out, qzeros_out, K, N, G,
+                             reinterpret_cast<hipStream_t>(stream));
+}
+
+int gptqhip_repack_rows(const int32_t* qweight, const int32_t* perm, int32_t* qweight_out, int K, int N, int bits,
+                        gptqhip_stream_t stream) {
+    if (!qweight || !perm || !qweight_out) {
+        set_error("gptqhip_repack_rows: null tensor pointer");
+        return GPTQHIP_EINVAL;
+    }
+    if ((bits != 4 && bits != 8) || K <= 0 || N <= 0 || K % (32 / bits) != 0) {
+        set_error("gptqhip_repack_rows: bad args K=%d N=%d bits=%d", K, N, bits);
+        return GPTQHIP_EINVAL;
+    }
+    return launch_repack_rows(qweight, perm, qweight_out, K, N, bits, reinterpret_cast<hipStream_t>(stream));
+}
+
+int gptqhip_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, gptqhip_stream_t stream) {
+    if (M == 0) return GPTQHIP_OK;
+    if (!x || !perm || !out || M < 0 || K <= 0) {
+        set_error("gptqhip_gather_cols: bad args");
+        return GPTQHIP_EINVAL;
+    }
+    return launch_gather_cols(x, perm, out, M, K, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

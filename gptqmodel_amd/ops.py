@@ -1,0 +1,139 @@
+"""Thin torch-tensor wrappers over the C ABI (raw device pointers + the current HIP stream).
+
+PyTorch is plumbing here (device memory, streams); all arithmetic happens in libgptqhip.so.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+FP16, BF16 = 0, 1
+_DT = {torch.float16: FP16, torch.bfloat16: BF16}
+
+# per (device index, stream handle) zero-initialised scratch, grown on demand
+# (precedent: ExllamaV2 per-device ScratchSpace, gptqmodel/utils/model.py:1304-1313)
+_workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(device: torch.device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("gptqmodel_amd HIP ops need tensors on a ROCm device (got a CPU tensor); "
+                               "there is no CPU fallback")
+
+
+def device_info(device: int = 0):
+    lib = _lib.load()
+    cu = ctypes.c_int(0)
+    hbm = ctypes.c_size_t(0)
+    arch = ctypes.create_string_buffer(64)
+    rc = lib.gptqhip_device_info(device, ctypes.byref(cu), ctypes.byref(hbm), arch, 64)
+    _lib.check(rc, "gptqhip_device_info")
+    return {"cu_count": cu.value, "hbm_bytes": hbm.value, "arch": arch.value.decode()}
+
+
+def workspace_for(device: torch.device, nbytes: int) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        # zero-filled: the split-K arrival counters must start at 0 (kernels reset them after use)
+        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def gemm(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+         bias: Optional[torch.Tensor], perm: Optional[torch.Tensor], group_size: int, bits: int,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = x[M,K] @ dequant(canonical qweight/qzeros/scales) (+bias)  via gptqhip_gemm."""
+    lib = _lib.load()
+    _require_cuda(x, qweight, qzeros, scales, bias, perm)
+    if x.dim() != 2 or not x.is_contiguous():
+        raise RuntimeError("gemm: x must be a contiguous [M,K] tensor")
+    if x.dtype not in _DT or scales.dtype not in _DT:
+        raise RuntimeError(f"gemm: unsupported dtypes x={x.dtype} scales={scales.dtype}")
+    if bias is not None and bias.dtype != x.dtype:
+        raise RuntimeError("gemm: bias dtype must equal activation dtype")
+    M, K = x.shape
+    N = scales.shape[1]
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    if M == 0:
+        return out
+    with torch.cuda.device(x.device):
+        need = lib.gptqhip_workspace_bytes(M, K, N, 1 if perm is not None else 0)
+        ws = workspace_for(x.device, need)
+        rc = lib.gptqhip_gemm(_ptr(x), _ptr(qweight), _ptr(qzeros), _ptr(scales), _ptr(perm), _ptr(bias), _ptr(out),
+                              _ptr(ws), ws.numel(), M, K, N, group_size, bits, _DT[x.dtype], _DT[scales.dtype],
+                              _stream(x.device))
+    _lib.check(rc, "gptqhip_gemm")
+    return out
+
+
+def dequant(qweight, qzeros, scales, g_idx, group_size: int, bits: int, out_dtype=None) -> torch.Tensor:
+    lib = _lib.load()
+    _require_cuda(qweight, qzeros, scales, g_idx)
+    pf = 32 // bits
+    K, N = qweight.shape[0] * pf, qweight.shape[1]
+    out_dtype = out_dtype or scales.dtype
+    out = torch.empty((K, N), dtype=out_dtype, device=qweight.device)
+    with torch.cuda.device(qweight.device):
+        rc = lib.gptqhip_dequant(_ptr(qweight), _ptr(qzeros), _ptr(scales), _ptr(g_idx), _ptr(out), K, N, group_size,
+                                 bits, _DT[scales.dtype], _DT[out_dtype], _stream(qweight.device))
+    _lib.check(rc, "gptqhip_dequant")
+    return out
+
+
+def repack_awq(qweight_awq: torch.Tensor, qzeros_awq: torch.Tensor):
+    lib = _lib.load()
+    _require_cuda(qweight_awq, qzeros_awq)
+    K, N = qweight_awq.shape[0], qweight_awq.shape[1] * 8
+    G = qzeros_awq.shape[0]
+    qw = torch.empty((K // 8, N), dtype=torch.int32, device=qweight_awq.device)
+    qz = torch.empty_like(qzeros_awq)
+    with torch.cuda.device(qweight_awq.device):
+        rc = lib.gptqhip_repack_awq(_ptr(qweight_awq.contiguous()), _ptr(qzeros_awq.contiguous()), _ptr(qw), _ptr(qz),
+                                    K, N, G, _stream(qweight_awq.device))
+    _lib.check(rc, "gptqhip_repack_awq")
+    return qw, qz
+
+
+def repack_rows(qweight: torch.Tensor, perm: torch.Tensor, bits: int) -> torch.Tensor:
+    lib = _lib.load()
+    _require_cuda(qweight, perm)
+    pf = 32 // bits
+    K, N = qweight.shape[0] * pf, qweight.shape[1]
+    out = torch.empty_like(qweight)
+    with torch.cuda.device(qweight.device):
+        rc = lib.gptqhip_repack_rows(_ptr(qweight.contiguous()), _ptr(perm), _ptr(out), K, N, bits,
+                                     _stream(qweight.device))
+    _lib.check(rc, "gptqhip_repack_rows")
+    return out
+
+
+def gather_cols(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _require_cuda(x, perm)
+    M, K = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.gptqhip_gather_cols(_ptr(x), _ptr(perm), _ptr(out), M, K, _stream(x.device))
+    _lib.check(rc, "gptqhip_gather_cols")
+    return out
+
+
+def set_tuning(force_split_k: int = 0, force_kernel: int = 0) -> None:
+    _lib.check(_lib.load().gptqhip_set_tuning(force_split_k, force_kernel), "gptqhip_set_tuning")

@@ -1,0 +1,115 @@
+/*
+ * gptqhip.h -- C ABI of libgptqhip.so: the MI355X (gfx950 / CDNA4) GPTQ/AWQ grouped int4/int8
+ * dequant-matmul backend.  This is the whole drop-in boundary: plain pointers and sizes, no torch
+ * types.  The only callers are the two QuantLinear classes in gptqmodel_amd/nn_modules/qlinear/
+ * (HipGptqLinear, HipAwqLinear) through ctypes (gptqmodel_amd/_lib.py); INTEGRATION.md shows the
+ * binding a GPTQModel maintainer would add.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the upstream
+ * ModelCloud/GPTQModel tree).  Conventions:
+ *   - every call returns 0 on success, a negative GPTQHIP_E* code on failure; the message is
+ *     available from gptqhip_last_error() (thread-local).  The Python wrapper raises RuntimeError,
+ *     mirroring TORCH_CHECK -> RuntimeError of the reference natives
+ *     (gptqmodel_ext/exllamav2/ext_gptq.cpp:31-60).
+ *   - all tensor pointers are DEVICE pointers on the current HIP device; the module owns them, the
+ *     library borrows them for the duration of the call (no opaque handles; contrast the leaked
+ *     QMatrix* handle of ext_gptq.cpp:73-93).
+ *   - work is enqueued on `stream` (the caller passes torch.cuda.current_stream().cuda_stream, as
+ *     the reference natives use the current stream: ext_gptq.cpp:108); nothing synchronises.
+ *   - re-entrant across devices and streams provided each (device, stream) uses its own workspace.
+ *
+ * Canonical weight layout consumed by the kernels ("GPTQ v2, K-packed"):
+ *   qweight int32 [K*bits/32, N]   word (r,n) holds codes k = pf*r + j at bits [bits*j, bits*j+bits)
+ *   qzeros  int32 [G, N*bits/32]   word (g,c) holds zero  n = pf*c + j at bits [bits*j, ...)   (v2: used as-is)
+ *   scales  fp16|bf16 [G, N]
+ *   group of row k  =  k / group_size   (act-order checkpoints are row-sorted once by gptqhip_repack_rows
+ *                                        and x is gathered through the same permutation)
+ * = the buffer contract of gptqmodel/nn_modules/qlinear/__init__.py:827-865 after the loader's
+ *   v1->v2 conversion (gptqmodel/utils/model.py:750-844).
+ */
+#ifndef GPTQHIP_H
+#define GPTQHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPTQHIP_ABI_VERSION 1
+
+/* error codes */
+#define GPTQHIP_OK 0
+#define GPTQHIP_EINVAL (-22)   /* bad argument / unsupported shape       */
+#define GPTQHIP_ENOMEM (-12)   /* workspace too small                    */
+#define GPTQHIP_EHIP (-5)      /* a HIP runtime call failed              */
+#define GPTQHIP_ENODEV (-19)   /* no gfx950 device                       */
+
+/* dtype tags for activations / scales */
+#define GPTQHIP_FP16 0
+#define GPTQHIP_BF16 1
+
+/* opaque stream: a hipStream_t passed as void* so that callers need no HIP headers */
+typedef void* gptqhip_stream_t;
+
+int gptqhip_abi_version(void);
+const char* gptqhip_last_error(void);
+
+/* Device probe used by QuantLinear.validate_once() (gptqmodel/nn_modules/qlinear/__init__.py:257-270):
+ * fills CU count, bytes of HBM and the gcn arch name; returns GPTQHIP_ENODEV unless the device is gfx950. */
+int gptqhip_device_info(int device, int* cu_count, size_t* hbm_bytes, char* arch, int arch_len);
+
+/* Bytes of zero-initialised device scratch gptqhip_gemm needs for this problem (split-K fp32 slabs +
+ * arrival counters + act-order gather buffer).  Precedent: ExllamaV2 per-device ScratchSpace,
+ * gptqmodel/utils/model.py:1304-1313.  The workspace must be zero-filled once at allocation; the
+ * kernels leave it zeroed where it matters (counters). */
+size_t gptqhip_workspace_bytes(int M, int K, int N, int has_perm);
+
+/* THE HOT PATH.  out[M,N] = x[M,K] @ dequant(qweight,qzeros,scales) (+ bias), rounded like the reference:
+ *   W = round_scaledtype(scale * (code - zero)); W' = round_actdtype(W); y = round_actdtype(sum_k x*W');
+ *   y = round_actdtype(y + bias).
+ * Replaces TorchLinear.forward/_forward_eager (gptqmodel/nn_modules/qlinear/torch.py:302-347 with
+ * _dequantize_weight_cached_248 :700-717) and AwqTorchLinear.forward (torch_awq.py:157-195 with
+ * dequantize_gemm, quantization/awq/utils/packing_utils.py:106-121, after gptqhip_repack_awq).
+ *   x        [M,K]  act_dtype, row-major contiguous
+ *   perm     [K] int32 or NULL: x column gather for act-order (row k' of qweight is original row perm[k'])
+ *   bias     [N] act_dtype or NULL
+ *   out      [M,N] act_dtype
+ *   bits     4 or 8; group_size multiple of 32 dividing K; K % 32 == 0; N % 8 == 0
+ */
+int gptqhip_gemm(const void* x, const int32_t* qweight, const int32_t* qzeros, const void* scales,
+                 const int32_t* perm, const void* bias, void* out,
+                 void* workspace, size_t workspace_bytes,
+                 int M, int K, int N, int group_size, int bits,
+                 int act_dtype, int scale_dtype, gptqhip_stream_t stream);
+
+/* Materialise W[K,N] in `out_dtype` (= scales dtype in the reference).  Replaces
+ * TorchLinear.dequantize_weight (torch.py:225) / PackableQuantLinear.dequantize_weight
+ * (qlinear/__init__.py:947-1003); bit-exact with it.  g_idx [K] int32 or NULL (then k/group_size). */
+int gptqhip_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* g_idx,
+                    void* out, int K, int N, int group_size, int bits, int scale_dtype, int out_dtype,
+                    gptqhip_stream_t stream);
+
+/* post_init helper: AWQ GEMM layout (qweight [K,N/8], qzeros [G,N/8], nibble i <-> column 8c+[0,2,4,6,1,3,5,7][i])
+ * -> canonical layout.  Semantics of unpack_reorder_pack (packing_utils.py:90-103); zero-points kept as-is. */
+int gptqhip_repack_awq(const int32_t* qweight_awq, const int32_t* qzeros_awq,
+                       int32_t* qweight_out, int32_t* qzeros_out, int K, int N, int G,
+                       gptqhip_stream_t stream);
+
+/* post_init helper for desc_act: out row k' = row perm[k'] of qweight (nibble/byte granular), so that rows of
+ * one group become contiguous.  Same role as ExllamaV2 make_sequential (gptqmodel_ext/exllamav2/cuda/q_matrix.cu:502-604)
+ * and marlin_sort_g_idx (gptqmodel/utils/marlin.py:368-372). */
+int gptqhip_repack_rows(const int32_t* qweight, const int32_t* perm, int32_t* qweight_out,
+                        int K, int N, int bits, gptqhip_stream_t stream);
+
+/* out[m, k'] = x[m, perm[k']]  (16-bit elements).  Used by gptqhip_gemm internally and exported for tests. */
+int gptqhip_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, gptqhip_stream_t stream);
+
+/* Tuning hook (benchmarks / tests): force the split-K factor of the skinny kernel (0 = heuristic). */
+int gptqhip_set_tuning(int force_split_k, int force_kernel /*0 auto, 1 skinny, 2 tiled*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPTQHIP_H */
