@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X GPTQ/AWQ dequant-matmul backend.
+
+Workload (BASELINE.json configs[1]): Llama-3-8B GPTQ int4 group_size=128 desc_act=False, batch=1 decode.
+One "step" = one pass of the hot path over one token: the 224 quantised linears of the model
+(32 layers x {q,k,v,o,gate,up,down}), M=1, fp16, synthetic random packed weights of the real shapes
+(3.63 GB of distinct packed weight + scale/zero bytes, already resident in HBM), executed through the
+product path (HipGptqLinear.forward -> libgptqhip.so) and replayed as ONE captured HIP graph per token.
+value = tokens/s of that path (whole job; replicas x N for --gpus N: the 8B model fits one GPU so ranks
+are independent replicas, no data-path collective -- SURVEY.md §8e).
+
+Extra objects on the JSON line (tier contract):
+  roofline      dominant kernel = skinny fused dequant-GEMM; achieved = algorithmic bytes per launch
+                (K*N/2 + G*N*2 + G*N/2 + M*(K+N)*2, averaged over the 224 launches) / average
+                launch duration measured with HIP events on the launch stream over the timed region.
+  cpu_baseline  the oracle's torch-CPU port of BACKEND.TORCH (oracle/gptq_oracle.py:torch_cpu_forward_gptq)
+                timed on this host's cores on a bounded sample (one decoder layer), rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16
+
+LLAMA3_8B = dict(hidden=4096, inter=14336, q=4096, kv=1024, layers=32)
+LLAMA3_70B = dict(hidden=8192, inter=28672, q=8192, kv=1024, layers=80)
+
+
+def layer_shapes(cfg):
+    h, i = cfg["hidden"], cfg["inter"]
+    return [("q_proj", h, cfg["q"]), ("k_proj", h, cfg["kv"]), ("v_proj", h, cfg["kv"]), ("o_proj", cfg["q"], h),
+            ("gate_proj", h, i), ("up_proj", h, i), ("down_proj", i, h)]
+
+
+def algorithmic_bytes(m, k, n, gs=128):
+    g = k // gs
+    return k * n // 2 + g * n * 2 + g * n // 2 + m * (k + n) * 2
+
+
+def make_linear(k, n, gs, device, gen, dtype=torch.float16):
+    """Synthetic GPTQ-v2 tensors: random int32 qweight, scales rand*0.01+0.005, sym zeros 0x88888888."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    lin = HipGptqLinear(bits=4, group_size=gs, sym=True, desc_act=False, in_features=k, out_features=n, bias=False,
+                        register_buffers=False)
+    lin.qweight = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=device, generator=gen)
+    lin.qzeros = torch.full((k // gs, n // 8), -2004318072, dtype=torch.int32, device=device)  # 0x88888888
+    lin.scales = (torch.rand((k // gs, n), device=device, generator=gen) * 0.01 + 0.005).to(dtype)
+    lin.g_idx = (torch.arange(k, device=device, dtype=torch.int32) // gs)
+    lin.bias = None
+    lin.qzero_format(format=2)
+    lin.eval()
+    lin.post_init()
+    return lin
+
+
+def cpu_baseline(cfg, gs=128, budget_s=20.0):
+    """Oracle torch-CPU port of the reference BACKEND.TORCH forward on ONE decoder layer's 7 linears, M=1 fp16...
+    timed on all host cores; extrapolated x layers to tokens/s."""
+    from oracle.gptq_oracle import torch_cpu_forward_gptq
+    torch.manual_seed(1234)
+    mods = []
+    for _, k, n in layer_shapes(cfg):
+        qw = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32)
+        qz = torch.full((k // gs, n // 8), -2004318072, dtype=torch.int32)
+        sc = (torch.rand((k // gs, n)) * 0.01 + 0.005).to(torch.bfloat16)
+        gi = (torch.arange(k, dtype=torch.int32) // gs)
+        x = (torch.randn(1, k) * 0.5).to(torch.bfloat16)  # upstream's CPU test runs bf16 (tests/test_q4_torch.py:27,50)
+        mods.append((x, qw, qz, sc, gi))
+    def one_pass():
+        for x, qw, qz, sc, gi in mods:
+            torch_cpu_forward_gptq(x, qw, qz, sc, gi, 4)
+    one_pass()
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        one_pass()
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or iters >= 50:
+            break
+    per_layer = el / iters
+    return {
+        "value": 1.0 / (per_layer * cfg["layers"]), "unit": "tokens/s", "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"1 of {cfg['layers']} decoder layers (7 linears, M=1, bf16 like upstream's CPU test), {iters} passes "
+                  f"in {el:.1f}s, extrapolated x{cfg['layers']}; host os.cpu_count()={os.cpu_count()}",
+        "ms_per_layer": per_layer * 1e3,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per token")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = LLAMA3_8B
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    gs = 128
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    layers = []
+    for _ in range(cfg["layers"]):
+        layers.append([make_linear(k, n, gs, dev, gen, dtype) for _, k, n in layer_shapes(cfg)])
+    xs = {k: (torch.randn((1, k), device=dev, generator=gen) * 0.5).to(dtype) for k in (cfg["hidden"], cfg["inter"])}
+    n_launch = cfg["layers"] * len(layer_shapes(cfg))
+    step_bytes = cfg["layers"] * sum(algorithmic_bytes(1, k, n, gs) for _, k, n in layer_shapes(cfg))
+    step_flops = cfg["layers"] * sum(2 * k * n for _, k, n in layer_shapes(cfg))
+
+    def token_step():
+        for layer in layers:
+            for lin in layer:
+                lin(xs[lin.in_features])
+
+    stream = torch.cuda.Stream(device=dev)
+    graph = None
+    with torch.cuda.stream(stream):
+        token_step()  # allocates the workspace for this stream outside of capture
+        stream.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                token_step()
+
+    def run(n):
+        with torch.cuda.stream(stream):
+            for _ in range(n):
+                if graph is not None:
+                    graph.replay()
+                else:
+                    token_step()
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        ev0.record(stream)
+    run(args.steps)
+    with torch.cuda.stream(stream):
+        ev1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+
+    tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall = float(tmax.item())
+    ms_per_step = wall * 1e3 / args.steps
+    value = world * args.steps / wall
+
+    if rank == 0:
+        launch_us = ev_ms * 1e3 / (args.steps * n_launch)  # average launch duration incl. inter-kernel gaps
+        bytes_per_launch = step_bytes / n_launch
+        achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
+        out = {
+            "metric": "llama3_8b_gptq_int4_g128_decode_tokens_per_s", "value": value, "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16",
+            "data": "synthetic",
+            "config": {"workload": "Llama-3-8B GPTQ int4 g128 desc_act=False batch=1 decode: 224 quantised linears per token "
+                                   "(q,k,v,o,gate,up,down x 32), M=1, random packed weights",
+                       "launches_per_step": n_launch, "graph": graph is not None, "replicas": world,
+                       "weight_bytes_per_token": step_bytes},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "gptqhip::skinny_kernel<4,fp16,fp16,MT=1,SPG=4>",
+                         "bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_us,
+                         "note": "event-timed average over the timed region incl. inter-kernel gaps of the graph"},
+            "gemm_tflops_equiv": step_flops * value / world / 1e12,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, gs)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

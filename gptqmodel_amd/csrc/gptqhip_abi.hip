@@ -32,6 +32,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 constexpr int kSkinnyMaxM = 64;
 constexpr bool kHaveTiled = false;
+constexpr size_t kCounterBytes = 64 * 1024;  // 16384 arrival counters
 
 struct WorkspaceLayout {
     size_t counters_off, counters_bytes;
@@ -44,7 +45,10 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
     WorkspaceLayout L;
     const int strips = (N + 63) / 64;
     L.counters_off = 0;
-    L.counters_bytes = align_up((size_t)strips * sizeof(int), 256);
+    // FIXED-size counter region: it must stay zero between calls, so no other data may ever alias it
+    // whatever N the previous call had (the kernels reset their counters after use).
+    (void)strips;
+    L.counters_bytes = kCounterBytes;
     L.gather_off = L.counters_off + L.counters_bytes;
     L.gather_bytes = has_perm ? align_up((size_t)M * K * 2, 256) : 0;
     L.slabs_off = L.gather_off + L.gather_bytes;
@@ -138,6 +142,10 @@ int gptqhip_gemm(const void* x, const int32_t* qweight, const int32_t* qzeros, c
     if ((act_dtype != GPTQHIP_FP16 && act_dtype != GPTQHIP_BF16) ||
         (scale_dtype != GPTQHIP_FP16 && scale_dtype != GPTQHIP_BF16)) {
         set_error("gptqhip_gemm: dtype tags must be GPTQHIP_FP16/BF16");
+        return GPTQHIP_EINVAL;
+    }
+    if ((size_t)((N + 63) / 64) * sizeof(int) > kCounterBytes) {
+        set_error("gptqhip_gemm: N=%d too large (max %zu columns)", N, kCounterBytes / sizeof(int) * 64);
         return GPTQHIP_EINVAL;
     }
     const WorkspaceLayout L = layout_workspace(M, K, N, group_size, perm != nullptr);

@@ -1,0 +1,122 @@
+"""HipGptqLinear -- BACKEND.GPTQ_HIP: the MI355X (gfx950) fused dequant-matmul QuantLinear for GPTQ checkpoints.
+
+Drop-in for the reference's TorchLinear (gptqmodel/nn_modules/qlinear/torch.py:114) on DEVICE.ROCM: same
+constructor, buffers, post_init()/forward()/dequantize_weight() semantics and rounding, but forward() is ONE
+HIP kernel (libgptqhip.so: gptqhip_gemm) instead of ~10 elementwise torch kernels + a dense GEMM.
+Selection priority 120 beats every kernel upstream lists for ROCm.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ...utils.adapter import Adapter, Lora
+from ...utils.backend import BACKEND
+from ...utils.const import DEVICE, FORMAT, METHOD, PLATFORM
+from . import GPTQQuantLinear
+from .hip_common import act_order_permutation, flatten_input, hip_validate_once
+
+
+class HipGptqLinear(GPTQQuantLinear):
+    SUPPORTS_BACKENDS = [BACKEND.GPTQ_HIP]
+    SUPPORTS_METHODS = [METHOD.GPTQ]
+    SUPPORTS_FORMATS = {FORMAT.GPTQ: 120, FORMAT.GPTQ_V2: 120}
+    SUPPORTS_BITS = [4, 8]
+    SUPPORTS_GROUP_SIZE = [-1, 32, 64, 128, 256, 512, 1024]
+    SUPPORTS_DESC_ACT = [True, False]
+    SUPPORTS_SYM = [True, False]
+    SUPPORTS_SHARDS = True
+    SUPPORTS_TRAINING = False
+    SUPPORTS_AUTO_PADDING = False
+    SUPPORTS_IN_FEATURES_DIVISIBLE_BY = [32]
+    SUPPORTS_OUT_FEATURES_DIVISIBLE_BY = [8]
+    SUPPORTS_DEVICES = [DEVICE.ROCM]
+    SUPPORTS_PLATFORM = [PLATFORM.LINUX]
+    SUPPORTS_PACK_DTYPES = [torch.int32]
+    SUPPORTS_ADAPTERS = [Lora]
+    SUPPORTS_DTYPES = [torch.float16, torch.bfloat16]
+
+    REQUIRES_FORMAT_V2 = True  # the loader converts v1 qzeros (+0x11111111) first: utils/model.py:750-844
+    QUANT_TYPE = "hip_gptq"
+
+    def __init__(self, bits: int, group_size: int, sym: bool, desc_act: bool, in_features: int, out_features: int,
+                 bias: bool = False, pack_dtype: torch.dtype = torch.int32, adapter: Adapter = None,
+                 register_buffers: bool = True, format: Optional[FORMAT] = None, **kwargs):
+        super().__init__(bits=bits, group_size=group_size, sym=sym, desc_act=desc_act, in_features=in_features,
+                         out_features=out_features, bias=bias, pack_dtype=pack_dtype,
+                         backend=kwargs.pop("backend", BACKEND.GPTQ_HIP), adapter=adapter,
+                         register_buffers=register_buffers, format=format, **kwargs)
+        self.perm: Optional[torch.Tensor] = None  # act-order row permutation (device int32 [K]) after post_init
+        self._ready = False
+        self._bias_cache = None
+
+    @classmethod
+    def validate_once(cls):
+        return hip_validate_once()
+
+    def post_init(self):
+        """One-time device-side preparation (the reference kernels repack here too: marlin.py:246-293,
+        exllamav2.py:114-140).  desc_act=False needs nothing: the checkpoint layout IS the kernel layout."""
+        super().post_init()
+        from gptqmodel_amd import ops
+        if not self.qweight.is_cuda:
+            raise RuntimeError("HipGptqLinear.post_init: buffers must be on the ROCm device (no CPU fallback)")
+        groups = self.scales.shape[0]
+        if self.g_idx is not None and self.g_idx.numel() == self.in_features:
+            perm = act_order_permutation(self.g_idx, self.group_size, groups)
+        elif self.g_idx is not None and self.g_idx.numel() not in (0, self.in_features):
+            raise NotImplementedError("stacked g_idx (num_itr > 1, torch.py:327) is not supported by the HIP kernel")
+        else:
+            perm = None
+        if perm is not None:
+            self.qweight.data = ops.repack_rows(self.qweight.data.contiguous(), perm, self.bits)
+            self.perm = perm
+        self.qweight.data = self.qweight.data.contiguous()
+        self.qzeros.data = self.qzeros.data.contiguous()
+        self.scales.data = self.scales.data.contiguous()
+        self._ready = True
+
+    def list_buffers(self):
+        buf = super().list_buffers()
+        if self.perm is not None:
+            buf.append(self.perm)
+        return buf
+
+    def _bias_for(self, dtype: torch.dtype, device: torch.device):
+        if self.bias is None:
+            return None
+        c = self._bias_cache
+        if c is None or c.dtype != dtype or c.device != device or c.data_ptr() == 0:
+            c = self.bias.to(device=device, dtype=dtype).contiguous()  # torch.py:338-342 casts bias to out dtype
+            self._bias_cache = c
+        return c
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self._ready:
+            raise RuntimeError("HipGptqLinear.forward called before post_init()")
+        from gptqmodel_amd import ops
+        out_shape = x.shape[:-1] + (self.out_features,)
+        x2, in_dtype = flatten_input(x, self.in_features)
+        out = ops.gemm(x2, self.qweight, self.qzeros, self.scales, self._bias_for(x2.dtype, x2.device), self.perm,
+                       self.group_size, self.bits)
+        if self.adapter:
+            out = self.adapter.apply(x=x2, out=out)  # torch.py:344-345
+        if out.dtype != in_dtype:
+            out = out.to(in_dtype)
+        return out.reshape(out_shape)
+
+    def dequantize_weight(self, num_itr: int = 1) -> torch.Tensor:
+        """[K,N] weights in scales.dtype, bit-exact with TorchLinear.dequantize_weight (torch.py:225)."""
+        if num_itr != 1:
+            raise NotImplementedError("num_itr > 1 is not supported")
+        from gptqmodel_amd import ops
+        w = ops.dequant(self.qweight, self.qzeros, self.scales, None, self.group_size, self.bits)
+        if self.perm is not None:  # rows are stored group-sorted; return them in checkpoint order
+            out = torch.empty_like(w)
+            out[self.perm.long()] = w
+            return out
+        return w
+
+
+__all__ = ["HipGptqLinear"]

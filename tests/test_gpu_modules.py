@@ -1,0 +1,113 @@
+"""GPU tests of the plugin classes (HipGptqLinear / HipAwqLinear) behind the BACKEND selector -- the product path
+the reference's callers use (make_quant -> post_init -> forward)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import load_golden
+from helpers import bits_to_f32, bits_to_torch, f32_to_torch, rel_err, synth_gptq, torch_to_bits, torch_to_f32
+from oracle import gptq_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_auto_select_and_forward_gptq_v1_checkpoint():
+    """v1 checkpoint (zero-1 on disk) -> make_quant(AUTO) -> v1->v2 conversion -> post_init -> forward."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    from gptqmodel_amd.utils.backend import BACKEND
+    from gptqmodel_amd.utils.const import FORMAT, METHOD
+    from gptqmodel_amd.utils.model import convert_gptq_v1_to_v2_format, gptqmodel_post_init, make_quant
+
+    K, N, gs = 512, 256, 128
+    qweight, qzeros_v2, scales, g_idx = synth_gptq(5, 4, K, N, gs)
+    qzeros_v1 = (qzeros_v2.view(np.uint32) - np.uint32(0x11111111)).view(np.int32)
+
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.proj = nn.Linear(K, N, bias=False)
+
+    model = Block()
+    picked = make_quant(model, ["proj"], bits=4, group_size=gs, desc_act=False, sym=False, backend=BACKEND.AUTO,
+                        format=FORMAT.GPTQ, quant_method=METHOD.GPTQ)
+    assert picked[0] is HipGptqLinear and isinstance(model.proj, HipGptqLinear)
+    sd = {"proj.qweight": torch.from_numpy(qweight), "proj.qzeros": torch.from_numpy(qzeros_v1),
+          "proj.scales": f32_to_torch(scales, "fp16"), "proj.g_idx": torch.from_numpy(g_idx)}
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    convert_gptq_v1_to_v2_format(model, bits=4)
+    assert model.proj.qzero_format() == 2
+    gptqmodel_post_init(model)
+    x = O.round_to(np.random.RandomState(0).randn(2, 3, K).astype(np.float32) * 0.5, "fp16")
+    out = model.proj(f32_to_torch(x, "fp16", DEV))
+    assert out.shape == (2, 3, N)
+    ref = O.forward_gptq(x, qweight, qzeros_v2, scales, g_idx, 4)
+    assert rel_err(torch_to_f32(out), ref) <= 1e-3
+    with pytest.raises(NotImplementedError):
+        model.proj.train(True)
+
+
+def test_gptq_module_act_order_dequantize_weight_bit_exact():
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    g = load_golden("ref_gptq_g128_actorder_fp16.npz")
+    K, N = g["qweight"].shape[0] * 8, g["qweight"].shape[1]
+    lin = HipGptqLinear(bits=4, group_size=128, sym=False, desc_act=True, in_features=K, out_features=N, bias=False)
+    lin.qweight = torch.from_numpy(g["qweight"])
+    lin.qzeros = torch.from_numpy(g["qzeros"])
+    lin.scales = bits_to_torch(g["scales"], "fp16")
+    lin.g_idx = torch.from_numpy(g["g_idx"])
+    lin.qzero_format(format=2)
+    lin = lin.to(DEV).eval()
+    lin.post_init()
+    assert lin.perm is not None
+    w = lin.dequantize_weight()
+    assert np.array_equal(torch_to_bits(w), g["w_ref"].reshape(K, N))
+    out = lin(bits_to_torch(g["x"], "fp16", DEV))
+    assert rel_err(torch_to_f32(out), bits_to_f32(g["out_ref"], "fp16")) <= 1e-3
+
+
+@pytest.mark.parametrize("name", ["ref_awq_g128_bias_fp16.npz", "ref_awq_g128_bf16.npz"])
+def test_awq_module(name):
+    from gptqmodel_amd.nn_modules.qlinear.hip_awq import HipAwqLinear
+    from gptqmodel_amd.utils.backend import BACKEND
+    from gptqmodel_amd.utils.const import DEVICE, FORMAT, METHOD
+    from gptqmodel_amd.utils.importer import select_quant_linear
+    g = load_golden(name)
+    act, sdt, gs = str(g["act"]), str(g["scale_dtype"]), int(g["group_size"])
+    K, N = g["qweight"].shape[0], g["qweight"].shape[1] * 8
+    cls = select_quant_linear(bits=4, group_size=gs, desc_act=False, sym=False, device=DEVICE.ROCM,
+                              backend=BACKEND.HIP, format=FORMAT.GEMM, quant_method=METHOD.AWQ)
+    assert cls is HipAwqLinear
+    lin = cls(bits=4, group_size=gs, sym=False, desc_act=False, in_features=K, out_features=N, bias=bool(g["bias"].size))
+    lin.qweight = torch.from_numpy(g["qweight"])
+    lin.qzeros = torch.from_numpy(g["qzeros"])
+    lin.scales = bits_to_torch(g["scales"], sdt)
+    if g["bias"].size:
+        lin.bias = bits_to_torch(g["bias"], sdt)
+    lin = lin.to(DEV).eval()
+    lin.post_init()
+    out = lin(bits_to_torch(g["x"], act, DEV))
+    assert rel_err(torch_to_f32(out), bits_to_f32(g["out_ref"], act)) <= (1e-3 if act == "fp16" else 8e-3)
+
+
+def test_graph_capture_replay_matches_eager():
+    """The decode loop is replayed as a HIP graph in bench.py: capture must be legal and deterministic."""
+    from gptqmodel_amd import ops
+    K, N, gs = 4096, 4096, 128
+    qweight, qzeros, scales, _ = synth_gptq(9, 4, K, N, gs)
+    qw, qz = torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV)
+    sc = f32_to_torch(scales, "fp16", DEV)
+    x = torch.randn((1, K), device=DEV, dtype=torch.float16)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        eager = ops.gemm(x, qw, qz, sc, None, None, gs, 4).clone()
+        s.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            out = ops.gemm(x, qw, qz, sc, None, None, gs, 4)
+        for _ in range(3):
+            graph.replay()
+        s.synchronize()
+    assert torch.equal(out, eager)
