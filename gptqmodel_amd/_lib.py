@@ -27,12 +27,15 @@ SIGNATURES = {
     "gptqhip_last_error": (_c.c_char_p, []),
     "gptqhip_device_info": (_i, [_i, _c.POINTER(_i), _c.POINTER(_sz), _c.c_char_p, _i]),
     "gptqhip_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "gptqhip_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "gptqhip_tiled_words": (_sz, [_i, _i, _i]),
+    "gptqhip_meta_words": (_sz, [_i, _i, _i]),
+    "gptqhip_repack_tiled": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "gptqhip_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_dequant": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "gptqhip_dequant_tiled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_repack_awq": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "gptqhip_repack_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "gptqhip_gather_cols": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
-    "gptqhip_set_tuning": (_i, [_i, _i]),
+    "gptqhip_set_tuning": (_i, [_i, _i, _i]),
 }
 
 _lock = threading.Lock()
@@ -64,6 +67,10 @@ def load() -> ctypes.CDLL:
                 f"libgptqhip.so not found at {LIB_PATH}; run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C gptqmodel_amd/csrc`.  There is no CPU/PyTorch fallback for the HIP backend."
             )
+        # Import torch FIRST: libgptqhip.so needs libamdhip64.so.7 and must bind to the HIP runtime torch already
+        # loaded (its bundled copy has that SONAME).  Loading ours first would map /opt/rocm's runtime as a second
+        # copy next to torch's and the two would not share devices/streams.
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

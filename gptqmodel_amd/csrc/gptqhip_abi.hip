@@ -14,6 +14,7 @@ namespace gptqhip {
 static thread_local char g_err[512] = "";
 static int g_force_split = 0;
 static int g_force_kernel = 0;
+static int g_force_waves = 0;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -43,11 +44,9 @@ struct WorkspaceLayout {
 
 static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int has_perm) {
     WorkspaceLayout L;
-    const int strips = (N + 63) / 64;
     L.counters_off = 0;
     // FIXED-size counter region: it must stay zero between calls, so no other data may ever alias it
     // whatever N the previous call had (the kernels reset their counters after use).
-    (void)strips;
     L.counters_bytes = kCounterBytes;
     L.gather_off = L.counters_off + L.counters_bytes;
     L.gather_bytes = has_perm ? align_up((size_t)M * K * 2, 256) : 0;
@@ -57,7 +56,7 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
     size_t floats = 0;
     for (int gs : {group_size, 128, 32}) {
         if (gs <= 0 || K % gs != 0) continue;
-        const SkinnyPlan pl = plan_skinny(mchunk, K, N, gs, g_force_split);
+        const SkinnyPlan pl = plan_skinny(mchunk, K, N, gs, g_force_split, g_force_waves);
         if (pl.slab_floats > floats) floats = pl.slab_floats;
     }
     L.slabs_bytes = align_up(floats * sizeof(float), 256);
@@ -75,9 +74,10 @@ int gptqhip_abi_version(void) { return GPTQHIP_ABI_VERSION; }
 
 const char* gptqhip_last_error(void) { return g_err; }
 
-int gptqhip_set_tuning(int force_split_k, int force_kernel) {
+int gptqhip_set_tuning(int force_split_k, int force_kernel, int force_waves) {
     g_force_split = force_split_k;
     g_force_kernel = force_kernel;
+    g_force_waves = force_waves;
     return GPTQHIP_OK;
 }
 
@@ -124,12 +124,35 @@ static int validate_common(const char* fn, int K, int N, int group_size, int bit
     return GPTQHIP_OK;
 }
 
-int gptqhip_gemm(const void* x, const int32_t* qweight, const int32_t* qzeros, const void* scales,
+size_t gptqhip_tiled_words(int K, int N, int bits) {
+    if (K <= 0 || N <= 0 || (bits != 4 && bits != 8)) return 0;
+    return (size_t)ceil_div(N, kTileN) * ceil_div(K, kChunkK) * (bits == 4 ? 256 : 512);
+}
+
+size_t gptqhip_meta_words(int K, int N, int group_size) {
+    if (K <= 0 || N <= 0 || group_size <= 0 || K % group_size != 0) return 0;
+    return (size_t)ceil_div(N, kTileN) * (K / group_size) * 16;
+}
+
+int gptqhip_repack_tiled(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* perm,
+                         uint32_t* qweight_t, uint32_t* meta, int K, int N, int group_size, int bits,
+                         gptqhip_stream_t stream) {
+    if (!qzeros || !scales || !meta || ((qweight == nullptr) != (qweight_t == nullptr))) {
+        set_error("gptqhip_repack_tiled: null tensor pointer (qweight/qweight_t may only be NULL together)");
+        return GPTQHIP_EINVAL;
+    }
+    int rc = validate_common("gptqhip_repack_tiled", K, N, group_size, bits);
+    if (rc) return rc;
+    return launch_repack_tiled(qweight, qzeros, scales, perm, qweight_t, meta, K, N, group_size, bits,
+                               reinterpret_cast<hipStream_t>(stream));
+}
+
+int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
                  const int32_t* perm, const void* bias, void* out, void* workspace, size_t workspace_bytes, int M,
                  int K, int N, int group_size, int bits, int act_dtype, int scale_dtype, gptqhip_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (M == 0) return GPTQHIP_OK;  // empty batch: nothing to do (reference returns an empty tensor)
-    if (!x || !qweight || !qzeros || !scales || !out) {
+    if (!x || !qweight || !meta || !out) {
         set_error("gptqhip_gemm: null tensor pointer");
         return GPTQHIP_EINVAL;
     }
@@ -144,8 +167,8 @@ int gptqhip_gemm(const void* x, const int32_t* qweight, const int32_t* qzeros, c
         set_error("gptqhip_gemm: dtype tags must be GPTQHIP_FP16/BF16");
         return GPTQHIP_EINVAL;
     }
-    if ((size_t)((N + 63) / 64) * sizeof(int) > kCounterBytes) {
-        set_error("gptqhip_gemm: N=%d too large (max %zu columns)", N, kCounterBytes / sizeof(int) * 64);
+    if ((size_t)ceil_div(N, kTileN) * sizeof(int) > kCounterBytes) {
+        set_error("gptqhip_gemm: N=%d too large (max %zu columns)", N, kCounterBytes / sizeof(int) * kTileN);
         return GPTQHIP_EINVAL;
     }
     const WorkspaceLayout L = layout_workspace(M, K, N, group_size, perm != nullptr);
@@ -167,8 +190,7 @@ int gptqhip_gemm(const void* x, const int32_t* qweight, const int32_t* qzeros, c
 
     GemmArgs a;
     a.qweight = qweight;
-    a.qzeros = qzeros;
-    a.scales = scales;
+    a.meta = meta;
     a.bias = bias;
     a.K = K;
     a.N = N;
@@ -191,7 +213,7 @@ int gptqhip_gemm(const void* x, const int32_t* qweight, const int32_t* qzeros, c
         a.x = reinterpret_cast<const char*>(xin) + (size_t)m0 * K * 2;
         a.out = reinterpret_cast<char*>(out) + (size_t)m0 * N * 2;
         a.M = mc;
-        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split);
+        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves);
         rc = launch_skinny(a, pl, slabs, counters, stream);
         if (rc) return rc;
     }
@@ -232,17 +254,16 @@ int gptqhip_repack_awq(const int32_t* qweight_awq, const int32_t* qzeros_awq, in
                              reinterpret_cast<hipStream_t>(stream));
 }
 
-int gptqhip_repack_rows(const int32_t* qweight, const int32_t* perm, int32_t* qweight_out, int K, int N, int bits,
-                        gptqhip_stream_t stream) {
-    if (!qweight || !perm || !qweight_out) {
-        set_error("gptqhip_repack_rows: null tensor pointer");
+int gptqhip_dequant_tiled(const uint32_t* qweight_t, const uint32_t* meta, const int32_t* perm, void* out, int K,
+                          int N, int group_size, int bits, int scale_dtype, int out_dtype, gptqhip_stream_t stream) {
+    if (!qweight_t || !meta || !out) {
+        set_error("gptqhip_dequant_tiled: null tensor pointer");
         return GPTQHIP_EINVAL;
     }
-    if ((bits != 4 && bits != 8) || K <= 0 || N <= 0 || K % (32 / bits) != 0) {
-        set_error("gptqhip_repack_rows: bad args K=%d N=%d bits=%d", K, N, bits);
-        return GPTQHIP_EINVAL;
-    }
-    return launch_repack_rows(qweight, perm, qweight_out, K, N, bits, reinterpret_cast<hipStream_t>(stream));
+    int rc = validate_common("gptqhip_dequant_tiled", K, N, group_size, bits);
+    if (rc) return rc;
+    return launch_dequant_tiled(qweight_t, meta, perm, out, K, N, group_size, bits, scale_dtype, out_dtype,
+                                reinterpret_cast<hipStream_t>(stream));
 }
 
 int gptqhip_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, gptqhip_stream_t stream) {

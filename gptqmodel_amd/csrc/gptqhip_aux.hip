@@ -104,37 +104,174 @@ int launch_repack_awq(const int32_t* qw_awq, const int32_t* qz_awq, int32_t* qw_
 }
 
 // ---------------------------------------------------------------------------------------------
-// act-order row sort: out row k' = in row perm[k'] at code granularity.
+// canonical GPTQ layout (+ optional act-order row permutation) -> tile-major layout + meta constants.
+// One thread per output word.  With perm, sorted row k' is checkpoint row perm[k'] (stable argsort of
+// g_idx), so rows of one group become contiguous -- same role as ExllamaV2 make_sequential
+// (gptqmodel_ext/exllamav2/cuda/q_matrix.cu:502-604) and marlin_sort_g_idx (gptqmodel/utils/marlin.py:368-372).
 // ---------------------------------------------------------------------------------------------
 template <int BITS>
-__global__ __launch_bounds__(256) void repack_rows_kernel(const int32_t* __restrict__ src,
-                                                          const int32_t* __restrict__ perm,
-                                                          int32_t* __restrict__ dst, int K, int N) {
+__global__ __launch_bounds__(256) void repack_tiled_kernel(const int32_t* __restrict__ src,
+                                                           const int32_t* __restrict__ perm,
+                                                           uint32_t* __restrict__ dst, int K, int N, int chunks,
+                                                           size_t total_words) {
     constexpr int PF = 32 / BITS;
     constexpr uint32_t MASK = (1u << BITS) - 1u;
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (n >= N) return;
-    uint32_t w = 0;
-#pragma unroll
-    for (int j = 0; j < PF; ++j) {
-        const int k = perm[r * PF + j];
-        const uint32_t s = (uint32_t)src[(size_t)(k / PF) * N + n];
-        w |= ((s >> (BITS * (k % PF))) & MASK) << (BITS * j);
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_words) return;
+    const int jj = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    size_t blk;
+    int kbase;
+    if constexpr (BITS == 4) {
+        blk = idx >> 8;
+        const int chunk = (int)(blk % chunks);
+        kbase = kChunkK * chunk + 32 * jj + 8 * (lane >> 4);
+    } else {
+        const int h = (int)((idx >> 8) & 1);
+        blk = idx >> 9;
+        const int chunk = (int)(blk % chunks);
+        kbase = kChunkK * chunk + 32 * (2 * h + (jj >> 1)) + 8 * (lane >> 4) + 4 * (jj & 1);
     }
-    dst[(size_t)r * N + n] = (int32_t)w;
+    const int tile = (int)(blk / chunks);
+    const int n = tile * kTileN + (lane & 15);
+    uint32_t w = 0;
+    if (n < N && kbase < K) {
+        if (perm == nullptr) {
+            const uint32_t s = (uint32_t)src[(size_t)(kbase / PF) * N + n];
+#pragma unroll
+            for (int e = 0; e < PF; ++e) {
+                const uint32_t code = (s >> (BITS * e)) & MASK;
+                w |= code << (BITS == 4 ? tiled_shift4(e) : tiled_shift8(e));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < PF; ++e) {
+                const int k = perm[kbase + e];
+                const uint32_t s = (uint32_t)src[(size_t)(k / PF) * N + n];
+                const uint32_t code = (s >> (BITS * (k % PF))) & MASK;
+                w |= code << (BITS == 4 ? tiled_shift4(e) : tiled_shift8(e));
+            }
+        }
+    }
+    dst[idx] = w;
 }
 
-int launch_repack_rows(const int32_t* qweight, const int32_t* perm, int32_t* out, int K, int N, int bits,
-                       hipStream_t stream) {
-    const int pf = 32 / bits;
-    const dim3 grid((N + 255) / 256, K / pf);
-    if (bits == 4) {
-        hipLaunchKernelGGL(repack_rows_kernel<4>, grid, dim3(256), 0, stream, qweight, perm, out, K, N);
-    } else {
-        hipLaunchKernelGGL(repack_rows_kernel<8>, grid, dim3(256), 0, stream, qweight, perm, out, K, N);
+template <int BITS>
+__global__ __launch_bounds__(256) void build_meta_kernel(const int32_t* __restrict__ qz,
+                                                         const uint16_t* __restrict__ scales,
+                                                         uint32_t* __restrict__ meta, int N, int G, size_t total) {
+    constexpr int PF = 32 / BITS;
+    constexpr uint32_t MASK = (1u << BITS) - 1u;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx & 15);
+    const int g = (int)((idx >> 4) % G);
+    const int tile = (int)((idx >> 4) / G);
+    const int n = tile * kTileN + c;
+    uint32_t sb = 0, z = 0;
+    if (n < N) {
+        sb = scales[(size_t)g * N + n];
+        z = ((uint32_t)qz[(size_t)g * (N / PF) + n / PF] >> (BITS * (n % PF))) & MASK;
     }
-    return check_hip(hipGetLastError(), "repack_rows launch");
+    meta[idx] = sb | ((0xE400u | z) << 16);
+}
+
+int launch_repack_tiled(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* perm,
+                        uint32_t* qweight_t, uint32_t* meta, int K, int N, int group_size, int bits,
+                        hipStream_t stream) {
+    const int chunks = ceil_div(K, kChunkK);
+    const int tiles = ceil_div(N, kTileN);
+    const int G = K / group_size;
+    const size_t words = (size_t)tiles * chunks * (bits == 4 ? 256 : 512);
+    const unsigned gw = (unsigned)((words + 255) / 256);
+    if (qweight != nullptr) {  // NULL qweight/qweight_t: rebuild the meta constants only (e.g. new scale dtype)
+        if (bits == 4) {
+            hipLaunchKernelGGL(repack_tiled_kernel<4>, dim3(gw), dim3(256), 0, stream, qweight, perm, qweight_t, K, N,
+                               chunks, words);
+        } else {
+            hipLaunchKernelGGL(repack_tiled_kernel<8>, dim3(gw), dim3(256), 0, stream, qweight, perm, qweight_t, K, N,
+                               chunks, words);
+        }
+    }
+    const size_t metas = (size_t)tiles * G * 16;
+    const unsigned gm = (unsigned)((metas + 255) / 256);
+    const uint16_t* sc = reinterpret_cast<const uint16_t*>(scales);
+    if (bits == 4) {
+        hipLaunchKernelGGL(build_meta_kernel<4>, dim3(gm), dim3(256), 0, stream, qzeros, sc, meta, N, G, metas);
+    } else {
+        hipLaunchKernelGGL(build_meta_kernel<8>, dim3(gm), dim3(256), 0, stream, qzeros, sc, meta, N, G, metas);
+    }
+    return check_hip(hipGetLastError(), "repack_tiled launch");
+}
+
+// ---------------------------------------------------------------------------------------------
+// dequantise FROM the tile-major layout (module.dequantize_weight() after post_init).  Row k' of the tiled
+// matrix is written to output row perm[k'] (checkpoint order) when perm is given.
+// ---------------------------------------------------------------------------------------------
+template <int BITS, int SCL, int OUT>
+__global__ __launch_bounds__(256) void dequant_tiled_kernel(const uint32_t* __restrict__ qw,
+                                                            const uint32_t* __restrict__ meta,
+                                                            const int32_t* __restrict__ perm,
+                                                            uint16_t* __restrict__ out, int K, int N, int G,
+                                                            int group_size, int chunks, size_t total_words) {
+    constexpr int PF = 32 / BITS;
+    constexpr uint32_t MASK = (1u << BITS) - 1u;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_words) return;
+    const int jj = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    size_t blk;
+    int kbase;
+    if constexpr (BITS == 4) {
+        blk = idx >> 8;
+        kbase = kChunkK * (int)(blk % chunks) + 32 * jj + 8 * (lane >> 4);
+    } else {
+        const int h = (int)((idx >> 8) & 1);
+        blk = idx >> 9;
+        kbase = kChunkK * (int)(blk % chunks) + 32 * (2 * h + (jj >> 1)) + 8 * (lane >> 4) + 4 * (jj & 1);
+    }
+    const int tile = (int)(blk / chunks);
+    const int n = tile * kTileN + (lane & 15);
+    if (n >= N || kbase >= K) return;
+    const uint32_t w = qw[idx];
+#pragma unroll
+    for (int e = 0; e < PF; ++e) {
+        const int k = kbase + e;
+        const int g = k / group_size;
+        const uint32_t mw = meta[((size_t)tile * G + g) * 16 + (lane & 15)];
+        const int zero = (int)((mw >> 16) & 0x3FFu);  // 0xE400|z -> low 10 bits hold z
+        const int code = (int)((w >> (BITS == 4 ? tiled_shift4(e) : tiled_shift8(e))) & MASK);
+        const float s = bits16_to_f32<SCL>((uint16_t)(mw & 0xffffu));
+        const float v = round_through<SCL>(s * (float)(code - zero));
+        const int row = perm ? perm[k] : k;
+        out[(size_t)row * N + n] = f32_to_16<OUT>(v);
+    }
+}
+
+int launch_dequant_tiled(const uint32_t* qweight_t, const uint32_t* meta, const int32_t* perm, void* out, int K, int N,
+                         int group_size, int bits, int scale_dtype, int out_dtype, hipStream_t stream) {
+    const int chunks = ceil_div(K, kChunkK);
+    const int tiles = ceil_div(N, kTileN);
+    const int G = K / group_size;
+    const size_t words = (size_t)tiles * chunks * (bits == 4 ? 256 : 512);
+    const dim3 grid((unsigned)((words + 255) / 256));
+    uint16_t* o = reinterpret_cast<uint16_t*>(out);
+#define GPTQHIP_DQT(B, S_, O_)                                                                                    \
+    hipLaunchKernelGGL((dequant_tiled_kernel<B, S_, O_>), grid, dim3(256), 0, stream, qweight_t, meta, perm, o, K, N, \
+                       G, group_size, chunks, words)
+    if (bits == 4) {
+        if (scale_dtype == kFP16 && out_dtype == kFP16) GPTQHIP_DQT(4, kFP16, kFP16);
+        else if (scale_dtype == kFP16) GPTQHIP_DQT(4, kFP16, kBF16);
+        else if (out_dtype == kFP16) GPTQHIP_DQT(4, kBF16, kFP16);
+        else GPTQHIP_DQT(4, kBF16, kBF16);
+    } else {
+        if (scale_dtype == kFP16 && out_dtype == kFP16) GPTQHIP_DQT(8, kFP16, kFP16);
+        else if (scale_dtype == kFP16) GPTQHIP_DQT(8, kFP16, kBF16);
+        else if (out_dtype == kFP16) GPTQHIP_DQT(8, kBF16, kFP16);
+        else GPTQHIP_DQT(8, kBF16, kBF16);
+    }
+#undef GPTQHIP_DQT
+    return check_hip(hipGetLastError(), "dequant_tiled_kernel launch");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,5 +1,6 @@
-// Device-side building blocks shared by the gfx950 kernels: vector types, the int4/int8 -> fp16/bf16
-// dequantisation that reproduces the reference's rounding bit-for-bit, and MFMA wrappers.
+// Device-side building blocks shared by the gfx950 kernels: vector types, the tile-major weight layout,
+// the int4/int8 -> fp16/bf16 dequantisation that reproduces the reference's rounding bit-for-bit, and
+// MFMA wrappers.
 //
 // Rounding contract being reproduced (reference gptqmodel/nn_modules/qlinear/torch.py:716-717,
 // torch_awq.py:149-155, packing_utils.py:117-119):
@@ -7,7 +8,26 @@
 //     W' = round_to(x.dtype)(W)                                           (only if dtypes differ)
 // (code - zero) is a small exact integer.  We get it without any int->float convert: OR the nibble
 // into the mantissa of 1024.0h (0x6400 | q  ==  1024 + q exactly) and add the precomputed constant
-// -(1024 + zero); the fp16 multiply by the scale is then the single correctly-rounded product.
+// -(1024 + zero); for the nibbles sitting 4 bits higher (0x6400 | q<<4 == 1024 + 16q) one fma by 1/16 with
+// -(64 + zero) gives the same exact integer.  The fp16 multiply by the scale is then the single
+// correctly-rounded product torch computes.
+//
+// ------------------------------------------------------------------------------------------------
+// TILE-MAJOR LAYOUT ("tiled"), produced once in post_init by gptqhip_repack_tiled:
+//   Kp = ceil(K/128)*128, Np = ceil(N/16)*16, tiles = Np/16, chunks = Kp/128.
+//   A (tile, chunk) block is the B operand of four mfma_f32_16x16x32 K-steps: 16 columns x 128 rows.
+//   4-bit:  word[((tile*chunks + chunk)*64 + lane)*4 + j]          lane = (rq<<4)|c, rq=0..3, c=0..15, j=0..3
+//           holds column n = 16*tile + c, rows k = 128*chunk + 32*j + 8*rq + e (e=0..7), code e at bit
+//           offset 4*(e>>1) + 16*(e&1):   [k0|k2|k4|k6 | k1|k3|k5|k7]  (low nibble first)
+//           => (w & 0x000F000F) = (k0,k1), (w & 0x00F000F0) = (k2,k3)<<4, same on w>>8 for k4..k7:
+//           the 8 halves come out in NATURAL k order, so activations need no permutation.
+//   8-bit:  word[(((tile*chunks + chunk)*2 + h)*64 + lane)*4 + jj]  K-step j = 2h + (jj>>1), half = jj&1
+//           rows k = 128*chunk + 32*j + 8*rq + 4*half + e (e=0..3), code e at bit offset 8*(e>>1) + 16*(e&1).
+//   One wave-instruction (dwordx4 per lane) therefore reads 1 KiB CONTIGUOUS bytes = a whole (tile, chunk)
+//   block, and consecutive chunks of a tile are contiguous: every wave streams a linear address range.
+//   meta[(tile*G + g)*16 + c] = scale16 | (0xE400|zero)<<16   -- the per-(group, column) constants, pre-baked
+//   (scale bits in the scales dtype; -(1024+zero) as fp16).  Padded rows/columns carry code 0 / scale 0.
+// ------------------------------------------------------------------------------------------------
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,6 +44,14 @@ typedef uint32_t u2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kFP16 = 0;
 constexpr int kBF16 = 1;
+constexpr int kChunkK = 128;  // rows per (tile, chunk) block
+constexpr int kTileN = 16;    // columns per tile
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// bit offset of code e (0..pf-1) inside a tiled word
+__host__ __device__ inline int tiled_shift4(int e) { return 4 * (e >> 1) + 16 * (e & 1); }
+__host__ __device__ inline int tiled_shift8(int e) { return 8 * (e >> 1) + 16 * (e & 1); }
 
 __device__ __forceinline__ h2_t as_h2(uint32_t u) { return __builtin_bit_cast(h2_t, u); }
 __device__ __forceinline__ uint32_t as_u32(h2_t h) { return __builtin_bit_cast(uint32_t, h); }
@@ -45,15 +73,18 @@ __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
 __device__ __forceinline__ float bf16lo_to_f32(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
-// 16-bit scalar load helpers ------------------------------------------------------------------
+// 16-bit scalar helpers ------------------------------------------------------------------------
 template <int DT>
-__device__ __forceinline__ float load16_as_f32(const void* p, size_t idx) {
-    const uint16_t v = reinterpret_cast<const uint16_t*>(p)[idx];
+__device__ __forceinline__ float bits16_to_f32(uint16_t v) {
     if constexpr (DT == kFP16) {
         return (float)__builtin_bit_cast(_Float16, v);
     } else {
         return __builtin_bit_cast(float, (uint32_t)v << 16);
     }
+}
+template <int DT>
+__device__ __forceinline__ float load16_as_f32(const void* p, size_t idx) {
+    return bits16_to_f32<DT>(reinterpret_cast<const uint16_t*>(p)[idx]);
 }
 template <int DT>
 __device__ __forceinline__ uint16_t f32_to_16(float f) {
@@ -72,33 +103,36 @@ __device__ __forceinline__ float round_through(float f) {  // round fp32 to DT a
     }
 }
 
-// Per-(group, column) dequant constants.
-//   SCL == fp16: s = half2(scale, scale) bits
-//   SCL == bf16: s = fp32 scale bits
-//   zc  = half2(-(1024+zero), -(1024+zero)) bits   (bits 4) -- for 8-bit codes the same form works
-//         because 1024 + q is exact in fp16 for q <= 1023.
+// Per-(group, column) dequant constants expanded from one meta word.
 struct ColConst {
-    uint32_t s;
-    uint32_t zc;
+    uint32_t s;    // SCL fp16: half2(scale,scale);  SCL bf16: fp32 scale bits
+    uint32_t zlo;  // half2(-(1024+z), -(1024+z))
+    uint32_t zhi;  // half2(-(64+z),   -(64+z))      (4-bit high nibbles only)
 };
 
-template <int SCL>
-__device__ __forceinline__ ColConst make_col_const(uint16_t scale_bits, uint32_t zero) {
+template <int BITS, int SCL>
+__device__ __forceinline__ ColConst expand_meta(uint32_t meta) {
     ColConst c;
+    const uint32_t sb = meta & 0xffffu;
     if constexpr (SCL == kFP16) {
-        c.s = (uint32_t)scale_bits | ((uint32_t)scale_bits << 16);
+        c.s = sb | (sb << 16);
     } else {
-        c.s = (uint32_t)scale_bits << 16;
+        c.s = sb << 16;
     }
-    const uint32_t z = 0xE400u | zero;  // -(1024 + zero) in fp16
-    c.zc = z | (z << 16);
+    const uint32_t zc = meta >> 16;  // 0xE400 | zero
+    c.zlo = zc | (zc << 16);
+    if constexpr (BITS == 4) {
+        const uint32_t zh = 0xD400u | ((zc & 0xFu) << 4);  // -(64 + zero): ulp(64) = 1/16
+        c.zhi = zh | (zh << 16);
+    } else {
+        c.zhi = 0;
+    }
     return c;
 }
 
-// q2 = half2 bits (1024+qa, 1024+qb)  ->  two dequantised weights packed in ACT dtype.
+// d = half2 of exact integers (code - zero)  ->  two dequantised weights packed in ACT dtype.
 template <int ACT, int SCL>
-__device__ __forceinline__ uint32_t dequant_pair(uint32_t q2, const ColConst& c) {
-    const h2_t d = as_h2(q2) + as_h2(c.zc);  // exact small integers (code - zero)
+__device__ __forceinline__ uint32_t scale_pair(h2_t d, const ColConst& c) {
     if constexpr (SCL == kFP16) {
         const h2_t w = d * as_h2(c.s);  // single fp16 rounding == torch fp16 mul
         if constexpr (ACT == kFP16) {
@@ -117,48 +151,29 @@ __device__ __forceinline__ uint32_t dequant_pair(uint32_t q2, const ColConst& c)
     }
 }
 
-// One int32 word of 4-bit codes (k = 8r .. 8r+7 of one column) -> MFMA B fragment (8 x 16-bit) in the
-// k-order [0,4,1,5,2,6,3,7] (the order the masks produce for free); the A fragment is permuted to match.
+// One tiled int32 word of 4-bit codes -> MFMA B fragment (8 x 16-bit, natural k order).
 template <int ACT, int SCL>
 __device__ __forceinline__ u4_t dequant_word4(uint32_t w, const ColConst& c) {
-    constexpr uint32_t MAGIC = 0x64006400u, MASK = 0x000F000Fu;
+    constexpr uint32_t MAGIC = 0x64006400u, LO = 0x000F000Fu, HI = 0x00F000F0u;
+    const h2_t sixteenth = as_h2(0x2C002C00u);  // 1/16
+    const uint32_t w8 = w >> 8;
     u4_t r;
-    r.x = dequant_pair<ACT, SCL>((w & MASK) | MAGIC, c);          // k0, k4
-    r.y = dequant_pair<ACT, SCL>(((w >> 4) & MASK) | MAGIC, c);   // k1, k5
-    r.z = dequant_pair<ACT, SCL>(((w >> 8) & MASK) | MAGIC, c);   // k2, k6
-    r.w = dequant_pair<ACT, SCL>(((w >> 12) & MASK) | MAGIC, c);  // k3, k7
+    r.x = scale_pair<ACT, SCL>(as_h2((w & LO) | MAGIC) + as_h2(c.zlo), c);                                 // k0,k1
+    r.y = scale_pair<ACT, SCL>(__builtin_elementwise_fma(as_h2((w & HI) | MAGIC), sixteenth, as_h2(c.zhi)), c);   // k2,k3
+    r.z = scale_pair<ACT, SCL>(as_h2((w8 & LO) | MAGIC) + as_h2(c.zlo), c);                                // k4,k5
+    r.w = scale_pair<ACT, SCL>(__builtin_elementwise_fma(as_h2((w8 & HI) | MAGIC), sixteenth, as_h2(c.zhi)), c);  // k6,k7
     return r;
 }
 
-// Two int32 words of 8-bit codes (k = 8R..8R+3 and 8R+4..8R+7) -> B fragment in k-order [0,2,1,3,4,6,5,7].
+// Two tiled int32 words of 8-bit codes (rows e=0..3 and 4..7) -> B fragment, natural k order.
 template <int ACT, int SCL>
 __device__ __forceinline__ u4_t dequant_word8(uint32_t w0, uint32_t w1, const ColConst& c) {
     constexpr uint32_t MAGIC = 0x64006400u, MASK = 0x00FF00FFu;
     u4_t r;
-    r.x = dequant_pair<ACT, SCL>((w0 & MASK) | MAGIC, c);         // k0, k2
-    r.y = dequant_pair<ACT, SCL>(((w0 >> 8) & MASK) | MAGIC, c);  // k1, k3
-    r.z = dequant_pair<ACT, SCL>((w1 & MASK) | MAGIC, c);         // k4, k6
-    r.w = dequant_pair<ACT, SCL>(((w1 >> 8) & MASK) | MAGIC, c);  // k5, k7
-    return r;
-}
-
-// Permute 8 consecutive activations (x0..x7 as 4 dwords) into the B-fragment k-order.
-template <int BITS>
-__device__ __forceinline__ u4_t permute_a(u4_t a) {
-    u4_t r;
-    if constexpr (BITS == 4) {
-        // [x0,x4,x1,x5,x2,x6,x3,x7]
-        r.x = __builtin_amdgcn_perm(a.z, a.x, 0x05040100u);
-        r.y = __builtin_amdgcn_perm(a.z, a.x, 0x07060302u);
-        r.z = __builtin_amdgcn_perm(a.w, a.y, 0x05040100u);
-        r.w = __builtin_amdgcn_perm(a.w, a.y, 0x07060302u);
-    } else {
-        // [x0,x2,x1,x3,x4,x6,x5,x7]
-        r.x = __builtin_amdgcn_perm(a.y, a.x, 0x05040100u);
-        r.y = __builtin_amdgcn_perm(a.y, a.x, 0x07060302u);
-        r.z = __builtin_amdgcn_perm(a.w, a.z, 0x05040100u);
-        r.w = __builtin_amdgcn_perm(a.w, a.z, 0x07060302u);
-    }
+    r.x = scale_pair<ACT, SCL>(as_h2((w0 & MASK) | MAGIC) + as_h2(c.zlo), c);         // k0,k1
+    r.y = scale_pair<ACT, SCL>(as_h2(((w0 >> 8) & MASK) | MAGIC) + as_h2(c.zlo), c);  // k2,k3
+    r.z = scale_pair<ACT, SCL>(as_h2((w1 & MASK) | MAGIC) + as_h2(c.zlo), c);         // k4,k5
+    r.w = scale_pair<ACT, SCL>(as_h2(((w1 >> 8) & MASK) | MAGIC) + as_h2(c.zlo), c);  // k6,k7
     return r;
 }
 
@@ -170,17 +185,6 @@ __device__ __forceinline__ f4_t mfma16(u4_t a, u4_t b, f4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
     } else {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
-    }
-}
-
-// D(32x32) += A(32x16) * B(16x32); lane l: A[m=l&31][k=8*(l>>5)+j], B[k=8*(l>>5)+j][n=l&31],
-// D[m=(i&3)+8*(i>>2)+4*(l>>5)][n=l&31].
-template <int ACT>
-__device__ __forceinline__ f16_t mfma32(u4_t a, u4_t b, f16_t c) {
-    if constexpr (ACT == kFP16) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
-    } else {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
     }
 }
 

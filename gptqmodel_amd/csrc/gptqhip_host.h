@@ -8,33 +8,32 @@ namespace gptqhip {
 
 struct GemmArgs {
     const void* x;
-    const int32_t* qweight;
-    const int32_t* qzeros;
-    const void* scales;
+    const uint32_t* qweight;  // tile-major words (gptqhip_device.h)
+    const uint32_t* meta;     // [tiles][G][16] scale|zero constants
     const void* bias;
     void* out;
     int M, K, N, group_size, bits, act_dtype, scale_dtype;
 };
 
 struct SkinnyPlan {
-    int spg;               // K-steps (32 k) that share one group's scale/zero per loop iteration
-    int chunks_total;      // K / (32*spg)
-    int chunks_per_split;  // chunks handled by one block (its 4 waves split them again)
-    int splits;            // grid.y
+    int mt;                // 16-row activation tiles per block (1, 2, 4)
+    int gpc;               // meta words per 128-row chunk (1: group_size % 128 == 0, else 4 = per K-step)
+    int chunks;            // ceil(K / 128)
+    int waves;             // waves per block (in-block split-K)
+    int chunks_per_split;  // chunks handled by one block
+    int splits;            // grid.y (cross-block split-K)
     size_t slab_floats;    // fp32 partial slabs, 0 when splits == 1
-    int counters;          // one arrival counter per 64-column strip
 };
 
 struct TiledPlan {
     int splits;
     size_t slab_floats;
-    int counters;
 };
 
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
-SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split);
+SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves);
 int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* counters, hipStream_t stream);
 
 TiledPlan plan_tiled(int M, int K, int N, int group_size);
@@ -42,10 +41,13 @@ int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, int* coun
 
 int launch_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* g_idx, void* out,
                    int K, int N, int group_size, int bits, int scale_dtype, int out_dtype, hipStream_t stream);
+int launch_dequant_tiled(const uint32_t* qweight_t, const uint32_t* meta, const int32_t* perm, void* out, int K, int N,
+                         int group_size, int bits, int scale_dtype, int out_dtype, hipStream_t stream);
 int launch_repack_awq(const int32_t* qw_awq, const int32_t* qz_awq, int32_t* qw_out, int32_t* qz_out, int K, int N,
                       int G, hipStream_t stream);
-int launch_repack_rows(const int32_t* qweight, const int32_t* perm, int32_t* out, int K, int N, int bits,
-                       hipStream_t stream);
+int launch_repack_tiled(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* perm,
+                        uint32_t* qweight_t, uint32_t* meta, int K, int N, int group_size, int bits,
+                        hipStream_t stream);
 int launch_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, hipStream_t stream);
 
 }  // namespace gptqhip

@@ -2,7 +2,7 @@
 #include "gptqhip_device.h"
 #include "gptqhip_host.h"
 namespace gptqhip {
-TiledPlan plan_tiled(int, int, int, int) { return TiledPlan{1, 0, 0}; }
+TiledPlan plan_tiled(int, int, int, int) { return TiledPlan{1, 0}; }
 int launch_tiled(const GemmArgs&, const TiledPlan&, float*, int*, hipStream_t) {
     set_error("tiled kernel not built");
     return -22;

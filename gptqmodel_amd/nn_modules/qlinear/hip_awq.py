@@ -48,7 +48,7 @@ class HipAwqLinear(AWQuantLinear):
                          backend=kwargs.pop("backend", BACKEND.AWQ_HIP), adapter=adapter,
                          register_buffers=register_buffers, **kwargs)
         self._ready = False
-        self._rt = {}  # dtype -> (scales, bias) cast to the runtime compute dtype
+        self._rt = {}  # compute dtype -> (meta, bias): dequant constants with scales cast to that dtype
 
     @classmethod
     def validate_once(cls):
@@ -65,23 +65,27 @@ class HipAwqLinear(AWQuantLinear):
             raise RuntimeError("HipAwqLinear.post_init: buffers must be on the ROCm device (no CPU fallback)")
         if self.qweight.shape != (self.in_features, self.out_features // 8):
             raise RuntimeError(f"unexpected AWQ qweight shape {tuple(self.qweight.shape)}")
-        qw, qz = ops.repack_awq(self.qweight.data, self.qzeros.data)
-        self.qweight.data = qw   # now [K/8, N], K-packed sequential
-        self.qzeros.data = qz    # now sequential nibble order
+        qw, qz = ops.repack_awq(self.qweight.data, self.qzeros.data)  # AWQ -> K-packed sequential
         self.scales.data = self.scales.data.contiguous()
+        qw_t, meta = ops.repack_tiled(qw, qz, self.scales.data, None, self.group_size, self.bits)
+        self.qweight.data = qw_t  # tiled words; the AWQ-layout copy is released
+        self.qzeros.data = qz     # sequential nibble order (kept: meta is rebuilt from it on a dtype change)
+        self._rt = {self.scales.dtype: (meta, self.bias)}
         self._ready = True
 
     def _runtime(self, dtype: torch.dtype):
         """AwqTorchLinear._ensure_runtime_dtype (torch_awq.py:149-155): scales and bias are cast to the compute
         dtype BEFORE the dequant multiply."""
         hit = self._rt.get(dtype)
-        if hit is None or hit[0].device != self.scales.device:
+        if hit is None:
+            from gptqmodel_amd import ops
             sc = self.scales if self.scales.dtype == dtype else self.scales.to(dtype).contiguous()
             b = None
             if self.bias is not None:
                 b = self.bias if self.bias.dtype == dtype else self.bias.to(dtype).contiguous()
-            hit = (sc, b)
-            self._rt = {dtype: hit}
+            _, meta = ops.repack_tiled(None, self.qzeros, sc, None, self.group_size, self.bits)  # meta only
+            hit = (meta, b)
+            self._rt = {dtype: hit}  # one compute dtype at a time (a model runs in one dtype)
         return hit
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -90,8 +94,8 @@ class HipAwqLinear(AWQuantLinear):
         from gptqmodel_amd import ops
         out_shape = x.shape[:-1] + (self.out_features,)
         x2, in_dtype = flatten_input(x, self.in_features)
-        scales, bias = self._runtime(x2.dtype)
-        out = ops.gemm(x2, self.qweight, self.qzeros, scales, bias, None, self.group_size, self.bits)
+        meta, bias = self._runtime(x2.dtype)
+        out = ops.gemm(x2, self.qweight, meta, bias, None, self.out_features, self.group_size, self.bits, x2.dtype)
         if self.adapter:
             out = self.adapter.apply(x=x2, out=out)
         if out.dtype != in_dtype:
@@ -100,7 +104,9 @@ class HipAwqLinear(AWQuantLinear):
 
     def dequantize_weight(self) -> torch.Tensor:
         from gptqmodel_amd import ops
-        return ops.dequant(self.qweight, self.qzeros, self.scales, None, self.group_size, self.bits)
+        meta, _ = self._runtime(self.scales.dtype)
+        return ops.dequant_tiled(self.qweight, meta, None, self.in_features, self.out_features, self.group_size,
+                                 self.bits, self.scales.dtype)
 
 
 __all__ = ["HipAwqLinear"]

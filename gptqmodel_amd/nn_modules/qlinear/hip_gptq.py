@@ -48,6 +48,8 @@ class HipGptqLinear(GPTQQuantLinear):
                          backend=kwargs.pop("backend", BACKEND.GPTQ_HIP), adapter=adapter,
                          register_buffers=register_buffers, format=format, **kwargs)
         self.perm: Optional[torch.Tensor] = None  # act-order row permutation (device int32 [K]) after post_init
+        self.meta: Optional[torch.Tensor] = None  # pre-baked per-(group, column) constants after post_init
+        self._scale_dtype = torch.float16
         self._ready = False
         self._bias_cache = None
 
@@ -56,31 +58,34 @@ class HipGptqLinear(GPTQQuantLinear):
         return hip_validate_once()
 
     def post_init(self):
-        """One-time device-side preparation (the reference kernels repack here too: marlin.py:246-293,
-        exllamav2.py:114-140).  desc_act=False needs nothing: the checkpoint layout IS the kernel layout."""
+        """One-time device-side relayout into the MFMA-tile-major kernel layout (+ act-order row sort).  The
+        reference's fast kernels repack here too (marlin.py:246-293, exllamav2.py:114-140); saving a loaded model
+        re-reads the checkpoint from disk (models/writer.py:681-685), so replacing `qweight` in place is safe."""
         super().post_init()
         from gptqmodel_amd import ops
         if not self.qweight.is_cuda:
             raise RuntimeError("HipGptqLinear.post_init: buffers must be on the ROCm device (no CPU fallback)")
+        if self.scales.dtype not in (torch.float16, torch.bfloat16):
+            self.scales.data = self.scales.data.to(torch.float16)
         groups = self.scales.shape[0]
+        perm = None
         if self.g_idx is not None and self.g_idx.numel() == self.in_features:
             perm = act_order_permutation(self.g_idx, self.group_size, groups)
         elif self.g_idx is not None and self.g_idx.numel() not in (0, self.in_features):
             raise NotImplementedError("stacked g_idx (num_itr > 1, torch.py:327) is not supported by the HIP kernel")
-        else:
-            perm = None
-        if perm is not None:
-            self.qweight.data = ops.repack_rows(self.qweight.data.contiguous(), perm, self.bits)
-            self.perm = perm
-        self.qweight.data = self.qweight.data.contiguous()
-        self.qzeros.data = self.qzeros.data.contiguous()
-        self.scales.data = self.scales.data.contiguous()
+        qw_t, meta = ops.repack_tiled(self.qweight.data, self.qzeros.data, self.scales.data, perm, self.group_size,
+                                      self.bits)
+        self.qweight.data = qw_t  # tiled words; the checkpoint-layout copy is released
+        self.meta = meta
+        self.perm = perm
+        self._scale_dtype = self.scales.dtype
         self._ready = True
 
     def list_buffers(self):
         buf = super().list_buffers()
-        if self.perm is not None:
-            buf.append(self.perm)
+        for t in (self.perm, getattr(self, "meta", None)):
+            if t is not None:
+                buf.append(t)
         return buf
 
     def _bias_for(self, dtype: torch.dtype, device: torch.device):
@@ -98,8 +103,8 @@ class HipGptqLinear(GPTQQuantLinear):
         from gptqmodel_amd import ops
         out_shape = x.shape[:-1] + (self.out_features,)
         x2, in_dtype = flatten_input(x, self.in_features)
-        out = ops.gemm(x2, self.qweight, self.qzeros, self.scales, self._bias_for(x2.dtype, x2.device), self.perm,
-                       self.group_size, self.bits)
+        out = ops.gemm(x2, self.qweight, self.meta, self._bias_for(x2.dtype, x2.device), self.perm, self.out_features,
+                       self.group_size, self.bits, self._scale_dtype)
         if self.adapter:
             out = self.adapter.apply(x=x2, out=out)  # torch.py:344-345
         if out.dtype != in_dtype:
@@ -111,12 +116,10 @@ class HipGptqLinear(GPTQQuantLinear):
         if num_itr != 1:
             raise NotImplementedError("num_itr > 1 is not supported")
         from gptqmodel_amd import ops
-        w = ops.dequant(self.qweight, self.qzeros, self.scales, None, self.group_size, self.bits)
-        if self.perm is not None:  # rows are stored group-sorted; return them in checkpoint order
-            out = torch.empty_like(w)
-            out[self.perm.long()] = w
-            return out
-        return w
+        if not self._ready:  # still in checkpoint layout
+            return ops.dequant(self.qweight, self.qzeros, self.scales, self.g_idx, self.group_size, self.bits)
+        return ops.dequant_tiled(self.qweight, self.meta, self.perm, self.in_features, self.out_features,
+                                 self.group_size, self.bits, self._scale_dtype)
 
 
 __all__ = ["HipGptqLinear"]

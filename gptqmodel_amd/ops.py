@@ -55,20 +55,49 @@ def workspace_for(device: torch.device, nbytes: int) -> torch.Tensor:
     return ws
 
 
-def gemm(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
-         bias: Optional[torch.Tensor], perm: Optional[torch.Tensor], group_size: int, bits: int,
-         out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M,N] = x[M,K] @ dequant(canonical qweight/qzeros/scales) (+bias)  via gptqhip_gemm."""
+def repack_tiled(qweight: Optional[torch.Tensor], qzeros: torch.Tensor, scales: torch.Tensor,
+                 perm: Optional[torch.Tensor], group_size: int, bits: int):
+    """Checkpoint layout (qweight [K*bits/32,N], qzeros [G,N*bits/32], scales [G,N]) -> (qweight_t, meta) in the
+    MFMA-tile-major kernel layout (include/gptqhip.h).  One-time, on device, in post_init.
+    qweight=None rebuilds only `meta` (returns (None, meta))."""
     lib = _lib.load()
-    _require_cuda(x, qweight, qzeros, scales, bias, perm)
+    _require_cuda(qweight, qzeros, scales, perm)
+    if scales.dtype not in _DT:
+        raise RuntimeError(f"repack_tiled: unsupported scales dtype {scales.dtype}")
+    pf = 32 // bits
+    G, N = scales.shape
+    K = G * group_size
+    if qweight is not None:
+        if tuple(qweight.shape) != (K // pf, N):
+            raise RuntimeError(f"repack_tiled: qweight shape {tuple(qweight.shape)} != {(K // pf, N)}")
+        qweight = qweight.contiguous()
+    qzeros, scales = qzeros.contiguous(), scales.contiguous()
+    nw = lib.gptqhip_tiled_words(K, N, bits)
+    nm = lib.gptqhip_meta_words(K, N, group_size)
+    if nw == 0 or nm == 0:
+        raise RuntimeError(f"repack_tiled: unsupported shape K={K} N={N} group_size={group_size} bits={bits}")
+    qw_t = torch.empty(nw, dtype=torch.int32, device=scales.device) if qweight is not None else None
+    meta = torch.empty(nm, dtype=torch.int32, device=scales.device)
+    with torch.cuda.device(scales.device):
+        rc = lib.gptqhip_repack_tiled(_ptr(qweight), _ptr(qzeros), _ptr(scales), _ptr(perm), _ptr(qw_t), _ptr(meta),
+                                      K, N, group_size, bits, _stream(scales.device))
+    _lib.check(rc, "gptqhip_repack_tiled")
+    return qw_t, meta
+
+
+def gemm(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Optional[torch.Tensor],
+         perm: Optional[torch.Tensor], N: int, group_size: int, bits: int, scale_dtype: torch.dtype,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = x[M,K] @ dequant(qweight_t, meta) (+bias)  via gptqhip_gemm (tiled layout)."""
+    lib = _lib.load()
+    _require_cuda(x, qweight_t, meta, bias, perm)
     if x.dim() != 2 or not x.is_contiguous():
         raise RuntimeError("gemm: x must be a contiguous [M,K] tensor")
-    if x.dtype not in _DT or scales.dtype not in _DT:
-        raise RuntimeError(f"gemm: unsupported dtypes x={x.dtype} scales={scales.dtype}")
+    if x.dtype not in _DT or scale_dtype not in _DT:
+        raise RuntimeError(f"gemm: unsupported dtypes x={x.dtype} scales={scale_dtype}")
     if bias is not None and bias.dtype != x.dtype:
         raise RuntimeError("gemm: bias dtype must equal activation dtype")
     M, K = x.shape
-    N = scales.shape[1]
     if out is None:
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     if M == 0:
@@ -76,14 +105,15 @@ def gemm(x: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scales: t
     with torch.cuda.device(x.device):
         need = lib.gptqhip_workspace_bytes(M, K, N, 1 if perm is not None else 0)
         ws = workspace_for(x.device, need)
-        rc = lib.gptqhip_gemm(_ptr(x), _ptr(qweight), _ptr(qzeros), _ptr(scales), _ptr(perm), _ptr(bias), _ptr(out),
-                              _ptr(ws), ws.numel(), M, K, N, group_size, bits, _DT[x.dtype], _DT[scales.dtype],
+        rc = lib.gptqhip_gemm(_ptr(x), _ptr(qweight_t), _ptr(meta), _ptr(perm), _ptr(bias), _ptr(out), _ptr(ws),
+                              ws.numel(), M, K, N, group_size, bits, _DT[x.dtype], _DT[scale_dtype],
                               _stream(x.device))
     _lib.check(rc, "gptqhip_gemm")
     return out
 
 
 def dequant(qweight, qzeros, scales, g_idx, group_size: int, bits: int, out_dtype=None) -> torch.Tensor:
+    """[K,N] weights from the CHECKPOINT layout (bit-exact with the reference's dequantize_weight())."""
     lib = _lib.load()
     _require_cuda(qweight, qzeros, scales, g_idx)
     pf = 32 // bits
@@ -94,6 +124,19 @@ def dequant(qweight, qzeros, scales, g_idx, group_size: int, bits: int, out_dtyp
         rc = lib.gptqhip_dequant(_ptr(qweight), _ptr(qzeros), _ptr(scales), _ptr(g_idx), _ptr(out), K, N, group_size,
                                  bits, _DT[scales.dtype], _DT[out_dtype], _stream(qweight.device))
     _lib.check(rc, "gptqhip_dequant")
+    return out
+
+
+def dequant_tiled(qweight_t, meta, perm, K: int, N: int, group_size: int, bits: int, scale_dtype, out_dtype=None):
+    """[K,N] weights from the TILED layout; rows come back in checkpoint order when perm is given."""
+    lib = _lib.load()
+    _require_cuda(qweight_t, meta, perm)
+    out_dtype = out_dtype or scale_dtype
+    out = torch.empty((K, N), dtype=out_dtype, device=qweight_t.device)
+    with torch.cuda.device(qweight_t.device):
+        rc = lib.gptqhip_dequant_tiled(_ptr(qweight_t), _ptr(meta), _ptr(perm), _ptr(out), K, N, group_size, bits,
+                                       _DT[scale_dtype], _DT[out_dtype], _stream(qweight_t.device))
+    _lib.check(rc, "gptqhip_dequant_tiled")
     return out
 
 
@@ -111,19 +154,6 @@ def repack_awq(qweight_awq: torch.Tensor, qzeros_awq: torch.Tensor):
     return qw, qz
 
 
-def repack_rows(qweight: torch.Tensor, perm: torch.Tensor, bits: int) -> torch.Tensor:
-    lib = _lib.load()
-    _require_cuda(qweight, perm)
-    pf = 32 // bits
-    K, N = qweight.shape[0] * pf, qweight.shape[1]
-    out = torch.empty_like(qweight)
-    with torch.cuda.device(qweight.device):
-        rc = lib.gptqhip_repack_rows(_ptr(qweight.contiguous()), _ptr(perm), _ptr(out), K, N, bits,
-                                     _stream(qweight.device))
-    _lib.check(rc, "gptqhip_repack_rows")
-    return out
-
-
 def gather_cols(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     _require_cuda(x, perm)
@@ -135,5 +165,5 @@ def gather_cols(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def set_tuning(force_split_k: int = 0, force_kernel: int = 0) -> None:
-    _lib.check(_lib.load().gptqhip_set_tuning(force_split_k, force_kernel), "gptqhip_set_tuning")
+def set_tuning(force_split_k: int = 0, force_kernel: int = 0, force_waves: int = 0) -> None:
+    _lib.check(_lib.load().gptqhip_set_tuning(force_split_k, force_kernel, force_waves), "gptqhip_set_tuning")

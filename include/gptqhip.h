@@ -18,14 +18,23 @@
  *     the reference natives use the current stream: ext_gptq.cpp:108); nothing synchronises.
  *   - re-entrant across devices and streams provided each (device, stream) uses its own workspace.
  *
- * Canonical weight layout consumed by the kernels ("GPTQ v2, K-packed"):
+ * Checkpoint ("canonical", GPTQ v2 K-packed) layout accepted by gptqhip_repack_tiled / gptqhip_dequant:
  *   qweight int32 [K*bits/32, N]   word (r,n) holds codes k = pf*r + j at bits [bits*j, bits*j+bits)
  *   qzeros  int32 [G, N*bits/32]   word (g,c) holds zero  n = pf*c + j at bits [bits*j, ...)   (v2: used as-is)
  *   scales  fp16|bf16 [G, N]
- *   group of row k  =  k / group_size   (act-order checkpoints are row-sorted once by gptqhip_repack_rows
- *                                        and x is gathered through the same permutation)
  * = the buffer contract of gptqmodel/nn_modules/qlinear/__init__.py:827-865 after the loader's
- *   v1->v2 conversion (gptqmodel/utils/model.py:750-844).
+ *   v1->v2 conversion (gptqmodel/utils/model.py:750-844).  AWQ checkpoints are first brought to this
+ *   layout by gptqhip_repack_awq.
+ *
+ * Kernel ("tiled", MFMA-tile-major) layout consumed by gptqhip_gemm, produced ONCE in post_init by
+ * gptqhip_repack_tiled (the reference's fast kernels repack in post_init too: marlin.py:246-293,
+ * exllamav2.py:114-140):
+ *   qweight_t uint32 [ceil(N/16)][ceil(K/128)][64 lanes][4]   (x2 for 8-bit)  -- one (tile, chunk) block is
+ *             the B operand of four mfma_f32_16x16x32 steps and exactly one 1 KiB wave load; see
+ *             gptqmodel_amd/csrc/gptqhip_device.h for the nibble order.
+ *   meta      uint32 [ceil(N/16)][G][16] = scale16 | (0xE400|zero)<<16  (pre-baked dequant constants)
+ *   act-order: rows are stored group-sorted (row k' = checkpoint row perm[k'], perm = stable argsort(g_idx));
+ *             gptqhip_gemm gathers x through the same perm.
  */
 #ifndef GPTQHIP_H
 #define GPTQHIP_H
@@ -66,48 +75,62 @@ int gptqhip_device_info(int device, int* cu_count, size_t* hbm_bytes, char* arch
  * kernels leave it zeroed where it matters (counters). */
 size_t gptqhip_workspace_bytes(int M, int K, int N, int has_perm);
 
-/* THE HOT PATH.  out[M,N] = x[M,K] @ dequant(qweight,qzeros,scales) (+ bias), rounded like the reference:
+/* Sizes (in 32-bit words) of the tiled weight / meta arrays for a [K,N] layer. */
+size_t gptqhip_tiled_words(int K, int N, int bits);
+size_t gptqhip_meta_words(int K, int N, int group_size);
+
+/* post_init: checkpoint layout -> tiled layout + meta.  perm [K] int32 or NULL (act-order: sorted row k' is
+ * checkpoint row perm[k']).  Same role as gptq_marlin_repack (gptqmodel_ext/marlin/gptq_marlin_repack.cu:250)
+ * and ExllamaV2 make_sequential/shuffle (gptqmodel_ext/exllamav2/cuda/q_matrix.cu:19-45,502-604).
+ *   bits 4|8; K % 32 == 0; N % 8 == 0; group_size % 32 == 0 and K % group_size == 0.
+ * qweight and qweight_t may both be NULL: only the meta constants are (re)built (e.g. scales cast to a new dtype). */
+int gptqhip_repack_tiled(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* perm,
+                         uint32_t* qweight_t, uint32_t* meta, int K, int N, int group_size, int bits,
+                         gptqhip_stream_t stream);
+
+/* THE HOT PATH.  out[M,N] = x[M,K] @ dequant(qweight_t, meta) (+ bias), rounded like the reference:
  *   W = round_scaledtype(scale * (code - zero)); W' = round_actdtype(W); y = round_actdtype(sum_k x*W');
  *   y = round_actdtype(y + bias).
  * Replaces TorchLinear.forward/_forward_eager (gptqmodel/nn_modules/qlinear/torch.py:302-347 with
  * _dequantize_weight_cached_248 :700-717) and AwqTorchLinear.forward (torch_awq.py:157-195 with
- * dequantize_gemm, quantization/awq/utils/packing_utils.py:106-121, after gptqhip_repack_awq).
+ * dequantize_gemm, quantization/awq/utils/packing_utils.py:106-121).
  *   x        [M,K]  act_dtype, row-major contiguous
- *   perm     [K] int32 or NULL: x column gather for act-order (row k' of qweight is original row perm[k'])
+ *   perm     [K] int32 or NULL: x column gather for act-order
  *   bias     [N] act_dtype or NULL
  *   out      [M,N] act_dtype
- *   bits     4 or 8; group_size multiple of 32 dividing K; K % 32 == 0; N % 8 == 0
- */
-int gptqhip_gemm(const void* x, const int32_t* qweight, const int32_t* qzeros, const void* scales,
+ *   scale_dtype: dtype of the scale bits inside meta */
+int gptqhip_gemm(const void* x, const uint32_t* qweight_t, const uint32_t* meta,
                  const int32_t* perm, const void* bias, void* out,
                  void* workspace, size_t workspace_bytes,
                  int M, int K, int N, int group_size, int bits,
                  int act_dtype, int scale_dtype, gptqhip_stream_t stream);
 
-/* Materialise W[K,N] in `out_dtype` (= scales dtype in the reference).  Replaces
+/* Materialise W[K,N] from the CHECKPOINT layout in `out_dtype` (= scales dtype in the reference).  Replaces
  * TorchLinear.dequantize_weight (torch.py:225) / PackableQuantLinear.dequantize_weight
  * (qlinear/__init__.py:947-1003); bit-exact with it.  g_idx [K] int32 or NULL (then k/group_size). */
 int gptqhip_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* g_idx,
                     void* out, int K, int N, int group_size, int bits, int scale_dtype, int out_dtype,
                     gptqhip_stream_t stream);
 
+/* Same from the TILED layout (what a module holds after post_init); with perm the rows are written back in
+ * checkpoint order. */
+int gptqhip_dequant_tiled(const uint32_t* qweight_t, const uint32_t* meta, const int32_t* perm, void* out,
+                          int K, int N, int group_size, int bits, int scale_dtype, int out_dtype,
+                          gptqhip_stream_t stream);
+
 /* post_init helper: AWQ GEMM layout (qweight [K,N/8], qzeros [G,N/8], nibble i <-> column 8c+[0,2,4,6,1,3,5,7][i])
- * -> canonical layout.  Semantics of unpack_reorder_pack (packing_utils.py:90-103); zero-points kept as-is. */
+ * -> checkpoint-canonical layout.  Semantics of unpack_reorder_pack (packing_utils.py:90-103); zero-points kept as-is. */
 int gptqhip_repack_awq(const int32_t* qweight_awq, const int32_t* qzeros_awq,
                        int32_t* qweight_out, int32_t* qzeros_out, int K, int N, int G,
                        gptqhip_stream_t stream);
 
-/* post_init helper for desc_act: out row k' = row perm[k'] of qweight (nibble/byte granular), so that rows of
- * one group become contiguous.  Same role as ExllamaV2 make_sequential (gptqmodel_ext/exllamav2/cuda/q_matrix.cu:502-604)
- * and marlin_sort_g_idx (gptqmodel/utils/marlin.py:368-372). */
-int gptqhip_repack_rows(const int32_t* qweight, const int32_t* perm, int32_t* qweight_out,
-                        int K, int N, int bits, gptqhip_stream_t stream);
-
-/* out[m, k'] = x[m, perm[k']]  (16-bit elements).  Used by gptqhip_gemm internally and exported for tests. */
+/* out[m, k'] = x[m, perm[k']]  (16-bit elements).  Used by gptqhip_gemm internally and exported for tests
+ * (ExllamaV2 gathers A through q_perm: gptqmodel_ext/exllamav2/cuda/q_gemm_kernel_gptq.cuh:79-90). */
 int gptqhip_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, gptqhip_stream_t stream);
 
-/* Tuning hook (benchmarks / tests): force the split-K factor of the skinny kernel (0 = heuristic). */
-int gptqhip_set_tuning(int force_split_k, int force_kernel /*0 auto, 1 skinny, 2 tiled*/);
+/* Tuning hook (benchmarks / tests): force the cross-block split-K factor and the waves per block of the skinny
+ * kernel (0 = heuristic), or the kernel family (0 auto, 1 skinny, 2 tiled-prefill). */
+int gptqhip_set_tuning(int force_split_k, int force_kernel, int force_waves);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,8 @@ def test_auto_select_and_forward_gptq_v1_checkpoint():
     assert out.shape == (2, 3, N)
     ref = O.forward_gptq(x, qweight, qzeros_v2, scales, g_idx, 4)
     assert rel_err(torch_to_f32(out), ref) <= 1e-3
-    with pytest.raises(NotImplementedError):
+    model.eval()
+    with pytest.raises(NotImplementedError):  # inference-only kernel (SUPPORTS_TRAINING=False, qlinear/__init__.py:463-483)
         model.proj.train(True)
 
 
@@ -100,13 +101,14 @@ def test_graph_capture_replay_matches_eager():
     qw, qz = torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV)
     sc = f32_to_torch(scales, "fp16", DEV)
     x = torch.randn((1, K), device=DEV, dtype=torch.float16)
+    qw_t, meta = ops.repack_tiled(qw, qz, sc, None, gs, 4)
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
-        eager = ops.gemm(x, qw, qz, sc, None, None, gs, 4).clone()
+        eager = ops.gemm(x, qw_t, meta, None, None, N, gs, 4, sc.dtype).clone()
         s.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=s):
-            out = ops.gemm(x, qw, qz, sc, None, None, gs, 4)
+            out = ops.gemm(x, qw_t, meta, None, None, N, gs, 4, sc.dtype)
         for _ in range(3):
             graph.replay()
         s.synchronize()

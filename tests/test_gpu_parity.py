@@ -40,18 +40,18 @@ def run_gptq(ops, x_f32, qweight, qzeros, scales_f32, g_idx, bits, gs, bias_f32,
     k = x_f32.shape[-1]
     perm = None
     if not np.array_equal(g_idx, np.arange(k) // gs):
-        perm_np = O.act_order_perm(g_idx)
-        perm = torch.from_numpy(perm_np).to(dev)
-        qw = ops.repack_rows(qw, perm, bits)
-    out = ops.gemm(x, qw, qz, sc, b, perm, gs, bits)
+        perm = torch.from_numpy(O.act_order_perm(g_idx)).to(dev)
+    qw_t, meta = ops.repack_tiled(qw, qz, sc, perm, gs, bits)  # what post_init does
+    out = ops.gemm(x, qw_t, meta, b, perm, sc.shape[1], gs, bits, sc.dtype)
     torch.cuda.synchronize()
     return out
 
 
 def test_known_answer_vector(ops):
     g = load_golden("q4_kat_1024.npz")
-    out = ops.gemm(bits_to_torch(g["x"], "fp16", DEV), torch.from_numpy(g["qweight"]).to(DEV),
-                   torch.from_numpy(g["qzeros"]).to(DEV), bits_to_torch(g["scales"], "fp16", DEV), None, None, 128, 4)
+    qw_t, meta = ops.repack_tiled(torch.from_numpy(g["qweight"]).to(DEV), torch.from_numpy(g["qzeros"]).to(DEV),
+                                  bits_to_torch(g["scales"], "fp16", DEV), None, 128, 4)
+    out = ops.gemm(bits_to_torch(g["x"], "fp16", DEV), qw_t, meta, None, None, 1024, 128, 4, torch.float16)
     got = torch_to_f32(out)
     exp = bits_to_f32(g["expected"], "fp16")
     assert np.allclose(got, exp, rtol=3e-5, atol=2e-2)  # the reference's own assertion
@@ -70,9 +70,18 @@ def test_gptq_golden(ops, name):
     assert rel_err(torch_to_f32(out), ref) <= tol(act)
     # standalone dequant is bit-exact with the reference's dequantize_weight()
     if g["w_ref"].size:
-        w = ops.dequant(torch.from_numpy(g["qweight"]).to(DEV), torch.from_numpy(g["qzeros"]).to(DEV),
-                        bits_to_torch(g["scales"], sdt, DEV), torch.from_numpy(g["g_idx"]).to(DEV), gs, bits)
+        qw, qz = torch.from_numpy(g["qweight"]).to(DEV), torch.from_numpy(g["qzeros"]).to(DEV)
+        sc, gi = bits_to_torch(g["scales"], sdt, DEV), torch.from_numpy(g["g_idx"]).to(DEV)
+        w = ops.dequant(qw, qz, sc, gi, gs, bits)
         assert np.array_equal(torch_to_bits(w), g["w_ref"].reshape(w.shape))
+        # ... and so is the dequant FROM the tiled layout (integer relayout + same rounding), act-order included
+        k = w.shape[0]
+        perm = None
+        if not np.array_equal(g["g_idx"], np.arange(k) // gs):
+            perm = torch.from_numpy(O.act_order_perm(g["g_idx"])).to(DEV)
+        qw_t, meta = ops.repack_tiled(qw, qz, sc, perm, gs, bits)
+        w2 = ops.dequant_tiled(qw_t, meta, perm, k, w.shape[1], gs, bits, sc.dtype)
+        assert np.array_equal(torch_to_bits(w2), g["w_ref"].reshape(w.shape))
 
 
 @pytest.mark.parametrize("name", golden_files("ref_awq_"))
@@ -90,12 +99,15 @@ def test_awq_golden(ops, name):
     if g["bias"].size:
         b = bits_to_torch(g["bias"], sdt, DEV).to(sc.dtype)
     x = bits_to_torch(g["x"], act, DEV)
-    out = ops.gemm(x, qw, qz, sc, b, None, gs, 4)
+    qw_t, meta = ops.repack_tiled(qw, qz, sc, None, gs, 4)
+    out = ops.gemm(x, qw_t, meta, b, None, sc.shape[1], gs, 4, sc.dtype)
     ref = bits_to_f32(g["out_ref"], act)
     assert rel_err(torch_to_f32(out), ref) <= tol(act)
     if g["w_ref"].size:
         w = ops.dequant(qw, qz, sc, None, gs, 4)
         assert np.array_equal(torch_to_bits(w), g["w_ref"].reshape(w.shape))
+        w2 = ops.dequant_tiled(qw_t, meta, None, w.shape[0], w.shape[1], gs, 4, sc.dtype)
+        assert np.array_equal(torch_to_bits(w2), g["w_ref"].reshape(w.shape))
 
 
 SHAPES = [
@@ -112,6 +124,8 @@ SHAPES = [
     (1024, 1000, 64, 3),     # N not a multiple of 64 (ragged strip)
     (2048, 2048, 32, 5),
     (2048, 512, 2048, 2),    # group_size == K
+    (64, 32, 32, 4),         # the reference's own unit-test shape (K < one 128-row chunk, N = 2 tiles)
+    (96, 8, 32, 1),          # ragged everywhere: K % 128 != 0, N < one tile
 ]
 
 
@@ -149,9 +163,24 @@ def test_split_k_is_deterministic_and_counters_reset(ops, split):
         outs = [torch_to_bits(run_gptq(ops, x, qweight, qzeros, scales, g_idx, 4, gs, None, "fp16", "fp16"))
                 for _ in range(3)]
     finally:
-        ops.set_tuning(0, 0)
+        ops.set_tuning(0, 0, 0)
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])  # fixed reduction order
     assert rel_err(outs[0].view(np.float16).astype(np.float32), ref) <= 1e-3
+
+
+@pytest.mark.parametrize("waves", [4, 8, 16])
+@pytest.mark.parametrize("M", [1, 40])
+def test_waves_per_block_variants(ops, waves, M):
+    K, N, gs = 4096, 1024, 128
+    qweight, qzeros, scales, g_idx = synth_gptq(13, 4, K, N, gs)
+    x = O.round_to(np.random.RandomState(6).randn(M, K).astype(np.float32) * 0.5, "fp16")
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, None, "fp16", "fp16")
+    try:
+        ops.set_tuning(0, 0, waves)
+        out = run_gptq(ops, x, qweight, qzeros, scales, g_idx, 4, gs, None, "fp16", "fp16")
+    finally:
+        ops.set_tuning(0, 0, 0)
+    assert rel_err(torch_to_f32(out), ref) <= 1e-3
 
 
 def test_linearity_property_full_size(ops):
@@ -171,9 +200,13 @@ def test_empty_batch_and_errors(ops):
     qweight, qzeros, scales, _ = synth_gptq(1, 4, 256, 64, 128)
     qw, qz = torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV)
     sc = f32_to_torch(scales, "fp16", DEV)
-    out = ops.gemm(torch.empty((0, 256), dtype=torch.float16, device=DEV), qw, qz, sc, None, None, 128, 4)
+    qw_t, meta = ops.repack_tiled(qw, qz, sc, None, 128, 4)
+    f16 = torch.float16
+    out = ops.gemm(torch.empty((0, 256), dtype=f16, device=DEV), qw_t, meta, None, None, 64, 128, 4, f16)
     assert out.shape == (0, 64)
     with pytest.raises(RuntimeError):
-        ops.gemm(torch.zeros((1, 256), dtype=torch.float16, device=DEV), qw, qz, sc, None, None, 96, 4)  # bad group
+        ops.gemm(torch.zeros((1, 256), dtype=f16, device=DEV), qw_t, meta, None, None, 64, 96, 4, f16)  # bad group
     with pytest.raises(RuntimeError):
-        ops.gemm(torch.zeros((1, 256), dtype=torch.float16), qw, qz, sc, None, None, 128, 4)  # CPU tensor: loud
+        ops.gemm(torch.zeros((1, 256), dtype=f16), qw_t, meta, None, None, 64, 128, 4, f16)  # CPU tensor: loud
+    with pytest.raises(RuntimeError):
+        ops.repack_tiled(qw, qz, sc, None, 96, 4)  # group size not a multiple of 32
