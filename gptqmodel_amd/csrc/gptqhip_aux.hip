@@ -112,7 +112,8 @@ int launch_repack_awq(const int32_t* qw_awq, const int32_t* qz_awq, int32_t* qw_
 template <int BITS>
 __global__ __launch_bounds__(256) void repack_tiled_kernel(const int32_t* __restrict__ src,
                                                            const int32_t* __restrict__ perm,
-                                                           uint32_t* __restrict__ dst, int K, int N, int chunks,
+                                                           const int32_t* __restrict__ qz,
+                                                           uint32_t* __restrict__ dst, int K, int N, int G, int chunks,
                                                            size_t total_words) {
     constexpr int PF = 32 / BITS;
     constexpr uint32_t MASK = (1u << BITS) - 1u;
@@ -135,7 +136,13 @@ __global__ __launch_bounds__(256) void repack_tiled_kernel(const int32_t* __rest
     const int tile = (int)(blk / chunks);
     const int n = tile * kTileN + (lane & 15);
     uint32_t w = 0;
-    if (n < N && kbase < K) {
+    if (n < N && kbase >= K) {
+        // zero-padded tail of a K that is not a multiple of 128: store code == zero-point of the last group, so
+        // the padded rows dequantise to EXACTLY 0 and the kernel needs no masking of the activations
+        const uint32_t z = ((uint32_t)qz[(size_t)(G - 1) * (N / PF) + n / PF] >> (BITS * (n % PF))) & MASK;
+#pragma unroll
+        for (int e = 0; e < PF; ++e) w |= z << (BITS == 4 ? tiled_shift4(e) : tiled_shift8(e));
+    } else if (n < N) {
         if (perm == nullptr) {
             const uint32_t s = (uint32_t)src[(size_t)(kbase / PF) * N + n];
 #pragma unroll
@@ -186,11 +193,11 @@ int launch_repack_tiled(const int32_t* qweight, const int32_t* qzeros, const voi
     const unsigned gw = (unsigned)((words + 255) / 256);
     if (qweight != nullptr) {  // NULL qweight/qweight_t: rebuild the meta constants only (e.g. new scale dtype)
         if (bits == 4) {
-            hipLaunchKernelGGL(repack_tiled_kernel<4>, dim3(gw), dim3(256), 0, stream, qweight, perm, qweight_t, K, N,
-                               chunks, words);
+            hipLaunchKernelGGL(repack_tiled_kernel<4>, dim3(gw), dim3(256), 0, stream, qweight, perm, qzeros,
+                               qweight_t, K, N, G, chunks, words);
         } else {
-            hipLaunchKernelGGL(repack_tiled_kernel<8>, dim3(gw), dim3(256), 0, stream, qweight, perm, qweight_t, K, N,
-                               chunks, words);
+            hipLaunchKernelGGL(repack_tiled_kernel<8>, dim3(gw), dim3(256), 0, stream, qweight, perm, qzeros,
+                               qweight_t, K, N, G, chunks, words);
         }
     }
     const size_t metas = (size_t)tiles * G * 16;

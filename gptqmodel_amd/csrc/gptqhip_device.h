@@ -26,7 +26,8 @@
 //   One wave-instruction (dwordx4 per lane) therefore reads 1 KiB CONTIGUOUS bytes = a whole (tile, chunk)
 //   block, and consecutive chunks of a tile are contiguous: every wave streams a linear address range.
 //   meta[(tile*G + g)*16 + c] = scale16 | (0xE400|zero)<<16   -- the per-(group, column) constants, pre-baked
-//   (scale bits in the scales dtype; -(1024+zero) as fp16).  Padded rows/columns carry code 0 / scale 0.
+//   (scale bits in the scales dtype; -(1024+zero) as fp16).  Padded rows (k >= K) carry code == zero-point of the
+//   last group (they dequantise to exactly 0); padded columns carry code 0 / scale 0 and are never stored.
 // ------------------------------------------------------------------------------------------------
 #pragma once
 #include <hip/hip_runtime.h>
@@ -151,29 +152,53 @@ __device__ __forceinline__ uint32_t scale_pair(h2_t d, const ColConst& c) {
     }
 }
 
+// (w & mask) | magic must be ONE VALU op (v_and_or_b32).  With two literal constants hipcc has to split it into
+// v_and + v_or (a VOP3 encoding reads at most one constant-bus value on gfx9): we hand it the masks in SGPRs and
+// the magic in a VGPR, made opaque once per kernel so they stay in registers, and the pattern then selects itself.
+struct DequantConsts {
+    uint32_t magic;      // 0x64006400 in a VGPR
+    uint32_t lo, hi;     // nibble (or byte) masks in SGPRs
+    uint32_t sixteenth;  // half2(1/16, 1/16)
+};
+template <int BITS>
+__device__ __forceinline__ DequantConsts make_dequant_consts() {
+    DequantConsts k;
+    k.magic = 0x64006400u;
+    k.lo = BITS == 4 ? 0x000F000Fu : 0x00FF00FFu;
+    k.hi = 0x00F000F0u;
+    k.sixteenth = 0x2C002C00u;
+    asm volatile("" : "+v"(k.magic));
+    asm volatile("" : "+s"(k.lo));
+    asm volatile("" : "+s"(k.hi));
+    return k;
+}
+__device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask_sgpr, uint32_t magic_vgpr) {
+    return (w & mask_sgpr) | magic_vgpr;
+}
+
 // One tiled int32 word of 4-bit codes -> MFMA B fragment (8 x 16-bit, natural k order).
 template <int ACT, int SCL>
-__device__ __forceinline__ u4_t dequant_word4(uint32_t w, const ColConst& c) {
-    constexpr uint32_t MAGIC = 0x64006400u, LO = 0x000F000Fu, HI = 0x00F000F0u;
-    const h2_t sixteenth = as_h2(0x2C002C00u);  // 1/16
+__device__ __forceinline__ u4_t dequant_word4(uint32_t w, const ColConst& c, const DequantConsts& k) {
+    const uint32_t LO = k.lo, HI = k.hi;
+    const h2_t sixteenth = as_h2(k.sixteenth);
     const uint32_t w8 = w >> 8;
     u4_t r;
-    r.x = scale_pair<ACT, SCL>(as_h2((w & LO) | MAGIC) + as_h2(c.zlo), c);                                 // k0,k1
-    r.y = scale_pair<ACT, SCL>(__builtin_elementwise_fma(as_h2((w & HI) | MAGIC), sixteenth, as_h2(c.zhi)), c);   // k2,k3
-    r.z = scale_pair<ACT, SCL>(as_h2((w8 & LO) | MAGIC) + as_h2(c.zlo), c);                                // k4,k5
-    r.w = scale_pair<ACT, SCL>(__builtin_elementwise_fma(as_h2((w8 & HI) | MAGIC), sixteenth, as_h2(c.zhi)), c);  // k6,k7
+    r.x = scale_pair<ACT, SCL>(as_h2(and_or(w, LO, k.magic)) + as_h2(c.zlo), c);                                   // k0,k1
+    r.y = scale_pair<ACT, SCL>(__builtin_elementwise_fma(as_h2(and_or(w, HI, k.magic)), sixteenth, as_h2(c.zhi)), c);   // k2,k3
+    r.z = scale_pair<ACT, SCL>(as_h2(and_or(w8, LO, k.magic)) + as_h2(c.zlo), c);                                  // k4,k5
+    r.w = scale_pair<ACT, SCL>(__builtin_elementwise_fma(as_h2(and_or(w8, HI, k.magic)), sixteenth, as_h2(c.zhi)), c);  // k6,k7
     return r;
 }
 
 // Two tiled int32 words of 8-bit codes (rows e=0..3 and 4..7) -> B fragment, natural k order.
 template <int ACT, int SCL>
-__device__ __forceinline__ u4_t dequant_word8(uint32_t w0, uint32_t w1, const ColConst& c) {
-    constexpr uint32_t MAGIC = 0x64006400u, MASK = 0x00FF00FFu;
+__device__ __forceinline__ u4_t dequant_word8(uint32_t w0, uint32_t w1, const ColConst& c, const DequantConsts& k) {
+    const uint32_t MASK = k.lo;
     u4_t r;
-    r.x = scale_pair<ACT, SCL>(as_h2((w0 & MASK) | MAGIC) + as_h2(c.zlo), c);         // k0,k1
-    r.y = scale_pair<ACT, SCL>(as_h2(((w0 >> 8) & MASK) | MAGIC) + as_h2(c.zlo), c);  // k2,k3
-    r.z = scale_pair<ACT, SCL>(as_h2((w1 & MASK) | MAGIC) + as_h2(c.zlo), c);         // k4,k5
-    r.w = scale_pair<ACT, SCL>(as_h2(((w1 >> 8) & MASK) | MAGIC) + as_h2(c.zlo), c);  // k6,k7
+    r.x = scale_pair<ACT, SCL>(as_h2(and_or(w0, MASK, k.magic)) + as_h2(c.zlo), c);       // k0,k1
+    r.y = scale_pair<ACT, SCL>(as_h2(and_or(w0 >> 8, MASK, k.magic)) + as_h2(c.zlo), c);  // k2,k3
+    r.z = scale_pair<ACT, SCL>(as_h2(and_or(w1, MASK, k.magic)) + as_h2(c.zlo), c);       // k4,k5
+    r.w = scale_pair<ACT, SCL>(as_h2(and_or(w1 >> 8, MASK, k.magic)) + as_h2(c.zlo), c);  // k6,k7
     return r;
 }
 

@@ -11,8 +11,9 @@
 //     "round" and every byte is fetched exactly once (non-temporal: no reuse).
 //   * Each int32 word is one lane's B fragment (8 consecutive k of its column): HBM -> VGPR ->
 //     (and_or magic, pk_add/pk_fma, pk_mul) -> MFMA operand.  No LDS, no cross-lane traffic for weights.
-//   * Activations: lane l loads 16 B  x[m = l&15][k0 + 8*(l>>4) .. +7] straight from L2 (x is M*K*2 bytes,
-//     cache resident); natural k order matches the tiled nibble order.
+//   * Activations (x is M*K*2 bytes, L2 resident; natural k order matches the tiled nibble order): for M <= 4
+//     ONE 16-byte load per lane per chunk + ds_bpermute to build the A fragments; otherwise fragment-shaped
+//     loads x[m = l&15][k0 + 8*(l>>4) .. +7].  Both are prefetched in the same register ring as the weights.
 //   * Reduction: the W partial 16xMT*16 accumulators meet in LDS (in-block split-K).  Only when N/16 tiles
 //     cannot fill the 256 CUs does K also split across blocks (grid.y): fp32 slabs published with
 //     write-through (sc1) stores + one relaxed agent-scope ticket, reduced by the last arriver in a fixed
@@ -34,37 +35,112 @@ struct SkinnyParams {
     int chunks;            // ceil(K/128)
     int chunks_per_split;  // chunks handled by one block
     int splits;
+    int cpg_shift;         // log2(chunks per group) when group_size is 128 * 2^n, else -1 (integer division)
 };
 
-template <int BITS, int GPC>
+// AM: how a wave gets its activations.
+//   AM_ROW4  (M <= 4):  ONE 16-byte load per lane per chunk (lane = row*16 + segment: 4 rows x 256 B), prefetched
+//                       with the weights; at compute time the wave parks them in its private 1 KiB LDS slot and
+//                       reads the four MFMA A fragments back with broadcast ds_read_b128 (rows >= M give unused
+//                       output rows, so no masking).
+//   AM_FRAG  (M <= 16*MT): fragment-shaped loads, 4*MT x 16 B per lane per chunk, prefetched with the weights.
+constexpr int AM_ROW4 = 0;
+constexpr int AM_FRAG = 1;
+
+template <int BITS, int GPC, int MT, int AM>
 struct Stage {
     u4_t w[BITS == 4 ? 1 : 2];
     uint32_t meta[GPC];
+    u4_t a[AM == AM_ROW4 ? 1 : 4 * MT];
 };
 
-template <int BITS, int GPC>
-__device__ __forceinline__ void load_stage(Stage<BITS, GPC>& st, const SkinnyParams& p, int tile, int chunk,
-                                           int lane) {
+__device__ __forceinline__ int group_of(const SkinnyParams& p, int k) {  // k is wave-uniform
+    int g;
+    if (p.cpg_shift >= 0) {
+        g = k >> (7 + p.cpg_shift);
+    } else {
+        g = k / p.group_size;
+    }
+    return g < p.G ? g : p.G - 1;  // padded rows beyond K: any finite scale (their activations are 0)
+}
+
+template <int BITS, int GPC, int MT, int AM>
+__device__ __forceinline__ void load_stage(Stage<BITS, GPC, MT, AM>& st, const SkinnyParams& p, const u4_t* wbase,
+                                           const uint32_t* mbase, int chunk, int lane) {
     constexpr int WPC = BITS == 4 ? 1 : 2;
-    const u4_t* src = reinterpret_cast<const u4_t*>(p.qw) + ((size_t)tile * p.chunks + chunk) * WPC * 64 + lane;
+    const u4_t* src = wbase + (size_t)chunk * (WPC * 64);
 #pragma unroll
     for (int h = 0; h < WPC; ++h) st.w[h] = __builtin_nontemporal_load(src + h * 64);
-    const uint32_t* mt = p.meta + (size_t)tile * p.G * 16 + (lane & 15);
 #pragma unroll
-    for (int j = 0; j < GPC; ++j) {
-        int g = (chunk * kChunkK + j * (kChunkK / GPC)) / p.group_size;
-        g = g < p.G ? g : p.G - 1;  // padded rows beyond K: any finite scale (their activations are 0)
-        st.meta[j] = mt[(size_t)g * 16];
+    for (int j = 0; j < GPC; ++j) st.meta[j] = mbase[group_of(p, chunk * kChunkK + j * (kChunkK / GPC)) * 16];
+    // activations: no masking anywhere.  Rows >= M only feed output rows nobody stores (address clamped to row 0);
+    // k >= K happens only in the zero-padded tail chunk of a ragged K, whose weights dequantise to exactly 0
+    // (repack_tiled stores code == zero-point there), so the clamped address may read any finite x.
+    const uint16_t* xs = reinterpret_cast<const uint16_t*>(p.x);
+    if constexpr (AM == AM_ROW4) {
+        int row = lane >> 4;
+        row = row < p.M ? row : 0;
+        int k0 = chunk * kChunkK + 8 * (lane & 15);
+        k0 = k0 < p.K ? k0 : 0;
+        st.a[0] = *reinterpret_cast<const u4_t*>(xs + (size_t)row * p.K + k0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int k0 = chunk * kChunkK + 32 * j + 8 * (lane >> 4);
+            k0 = k0 < p.K ? k0 : 0;
+#pragma unroll
+            for (int mtile = 0; mtile < MT; ++mtile) {
+                int m = mtile * 16 + (lane & 15);
+                m = m < p.M ? m : 0;
+                st.a[j * MT + mtile] = *reinterpret_cast<const u4_t*>(xs + (size_t)m * p.K + k0);
+            }
+        }
     }
 }
 
-template <int BITS, int ACT, int SCL, int MT, int GPC>
+template <int BITS, int ACT, int SCL, int MT, int GPC, int AM>
+__device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st, const SkinnyParams& p, int chunk,
+                                              int lane, u4_t* aslot, const DequantConsts& dk, f4_t (&acc)[2][MT]) {
+    const int c = lane & 15;
+    const int rq = lane >> 4;
+    if constexpr (AM == AM_ROW4) aslot[lane] = st.a[0];
+    const int arow = c < p.M ? c : 0;  // lanes of unused rows re-read row 0: a broadcast, no extra bank traffic
+    ColConst cc = expand_meta<BITS, SCL>(st.meta[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (GPC == 4) {
+            if (j > 0) cc = expand_meta<BITS, SCL>(st.meta[j]);
+        }
+        u4_t b;
+        if constexpr (BITS == 4) {
+            b = dequant_word4<ACT, SCL>(st.w[0][j], cc, dk);
+        } else {
+            b = dequant_word8<ACT, SCL>(st.w[j >> 1][(j & 1) * 2], st.w[j >> 1][(j & 1) * 2 + 1], cc, dk);
+        }
+        if constexpr (AM == AM_ROW4) {
+            // fragment of lane (m = c, rq) = the 16 bytes loaded by lane (c&3)*16 + 4*j + rq (same-wave LDS
+            // accesses execute in order, so the read needs no barrier after the write above)
+            const u4_t av = aslot[(arow << 4) + 4 * j + rq];
+            acc[j & 1][0] = mfma16<ACT>(av, b, acc[j & 1][0]);
+        } else {
+#pragma unroll
+            for (int mtile = 0; mtile < MT; ++mtile) {
+                acc[j & 1][mtile] = mfma16<ACT>(st.a[j * MT + mtile], b, acc[j & 1][mtile]);
+            }
+        }
+    }
+}
+
+template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int D>
 __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
-    __shared__ float red[16][MT * 4][64];
-    __shared__ int s_last;
+    // one LDS array: per-wave activation slots (AM_ROW4, 16 x 1 KiB) during the K loop, then the split-K
+    // reduction buffer red[16][MT*4][64]
+    __shared__ __attribute__((aligned(16))) float lds[16 * MT * 4 * 64 + 4];
+    float(*red)[MT * 4][64] = reinterpret_cast<float(*)[MT * 4][64]>(lds);
+    int* s_last = reinterpret_cast<int*>(lds + 16 * MT * 4 * 64);
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform -> scalar branches
     const int W = blockDim.x >> 6;
     const int c = lane & 15;
     const int rq = lane >> 4;
@@ -80,49 +156,36 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[h][mt] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-    const uint16_t* xs = reinterpret_cast<const uint16_t*>(p.x);
+    const u4_t* wbase = reinterpret_cast<const u4_t*>(p.qw) + (size_t)tile * p.chunks * (BITS == 4 ? 64 : 128) + lane;
+    const uint32_t* mbase = p.meta + (size_t)tile * p.G * 16 + c;
+    u4_t* aslot = reinterpret_cast<u4_t*>(lds) + wave * 64;
+    const DequantConsts dk = make_dequant_consts<BITS>();
 
-    Stage<BITS, GPC> cur, nxt;
-    int chunk = c_begin + wave;
-    if (chunk < c_end) load_stage<BITS, GPC>(cur, p, tile, chunk, lane);
-
-    for (; chunk < c_end; chunk += W) {
-        const bool more = chunk + W < c_end;
-        if (more) load_stage<BITS, GPC>(nxt, p, tile, chunk + W, lane);
-
-        // activations of this chunk (L2 resident): 4 K-steps x MT row tiles
-        u4_t a[4][MT];
+    // D-deep register ring: every load of a chunk (weights, constants, activations) is issued D chunks ahead,
+    // so a wave keeps D KiB of HBM reads in flight and waits only for the oldest stage.
+    Stage<BITS, GPC, MT, AM> st[D];
+    {
+        int nxt = c_begin + wave;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k0 = chunk * kChunkK + 32 * j + 8 * rq;
+        for (int d = 0; d < D; ++d) {
+            if (nxt < c_end) load_stage<BITS, GPC, MT, AM>(st[d], p, wbase, mbase, nxt, lane);
+            nxt += W;
+        }
+    }
+    for (int cur = c_begin + wave; cur < c_end;) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int m = mt * 16 + c;
-                u4_t v = u4_t{0, 0, 0, 0};
-                if (m < p.M && k0 < p.K) v = *reinterpret_cast<const u4_t*>(xs + (size_t)m * p.K + k0);
-                a[j][mt] = v;
+        for (int d = 0; d < D; ++d) {
+            if (cur < c_end) {
+                compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc);
+                const int nxt = cur + D * W;
+                if (nxt < c_end) load_stage<BITS, GPC, MT, AM>(st[d], p, wbase, mbase, nxt, lane);
+                cur += W;
             }
         }
-
-        ColConst cc = expand_meta<BITS, SCL>(cur.meta[0]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if constexpr (GPC == 4) {
-                if (j > 0) cc = expand_meta<BITS, SCL>(cur.meta[j]);
-            }
-            u4_t b;
-            if constexpr (BITS == 4) {
-                b = dequant_word4<ACT, SCL>(cur.w[0][j], cc);
-            } else {
-                b = dequant_word8<ACT, SCL>(cur.w[j >> 1][(j & 1) * 2], cur.w[j >> 1][(j & 1) * 2 + 1], cc);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[j & 1][mt] = mfma16<ACT>(a[j][mt], b, acc[j & 1][mt]);
-        }
-        if (more) cur = nxt;
     }
 
     // ---- in-block split-K reduction through LDS -------------------------------------------------
+    if constexpr (AM == AM_ROW4) __syncthreads();  // activation slots alias the reduction buffer
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const f4_t s = acc[0][mt] + acc[1][mt];
@@ -151,10 +214,10 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
         __syncthreads();
         if (threadIdx.x == 0) {
             const int old = __hip_atomic_fetch_add(p.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = (old == p.splits - 1);
+            *s_last = (old == p.splits - 1);
         }
         __syncthreads();
-        if (!s_last) return;
+        if (!*s_last) return;
         // last arriver: deterministic reduction over the splits; slabs read with sc1 (L1-bypassing) loads
         if (live) {
             float s = 0.f;
@@ -178,23 +241,24 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int BITS, int ACT, int SCL, int MT>
+template <int BITS, int ACT, int SCL, int MT, int AM, int D>
 static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
     const dim3 grid(ceil_div(p.N, kTileN), p.splits);
     const dim3 block(64 * pl.waves);
     if (pl.gpc == 1) {
-        hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D>), grid, block, 0, stream, p);
     } else {
-        hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 4>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 4, AM, D>), grid, block, 0, stream, p);
     }
     return check_hip(hipGetLastError(), "skinny_kernel launch");
 }
 
 template <int BITS, int ACT, int SCL>
 static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
-    if (pl.mt == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1>(p, pl, stream);
-    if (pl.mt == 2) return launch_skinny_gpc<BITS, ACT, SCL, 2>(p, pl, stream);
-    return launch_skinny_gpc<BITS, ACT, SCL, 4>(p, pl, stream);
+    if (pl.mt == 1 && p.M <= 4) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW4, 4>(p, pl, stream);
+    if (pl.mt == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_FRAG, 2>(p, pl, stream);
+    if (pl.mt == 2) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_FRAG, 2>(p, pl, stream);
+    return launch_skinny_gpc<BITS, ACT, SCL, 4, AM_FRAG, 1>(p, pl, stream);
 }
 
 SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves) {
@@ -204,15 +268,18 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     pl.gpc = (group_size % kChunkK == 0) ? 1 : 4;
     pl.chunks = ceil_div(K, kChunkK);
     const int tiles = ceil_div(N, kTileN);
-    // waves per block: enough to cover the LDS reduce mapping (4*MT), more when the tile's K range is long
-    int waves = pl.chunks >= 16 ? 16 : (pl.chunks >= 8 ? 8 : 4);
+    // waves per block: ~4 chunks per wave (= ring depth, all of a wave's loads in flight at once), at least
+    // the 4*MT waves the LDS reduce mapping needs
+    int waves = pl.chunks >= 64 ? 16 : (pl.chunks >= 32 ? 8 : 4);
+    if (tiles <= 256 && pl.chunks >= 16) waves = 16;  // few tiles: one block per CU, go wide on K
     if (waves < 4 * pl.mt) waves = 4 * pl.mt;
     if (force_waves > 0) waves = force_waves < 4 * pl.mt ? 4 * pl.mt : force_waves;
     pl.waves = waves;
-    // cross-block split-K only when the tiles alone cannot occupy the chip (~2 blocks per CU)
-    const int target_blocks = 512;
+    // cross-block split-K costs a publish + ticket + re-read round trip (~1.5-2 us measured): only worth it
+    // when the tiles alone leave most of the chip idle AND there is a long K range to share
+    const int target_blocks = 128;
     int s = 1;
-    if (tiles < target_blocks) s = ceil_div(target_blocks, tiles);
+    if (tiles < target_blocks && pl.chunks >= 4 * waves) s = ceil_div(target_blocks, tiles);
     int max_s = pl.chunks / waves;  // keep >= 1 chunk per wave
     if (max_s < 1) max_s = 1;
     if (s > max_s) s = max_s;
@@ -240,6 +307,15 @@ int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* co
     p.chunks = pl.chunks;
     p.chunks_per_split = pl.chunks_per_split;
     p.splits = pl.splits;
+    p.cpg_shift = -1;
+    if (a.group_size % kChunkK == 0) {
+        const int cpg = a.group_size / kChunkK;
+        if ((cpg & (cpg - 1)) == 0) {
+            int sh = 0;
+            while ((1 << sh) < cpg) ++sh;
+            p.cpg_shift = sh;
+        }
+    }
 #define GPTQHIP_DISPATCH(B, A_, S_) return launch_skinny_mt<B, A_, S_>(p, pl, stream)
     if (a.bits == 4) {
         if (a.act_dtype == kFP16 && a.scale_dtype == kFP16) GPTQHIP_DISPATCH(4, kFP16, kFP16);
