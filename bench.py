@@ -42,6 +42,15 @@ def layer_shapes(cfg):
             ("gate_proj", h, i), ("up_proj", h, i), ("down_proj", i, h)]
 
 
+def launch_shapes(cfg, fuse):
+    """Kernel launches per decoder layer.  With sibling fusion (gptqmodel_amd.utils.model.
+    fuse_siblings) q/k/v and gate/up -- which read the same x -- are concatenated along N: 7 linears, 4 launches."""
+    if not fuse:
+        return [(k, n, 1) for _, k, n in layer_shapes(cfg)]
+    h, i = cfg["hidden"], cfg["inter"]
+    return [(h, cfg["q"] + 2 * cfg["kv"], 3), (cfg["q"], h, 1), (h, 2 * i, 2), (i, h, 1)]
+
+
 def algorithmic_bytes(m, k, n, gs=128):
     g = k // gs
     return k * n // 2 + g * n * 2 + g * n // 2 + m * (k + n) * 2
@@ -104,6 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per token")
+    ap.add_argument("--no-fuse", action="store_true", help="7 launches per layer instead of fused qkv / gate_up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     args = ap.parse_args()
@@ -127,11 +137,14 @@ def main():
     gs = 128
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
+    fuse = not args.no_fuse
+    lshapes = launch_shapes(cfg, fuse)
     layers = []
     for _ in range(cfg["layers"]):
-        layers.append([make_linear(k, n, gs, dev, gen, dtype) for _, k, n in layer_shapes(cfg)])
+        layers.append([make_linear(k, n, gs, dev, gen, dtype) for k, n, _ in lshapes])
     xs = {k: (torch.randn((1, k), device=dev, generator=gen) * 0.5).to(dtype) for k in (cfg["hidden"], cfg["inter"])}
-    n_launch = cfg["layers"] * len(layer_shapes(cfg))
+    n_launch = cfg["layers"] * len(lshapes)
+    n_linear = cfg["layers"] * sum(c for _, _, c in lshapes)
     step_bytes = cfg["layers"] * sum(algorithmic_bytes(1, k, n, gs) for _, k, n in layer_shapes(cfg))
     step_flops = cfg["layers"] * sum(2 * k * n for _, k, n in layer_shapes(cfg))
 
@@ -195,11 +208,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": "Llama-3-8B GPTQ int4 g128 desc_act=False batch=1 decode: 224 quantised linears per token "
                                    "(q,k,v,o,gate,up,down x 32), M=1, random packed weights",
-                       "launches_per_step": n_launch, "graph": graph is not None, "replicas": world,
+                       "linears_per_step": n_linear, "launches_per_step": n_launch, "fused_siblings": fuse,
+                       "graph": graph is not None, "replicas": world,
                        "weight_bytes_per_token": step_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "gptqhip::skinny_kernel<4,fp16,fp16,MT=1,SPG=4>",
+                         "kernel": "gptqhip::skinny_kernel<BITS=4,ACT=f16,SCL=f16,MT=1,GPC=1,AM_ROW4,D=4>",
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_us,
                          "note": "event-timed average over the timed region incl. inter-kernel gaps of the graph"},
             "gemm_tflops_equiv": step_flops * value / world / 1e12,

@@ -91,3 +91,90 @@ def gptqmodel_post_init(model: nn.Module, use_act_order: bool = False, **_kw) ->
         if isinstance(m, BaseQuantLinear):
             m.post_init()
     return model
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Fused sibling projections: q/k/v and gate/up read the same x, so their checkpoint tensors are
+# concatenated along N BEFORE post_init and run as ONE kernel launch (7 -> 4 launches per decoder layer, x read
+# once).  HF decoder layers keep calling q_proj(x), k_proj(x), v_proj(x): each name is replaced by a view module
+# that returns its column slice of the fused result computed once per distinct input tensor.
+# ---------------------------------------------------------------------------------------------------------
+class _FusedGroup(nn.Module):
+    def __init__(self, fused: BaseQuantLinear, sizes: List[int]):
+        super().__init__()
+        self.fused = fused
+        self.sizes = list(sizes)
+        self.offsets = [sum(sizes[:i]) for i in range(len(sizes))]
+        self._key = None
+        self._out = None
+
+    def slice_for(self, x: torch.Tensor, index: int) -> torch.Tensor:
+        key = (id(x), x.data_ptr(), x._version, tuple(x.shape))
+        if key != self._key or self._out is None:
+            self._out = self.fused(x)
+            self._key = key
+        o = self.offsets[index]
+        return self._out[..., o:o + self.sizes[index]]
+
+
+class FusedSiblingView(nn.Module):
+    """Stands in for one sibling projection (e.g. `k_proj`) after fusion."""
+
+    def __init__(self, group: _FusedGroup, index: int, in_features: int, out_features: int):
+        super().__init__()
+        self._group = [group]  # list: do not register the shared group as a child of every view
+        self.index = index
+        self.in_features = in_features
+        self.out_features = out_features
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._group[0].slice_for(x, self.index)
+
+
+def fuse_quant_linears(mods: List[BaseQuantLinear]) -> BaseQuantLinear:
+    """Concatenate checkpoint-layout GPTQ/AWQ modules along N into one module of the same class.  Must run BEFORE
+    post_init().  Raises NotImplementedError when the siblings cannot share one kernel launch (different
+    quantisation parameters, or act-order with different permutations)."""
+    m0 = mods[0]
+    for m in mods[1:]:
+        same = (type(m) is type(m0) and m.bits == m0.bits and m.group_size == m0.group_size
+                and m.in_features == m0.in_features and m.sym == m0.sym and m.desc_act == m0.desc_act
+                and m.scales.dtype == m0.scales.dtype and (m.bias is None) == (m0.bias is None))
+        if not same:
+            raise NotImplementedError("siblings differ in quantisation parameters; not fusing")
+        g0, g1 = getattr(m0, "g_idx", None), getattr(m, "g_idx", None)
+        if (g0 is None) != (g1 is None) or (g0 is not None and not torch.equal(g0, g1)):
+            raise NotImplementedError("siblings have different g_idx (act-order); not fusing")
+    if getattr(m0, "_ready", False):
+        raise RuntimeError("fuse_quant_linears must be called before post_init()")
+    n_total = sum(m.out_features for m in mods)
+    fused = type(m0)(bits=m0.bits, group_size=m0.requested_group_size, sym=m0.sym, desc_act=m0.desc_act,
+                     in_features=m0.in_features, out_features=n_total, bias=m0.bias is not None,
+                     register_buffers=False, name="+".join(m.name for m in mods), adapter=None)
+    fused.qweight = torch.cat([m.qweight for m in mods], dim=1).contiguous()
+    fused.qzeros = torch.cat([m.qzeros for m in mods], dim=1).contiguous()
+    fused.scales = torch.cat([m.scales for m in mods], dim=1).contiguous()
+    if hasattr(m0, "g_idx"):
+        fused.g_idx = m0.g_idx
+    fused.bias = torch.cat([m.bias for m in mods]).contiguous() if m0.bias is not None else None
+    if hasattr(m0, "qzero_format"):
+        fused.qzero_format(format=m0.qzero_format())
+    fused.train(m0.training)
+    return fused
+
+
+def fuse_siblings(parent: nn.Module, names: List[str]) -> Optional[_FusedGroup]:
+    """Fuse parent.<names> (quant modules sharing their input) and replace them by views.  Returns the group, or None
+    when fusion is not possible (the original modules are left untouched)."""
+    mods = [getattr(parent, n) for n in names]
+    if not all(isinstance(m, BaseQuantLinear) for m in mods) or any(m.adapter is not None for m in mods):
+        return None
+    try:
+        fused = fuse_quant_linears(mods)
+    except NotImplementedError:
+        return None
+    group = _FusedGroup(fused, [m.out_features for m in mods])
+    setattr(parent, "fused_" + "_".join(names), group)  # registered once: post_init / .to() reach the fused module
+    for i, (n, m) in enumerate(zip(names, mods)):
+        setattr(parent, n, FusedSiblingView(group, i, m.in_features, m.out_features))
+    return group

@@ -49,3 +49,46 @@ def synth_gptq(seed, bits, k, n, gs, desc_act=False, sym=False, scale_dtype="fp1
 
 def f32_to_torch(a: np.ndarray, dtype: str, device="cpu") -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(TDT[dtype]).to(device)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# numpy model of the MFMA-tile-major kernel layout (gptqmodel_amd/csrc/gptqhip_device.h) -- the checker for the
+# device repack kernel (integer work: compared bit-exactly)
+# ----------------------------------------------------------------------------------------------------------
+def np_repack_tiled(qweight, qzeros, scales_bits, perm, group_size, bits):
+    pf = 32 // bits
+    codes = O.unpack_rows(qweight, bits).astype(np.uint32)          # [K, N]
+    zeros = O.unpack_cols(qzeros, bits).astype(np.uint32)           # [G, N]
+    K, N = codes.shape
+    G = K // group_size
+    if perm is not None:
+        codes = codes[np.asarray(perm).astype(np.int64)]
+    chunks, tiles = -(-K // 128), -(-N // 16)
+    Kp, Np = chunks * 128, tiles * 16
+    full = np.zeros((Kp, Np), dtype=np.uint32)
+    full[:K, :N] = codes
+    if Kp > K:
+        full[K:, :N] = zeros[G - 1][None, :]                          # padded rows dequantise to exactly 0
+    steps = 4
+    if bits == 4:
+        # word[tile, chunk, lane=(rq,c), j]: rows 128*chunk + 32*j + 8*rq + e, e at bit 4*(e>>1) + 16*(e&1)
+        v = full.reshape(chunks, steps, 4, 8, tiles, 16)              # [chunk, j, rq, e, tile, c]
+        sh = np.array([4 * (e >> 1) + 16 * (e & 1) for e in range(8)], dtype=np.uint32)
+        words = np.bitwise_or.reduce(v << sh[None, None, None, :, None, None], axis=3)   # [chunk, j, rq, tile, c]
+        words = words.transpose(3, 0, 2, 4, 1)                         # [tile, chunk, rq, c, j]
+        qw_t = np.ascontiguousarray(words).reshape(-1)
+    else:
+        # word[tile, chunk, h, lane, jj]: j = 2h + (jj>>1), half = jj&1, rows ... + 4*half + e, e at 8*(e>>1)+16*(e&1)
+        v = full.reshape(chunks, 2, 2, 4, 2, 4, tiles, 16)            # [chunk, h, jlo, rq, half, e, tile, c]
+        sh = np.array([8 * (e >> 1) + 16 * (e & 1) for e in range(4)], dtype=np.uint32)
+        words = np.bitwise_or.reduce(v << sh[None, None, None, None, None, :, None, None], axis=5)
+        words = words.transpose(5, 0, 1, 3, 6, 2, 4)                   # [tile, chunk, h, rq, c, jlo, half]
+        qw_t = np.ascontiguousarray(words).reshape(-1)
+    meta = np.zeros((tiles, G, 16), dtype=np.uint32)
+    sb = np.zeros((G, Np), dtype=np.uint32)
+    sb[:, :N] = scales_bits.astype(np.uint32)
+    zz = np.zeros((G, Np), dtype=np.uint32)
+    zz[:, :N] = zeros
+    m = sb | ((np.uint32(0xE400) | zz) << np.uint32(16))
+    meta = m.reshape(G, tiles, 16).transpose(1, 0, 2)
+    return qw_t.view(np.int32), np.ascontiguousarray(meta).reshape(-1).view(np.int32)

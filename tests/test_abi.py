@@ -1,0 +1,95 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/gptqhip.h declares; argument
+validation returns error codes + messages without touching a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gptqmodel_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gptqhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gptqhip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    syms = declared_symbols()
+    for must in ("gptqhip_gemm", "gptqhip_repack_tiled", "gptqhip_repack_awq", "gptqhip_dequant",
+                 "gptqhip_dequant_tiled", "gptqhip_workspace_bytes", "gptqhip_last_error", "gptqhip_device_info"):
+        assert must in syms
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from gptqmodel_amd import _lib
+    syms = declared_symbols()
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes binding table must mirror include/gptqhip.h exactly"
+    for s in syms:
+        assert hasattr(lib, s), f"libgptqhip.so does not export {s}"
+    assert lib.gptqhip_abi_version() == _lib.ABI_VERSION
+
+
+def test_no_torch_types_in_the_abi():
+    text = open(os.path.join(ROOT, "include", "gptqhip.h")).read()
+    assert "torch" not in re.sub(r"/\*.*?\*/", "", text, flags=re.S).lower()
+    assert "at::Tensor" not in text and "#include <hip" not in text  # callers need no HIP/torch headers
+
+
+def test_size_helpers(lib):
+    # 4-bit: one 1 KiB block (256 words) per (16-column tile, 128-row chunk); ragged shapes round up
+    assert lib.gptqhip_tiled_words(4096, 4096, 4) == 4096 * 4096 // 8
+    assert lib.gptqhip_tiled_words(4096, 4096, 8) == 4096 * 4096 // 4
+    assert lib.gptqhip_tiled_words(96, 8, 4) == 256
+    assert lib.gptqhip_meta_words(4096, 4096, 128) == 32 * 4096
+    assert lib.gptqhip_meta_words(4096, 4096, 96) == 0  # K % group_size != 0
+    assert lib.gptqhip_tiled_words(4096, 4096, 3) == 0
+    assert lib.gptqhip_workspace_bytes(1, 4096, 4096, 0) >= 64 * 1024
+    assert lib.gptqhip_workspace_bytes(8, 4096, 4096, 1) >= lib.gptqhip_workspace_bytes(8, 4096, 4096, 0) + 8 * 4096 * 2
+    assert lib.gptqhip_workspace_bytes(0, 4096, 4096, 0) == 0
+
+
+def test_argument_validation_reports_errors_without_a_gpu(lib):
+    EINVAL = -22
+    one = ctypes.c_void_p(16)  # non-null dummy; validation fails before any dereference
+    rc = lib.gptqhip_gemm(None, one, one, None, None, one, one, 1 << 20, 1, 4096, 4096, 128, 4, 0, 0, None)
+    assert rc == EINVAL and b"null" in lib.gptqhip_last_error()
+    rc = lib.gptqhip_gemm(one, one, one, None, None, one, one, 1 << 20, 1, 4096, 4096, 100, 4, 0, 0, None)
+    assert rc == EINVAL and b"group_size" in lib.gptqhip_last_error()
+    rc = lib.gptqhip_gemm(one, one, one, None, None, one, one, 1 << 20, 1, 4096, 4096, 128, 3, 0, 0, None)
+    assert rc == EINVAL and b"bits" in lib.gptqhip_last_error()
+    rc = lib.gptqhip_gemm(one, one, one, None, None, one, one, 1 << 20, 1, 4100, 4096, 128, 4, 0, 0, None)
+    assert rc == EINVAL
+    rc = lib.gptqhip_gemm(one, one, one, None, None, one, one, 16, 1, 4096, 4096, 128, 4, 0, 0, None)
+    assert rc == -12 and b"workspace" in lib.gptqhip_last_error()  # ENOMEM
+    # empty batch is a no-op success (the reference returns an empty tensor)
+    assert lib.gptqhip_gemm(None, None, None, None, None, None, None, 0, 0, 4096, 4096, 128, 4, 0, 0, None) == 0
+    rc = lib.gptqhip_repack_tiled(one, one, one, None, None, one, 4096, 4096, 128, 4, None)
+    assert rc == EINVAL  # qweight without qweight_t
+    assert lib.gptqhip_device_info(0, None, None, None, 0) in (0, -19)  # ENODEV on a CPU-only box
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from gptqmodel_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgptqhip.so")
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        _lib.load()
+
+
+def test_ops_refuse_cpu_tensors(lib):
+    import torch
+    from gptqmodel_amd import ops
+    x = torch.zeros((1, 128), dtype=torch.float16)
+    w = torch.zeros(256, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm(x, w, w, None, None, 16, 128, 4, torch.float16)

@@ -113,3 +113,40 @@ def test_graph_capture_replay_matches_eager():
             graph.replay()
         s.synchronize()
     assert torch.equal(out, eager)
+
+
+def test_fused_siblings_match_separate_projections():
+    """q/k/v fused along N (utils.model.fuse_siblings) must reproduce the three separate kernels' outputs."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    from gptqmodel_amd.utils.model import FusedSiblingView, fuse_siblings, gptqmodel_post_init
+
+    K, gs = 1024, 128
+    sizes = {"q_proj": 512, "k_proj": 128, "v_proj": 128}
+
+    def build():
+        blk = nn.Module()
+        for i, (name, n) in enumerate(sizes.items()):
+            qweight, qzeros, scales, g_idx = synth_gptq(100 + i, 4, K, n, gs)
+            lin = HipGptqLinear(bits=4, group_size=gs, sym=False, desc_act=False, in_features=K, out_features=n,
+                                bias=True, name=name)
+            lin.qweight = torch.from_numpy(qweight)
+            lin.qzeros = torch.from_numpy(qzeros)
+            lin.scales = f32_to_torch(scales, "fp16")
+            lin.g_idx = torch.from_numpy(g_idx)
+            lin.bias = f32_to_torch(np.random.RandomState(i).randn(n).astype(np.float32) * 0.1, "fp16")
+            lin.qzero_format(format=2)
+            setattr(blk, name, lin)
+        return blk.to(DEV).eval()
+
+    ref_blk, fused_blk = build(), build()
+    gptqmodel_post_init(ref_blk)
+    group = fuse_siblings(fused_blk, list(sizes))
+    assert group is not None and isinstance(fused_blk.k_proj, FusedSiblingView)
+    gptqmodel_post_init(fused_blk)
+    x = torch.randn(2, 3, K, device=DEV, dtype=torch.float16) * 0.5
+    for name, n in sizes.items():
+        a, b = getattr(ref_blk, name)(x), getattr(fused_blk, name)(x)
+        assert b.shape == (2, 3, n)
+        assert rel_err(torch_to_f32(b), torch_to_f32(a)) <= 1e-3
+    # one fused launch serves all three views of the same input tensor
+    assert group._out is not None and group._out.shape[-1] == sum(sizes.values())

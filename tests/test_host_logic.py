@@ -1,0 +1,220 @@
+"""CPU tests of the host-side mirror of the reference plugin interface: BACKEND/DEVICE normalisation, kernel
+discovery + selection, the validate() contract and its error conventions, act-order permutation, v1->v2 qzeros,
+sibling fusion.  Modelled on the reference's tests/kernels/test_selection.py, test_qlinear_hierarchy.py,
+test_backend_naming.py, test_qzero_offsets.py, test_triton_g_idx_bounds.py (which monkeypatch device probes the
+same way)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import load_golden
+from gptqmodel_amd.nn_modules.qlinear import AWQuantLinear, BaseQuantLinear, GPTQQuantLinear
+from gptqmodel_amd.nn_modules.qlinear.hip_awq import HipAwqLinear
+from gptqmodel_amd.nn_modules.qlinear.hip_common import act_order_permutation, check_g_idx
+from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+from gptqmodel_amd.utils import importer
+from gptqmodel_amd.utils.adapter import Lora
+from gptqmodel_amd.utils.backend import BACKEND, normalize_backend
+from gptqmodel_amd.utils.const import DEVICE, FORMAT, METHOD, normalize_device
+from gptqmodel_amd.utils.model import (convert_gptq_v1_to_v2_format_module, fuse_quant_linears, fuse_siblings,
+                                       make_quant)
+from helpers import synth_gptq
+from oracle import gptq_oracle as O
+
+
+@pytest.fixture
+def kernels_available(monkeypatch):
+    """Pretend the native library + a gfx950 device are usable (host-logic tests never launch a kernel)."""
+    for cls in (HipGptqLinear, HipAwqLinear):
+        monkeypatch.setattr(cls, "validate_once", classmethod(lambda c: (True, None)))
+        cls.cached_validate_once.cache_clear()
+    yield
+    for cls in (HipGptqLinear, HipAwqLinear):
+        cls.cached_validate_once.cache_clear()
+
+
+def test_backend_normalisation():
+    assert normalize_backend("gptq_hip") is BACKEND.GPTQ_HIP
+    assert normalize_backend("GPTQ_HIP") is BACKEND.GPTQ_HIP
+    assert normalize_backend("hip", quant_method=METHOD.GPTQ) is BACKEND.GPTQ_HIP
+    assert normalize_backend(BACKEND.HIP, quant_method="awq") is BACKEND.AWQ_HIP
+    assert normalize_backend(None) is None and normalize_backend("  ") is None
+    with pytest.raises(ValueError):
+        normalize_backend("no_such_backend")
+    with pytest.raises(TypeError):
+        normalize_backend(3)
+
+
+def test_device_normalisation_maps_cuda_to_rocm_on_a_rocm_build():
+    assert normalize_device("cuda:0") is DEVICE.ROCM  # torch here is a ROCm build (torch.version.hip set)
+    assert normalize_device(torch.device("cuda", 1)) is DEVICE.ROCM
+    assert normalize_device(0) is DEVICE.ROCM
+    assert normalize_device("cpu") is DEVICE.CPU
+    assert DEVICE.ROCM.type == "cuda"
+
+
+def test_class_contract_is_complete():
+    for cls in (HipGptqLinear, HipAwqLinear):
+        cls.verify_supports_params()  # every SUPPORTS_* overridden and non-None (qlinear/__init__.py:300-332)
+        assert cls.SUPPORTS_DEVICES == [DEVICE.ROCM]
+        assert torch.int32 in cls.SUPPORTS_PACK_DTYPES and Lora in cls.SUPPORTS_ADAPTERS
+    assert HipGptqLinear.REQUIRES_FORMAT_V2 is True and HipAwqLinear.REQUIRES_FORMAT_V2 is False
+    assert issubclass(HipGptqLinear, GPTQQuantLinear) and issubclass(HipAwqLinear, AWQuantLinear)
+
+    class Broken(BaseQuantLinear):
+        SUPPORTS_FORMATS = {}
+        SUPPORTS_BACKEND_SELECTION = False
+    with pytest.raises(ValueError):
+        Broken.verify_supports_params()
+
+
+def test_discovery_and_priority_maps():
+    kernels = importer.iter_quant_linear_kernels()
+    assert HipGptqLinear in kernels and HipAwqLinear in kernels
+    auto = importer.AUTO_BACKEND_KERNEL_MAPPING
+    assert auto[METHOD.GPTQ][FORMAT.GPTQ][BACKEND.GPTQ_HIP] is HipGptqLinear
+    assert auto[METHOD.GPTQ][FORMAT.GPTQ_V2][BACKEND.GPTQ_HIP] is HipGptqLinear
+    assert auto[METHOD.AWQ][FORMAT.GEMM][BACKEND.AWQ_HIP] is HipAwqLinear
+    assert importer.get_kernel_for_backend(BACKEND.HIP, METHOD.AWQ, FORMAT.GEMM) is HipAwqLinear
+    with pytest.raises(ValueError, match="Unsupported backend"):
+        importer.get_kernel_for_backend(BACKEND.TORCH, METHOD.GPTQ, FORMAT.GPTQ)
+
+
+def test_selection_soft_fails_without_a_gpu():
+    """validate_once() returns (False, ImportError) on a box without a usable device, so AUTO raises it
+    (upstream: falls through to the next candidate, importer.py:594-598)."""
+    for cls in (HipGptqLinear, HipAwqLinear):
+        cls.cached_validate_once.cache_clear()
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ImportError):
+        importer.select_quant_linear(4, 128, False, True, device="cuda", backend=BACKEND.AUTO)
+    with pytest.raises(ValueError):
+        importer.select_quant_linear(4, 128, False, True, device="cuda", backend=BACKEND.GPTQ_HIP)
+
+
+def test_selection_with_kernels_available(kernels_available):
+    sel = importer.select_quant_linear
+    assert sel(4, 128, True, False, device="cuda:0") is HipGptqLinear
+    assert sel(8, 32, False, True, device=DEVICE.ROCM, backend="hip", format="gptq_v2") is HipGptqLinear
+    assert sel(4, 128, False, False, device=DEVICE.ROCM, format=FORMAT.GEMM, quant_method=METHOD.AWQ) is HipAwqLinear
+    assert sel(4, 128, False, True, device=DEVICE.ROCM, multi_select=True) == [HipGptqLinear]
+    assert importer.hf_select_quant_linear(4, 128, False, True, "gptq", device_map={"": "cuda:0"}) is HipGptqLinear
+    with pytest.raises(NotImplementedError):      # unsupported contract under AUTO re-raises the last kernel error
+        sel(3, 128, False, True, device=DEVICE.ROCM)
+    with pytest.raises(ValueError):               # explicit backend: hard error
+        sel(3, 128, False, True, device=DEVICE.ROCM, backend=BACKEND.GPTQ_HIP)
+    with pytest.raises((ValueError, NotImplementedError)):   # CPU device is filtered out (SUPPORTS_DEVICES=[ROCM])
+        sel(4, 128, False, True, device="cpu")
+    with pytest.raises(ValueError, match="Unsupported format"):
+        sel(4, 128, False, True, device=DEVICE.ROCM, format=FORMAT.GEMM)  # AWQ layout under METHOD.GPTQ
+    with pytest.raises(ValueError):
+        sel(4, 128, False, True, device=DEVICE.ROCM, pack=True)
+
+
+@pytest.mark.parametrize("kw,ok", [
+    (dict(bits=4, group_size=128, in_features=4096, out_features=4096), True),
+    (dict(bits=8, group_size=-1, in_features=256, out_features=64), True),
+    (dict(bits=4, group_size=128, in_features=4096, out_features=4100), False),   # N % 8
+    (dict(bits=4, group_size=128, in_features=4100, out_features=4096), False),   # K % 32
+    (dict(bits=4, group_size=48, in_features=96, out_features=64), False),        # group size not listed
+    (dict(bits=2, group_size=128, in_features=4096, out_features=4096), False),
+    (dict(bits=4, group_size=128, in_features=4096, out_features=4096, dtype=torch.float32), False),
+    (dict(bits=4, group_size=128, in_features=4096, out_features=4096, pack_dtype=torch.int16), False),
+    (dict(bits=4, group_size=128, in_features=4096, out_features=4096, trainable=True), False),
+    (dict(bits=4, group_size=128, in_features=4096, out_features=4096, device=DEVICE.CPU), False),
+    (dict(bits=4, group_size=128, in_features=4096, out_features=4096, dynamic={"x": {"bits": 3}}), False),
+])
+def test_validate_contract(kernels_available, kw, ok):
+    kw.setdefault("pack_dtype", torch.int32)
+    got, err = HipGptqLinear.validate(desc_act=False, sym=True, **kw)
+    assert got is ok
+    assert (err is None) if ok else isinstance(err, NotImplementedError)
+
+
+def test_constructor_registers_checkpoint_buffers(kernels_available):
+    lin = HipGptqLinear(bits=4, group_size=128, sym=True, desc_act=False, in_features=512, out_features=256, bias=True)
+    sd = lin.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {
+        "qweight": (64, 256), "qzeros": (4, 32), "scales": (4, 256), "g_idx": (512,), "bias": (256,)}
+    assert sd["qweight"].dtype == torch.int32 and sd["scales"].dtype == torch.float16
+    awq = HipAwqLinear(bits=4, group_size=128, sym=False, desc_act=False, in_features=512, out_features=256)
+    assert {k: tuple(v.shape) for k, v in awq.state_dict().items()} == {
+        "qweight": (512, 32), "qzeros": (4, 32), "scales": (4, 256)}
+    with pytest.raises(NotImplementedError):
+        HipGptqLinear(bits=3, group_size=128, sym=True, desc_act=False, in_features=512, out_features=256)
+    with pytest.raises(RuntimeError):
+        lin(torch.zeros(1, 512, dtype=torch.float16))  # forward before post_init
+    with pytest.raises(RuntimeError):
+        lin.post_init()  # CPU buffers: loud, no fallback
+
+
+def test_make_quant_swaps_linears(kernels_available):
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj = nn.Linear(256, 128, bias=False)
+            self.keep = nn.Linear(256, 8)
+            self.norm = nn.LayerNorm(256)
+    m = nn.ModuleDict({"layer": Block()})
+    picked = make_quant(m, ["layer.q_proj"], bits=4, group_size=64, desc_act=False, sym=True)
+    assert picked == [HipGptqLinear]
+    assert isinstance(m["layer"].q_proj, HipGptqLinear) and isinstance(m["layer"].keep, nn.Linear)
+    assert m["layer"].q_proj.name == "layer.q_proj"
+    with pytest.raises(ValueError):
+        make_quant(m, ["layer.norm"], bits=4, group_size=64, desc_act=False, sym=True)
+
+
+def test_act_order_permutation_and_bounds():
+    gs, k = 4, 16
+    seq = torch.arange(k, dtype=torch.int32) // gs
+    assert act_order_permutation(seq, gs, 4) is None
+    perm0 = torch.randperm(k, generator=torch.Generator().manual_seed(0))
+    g_idx = (perm0 // gs).to(torch.int32)
+    perm = act_order_permutation(g_idx, gs, 4)
+    assert perm.dtype == torch.int32
+    assert torch.equal(g_idx[perm.long()].long(), torch.arange(k) // gs)
+    assert np.array_equal(perm.numpy(), O.act_order_perm(g_idx.numpy()))  # same stable order as the oracle
+    # negative indices wrap like torch indexing; out-of-range is rejected before any kernel trusts it
+    assert torch.equal(check_g_idx(torch.tensor([-1, 0, -4, 3]), 4), torch.tensor([3, 0, 0, 3]))
+    with pytest.raises(ValueError):
+        check_g_idx(torch.tensor([0, 4]), 4)
+    with pytest.raises(ValueError):
+        check_g_idx(torch.tensor([-5, 0]), 4)
+    with pytest.raises(NotImplementedError):  # unbalanced groups cannot be row-sorted into fixed-size groups
+        act_order_permutation(torch.tensor([0, 0, 0, 0, 0, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3], dtype=torch.int32), gs, 4)
+
+
+def test_v1_to_v2_qzeros(kernels_available):
+    g = load_golden("ref_v1v2.npz")
+    for bits in (4, 8):
+        lin = HipGptqLinear(bits=bits, group_size=32, sym=False, desc_act=False, in_features=64, out_features=64)
+        lin.qzeros = torch.from_numpy(g[f"v1_{bits}"].copy())
+        assert lin.qzero_format() == 1
+        convert_gptq_v1_to_v2_format_module(lin, bits=bits)
+        assert lin.qzero_format() == 2
+        assert np.array_equal(lin.qzeros.numpy(), g[f"v2_{bits}"])
+
+
+def test_fuse_quant_linears_concatenates_along_n(kernels_available):
+    K, gs = 256, 64
+    mods, parts = [], []
+    for i, n in enumerate((64, 32, 32)):
+        qweight, qzeros, scales, g_idx = synth_gptq(50 + i, 4, K, n, gs)
+        lin = HipGptqLinear(bits=4, group_size=gs, sym=False, desc_act=False, in_features=K, out_features=n, name=f"p{i}")
+        lin.qweight, lin.qzeros = torch.from_numpy(qweight), torch.from_numpy(qzeros)
+        lin.scales, lin.g_idx = torch.from_numpy(scales).half(), torch.from_numpy(g_idx)
+        mods.append(lin)
+        parts.append(O.dequant_gptq(qweight, qzeros, scales, g_idx, 4))
+    fused = fuse_quant_linears(mods)
+    assert fused.out_features == 128 and fused.qweight.shape == (K // 8, 128) and fused.qzeros.shape == (K // gs, 16)
+    w = O.dequant_gptq(fused.qweight.numpy(), fused.qzeros.numpy(), fused.scales.float().numpy(), fused.g_idx.numpy(), 4)
+    assert np.array_equal(w, np.concatenate(parts, axis=1))
+    # act-order siblings with different permutations are left alone
+    mods[1].g_idx = torch.from_numpy((np.random.RandomState(0).permutation(K) // gs).astype(np.int32))
+    with pytest.raises(NotImplementedError):
+        fuse_quant_linears(mods)
+    blk = nn.Module()
+    blk.a, blk.b = mods[0], mods[1]
+    assert fuse_siblings(blk, ["a", "b"]) is None and blk.a is mods[0]
