@@ -149,7 +149,8 @@ int gptqhip_repack_tiled(const int32_t* qweight, const int32_t* qzeros, const vo
 
 int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
                  const int32_t* perm, const void* bias, void* out, void* workspace, size_t workspace_bytes, int M,
-                 int K, int N, int group_size, int bits, int act_dtype, int scale_dtype, gptqhip_stream_t stream_) {
+                 int K, int N, int group_size, int bits, int act_dtype, int scale_dtype, int flags,
+                 gptqhip_stream_t stream_) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
     if (M == 0) return GPTQHIP_OK;  // empty batch: nothing to do (reference returns an empty tensor)
     if (!x || !qweight || !meta || !out) {
@@ -169,6 +170,11 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     }
     if ((size_t)ceil_div(N, kTileN) * sizeof(int) > kCounterBytes) {
         set_error("gptqhip_gemm: N=%d too large (max %zu columns)", N, kCounterBytes / sizeof(int) * kTileN);
+        return GPTQHIP_EINVAL;
+    }
+    const bool partial_f32 = (flags & GPTQHIP_GEMM_PARTIAL_F32) != 0;
+    if ((flags & ~GPTQHIP_GEMM_PARTIAL_F32) != 0 || (partial_f32 && bias != nullptr)) {
+        set_error("gptqhip_gemm: bad flags 0x%x (PARTIAL_F32 excludes bias)", flags);
         return GPTQHIP_EINVAL;
     }
     const WorkspaceLayout L = layout_workspace(M, K, N, group_size, perm != nullptr);
@@ -198,6 +204,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     a.bits = bits;
     a.act_dtype = act_dtype;
     a.scale_dtype = scale_dtype;
+    a.out_f32 = partial_f32 ? 1 : 0;
 
     const bool use_tiled = kHaveTiled && ((g_force_kernel == 2) || (g_force_kernel == 0 && M > kSkinnyMaxM));
     if (use_tiled && bits == 4) {
@@ -211,7 +218,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     for (int m0 = 0; m0 < M; m0 += kSkinnyMaxM) {
         const int mc = (M - m0) < kSkinnyMaxM ? (M - m0) : kSkinnyMaxM;
         a.x = reinterpret_cast<const char*>(xin) + (size_t)m0 * K * 2;
-        a.out = reinterpret_cast<char*>(out) + (size_t)m0 * N * 2;
+        a.out = reinterpret_cast<char*>(out) + (size_t)m0 * N * (partial_f32 ? 4 : 2);
         a.M = mc;
         const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves);
         rc = launch_skinny(a, pl, slabs, counters, stream);

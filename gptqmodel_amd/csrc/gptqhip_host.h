@@ -13,6 +13,7 @@ struct GemmArgs {
     const void* bias;
     void* out;
     int M, K, N, group_size, bits, act_dtype, scale_dtype;
+    int out_f32;  // write unrounded fp32 accumulators (tensor-parallel partial sums)
 };
 
 struct SkinnyPlan {

@@ -35,6 +35,7 @@ struct SkinnyParams {
     int chunks;            // ceil(K/128)
     int chunks_per_split;  // chunks handled by one block
     int splits;
+    int out_f32;           // epilogue writes raw fp32 accumulators (TP partial sums)
     int cpg_shift;         // log2(chunks per group) when group_size is 128 * 2^n, else -1 (integer division)
 };
 
@@ -231,7 +232,9 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     }
 
     // ---- epilogue: round like the reference (matmul result, then += bias in the activation dtype) ----
-    if (live) {
+    if (live && p.out_f32) {
+        reinterpret_cast<float*>(p.out)[(size_t)m * p.N + n] = v;
+    } else if (live) {
         float y = round_through<ACT>(v);
         if (p.bias != nullptr) y = y + load16_as_f32<ACT>(p.bias, (size_t)n);
         reinterpret_cast<uint16_t*>(p.out)[(size_t)m * p.N + n] = f32_to_16<ACT>(y);
@@ -307,6 +310,7 @@ int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* co
     p.chunks = pl.chunks;
     p.chunks_per_split = pl.chunks_per_split;
     p.splits = pl.splits;
+    p.out_f32 = a.out_f32;
     p.cpg_shift = -1;
     if (a.group_size % kChunkK == 0) {
         const int cpg = a.group_size / kChunkK;

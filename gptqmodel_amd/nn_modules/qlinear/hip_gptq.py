@@ -111,6 +111,17 @@ class HipGptqLinear(GPTQQuantLinear):
             out = out.to(in_dtype)
         return out.reshape(out_shape)
 
+    def forward_partial(self, x: torch.Tensor) -> torch.Tensor:
+        """float32 [.., N] unrounded accumulators without bias: what a row-parallel (K-sharded) tensor-parallel
+        layer all-reduces before the single final rounding (gptqmodel_amd/utils/tp.py)."""
+        if not self._ready:
+            raise RuntimeError("HipGptqLinear.forward_partial called before post_init()")
+        from gptqmodel_amd import ops
+        x2, _ = flatten_input(x, self.in_features)
+        out = ops.gemm(x2, self.qweight, self.meta, None, self.perm, self.out_features, self.group_size, self.bits,
+                       self._scale_dtype, partial_f32=True)
+        return out.reshape(x.shape[:-1] + (self.out_features,))
+
     def dequantize_weight(self, num_itr: int = 1) -> torch.Tensor:
         """[K,N] weights in scales.dtype, bit-exact with TorchLinear.dequantize_weight (torch.py:225)."""
         if num_itr != 1:

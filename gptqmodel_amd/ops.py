@@ -87,8 +87,9 @@ def repack_tiled(qweight: Optional[torch.Tensor], qzeros: torch.Tensor, scales: 
 
 def gemm(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Optional[torch.Tensor],
          perm: Optional[torch.Tensor], N: int, group_size: int, bits: int, scale_dtype: torch.dtype,
-         out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M,N] = x[M,K] @ dequant(qweight_t, meta) (+bias)  via gptqhip_gemm (tiled layout)."""
+         out: Optional[torch.Tensor] = None, partial_f32: bool = False) -> torch.Tensor:
+    """out[M,N] = x[M,K] @ dequant(qweight_t, meta) (+bias)  via gptqhip_gemm (tiled layout).
+    partial_f32=True returns the unrounded float32 accumulators (tensor-parallel partial sums, no bias)."""
     lib = _lib.load()
     _require_cuda(x, qweight_t, meta, bias, perm)
     if x.dim() != 2 or not x.is_contiguous():
@@ -98,8 +99,10 @@ def gemm(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Opt
     if bias is not None and bias.dtype != x.dtype:
         raise RuntimeError("gemm: bias dtype must equal activation dtype")
     M, K = x.shape
+    if partial_f32 and bias is not None:
+        raise RuntimeError("gemm: partial_f32 excludes bias (add it once after the all-reduce)")
     if out is None:
-        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        out = torch.empty((M, N), dtype=torch.float32 if partial_f32 else x.dtype, device=x.device)
     if M == 0:
         return out
     with torch.cuda.device(x.device):
@@ -107,7 +110,7 @@ def gemm(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Opt
         ws = workspace_for(x.device, need)
         rc = lib.gptqhip_gemm(_ptr(x), _ptr(qweight_t), _ptr(meta), _ptr(perm), _ptr(bias), _ptr(out), _ptr(ws),
                               ws.numel(), M, K, N, group_size, bits, _DT[x.dtype], _DT[scale_dtype],
-                              _stream(x.device))
+                              1 if partial_f32 else 0, _stream(x.device))
     _lib.check(rc, "gptqhip_gemm")
     return out
 

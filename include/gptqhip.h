@@ -98,12 +98,16 @@ int gptqhip_repack_tiled(const int32_t* qweight, const int32_t* qzeros, const vo
  *   perm     [K] int32 or NULL: x column gather for act-order
  *   bias     [N] act_dtype or NULL
  *   out      [M,N] act_dtype
- *   scale_dtype: dtype of the scale bits inside meta */
+ *   scale_dtype: dtype of the scale bits inside meta
+ *   flags    GPTQHIP_GEMM_PARTIAL_F32: `out` is float32 [M,N] and receives the UNROUNDED fp32 accumulators (bias
+ *            must be NULL) -- the partial sums a row-parallel (K-sharded) tensor-parallel layer all-reduces before
+ *            rounding once, so TP reproduces the single-GPU rounding chain. */
+#define GPTQHIP_GEMM_PARTIAL_F32 1
 int gptqhip_gemm(const void* x, const uint32_t* qweight_t, const uint32_t* meta,
                  const int32_t* perm, const void* bias, void* out,
                  void* workspace, size_t workspace_bytes,
                  int M, int K, int N, int group_size, int bits,
-                 int act_dtype, int scale_dtype, gptqhip_stream_t stream);
+                 int act_dtype, int scale_dtype, int flags, gptqhip_stream_t stream);
 
 /* Materialise W[K,N] from the CHECKPOINT layout in `out_dtype` (= scales dtype in the reference).  Replaces
  * TorchLinear.dequantize_weight (torch.py:225) / PackableQuantLinear.dequantize_weight

@@ -61,18 +61,18 @@ def test_size_helpers(lib):
 def test_argument_validation_reports_errors_without_a_gpu(lib):
     EINVAL = -22
     one = ctypes.c_void_p(16)  # non-null dummy; validation fails before any dereference
-    rc = lib.gptqhip_gemm(None, one, one, None, None, one, one, 1 << 20, 1, 4096, 4096, 128, 4, 0, 0, None)
+    rc = lib.gptqhip_gemm(None, one, one, None, None, one, one, 1 << 20, 1, 4096, 4096, 128, 4, 0, 0, 0, None)
     assert rc == EINVAL and b"null" in lib.gptqhip_last_error()
-    rc = lib.gptqhip_gemm(one, one, one, None, None, one, one, 1 << 20, 1, 4096, 4096, 100, 4, 0, 0, None)
+    rc = lib.gptqhip_gemm(one, one, one, None, None, one, one, 1 << 20, 1, 4096, 4096, 100, 4, 0, 0, 0, None)
     assert rc == EINVAL and b"group_size" in lib.gptqhip_last_error()
-    rc = lib.gptqhip_gemm(one, one, one, None, None, one, one, 1 << 20, 1, 4096, 4096, 128, 3, 0, 0, None)
+    rc = lib.gptqhip_gemm(one, one, one, None, None, one, one, 1 << 20, 1, 4096, 4096, 128, 3, 0, 0, 0, None)
     assert rc == EINVAL and b"bits" in lib.gptqhip_last_error()
-    rc = lib.gptqhip_gemm(one, one, one, None, None, one, one, 1 << 20, 1, 4100, 4096, 128, 4, 0, 0, None)
+    rc = lib.gptqhip_gemm(one, one, one, None, None, one, one, 1 << 20, 1, 4100, 4096, 128, 4, 0, 0, 0, None)
     assert rc == EINVAL
-    rc = lib.gptqhip_gemm(one, one, one, None, None, one, one, 16, 1, 4096, 4096, 128, 4, 0, 0, None)
+    rc = lib.gptqhip_gemm(one, one, one, None, None, one, one, 16, 1, 4096, 4096, 128, 4, 0, 0, 0, None)
     assert rc == -12 and b"workspace" in lib.gptqhip_last_error()  # ENOMEM
     # empty batch is a no-op success (the reference returns an empty tensor)
-    assert lib.gptqhip_gemm(None, None, None, None, None, None, None, 0, 0, 4096, 4096, 128, 4, 0, 0, None) == 0
+    assert lib.gptqhip_gemm(None, None, None, None, None, None, None, 0, 0, 4096, 4096, 128, 4, 0, 0, 0, None) == 0
     rc = lib.gptqhip_repack_tiled(one, one, one, None, None, one, 4096, 4096, 128, 4, None)
     assert rc == EINVAL  # qweight without qweight_t
     assert lib.gptqhip_device_info(0, None, None, None, 0) in (0, -19)  # ENODEV on a CPU-only box

@@ -150,3 +150,35 @@ def test_fused_siblings_match_separate_projections():
         assert rel_err(torch_to_f32(b), torch_to_f32(a)) <= 1e-3
     # one fused launch serves all three views of the same input tensor
     assert group._out is not None and group._out.shape[-1] == sum(sizes.values())
+
+
+def test_row_parallel_partials_on_one_gpu():
+    """TP row-parallel math with the real kernel: two K-shards of one layer, fp32 partial sums (PARTIAL_F32) added
+    like the all-reduce does, then the reference rounding chain == the unsharded module."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    from gptqmodel_amd.utils import tp
+
+    K, N, gs, M = 2048, 512, 128, 5
+    qweight, qzeros, scales, g_idx = synth_gptq(77, 4, K, N, gs)
+    t = {"qweight": torch.from_numpy(qweight), "qzeros": torch.from_numpy(qzeros),
+         "scales": f32_to_torch(scales, "fp16"), "g_idx": torch.from_numpy(g_idx), "bias": None}
+    bias = f32_to_torch(np.random.RandomState(1).randn(N).astype(np.float32) * 0.1, "fp16", DEV)
+
+    def module(tt, k):
+        lin = HipGptqLinear(bits=4, group_size=gs, sym=False, desc_act=False, in_features=k, out_features=N, bias=False)
+        lin.qweight, lin.qzeros, lin.scales, lin.g_idx = tt["qweight"], tt["qzeros"], tt["scales"], tt["g_idx"]
+        lin.qzero_format(format=2)
+        lin = lin.to(DEV).eval()
+        lin.post_init()
+        return lin
+
+    x = O.round_to(np.random.RandomState(2).randn(M, K).astype(np.float32) * 0.5, "fp16")
+    xt = f32_to_torch(x, "fp16", DEV)
+    shards = [module(tp.shard_gptq_row(t, r, 2, 4, gs), K // 2) for r in range(2)]
+    partial = sum(sh.forward_partial(xt[:, r * K // 2:(r + 1) * K // 2].contiguous()) for r, sh in enumerate(shards))
+    assert partial.dtype == torch.float32
+    y_tp = partial.to(torch.float16) + bias
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, torch_to_f32(bias))
+    assert rel_err(torch_to_f32(y_tp), ref) <= 1e-3
+    row = tp.RowParallelQuantLinear(shards[0], bias=None)  # world size 1 / no process group: no collective
+    assert row(xt[:, :K // 2].contiguous()).dtype == torch.float16

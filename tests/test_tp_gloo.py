@@ -1,0 +1,136 @@
+"""Tensor-parallel path on CPU: world_size 2, gloo, one process per rank.  The shard math (column/row slicing of the
+packed checkpoint tensors, g_idx rebasing), the collective wiring (one fp32 all-reduce per row-parallel layer) and the
+rounding chain are exercised with the ORACLE as each rank's local compute (the HIP kernel needs a GPU; the same
+RowParallel/ColumnParallel modules wrap HipGptqLinear there)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from helpers import synth_gptq
+from oracle import gptq_oracle as O
+
+from gptqmodel_amd.utils import tp
+
+
+class OracleLocal(nn.Module):
+    """Checker stand-in for a post_init'ed HipGptqLinear shard: same forward()/forward_partial() surface."""
+
+    def __init__(self, t, bits, gs):
+        super().__init__()
+        self.t, self.bits, self.gs = t, bits, gs
+
+    def _w(self):
+        t = self.t
+        return O.dequant_gptq(t["qweight"].numpy(), t["qzeros"].numpy(), t["scales"].float().numpy(),
+                              t["g_idx"].numpy(), self.bits)
+
+    def forward_partial(self, x):
+        return torch.from_numpy(x.float().numpy() @ self._w())
+
+    def forward(self, x):
+        b = None if self.t.get("bias") is None else self.t["bias"].float().numpy()
+        return torch.from_numpy(O.matmul_round(x.float().numpy(), self._w(), b, "fp16")).half()
+
+
+def _tensors(seed, bits, K, N, gs, bias=True):
+    qweight, qzeros, scales, g_idx = synth_gptq(seed, bits, K, N, gs)
+    t = {"qweight": torch.from_numpy(qweight), "qzeros": torch.from_numpy(qzeros),
+         "scales": torch.from_numpy(scales).half(), "g_idx": torch.from_numpy(g_idx)}
+    t["bias"] = torch.from_numpy(np.random.RandomState(seed).randn(N).astype(np.float32) * 0.1).half() if bias else None
+    return t
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bits, gs, H, I, M = 4, 64, 256, 512, 3
+        up = _tensors(1, bits, H, I, gs)      # column parallel (like gate/up)
+        down = _tensors(2, bits, I, H, gs)    # row parallel (like down)
+        x = torch.from_numpy(O.round_to(np.random.RandomState(7).randn(M, H).astype(np.float32) * 0.5, "fp16")).half()
+
+        col = tp.ColumnParallelQuantLinear(OracleLocal(tp.shard_gptq_column(up, rank, world, bits), bits, gs))
+        row = tp.RowParallelQuantLinear(OracleLocal(tp.shard_gptq_row(down, rank, world, bits, gs), bits, gs),
+                                        bias=down["bias"])
+        h_local = col(x)                                  # [M, I/world], no communication
+        y = row(h_local)                                  # one all-reduce
+
+        # single-process reference of the same two layers
+        h_full = OracleLocal(up, bits, gs)(x)
+        n0, n1 = rank * I // world, (rank + 1) * I // world
+        assert torch.equal(h_local, h_full[:, n0:n1]), "column shard must equal the full layer's column slice bit for bit"
+        y_full = OracleLocal(down, bits, gs)(h_full)
+        err = (y.float() - y_full.float()).abs().max().item() / y_full.float().abs().max().item()
+        assert err <= 1e-3, err
+        # gather_output variant reproduces the full output exactly
+        col_g = tp.ColumnParallelQuantLinear(OracleLocal(tp.shard_gptq_column(up, rank, world, bits), bits, gs),
+                                             gather_output=True)
+        assert torch.equal(col_g(x), h_full)
+        ret[rank] = err
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tp2_column_then_row_matches_single_process():
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert sorted(ret.keys()) == [0, 1]
+
+
+def test_shard_shapes_and_constraints():
+    t = _tensors(3, 4, 8192 // 8, 1024, 128)  # K=1024, N=1024
+    K, N = 1024, 1024
+    for world in (1, 2, 4, 8):
+        for r in range(world):
+            c = tp.shard_gptq_column(t, r, world, 4)
+            assert c["qweight"].shape == (K // 8, N // world) and c["qzeros"].shape == (K // 128, N // world // 8)
+            assert c["scales"].shape == (K // 128, N // world) and c["g_idx"].shape == (K,)
+            rw = tp.shard_gptq_row(t, r, world, 4, 128)
+            assert rw["qweight"].shape == (K // 8 // world, N) and rw["scales"].shape == (K // 128 // world, N)
+            assert rw["bias"] is None and int(rw["g_idx"].min()) == 0 and int(rw["g_idx"].max()) == K // 128 // world - 1
+    # shards tile the full matrix exactly
+    full = O.dequant_gptq(t["qweight"].numpy(), t["qzeros"].numpy(), t["scales"].float().numpy(), t["g_idx"].numpy(), 4)
+    cols = [tp.shard_gptq_column(t, r, 4, 4) for r in range(4)]
+    wc = np.concatenate([O.dequant_gptq(c["qweight"].numpy(), c["qzeros"].numpy(), c["scales"].float().numpy(),
+                                         c["g_idx"].numpy(), 4) for c in cols], axis=1)
+    assert np.array_equal(wc, full)
+    rows = [tp.shard_gptq_row(t, r, 4, 4, 128) for r in range(4)]
+    wr = np.concatenate([O.dequant_gptq(c["qweight"].numpy(), c["qzeros"].numpy(), c["scales"].float().numpy(),
+                                         c["g_idx"].numpy(), 4) for c in rows], axis=0)
+    assert np.array_equal(wr, full)
+    with pytest.raises(ValueError):
+        tp.shard_gptq_row(t, 0, 16, 4, 128)       # 1024/16 = 64 rows < one group
+    with pytest.raises(ValueError):
+        tp.shard_gptq_column(_tensors(4, 4, 256, 40, 64), 0, 8, 4)   # 40/8 = 5 columns, not a multiple of 8
+    act = dict(t)
+    act["g_idx"] = torch.from_numpy((np.random.RandomState(0).permutation(K) // 128).astype(np.int32))
+    with pytest.raises(NotImplementedError):
+        tp.shard_gptq_row(act, 0, 2, 4, 128)
+    # Llama-3-70B shapes satisfy the constraints up to TP=8
+    for (k, n) in [(8192, 8192), (8192, 1024), (8192, 28672), (28672, 8192)]:
+        for world in (1, 2, 4, 8):
+            tp._bounds(n, 0, world, 8, "N")
+            tp._bounds(k, 0, world, 128, "K")
+
+
+def test_awq_shards_tile_the_matrix():
+    rng = np.random.RandomState(9)
+    K, N, gs = 256, 128, 64
+    t = {"qweight": torch.from_numpy(rng.randint(-2**31, 2**31, size=(K, N // 8), dtype=np.int64).astype(np.int32)),
+         "qzeros": torch.from_numpy(rng.randint(-2**31, 2**31, size=(K // gs, N // 8), dtype=np.int64).astype(np.int32)),
+         "scales": torch.from_numpy(rng.rand(K // gs, N).astype(np.float32) * 0.01 + 0.005).half(), "bias": None}
+    full = O.dequant_awq(t["qweight"].numpy(), t["qzeros"].numpy(), t["scales"].float().numpy(), gs)
+    wc = np.concatenate([O.dequant_awq(c["qweight"].numpy(), c["qzeros"].numpy(), c["scales"].float().numpy(), gs)
+                         for c in (tp.shard_awq_column(t, r, 2) for r in range(2))], axis=1)
+    wr = np.concatenate([O.dequant_awq(c["qweight"].numpy(), c["qzeros"].numpy(), c["scales"].float().numpy(), gs)
+                         for c in (tp.shard_awq_row(t, r, 2, gs) for r in range(2))], axis=0)
+    assert np.array_equal(wc, full) and np.array_equal(wr, full)
