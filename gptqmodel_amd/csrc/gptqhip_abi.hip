@@ -32,7 +32,7 @@ int check_hip(hipError_t e, const char* what) {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 constexpr int kSkinnyMaxM = 64;
-constexpr bool kHaveTiled = false;
+constexpr bool kHaveTiled = true;
 constexpr size_t kCounterBytes = 64 * 1024;  // 16384 arrival counters
 
 struct WorkspaceLayout {
@@ -207,12 +207,12 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     a.out_f32 = partial_f32 ? 1 : 0;
 
     const bool use_tiled = kHaveTiled && ((g_force_kernel == 2) || (g_force_kernel == 0 && M > kSkinnyMaxM));
-    if (use_tiled && bits == 4) {
+    if (use_tiled) {
         a.x = xin;
         a.out = out;
         a.M = M;
         const TiledPlan tp = plan_tiled(M, K, N, group_size);
-        return launch_tiled(a, tp, slabs, counters, stream);
+        return launch_tiled(a, tp, stream);
     }
     // skinny kernel, 64 rows at a time
     for (int m0 = 0; m0 < M; m0 += kSkinnyMaxM) {

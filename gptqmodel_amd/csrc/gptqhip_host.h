@@ -27,8 +27,8 @@ struct SkinnyPlan {
 };
 
 struct TiledPlan {
-    int splits;
-    size_t slab_floats;
+    int gpc;  // meta words per chunk (1 or 4)
+    int bm;   // rows per block tile (256 or 128)
 };
 
 void set_error(const char* fmt, ...);
@@ -38,7 +38,7 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
 int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* counters, hipStream_t stream);
 
 TiledPlan plan_tiled(int M, int K, int N, int group_size);
-int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, int* counters, hipStream_t stream);
+int launch_tiled(const GemmArgs& a, const TiledPlan& pl, hipStream_t stream);
 
 int launch_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* g_idx, void* out,
                    int K, int N, int group_size, int bits, int scale_dtype, int out_dtype, hipStream_t stream);

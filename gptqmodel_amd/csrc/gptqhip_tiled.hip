@@ -1,10 +1,257 @@
-// placeholder until the MFMA-bound prefill kernel lands; gptqhip_gemm does not route here yet.
+// Prefill / large-batch fused dequant-GEMM (M > 64): MFMA-bound.
+//
+// Replaces, for large M, the reference's "dequantise the whole [K,N] weight to fp16, then aten matmul"
+// (gptqmodel/nn_modules/qlinear/torch.py:326-347) and plays the role Marlin / ExllamaV2's reconstruct+GEMM play
+// on NVIDIA (gptqmodel_ext/marlin/gptq_marlin.cu, gptqmodel_ext/exllamav2/cuda/q_gemm.cu:118-137) -- designed
+// for CDNA4 instead of translated:
+//
+//   block = 8 waves, output tile BM x 256 (BM = 256 or 128), K advanced one 128-row chunk at a time.
+//   * B (weights) never touches LDS: wave w owns column tiles 2w, 2w+1 of the block (32 columns) for ALL BM rows,
+//     so every packed word is fetched (one dwordx4 per lane per tile-chunk, 1 KiB contiguous) and dequantised
+//     exactly once per block, in registers, straight into mfma_f32_16x16x32 B fragments.
+//   * A (activations) is the shared operand: the BM x 128 tile is staged global -> registers -> LDS in full 256-byte
+//     rows (coalesced dwordx4), XOR-swizzled ((row&15)<<4) so the column-slice ds_read_b128 of the A fragments is
+//     bank-conflict free (cdna_hip_programming.md T2).  The next tile's global loads are issued before the MFMA
+//     phase and written to LDS after it (T14 async-stage split): one LDS buffer, two barriers per 128-deep tile
+//     (amortised over 4*BM/16*2 MFMAs per wave).
+//   * per K-step (32 rows) a wave issues 2 dequants (~24 VALU) + BM/16 ds_read_b128 + 2*BM/16 MFMAs: the VALU and
+//     LDS work hides under the matrix pipe.
+//   * epilogue rounds like the reference (round(acc), + bias, round) or writes fp32 partials for tensor parallel.
 #include "gptqhip_device.h"
 #include "gptqhip_host.h"
+
 namespace gptqhip {
-TiledPlan plan_tiled(int, int, int, int) { return TiledPlan{1, 0}; }
-int launch_tiled(const GemmArgs&, const TiledPlan&, float*, int*, hipStream_t) {
-    set_error("tiled kernel not built");
-    return -22;
+
+constexpr int kTiledBN = 256;     // columns per block = 8 waves x 2 tiles x 16
+constexpr int kTiledWaves = 8;  // block = 512 threads
+constexpr int kTilesPerWave = 2;
+
+struct TiledParams {
+    const void* x;
+    const uint32_t* qw;
+    const uint32_t* meta;
+    const void* bias;
+    void* out;
+    int M, K, N, G, group_size;
+    int chunks;
+    int tiles;  // ceil(N/16)
+    int out_f32;
+    int cpg_shift;
+};
+
+__device__ __forceinline__ int tiled_group_of(const TiledParams& p, int k) {
+    int g;
+    if (p.cpg_shift >= 0) {
+        g = k >> (7 + p.cpg_shift);
+    } else {
+        g = k / p.group_size;
+    }
+    return g < p.G ? g : p.G - 1;
 }
+
+template <int BITS, int GPC>
+struct BStage {
+    u4_t w[kTilesPerWave][BITS == 4 ? 1 : 2];
+    uint32_t meta[kTilesPerWave][GPC];
+};
+
+template <int BITS, int GPC>
+__device__ __forceinline__ void load_b(BStage<BITS, GPC>& st, const TiledParams& p, int tile0, int chunk, int lane) {
+    constexpr int WPC = BITS == 4 ? 1 : 2;
+#pragma unroll
+    for (int t = 0; t < kTilesPerWave; ++t) {
+        int tile = tile0 + t;
+        tile = tile < p.tiles ? tile : p.tiles - 1;  // ragged N: clamp (those columns are never stored)
+        const u4_t* src = reinterpret_cast<const u4_t*>(p.qw) + ((size_t)tile * p.chunks + chunk) * (WPC * 64) + lane;
+#pragma unroll
+        for (int h = 0; h < WPC; ++h) st.w[t][h] = src[h * 64];
+        const uint32_t* mb = p.meta + (size_t)tile * p.G * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < GPC; ++j) st.meta[t][j] = mb[tiled_group_of(p, chunk * kChunkK + j * (kChunkK / GPC)) * 16];
+    }
+}
+
+// A tile: BM rows x 128 halves (256 B per row), thread t moves 16-byte segments idx = i*512 + t, i < BM/32.
+template <int BM>
+__device__ __forceinline__ void load_a(u4_t (&stage)[BM / 32], const TiledParams& p, int m0, int chunk, int tid) {
+    const uint16_t* xs = reinterpret_cast<const uint16_t*>(p.x);
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {
+        const int idx = i * 512 + tid;
+        int row = m0 + (idx >> 4);
+        row = row < p.M ? row : p.M - 1;  // ragged M: duplicate the last row (its outputs are never stored)
+        int k = chunk * kChunkK + (idx & 15) * 8;
+        k = k < p.K ? k : 0;  // ragged K: the padded weights dequantise to exactly 0, any finite x will do
+        stage[i] = *reinterpret_cast<const u4_t*>(xs + (size_t)row * p.K + k);
+    }
+}
+
+template <int BM>
+__device__ __forceinline__ void store_a(const u4_t (&stage)[BM / 32], char* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {
+        const int idx = i * 512 + tid;
+        const int row = idx >> 4;
+        const int off = row * 256 + (((idx & 15) << 4) ^ ((row & 15) << 4));
+        *reinterpret_cast<u4_t*>(lds + off) = stage[i];
+    }
+}
+
+template <int BITS, int ACT, int SCL, int GPC, int BM>
+__global__ __launch_bounds__(64 * kTiledWaves) void tiled_kernel(TiledParams p) {
+    constexpr int MT = BM / 16;
+    __shared__ __attribute__((aligned(16))) char lds[BM * 256];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15;
+    const int rq = lane >> 4;
+    const int m0 = blockIdx.y * BM;
+    const int tile0 = blockIdx.x * (kTiledBN / kTileN) + wave * kTilesPerWave;
+
+    f4_t acc[MT][kTilesPerWave];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < kTilesPerWave; ++t) acc[mt][t] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    const DequantConsts dk = make_dequant_consts<BITS>();
+    u4_t astage[BM / 32];
+    BStage<BITS, GPC> bcur, bnxt;
+
+    load_a<BM>(astage, p, m0, 0, tid);
+    load_b<BITS, GPC>(bcur, p, tile0, 0, lane);
+    store_a<BM>(astage, lds, tid);
+    __syncthreads();
+
+    for (int chunk = 0; chunk < p.chunks; ++chunk) {
+        const bool more = chunk + 1 < p.chunks;
+        if (more) {
+            load_a<BM>(astage, p, m0, chunk + 1, tid);       // in flight during the MFMA phase
+            load_b<BITS, GPC>(bnxt, p, tile0, chunk + 1, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u4_t b[kTilesPerWave];
+#pragma unroll
+            for (int t = 0; t < kTilesPerWave; ++t) {
+                const ColConst cc = expand_meta<BITS, SCL>(bcur.meta[t][GPC == 4 ? j : 0]);
+                if constexpr (BITS == 4) {
+                    b[t] = dequant_word4<ACT, SCL>(bcur.w[t][0][j], cc, dk);
+                } else {
+                    b[t] = dequant_word8<ACT, SCL>(bcur.w[t][j >> 1][(j & 1) * 2], bcur.w[t][j >> 1][(j & 1) * 2 + 1], cc, dk);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = mt * 16 + c;
+                const int off = row * 256 + ((j * 64 + rq * 16) ^ (c << 4));  // (row & 15) == c
+                const u4_t a = *reinterpret_cast<const u4_t*>(lds + off);
+#pragma unroll
+                for (int t = 0; t < kTilesPerWave; ++t) acc[mt][t] = mfma16<ACT>(a, b[t], acc[mt][t]);
+            }
+        }
+        __syncthreads();  // every wave is done reading this A tile
+        if (more) {
+            store_a<BM>(astage, lds, tid);
+            bcur = bnxt;
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < kTilesPerWave; ++t) {
+        const int n = (tile0 + t) * kTileN + c;
+        if (n >= p.N) continue;
+        float bias = 0.f;
+        const bool has_bias = p.bias != nullptr;
+        if (has_bias) bias = load16_as_f32<ACT>(p.bias, (size_t)n);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + mt * 16 + 4 * rq + i;
+                if (m >= p.M) continue;
+                const float v = acc[mt][t][i];
+                if (p.out_f32) {
+                    reinterpret_cast<float*>(p.out)[(size_t)m * p.N + n] = v;
+                } else {
+                    float y = round_through<ACT>(v);
+                    if (has_bias) y = y + bias;
+                    reinterpret_cast<uint16_t*>(p.out)[(size_t)m * p.N + n] = f32_to_16<ACT>(y);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int BITS, int ACT, int SCL, int GPC>
+static int launch_tiled_bm(const TiledParams& p, int bm, hipStream_t stream) {
+    const dim3 grid(ceil_div(p.N, kTiledBN), ceil_div(p.M, bm));
+    if (bm == 256) {
+        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 256>), grid, dim3(512), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 128>), grid, dim3(512), 0, stream, p);
+    }
+    return check_hip(hipGetLastError(), "tiled_kernel launch");
+}
+
+template <int BITS, int ACT, int SCL>
+static int launch_tiled_gpc(const TiledParams& p, int gpc, int bm, hipStream_t stream) {
+    if (gpc == 1) return launch_tiled_bm<BITS, ACT, SCL, 1>(p, bm, stream);
+    return launch_tiled_bm<BITS, ACT, SCL, 4>(p, bm, stream);
+}
+
+TiledPlan plan_tiled(int M, int K, int N, int group_size) {
+    TiledPlan pl;
+    pl.gpc = (group_size % kChunkK == 0) ? 1 : 4;
+    // 256-row tiles when they alone fill the chip, else 128-row tiles (twice the blocks)
+    const long blocks256 = (long)ceil_div(M, 256) * ceil_div(N, kTiledBN);
+    pl.bm = blocks256 >= 256 ? 256 : 128;
+    (void)K;
+    return pl;
+}
+
+int launch_tiled(const GemmArgs& a, const TiledPlan& pl, hipStream_t stream) {
+    TiledParams p;
+    p.x = a.x;
+    p.qw = a.qweight;
+    p.meta = a.meta;
+    p.bias = a.bias;
+    p.out = a.out;
+    p.M = a.M;
+    p.K = a.K;
+    p.N = a.N;
+    p.G = a.K / a.group_size;
+    p.group_size = a.group_size;
+    p.chunks = ceil_div(a.K, kChunkK);
+    p.tiles = ceil_div(a.N, kTileN);
+    p.out_f32 = a.out_f32;
+    p.cpg_shift = -1;
+    if (a.group_size % kChunkK == 0) {
+        const int cpg = a.group_size / kChunkK;
+        if ((cpg & (cpg - 1)) == 0) {
+            int sh = 0;
+            while ((1 << sh) < cpg) ++sh;
+            p.cpg_shift = sh;
+        }
+    }
+#define GPTQHIP_TDISPATCH(B, A_, S_) return launch_tiled_gpc<B, A_, S_>(p, pl.gpc, pl.bm, stream)
+    if (a.bits == 4) {
+        if (a.act_dtype == kFP16 && a.scale_dtype == kFP16) GPTQHIP_TDISPATCH(4, kFP16, kFP16);
+        if (a.act_dtype == kBF16 && a.scale_dtype == kFP16) GPTQHIP_TDISPATCH(4, kBF16, kFP16);
+        if (a.act_dtype == kFP16 && a.scale_dtype == kBF16) GPTQHIP_TDISPATCH(4, kFP16, kBF16);
+        GPTQHIP_TDISPATCH(4, kBF16, kBF16);
+    } else {
+        if (a.act_dtype == kFP16 && a.scale_dtype == kFP16) GPTQHIP_TDISPATCH(8, kFP16, kFP16);
+        if (a.act_dtype == kBF16 && a.scale_dtype == kFP16) GPTQHIP_TDISPATCH(8, kBF16, kFP16);
+        if (a.act_dtype == kFP16 && a.scale_dtype == kBF16) GPTQHIP_TDISPATCH(8, kFP16, kBF16);
+        GPTQHIP_TDISPATCH(8, kBF16, kBF16);
+    }
+#undef GPTQHIP_TDISPATCH
+}
+
 }  // namespace gptqhip

@@ -1,0 +1,24 @@
+"""Dev tool: dequant-GEMM TFLOPS of the prefill kernel (methodology of the reference's
+scripts/benchmark_marlin_a100.py: tflops = 2*M*K*N / t, random int32 qweight, warmup then timed iters)."""
+import sys, torch
+sys.path.insert(0, "/root/repo")
+from gptqmodel_amd import ops
+dev = "cuda"
+def run(M, K, N, gs=128, iters=20):
+    qw = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=dev)
+    qz = torch.randint(-2**31, 2**31 - 1, (K // gs, N // 8), dtype=torch.int32, device=dev)
+    sc = (torch.rand((K // gs, N), device=dev) * 0.01 + 0.005).half()
+    qw_t, meta = ops.repack_tiled(qw, qz, sc, None, gs, 4)
+    x = (torch.randn(M, K, device=dev) * 0.5).half()
+    out = torch.empty((M, N), dtype=torch.float16, device=dev)
+    for _ in range(3): ops.gemm(x, qw_t, meta, None, None, N, gs, 4, torch.float16, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): ops.gemm(x, qw_t, meta, None, None, N, gs, 4, torch.float16, out=out)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, 2.0 * M * K * N / ms / 1e9
+for (M, K, N) in [(128,4096,4096),(512,4096,4096),(2048,4096,4096),(8192,4096,4096),(2048,4096,14336),(2048,14336,4096),(8192,4096,28672),(65536,4096,4096)]:
+    ms, tf = run(M, K, N)
+    print(f"M={M} K={K} N={N}: {ms:.3f} ms  {tf:.1f} TFLOPS", flush=True)

@@ -251,3 +251,48 @@ def test_random_shape_stress(ops):
         out = run_gptq(ops, x, qweight, qzeros, scales, g_idx, bits, gs, bias, act, "fp16")
         ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, bits, bias, act, "fp16")
         assert rel_err(torch_to_f32(out), ref) <= tol(act), (it, bits, gs, K, N, M, act, desc)
+
+
+TILED_CASES = [
+    # bits, K, N, gs, M, act, desc_act  (force_kernel=2 routes every M through the MFMA-tiled prefill kernel)
+    (4, 4096, 4096, 128, 300, "fp16", False),
+    (4, 4096, 4096, 128, 256, "bf16", False),
+    (4, 1024, 1000, 64, 129, "fp16", False),     # ragged N (not a multiple of 256 or 16*k), per-step groups
+    (4, 2048, 512, 2048, 65, "fp16", False),     # group_size == K
+    (4, 96, 40, 32, 70, "fp16", False),          # ragged K (< one chunk) and N
+    (4, 2048, 1024, 128, 513, "fp16", True),     # act-order: x gathered through perm
+    (8, 1024, 512, 128, 200, "fp16", False),
+    (8, 512, 256, 64, 77, "bf16", True),
+    (4, 512, 256, 128, 1, "fp16", False),        # tiny M through the tiled kernel (rows padded by duplication)
+    (4, 14336, 4096, 128, 128, "fp16", False),
+]
+
+
+@pytest.mark.parametrize("bits,K,N,gs,M,act,desc_act", TILED_CASES)
+def test_tiled_prefill_kernel_vs_oracle(ops, bits, K, N, gs, M, act, desc_act):
+    qweight, qzeros, scales, g_idx = synth_gptq(4321, bits, K, N, gs, desc_act=desc_act)
+    rng = np.random.RandomState(17)
+    x = O.round_to(rng.randn(M, K).astype(np.float32) * 0.5, act)
+    bias = O.round_to(rng.randn(N).astype(np.float32) * 0.1, act)
+    try:
+        ops.set_tuning(0, 2, 0)
+        out = run_gptq(ops, x, qweight, qzeros, scales, g_idx, bits, gs, bias, act, "fp16")
+    finally:
+        ops.set_tuning(0, 0, 0)
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, bits, bias, act, "fp16")
+    assert rel_err(torch_to_f32(out), ref) <= tol(act)
+
+
+def test_tiled_and_skinny_kernels_agree(ops):
+    """Same problem through both kernel families: identical weight rounding, only the accumulation order differs."""
+    K, N, gs, M = 2048, 768, 128, 48
+    qweight, qzeros, scales, g_idx = synth_gptq(99, 4, K, N, gs)
+    x = O.round_to(np.random.RandomState(1).randn(M, K).astype(np.float32) * 0.5, "fp16")
+    outs = []
+    for kern in (1, 2):
+        try:
+            ops.set_tuning(0, kern, 0)
+            outs.append(torch_to_f32(run_gptq(ops, x, qweight, qzeros, scales, g_idx, 4, gs, None, "fp16", "fp16")))
+        finally:
+            ops.set_tuning(0, 0, 0)
+    assert rel_err(outs[0], outs[1]) <= 5e-4
