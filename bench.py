@@ -198,6 +198,18 @@ def main():
     value = world * args.steps / wall
 
     if rank == 0:
+        # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this same command
+        # (profiles/*_pmc_summary.json; gfx950 FETCH_SIZE correction applied there).  PMC cannot be read live here.
+        traffic = None
+        try:
+            import glob
+            summ = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+            if summ and fuse:
+                with open(summ[-1]) as f:
+                    pm = json.load(f)
+                traffic = pm["hbm_read_bytes_per_launch_corrected"] + 1024.0 * pm.get("WRITE_SIZE_KB_per_launch_raw", 0.0)
+        except Exception:
+            traffic = None
         launch_us = ev_ms * 1e3 / (args.steps * n_launch)  # average launch duration incl. inter-kernel gaps
         bytes_per_launch = step_bytes / n_launch
         achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
@@ -212,7 +224,7 @@ def main():
                        "graph": graph is not None, "replicas": world,
                        "weight_bytes_per_token": step_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "gptqhip::skinny_kernel<BITS=4,ACT=f16,SCL=f16,MT=1,GPC=1,AM_ROW4,D=4>",
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_us,
                          "note": "event-timed average over the timed region incl. inter-kernel gaps of the graph"},
