@@ -21,6 +21,8 @@ struct SkinnyPlan {
     int gpc;               // meta words per 128-row chunk (1: group_size % 128 == 0, else 4 = per K-step)
     int chunks;            // ceil(K / 128)
     int waves;             // waves per block (in-block split-K)
+    int depth;             // register-ring depth of the kernel variant the launcher will pick
+    int regular;           // every wave owns a multiple of `depth` chunks
     int chunks_per_split;  // chunks handled by one block
     int splits;            // grid.y (cross-block split-K)
     size_t slab_floats;    // fp32 partial slabs, 0 when splits == 1

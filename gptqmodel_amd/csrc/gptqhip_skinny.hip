@@ -36,6 +36,7 @@ struct SkinnyParams {
     int chunks_per_split;  // chunks handled by one block
     int splits;
     int out_f32;           // epilogue writes raw fp32 accumulators (TP partial sums)
+    int regular;           // every wave owns a multiple of D chunks: straight-line counted-wait pipeline
     int cpg_shift;         // log2(chunks per group) when group_size is 128 * 2^n, else -1 (integer division)
 };
 
@@ -165,22 +166,47 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     // D-deep register ring: every load of a chunk (weights, constants, activations) is issued D chunks ahead,
     // so a wave keeps D KiB of HBM reads in flight and waits only for the oldest stage.
     Stage<BITS, GPC, MT, AM> st[D];
-    {
-        int nxt = c_begin + wave;
+    const int n_mine = c_begin + wave < c_end ? (c_end - c_begin - wave + W - 1) / W : 0;  // chunks of this wave
+    if (p.regular) {
+        // REGULAR: every wave owns a multiple of D chunks (the planner picks W for that).  Straight-line
+        // prologue / steady loop / drain with unconditional loads, so the compiler's s_waitcnt insertion can COUNT
+        // (vmcnt(3*(D-1)) style) instead of draining the queue -- with conditional loads it falls back to
+        // vmcnt(0) before every stage, which serialises the ring.
+        int cur = c_begin + wave;
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (nxt < c_end) load_stage<BITS, GPC, MT, AM>(st[d], p, wbase, mbase, nxt, lane);
-            nxt += W;
-        }
-    }
-    for (int cur = c_begin + wave; cur < c_end;) {
+        for (int d = 0; d < D; ++d) load_stage<BITS, GPC, MT, AM>(st[d], p, wbase, mbase, cur + d * W, lane);
+        for (int it = D; it < n_mine; it += D) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (cur < c_end) {
+            for (int d = 0; d < D; ++d) {
                 compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc);
-                const int nxt = cur + D * W;
-                if (nxt < c_end) load_stage<BITS, GPC, MT, AM>(st[d], p, wbase, mbase, nxt, lane);
+                load_stage<BITS, GPC, MT, AM>(st[d], p, wbase, mbase, cur + D * W, lane);
                 cur += W;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc);
+            cur += W;
+        }
+    } else {
+        // generic: any chunk count per wave (ragged K, forced geometry); conservative waits
+        {
+            int nxt = c_begin + wave;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (nxt < c_end) load_stage<BITS, GPC, MT, AM>(st[d], p, wbase, mbase, nxt, lane);
+                nxt += W;
+            }
+        }
+        for (int cur = c_begin + wave; cur < c_end;) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (cur < c_end) {
+                    compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc);
+                    const int nxt = cur + D * W;
+                    if (nxt < c_end) load_stage<BITS, GPC, MT, AM>(st[d], p, wbase, mbase, nxt, lane);
+                    cur += W;
+                }
             }
         }
     }
@@ -275,6 +301,16 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     // the 4*MT waves the LDS reduce mapping needs
     int waves = pl.chunks >= 64 ? 16 : (pl.chunks >= 32 ? 8 : 4);
     if (tiles <= 256 && pl.chunks >= 16) waves = 16;  // few tiles: one block per CU, go wide on K
+    // prefer a wave count that gives every wave a multiple of the ring depth (regular pipeline, counted waits):
+    // e.g. K=14336 -> 112 chunks -> 14 waves x 8 chunks
+    pl.depth = (pl.mt == 1 && M <= 4) ? 4 : (pl.mt <= 2 ? 2 : 1);
+    {
+        int best = 0;
+        for (int w = 16; w >= 4; --w) {
+            if (pl.chunks % (w * pl.depth) == 0 && w >= waves / 2) { best = w; break; }
+        }
+        if (best > 0 && (best >= waves || pl.chunks / (waves * pl.depth) * (waves * pl.depth) != pl.chunks)) waves = best;
+    }
     if (waves < 4 * pl.mt) waves = 4 * pl.mt;
     if (force_waves > 0) waves = force_waves < 4 * pl.mt ? 4 * pl.mt : force_waves;
     pl.waves = waves;
@@ -290,6 +326,7 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     pl.chunks_per_split = ceil_div(pl.chunks, s);
     pl.splits = ceil_div(pl.chunks, pl.chunks_per_split);
     pl.slab_floats = pl.splits > 1 ? (size_t)pl.splits * M * N : 0;
+    pl.regular = (pl.chunks % pl.chunks_per_split == 0) && (pl.chunks_per_split % (pl.waves * pl.depth) == 0) ? 1 : 0;
     return pl;
 }
 
@@ -311,6 +348,7 @@ int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* co
     p.chunks_per_split = pl.chunks_per_split;
     p.splits = pl.splits;
     p.out_f32 = a.out_f32;
+    p.regular = pl.regular;
     p.cpg_shift = -1;
     if (a.group_size % kChunkK == 0) {
         const int cpg = a.group_size / kChunkK;
