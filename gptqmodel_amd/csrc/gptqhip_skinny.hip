@@ -41,19 +41,30 @@ struct SkinnyParams {
 };
 
 // AM: how a wave gets its activations.
-//   AM_ROW4  (M <= 4):  ONE 16-byte load per lane per chunk (lane = row*16 + segment: 4 rows x 256 B), prefetched
-//                       with the weights; at compute time the wave parks them in its private 1 KiB LDS slot and
-//                       reads the four MFMA A fragments back with broadcast ds_read_b128 (rows >= M give unused
-//                       output rows, so no masking).
+//   AM_ROW1  (M == 1):  ONE 4-byte load per lane per chunk (the chunk's 256 B of the single row), prefetched with the
+//                       weights (1 VGPR per ring stage); at compute time the wave parks them in its private LDS slot
+//                       and reads the four MFMA A fragments back with broadcast ds_read_b128 (all 16 fragment rows
+//                       see row 0: rows >= M feed output rows nobody stores).
+//   AM_ROW4  (M <= 4):  the same with 16 bytes per lane (lane = row*16 + segment: 4 rows x 256 B).
 //   AM_FRAG  (M <= 16*MT): fragment-shaped loads, 4*MT x 16 B per lane per chunk, prefetched with the weights.
 constexpr int AM_ROW4 = 0;
 constexpr int AM_FRAG = 1;
+constexpr int AM_ROW1 = 2;
+
+template <int AM, int MT>
+struct AStage {
+    u4_t a[AM == AM_ROW4 ? 1 : 4 * MT];
+};
+template <int MT>
+struct AStage<AM_ROW1, MT> {
+    uint32_t a[1];
+};
 
 template <int BITS, int GPC, int MT, int AM>
 struct Stage {
     u4_t w[BITS == 4 ? 1 : 2];
     uint32_t meta[GPC];
-    u4_t a[AM == AM_ROW4 ? 1 : 4 * MT];
+    AStage<AM, MT> x;
 };
 
 __device__ __forceinline__ int group_of(const SkinnyParams& p, int k) {  // k is wave-uniform
@@ -66,25 +77,43 @@ __device__ __forceinline__ int group_of(const SkinnyParams& p, int k) {  // k is
     return g < p.G ? g : p.G - 1;  // padded rows beyond K: any finite scale (their activations are 0)
 }
 
+// Addressing: every base below is wave-uniform (kernel arguments, blockIdx, the readfirstlane'd wave id) and every
+// per-lane part is a 32-bit byte offset, so the loads select the scalar-base + vector-offset form and spend no
+// 64-bit VALU adds.
+struct TileBases {
+    const char* w;         // this tile's first (tile, chunk) block
+    const uint32_t* meta;  // this tile's [G][16] constants
+    const char* x;         // activations
+    uint32_t lane16;       // lane * 16
+    uint32_t c4;           // (lane & 15) * 4
+};
+
 template <int BITS, int GPC, int MT, int AM>
-__device__ __forceinline__ void load_stage(Stage<BITS, GPC, MT, AM>& st, const SkinnyParams& p, const u4_t* wbase,
-                                           const uint32_t* mbase, int chunk, int lane) {
+__device__ __forceinline__ void load_stage(Stage<BITS, GPC, MT, AM>& st, const SkinnyParams& p, const TileBases& tb,
+                                           int chunk, int lane) {
     constexpr int WPC = BITS == 4 ? 1 : 2;
-    const u4_t* src = wbase + (size_t)chunk * (WPC * 64);
+    const char* src = tb.w + (size_t)chunk * (WPC * 1024);
 #pragma unroll
-    for (int h = 0; h < WPC; ++h) st.w[h] = __builtin_nontemporal_load(src + h * 64);
+    for (int h = 0; h < WPC; ++h)
+        st.w[h] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(src + h * 1024 + tb.lane16));
 #pragma unroll
-    for (int j = 0; j < GPC; ++j) st.meta[j] = mbase[group_of(p, chunk * kChunkK + j * (kChunkK / GPC)) * 16];
+    for (int j = 0; j < GPC; ++j) {
+        const uint32_t* mrow = tb.meta + group_of(p, chunk * kChunkK + j * (kChunkK / GPC)) * 16;
+        st.meta[j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(mrow) + tb.c4);
+    }
     // activations: no masking anywhere.  Rows >= M only feed output rows nobody stores (address clamped to row 0);
     // k >= K happens only in the zero-padded tail chunk of a ragged K, whose weights dequantise to exactly 0
     // (repack_tiled stores code == zero-point there), so the clamped address may read any finite x.
-    const uint16_t* xs = reinterpret_cast<const uint16_t*>(p.x);
-    if constexpr (AM == AM_ROW4) {
+    if constexpr (AM == AM_ROW1) {
+        uint32_t off = (uint32_t)chunk * 256u + (uint32_t)lane * 4u;       // bytes into row 0
+        off = off < (uint32_t)p.K * 2u ? off : 0u;
+        st.x.a[0] = *reinterpret_cast<const uint32_t*>(tb.x + off);
+    } else if constexpr (AM == AM_ROW4) {
         int row = lane >> 4;
         row = row < p.M ? row : 0;
         int k0 = chunk * kChunkK + 8 * (lane & 15);
         k0 = k0 < p.K ? k0 : 0;
-        st.a[0] = *reinterpret_cast<const u4_t*>(xs + (size_t)row * p.K + k0);
+        st.x.a[0] = *reinterpret_cast<const u4_t*>(tb.x + ((size_t)row * p.K + k0) * 2);
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -94,19 +123,63 @@ __device__ __forceinline__ void load_stage(Stage<BITS, GPC, MT, AM>& st, const S
             for (int mtile = 0; mtile < MT; ++mtile) {
                 int m = mtile * 16 + (lane & 15);
                 m = m < p.M ? m : 0;
-                st.a[j * MT + mtile] = *reinterpret_cast<const u4_t*>(xs + (size_t)m * p.K + k0);
+                st.x.a[j * MT + mtile] = *reinterpret_cast<const u4_t*>(tb.x + ((size_t)m * p.K + k0) * 2);
             }
         }
     }
 }
 
+// FAST loader for the regular pipeline (K % 128 == 0, group_size = 128 * 2^n, every wave owns a multiple of D
+// chunks): a wave-uniform cursor (scalar pointers advanced by constant strides) + per-lane 32-bit offsets computed
+// once.  No clamps, no integer division, no 64-bit vector address arithmetic in the loop.
+struct Cursor {
+    const char* w;  // next (tile, chunk) block this wave loads
+    const char* x;  // activations, advanced to that chunk (row 0)
+    int chunk;
+};
+
+template <int MT, int AM>
+struct LaneOffs {
+    uint32_t x[AM == AM_FRAG ? MT : 1];  // byte offset of this lane's activation load(s) inside the chunk's columns
+};
+
+template <int BITS, int GPC, int MT, int AM>
+__device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, const SkinnyParams& p, const TileBases& tb,
+                                                const LaneOffs<MT, AM>& lo, Cursor& cu, int stride_chunks) {
+    constexpr int WPC = BITS == 4 ? 1 : 2;
+#pragma unroll
+    for (int h = 0; h < WPC; ++h)
+        st.w[h] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(cu.w + h * 1024 + tb.lane16));
+    const char* mrow = reinterpret_cast<const char*>(tb.meta) + ((size_t)(cu.chunk >> p.cpg_shift) << 6);
+    st.meta[0] = *reinterpret_cast<const uint32_t*>(mrow + tb.c4);
+    if constexpr (AM == AM_ROW1) {
+        st.x.a[0] = *reinterpret_cast<const uint32_t*>(cu.x + lo.x[0]);
+    } else if constexpr (AM == AM_ROW4) {
+        st.x.a[0] = *reinterpret_cast<const u4_t*>(cu.x + lo.x[0]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mtile = 0; mtile < MT; ++mtile)
+                st.x.a[j * MT + mtile] = *reinterpret_cast<const u4_t*>(cu.x + lo.x[mtile] + j * 64);
+    }
+    cu.w += (size_t)stride_chunks * (WPC * 1024);
+    cu.x += (size_t)stride_chunks * 256;
+    cu.chunk += stride_chunks;
+}
+
 template <int BITS, int ACT, int SCL, int MT, int GPC, int AM>
 __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st, const SkinnyParams& p, int chunk,
-                                              int lane, u4_t* aslot, const DequantConsts& dk, f4_t (&acc)[2][MT]) {
+                                              int lane, u4_t* aslot, const DequantConsts& dk, f4_t (&acc)[MT]) {
     const int c = lane & 15;
     const int rq = lane >> 4;
-    if constexpr (AM == AM_ROW4) aslot[lane] = st.a[0];
-    const int arow = c < p.M ? c : 0;  // lanes of unused rows re-read row 0: a broadcast, no extra bank traffic
+    int abase = 0;  // u4 index of this lane's fragment row inside the wave's LDS slot
+    if constexpr (AM == AM_ROW1) {
+        reinterpret_cast<uint32_t*>(aslot)[lane] = st.x.a[0];
+    } else if constexpr (AM == AM_ROW4) {
+        aslot[lane] = st.x.a[0];
+        abase = (c < p.M ? c : 0) << 4;  // lanes of unused rows re-read row 0: a broadcast, no extra bank traffic
+    }
     ColConst cc = expand_meta<BITS, SCL>(st.meta[0]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -119,16 +192,14 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
         } else {
             b = dequant_word8<ACT, SCL>(st.w[j >> 1][(j & 1) * 2], st.w[j >> 1][(j & 1) * 2 + 1], cc, dk);
         }
-        if constexpr (AM == AM_ROW4) {
-            // fragment of lane (m = c, rq) = the 16 bytes loaded by lane (c&3)*16 + 4*j + rq (same-wave LDS
-            // accesses execute in order, so the read needs no barrier after the write above)
-            const u4_t av = aslot[(arow << 4) + 4 * j + rq];
-            acc[j & 1][0] = mfma16<ACT>(av, b, acc[j & 1][0]);
+        if constexpr (AM != AM_FRAG) {
+            // fragment of lane (m = c, rq) = the 16 bytes at segment 4*j + rq of row m (same-wave LDS accesses
+            // execute in order, so the read needs no barrier after the write above)
+            const u4_t av = aslot[abase + 4 * j + rq];
+            acc[0] = mfma16<ACT>(av, b, acc[0]);
         } else {
 #pragma unroll
-            for (int mtile = 0; mtile < MT; ++mtile) {
-                acc[j & 1][mtile] = mfma16<ACT>(st.a[j * MT + mtile], b, acc[j & 1][mtile]);
-            }
+            for (int mtile = 0; mtile < MT; ++mtile) acc[mtile] = mfma16<ACT>(st.x.a[j * MT + mtile], b, acc[mtile]);
         }
     }
 }
@@ -152,14 +223,16 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     const int c_begin = split * p.chunks_per_split;
     const int c_end = min(p.chunks, c_begin + p.chunks_per_split);
 
-    f4_t acc[2][MT];
+    f4_t acc[MT];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[h][mt] = f4_t{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-    const u4_t* wbase = reinterpret_cast<const u4_t*>(p.qw) + (size_t)tile * p.chunks * (BITS == 4 ? 64 : 128) + lane;
-    const uint32_t* mbase = p.meta + (size_t)tile * p.G * 16 + c;
+    TileBases tb;
+    tb.w = reinterpret_cast<const char*>(p.qw) + (size_t)tile * p.chunks * (BITS == 4 ? 1024 : 2048);
+    tb.meta = p.meta + (size_t)tile * p.G * 16;
+    tb.x = reinterpret_cast<const char*>(p.x);
+    tb.lane16 = (uint32_t)lane * 16u;
+    tb.c4 = (uint32_t)c * 4u;
     u4_t* aslot = reinterpret_cast<u4_t*>(lds) + wave * 64;
     const DequantConsts dk = make_dequant_consts<BITS>();
 
@@ -168,25 +241,45 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     Stage<BITS, GPC, MT, AM> st[D];
     const int n_mine = c_begin + wave < c_end ? (c_end - c_begin - wave + W - 1) / W : 0;  // chunks of this wave
     if (p.regular) {
-        // REGULAR: every wave owns a multiple of D chunks (the planner picks W for that).  Straight-line
-        // prologue / steady loop / drain with unconditional loads, so the compiler's s_waitcnt insertion can COUNT
-        // (vmcnt(3*(D-1)) style) instead of draining the queue -- with conditional loads it falls back to
-        // vmcnt(0) before every stage, which serialises the ring.
-        int cur = c_begin + wave;
+        // REGULAR: every wave owns a multiple of D chunks (the planner picks W for that), K % 128 == 0 and one
+        // group constant per chunk.  Straight-line prologue / steady loop / drain with unconditional loads, so the
+        // compiler's s_waitcnt insertion can COUNT (vmcnt(3*(D-1)) style) instead of draining the queue -- with
+        // conditional loads it falls back to vmcnt(0) before every stage, which serialises the ring.
+        if constexpr (GPC == 1) {
+            LaneOffs<MT, AM> lo;
+            if constexpr (AM == AM_ROW1) {
+                lo.x[0] = (uint32_t)lane * 4u;
+            } else if constexpr (AM == AM_ROW4) {
+                const int row = rq < p.M ? rq : 0;
+                lo.x[0] = (uint32_t)row * (uint32_t)p.K * 2u + (uint32_t)c * 16u;
+            } else {
 #pragma unroll
-        for (int d = 0; d < D; ++d) load_stage<BITS, GPC, MT, AM>(st[d], p, wbase, mbase, cur + d * W, lane);
-        for (int it = D; it < n_mine; it += D) {
+                for (int mtile = 0; mtile < MT; ++mtile) {
+                    int m = mtile * 16 + c;
+                    m = m < p.M ? m : 0;
+                    lo.x[mtile] = (uint32_t)m * (uint32_t)p.K * 2u + (uint32_t)rq * 16u;
+                }
+            }
+            int cur = c_begin + wave;
+            Cursor cu;
+            cu.w = tb.w + (size_t)cur * (BITS == 4 ? 1024 : 2048);
+            cu.x = tb.x + (size_t)cur * 256;
+            cu.chunk = cur;
+#pragma unroll
+            for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM>(st[d], p, tb, lo, cu, W);
+            for (int it = D; it < n_mine; it += D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc);
+                    load_stage_fast<BITS, GPC, MT, AM>(st[d], p, tb, lo, cu, W);
+                    cur += W;
+                }
+            }
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc);
-                load_stage<BITS, GPC, MT, AM>(st[d], p, wbase, mbase, cur + D * W, lane);
                 cur += W;
             }
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc);
-            cur += W;
         }
     } else {
         // generic: any chunk count per wave (ragged K, forced geometry); conservative waits
@@ -194,7 +287,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
             int nxt = c_begin + wave;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                if (nxt < c_end) load_stage<BITS, GPC, MT, AM>(st[d], p, wbase, mbase, nxt, lane);
+                if (nxt < c_end) load_stage<BITS, GPC, MT, AM>(st[d], p, tb, nxt, lane);
                 nxt += W;
             }
         }
@@ -204,7 +297,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
                 if (cur < c_end) {
                     compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc);
                     const int nxt = cur + D * W;
-                    if (nxt < c_end) load_stage<BITS, GPC, MT, AM>(st[d], p, wbase, mbase, nxt, lane);
+                    if (nxt < c_end) load_stage<BITS, GPC, MT, AM>(st[d], p, tb, nxt, lane);
                     cur += W;
                 }
             }
@@ -212,12 +305,11 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     }
 
     // ---- in-block split-K reduction through LDS -------------------------------------------------
-    if constexpr (AM == AM_ROW4) __syncthreads();  // activation slots alias the reduction buffer
+    if constexpr (AM != AM_FRAG) __syncthreads();  // activation slots alias the reduction buffer
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const f4_t s = acc[0][mt] + acc[1][mt];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[wave][mt * 4 + i][lane] = s[i];
+        for (int i = 0; i < 4; ++i) red[wave][mt * 4 + i][lane] = acc[mt][i];
     }
     __syncthreads();
 
@@ -284,6 +376,7 @@ static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStr
 
 template <int BITS, int ACT, int SCL>
 static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
+    if (pl.mt == 1 && p.M == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1, 4>(p, pl, stream);
     if (pl.mt == 1 && p.M <= 4) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW4, 4>(p, pl, stream);
     if (pl.mt == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_FRAG, 2>(p, pl, stream);
     if (pl.mt == 2) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_FRAG, 2>(p, pl, stream);
@@ -316,7 +409,7 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     pl.waves = waves;
     // cross-block split-K costs a publish + ticket + re-read round trip (~1.5-2 us measured): only worth it
     // when the tiles alone leave most of the chip idle AND there is a long K range to share
-    const int target_blocks = 128;
+    const int target_blocks = 48;
     int s = 1;
     if (tiles < target_blocks && pl.chunks >= 4 * waves) s = ceil_div(target_blocks, tiles);
     int max_s = pl.chunks / waves;  // keep >= 1 chunk per wave
@@ -326,7 +419,10 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     pl.chunks_per_split = ceil_div(pl.chunks, s);
     pl.splits = ceil_div(pl.chunks, pl.chunks_per_split);
     pl.slab_floats = pl.splits > 1 ? (size_t)pl.splits * M * N : 0;
-    pl.regular = (pl.chunks % pl.chunks_per_split == 0) && (pl.chunks_per_split % (pl.waves * pl.depth) == 0) ? 1 : 0;
+    pl.regular = (pl.chunks % pl.chunks_per_split == 0) && (pl.chunks_per_split % (pl.waves * pl.depth) == 0) &&
+                         pl.gpc == 1 && K % kChunkK == 0 && ((group_size / kChunkK) & (group_size / kChunkK - 1)) == 0
+                     ? 1
+                     : 0;
     return pl;
 }
 
