@@ -100,15 +100,28 @@ __device__ __forceinline__ void store_a(const u4_t (&stage)[BM / 32], char* lds,
 template <int BITS, int ACT, int SCL, int GPC, int BM>
 __global__ __launch_bounds__(64 * kTiledWaves) void tiled_kernel(TiledParams p) {
     constexpr int MT = BM / 16;
-    __shared__ __attribute__((aligned(16))) char lds[BM * 256];
+    // two A-tile buffers: the next tile is written while slower waves may still read the current one -> ONE barrier
+    // per 128-deep tile
+    __shared__ __attribute__((aligned(16))) char lds_all[2 * BM * 256];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15;
     const int rq = lane >> 4;
-    const int m0 = blockIdx.y * BM;
-    const int tile0 = blockIdx.x * (kTiledBN / kTileN) + wave * kTilesPerWave;
+    // XCD-aware block order (cdna_hip_programming.md T1): hardware places linear block b on XCD b % 8; remap so each
+    // XCD works on a contiguous run of (bm, bn) pairs -> the blocks sharing one A row-panel reuse it from ONE L2.
+    const int nbx = gridDim.x;
+    const int nwg = nbx * gridDim.y;
+    int lin = blockIdx.y * nbx + blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, idx = lin >> 3;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective for any nwg
+    }
+    const int bm = lin / nbx;
+    const int bn = lin - bm * nbx;
+    const int m0 = bm * BM;
+    const int tile0 = bn * (kTiledBN / kTileN) + wave * kTilesPerWave;
 
     f4_t acc[MT][kTilesPerWave];
 #pragma unroll
@@ -122,11 +135,13 @@ __global__ __launch_bounds__(64 * kTiledWaves) void tiled_kernel(TiledParams p) 
 
     load_a<BM>(astage, p, m0, 0, tid);
     load_b<BITS, GPC>(bcur, p, tile0, 0, lane);
-    store_a<BM>(astage, lds, tid);
+    store_a<BM>(astage, lds_all, tid);
     __syncthreads();
 
     for (int chunk = 0; chunk < p.chunks; ++chunk) {
         const bool more = chunk + 1 < p.chunks;
+        char* lds = lds_all + (chunk & 1) * (BM * 256);
+        char* lds_next = lds_all + ((chunk + 1) & 1) * (BM * 256);
         if (more) {
             load_a<BM>(astage, p, m0, chunk + 1, tid);       // in flight during the MFMA phase
             load_b<BITS, GPC>(bnxt, p, tile0, chunk + 1, lane);
@@ -152,9 +167,8 @@ __global__ __launch_bounds__(64 * kTiledWaves) void tiled_kernel(TiledParams p) 
                 for (int t = 0; t < kTilesPerWave; ++t) acc[mt][t] = mfma16<ACT>(a, b[t], acc[mt][t]);
             }
         }
-        __syncthreads();  // every wave is done reading this A tile
         if (more) {
-            store_a<BM>(astage, lds, tid);
+            store_a<BM>(astage, lds_next, tid);  // the other buffer: its readers passed the previous barrier
             bcur = bnxt;
         }
         __syncthreads();
