@@ -111,7 +111,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b"])
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b"],
+                    help="llama3-8b: the headline config, ranks are independent replicas (weak scaling). "
+                         "llama3-70b: BASELINE configs[4], tensor parallel over all ranks (strong scaling): column-parallel "
+                         "qkv/gate_up, row-parallel o/down with one fp32 RCCL all-reduce each (gptqmodel_amd/utils/tp.py)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per token")
     ap.add_argument("--no-fuse", action="store_true", help="7 launches per layer instead of fused qkv / gate_up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,33 +135,57 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    cfg = LLAMA3_8B
+    cfg = LLAMA3_8B if args.model == "llama3-8b" else LLAMA3_70B
+    tp = world if args.model == "llama3-70b" else 1   # 8B: replicas only (fits one GPU); 70B: TP over the node
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     gs = 128
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     fuse = not args.no_fuse
     lshapes = launch_shapes(cfg, fuse)
+    if tp > 1:
+        # Megatron split of every launch: column-parallel (N / tp) when K == hidden, row-parallel (K / tp) otherwise
+        # (o_proj: K = q dim, down_proj: K = inter).  Shards are generated directly at their sharded shapes.
+        from gptqmodel_amd.utils.tp import _bounds
+        sharded = []
+        for k, n, cnt in lshapes:
+            row_parallel = (n == cfg["hidden"])
+            if row_parallel:
+                _bounds(k, 0, tp, gs, "in_features")
+                sharded.append((k // tp, n, cnt, True))
+            else:
+                _bounds(n, 0, tp, 8, "out_features")
+                sharded.append((k, n // tp, cnt, False))
+    else:
+        sharded = [(k, n, cnt, False) for k, n, cnt in lshapes]
     layers = []
     for _ in range(cfg["layers"]):
-        layers.append([make_linear(k, n, gs, dev, gen, dtype) for k, n, _ in lshapes])
-    xs = {k: (torch.randn((1, k), device=dev, generator=gen) * 0.5).to(dtype) for k in (cfg["hidden"], cfg["inter"])}
+        layers.append([(make_linear(k, n, gs, dev, gen, dtype), rowp) for k, n, _, rowp in sharded])
+    xs = {}
+    for k, _, _, _ in sharded:
+        if k not in xs:
+            xs[k] = (torch.randn((1, k), device=dev, generator=gen) * 0.5).to(dtype)
     n_launch = cfg["layers"] * len(lshapes)
     n_linear = cfg["layers"] * sum(c for _, _, c in lshapes)
-    step_bytes = cfg["layers"] * sum(algorithmic_bytes(1, k, n, gs) for _, k, n in layer_shapes(cfg))
+    step_bytes = cfg["layers"] * sum(algorithmic_bytes(1, k, n, gs) for _, k, n in layer_shapes(cfg))   # whole model
     step_flops = cfg["layers"] * sum(2 * k * n for _, k, n in layer_shapes(cfg))
 
     def token_step():
         for layer in layers:
-            for lin in layer:
-                lin(xs[lin.in_features])
+            for lin, rowp in layer:
+                if rowp and tp > 1:
+                    part = lin.forward_partial(xs[lin.in_features])          # fp32 partial sums of this K-shard
+                    dist.all_reduce(part, op=dist.ReduceOp.SUM)               # RCCL over xGMI, 2 per decoder layer
+                    part.to(dtype)                                            # the reference's single rounding
+                else:
+                    lin(xs[lin.in_features])
 
     stream = torch.cuda.Stream(device=dev)
     graph = None
     with torch.cuda.stream(stream):
         token_step()  # allocates the workspace for this stream outside of capture
         stream.synchronize()
-        if not args.no_graph:
+        if not args.no_graph and tp == 1:  # TP>1: eager (RCCL inside graph capture is untested on the 1-GPU dev box)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
                 token_step()
@@ -195,7 +222,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
     ms_per_step = wall * 1e3 / args.steps
-    value = world * args.steps / wall
+    value = (world if tp == 1 else 1) * args.steps / wall   # replicas add up; a TP group produces one token stream
 
     if rank == 0:
         # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this same command
@@ -211,25 +238,31 @@ def main():
         except Exception:
             traffic = None
         launch_us = ev_ms * 1e3 / (args.steps * n_launch)  # average launch duration incl. inter-kernel gaps
-        bytes_per_launch = step_bytes / n_launch
+        bytes_per_launch = step_bytes / n_launch / tp        # per rank
         achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
         out = {
-            "metric": "llama3_8b_gptq_int4_g128_decode_tokens_per_s", "value": value, "unit": "tokens/s",
+            "metric": ("llama3_8b" if args.model == "llama3-8b" else "llama3_70b") + "_gptq_int4_g128_decode_tokens_per_s",
+            "value": value, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16",
+            "higher_is_better": True, "scaling": "weak" if tp == 1 else "strong", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16",
             "data": "synthetic",
-            "config": {"workload": "Llama-3-8B GPTQ int4 g128 desc_act=False batch=1 decode: 224 quantised linears per token "
-                                   "(q,k,v,o,gate,up,down x 32), M=1, random packed weights",
+            "config": {"workload": ("Llama-3-8B GPTQ int4 g128 desc_act=False batch=1 decode: 224 quantised linears per token "
+                                    "(q,k,v,o,gate,up,down x 32), M=1, random packed weights") if args.model == "llama3-8b" else
+                                   ("Llama-3-70B GPTQ int4 g128 batch=1 decode: 560 quantised linears per token (x 80 layers), M=1, "
+                                    f"tensor parallel TP={tp} (column qkv/gate_up, row o/down + fp32 all-reduce), random packed weights"),
+                       "parallelism": f"replicas x{world}" if tp == 1 else f"tp{tp}",
                        "linears_per_step": n_linear, "launches_per_step": n_launch, "fused_siblings": fuse,
                        "graph": graph is not None, "replicas": world,
                        "weight_bytes_per_token": step_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "gptqhip::skinny_kernel<BITS=4,ACT=f16,SCL=f16,MT=1,GPC=1,AM_ROW4,D=4>",
+                         "kernel": "gptqhip::skinny_kernel<BITS=4,ACT,SCL,MT=1,GPC=1,AM_ROW1,D=4>",
                          "bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_us,
                          "note": "event-timed average over the timed region incl. inter-kernel gaps of the graph"},
             "gemm_tflops_equiv": step_flops * value / world / 1e12,
         }
+        if args.model != "llama3-8b":
+            out["roofline"]["traffic"] = None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, gs)
         print(json.dumps(out), flush=True)

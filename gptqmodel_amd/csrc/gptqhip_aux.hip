@@ -285,6 +285,35 @@ int launch_dequant_tiled(const uint32_t* qweight_t, const uint32_t* meta, const 
 // out[m, k'] = x[m, perm[k']]   (ExllamaV2 gathers A through q_perm the same way,
 // gptqmodel_ext/exllamav2/cuda/q_gemm_kernel_gptq.cuh:79-90)
 // ---------------------------------------------------------------------------------------------
+// One block stages whole rows of x in LDS with coalesced 16-byte loads, then every thread assembles 8 consecutive
+// output columns from LDS (2-byte reads at perm[k']) and writes them as one 16-byte store: both HBM streams are
+// fully coalesced, the random access happens on-chip.  Rows longer than kGatherMaxK halves fall back to the simple
+// kernel.
+constexpr int kGatherMaxK = 16384;  // 32 KiB of LDS per staged row
+
+__global__ __launch_bounds__(256) void gather_cols_lds_kernel(const uint16_t* __restrict__ x,
+                                                              const int32_t* __restrict__ perm,
+                                                              uint16_t* __restrict__ out, int M, int K) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t row[];
+    for (int m = blockIdx.x; m < M; m += gridDim.x) {
+        const u4_t* src = reinterpret_cast<const u4_t*>(x + (size_t)m * K);
+        for (int i = threadIdx.x; i < K / 8; i += blockDim.x) reinterpret_cast<u4_t*>(row)[i] = src[i];
+        __syncthreads();
+        u4_t* dst = reinterpret_cast<u4_t*>(out + (size_t)m * K);
+        for (int i = threadIdx.x; i < K / 8; i += blockDim.x) {
+            const u4_t p0 = *reinterpret_cast<const u4_t*>(perm + 8 * i);
+            const u4_t p1 = *reinterpret_cast<const u4_t*>(perm + 8 * i + 4);
+            u4_t v;
+            v.x = (uint32_t)row[p0.x] | ((uint32_t)row[p0.y] << 16);
+            v.y = (uint32_t)row[p0.z] | ((uint32_t)row[p0.w] << 16);
+            v.z = (uint32_t)row[p1.x] | ((uint32_t)row[p1.y] << 16);
+            v.w = (uint32_t)row[p1.z] | ((uint32_t)row[p1.w] << 16);
+            dst[i] = v;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_cols_kernel(const uint16_t* __restrict__ x,
                                                           const int32_t* __restrict__ perm,
                                                           uint16_t* __restrict__ out, int M, int K) {
@@ -295,10 +324,16 @@ __global__ __launch_bounds__(256) void gather_cols_kernel(const uint16_t* __rest
 }
 
 int launch_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, hipStream_t stream) {
-    const int gy = M < 1024 ? M : 1024;
-    const dim3 grid((K + 255) / 256, gy);
-    hipLaunchKernelGGL(gather_cols_kernel, grid, dim3(256), 0, stream, reinterpret_cast<const uint16_t*>(x), perm,
-                       reinterpret_cast<uint16_t*>(out), M, K);
+    const uint16_t* xs = reinterpret_cast<const uint16_t*>(x);
+    uint16_t* os = reinterpret_cast<uint16_t*>(out);
+    if (K % 8 == 0 && K <= kGatherMaxK && M >= 8) {
+        const int blocks = M < 2048 ? M : 2048;
+        hipLaunchKernelGGL(gather_cols_lds_kernel, dim3(blocks), dim3(256), (size_t)K * 2, stream, xs, perm, os, M, K);
+    } else {
+        const int gy = M < 1024 ? M : 1024;
+        const dim3 grid((K + 255) / 256, gy);
+        hipLaunchKernelGGL(gather_cols_kernel, grid, dim3(256), 0, stream, xs, perm, os, M, K);
+    }
     return check_hip(hipGetLastError(), "gather_cols launch");
 }
 
