@@ -273,6 +273,20 @@ int gptqhip_dequant_tiled(const uint32_t* qweight_t, const uint32_t* meta, const
                                 reinterpret_cast<hipStream_t>(stream));
 }
 
+int gptqhip_pack_gptq(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
+                      int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, gptqhip_stream_t stream) {
+    if (!weight || !scales || !zeros || !g_idx || !qweight || !qzeros) {
+        set_error("gptqhip_pack_gptq: null tensor pointer");
+        return GPTQHIP_EINVAL;
+    }
+    if ((bits != 4 && bits != 8) || K <= 0 || N <= 0 || G <= 0 || K % 32 != 0 || N % 32 != 0) {
+        set_error("gptqhip_pack_gptq: bad args K=%d N=%d G=%d bits=%d (K, N multiples of 32)", K, N, G, bits);
+        return GPTQHIP_EINVAL;
+    }
+    return launch_pack_gptq(weight, scales, zeros, g_idx, qweight, qzeros, K, N, G, bits,
+                            reinterpret_cast<hipStream_t>(stream));
+}
+
 int gptqhip_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, gptqhip_stream_t stream) {
     if (M == 0) return GPTQHIP_OK;
     if (!x || !perm || !out || M < 0 || K <= 0) {

@@ -337,4 +337,65 @@ int launch_gather_cols(const void* x, const int32_t* perm, void* out, int M, int
     return check_hip(hipGetLastError(), "gather_cols launch");
 }
 
+// ---------------------------------------------------------------------------------------------
+// quantise-and-pack (reference: gptqmodel_ext/pack_block_cpu.cpp:105-190).  Thread (r, n) packs the pf codes of
+// packed row r, column n.  __fdiv_rn / rintf keep the IEEE fp32 semantics of the CPU packer (no fast-math).
+// ---------------------------------------------------------------------------------------------
+template <int BITS>
+__global__ __launch_bounds__(256) void pack_qweight_kernel(const float* __restrict__ weight,
+                                                           const float* __restrict__ scales,
+                                                           const int32_t* __restrict__ zeros,
+                                                           const int32_t* __restrict__ g_idx,
+                                                           int32_t* __restrict__ qweight, int K, int N, int G) {
+    constexpr int PF = 32 / BITS;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (n >= N) return;
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        const int k = r * PF + j;
+        int g = g_idx[k];
+        if (g < 0) g += G;
+        g = g < 0 ? 0 : (g >= G ? G - 1 : g);  // range is validated on the host; never index out of bounds
+        float scale = scales[(size_t)g * N + n];
+        const float offset = __fmul_rn((float)zeros[(size_t)g * N + n], scale);
+        if (scale == 0.0f) scale = 1e-6f;
+        float q = rintf(__fdiv_rn(__fadd_rn(weight[(size_t)n * K + k], offset), scale));
+        q = fmaxf(0.0f, fminf(q, (float)((1 << BITS) - 1)));
+        w |= ((uint32_t)(int)q) << (BITS * j);
+    }
+    qweight[(size_t)r * N + n] = (int32_t)w;
+}
+
+template <int BITS>
+__global__ __launch_bounds__(256) void pack_qzeros_kernel(const int32_t* __restrict__ zeros,
+                                                          int32_t* __restrict__ qzeros, int N, size_t words) {
+    constexpr int PF = 32 / BITS;
+    constexpr uint32_t MASK = (1u << BITS) - 1u;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= words) return;
+    const size_t g = i / (N / PF), c = i % (N / PF);
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < PF; ++j) w |= ((uint32_t)zeros[g * N + c * PF + j] & MASK) << (BITS * j);
+    qzeros[i] = (int32_t)w;
+}
+
+int launch_pack_gptq(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
+                     int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, hipStream_t stream) {
+    const int pf = 32 / bits;
+    const dim3 grid((N + 255) / 256, K / pf);
+    const size_t words = (size_t)G * (N / pf);
+    const dim3 gz((unsigned)((words + 255) / 256));
+    if (bits == 4) {
+        hipLaunchKernelGGL(pack_qweight_kernel<4>, grid, dim3(256), 0, stream, weight, scales, zeros, g_idx, qweight, K, N, G);
+        hipLaunchKernelGGL(pack_qzeros_kernel<4>, gz, dim3(256), 0, stream, zeros, qzeros, N, words);
+    } else {
+        hipLaunchKernelGGL(pack_qweight_kernel<8>, grid, dim3(256), 0, stream, weight, scales, zeros, g_idx, qweight, K, N, G);
+        hipLaunchKernelGGL(pack_qzeros_kernel<8>, gz, dim3(256), 0, stream, zeros, qzeros, N, words);
+    }
+    return check_hip(hipGetLastError(), "pack_gptq launch");
+}
+
 }  // namespace gptqhip

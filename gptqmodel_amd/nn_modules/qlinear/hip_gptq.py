@@ -111,6 +111,30 @@ class HipGptqLinear(GPTQQuantLinear):
             out = out.to(in_dtype)
         return out.reshape(out_shape)
 
+    def pack_block(self, linear: torch.nn.Module, scales: torch.Tensor, zeros: torch.Tensor, g_idx: torch.Tensor,
+                   block_in: int = 8192, workers: int = 1):
+        """Quantise-and-pack a float Linear into this module's checkpoint-layout buffers ON THE DEVICE; same
+        signature and bit-exact output as PackableQuantLinear.pack_block (qlinear/__init__.py:1036-1323):
+        scales / zeros arrive as [out, G]."""
+        from gptqmodel_amd import ops
+        dev = linear.weight.device if linear.weight.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        w = linear.weight.detach().to(dev)
+        sc = scales.T.contiguous().to(dev)
+        zr = zeros.T.contiguous().to(dev)
+        qweight, qzeros = ops.pack_gptq(w, sc, zr, g_idx.to(dev), self.bits)
+        self.register_buffer("qweight", qweight)
+        self.register_buffer("qzeros", qzeros)
+        self.register_buffer("scales", sc.to(torch.float16))
+        self.register_buffer("g_idx", g_idx.to(device=dev, dtype=torch.int32))
+        if linear.bias is not None:
+            self.register_buffer("bias", linear.bias.detach().to(device=dev, dtype=torch.float16))
+        else:
+            self.bias = None
+        self.qzero_format(format=2)
+        self._ready = False
+
+    pack = pack_block
+
     def forward_partial(self, x: torch.Tensor) -> torch.Tensor:
         """float32 [.., N] unrounded accumulators without bias: what a row-parallel (K-sharded) tensor-parallel
         layer all-reduces before the single final rounding (gptqmodel_amd/utils/tp.py)."""

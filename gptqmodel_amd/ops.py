@@ -157,6 +157,32 @@ def repack_awq(qweight_awq: torch.Tensor, qzeros_awq: torch.Tensor):
     return qw, qz
 
 
+def pack_gptq(weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, g_idx: torch.Tensor, bits: int):
+    """Device quantise-and-pack: weight [N,K], scales [G,N], zeros [G,N], g_idx [K] -> (qweight, qzeros) in the
+    checkpoint layout, bit-exact with the reference's pack_block."""
+    lib = _lib.load()
+    _require_cuda(weight, scales, zeros, g_idx)
+    N, K = weight.shape
+    G = scales.shape[0]
+    pf = 32 // bits
+    w = weight.to(torch.float32).contiguous()
+    s = scales.to(torch.float32).contiguous()
+    z = zeros.to(torch.int32).contiguous()
+    gi = g_idx.to(torch.int32).contiguous()
+    if gi.numel() != K:
+        raise ValueError(f"g_idx length {gi.numel()} != in_features {K}")
+    gn = torch.where(gi < 0, gi + G, gi)
+    if gn.numel() and (int(gn.min()) < 0 or int(gn.max()) >= G):
+        raise IndexError(f"pack_gptq: g_idx values out of range (groups={G})")
+    qweight = torch.empty((K // pf, N), dtype=torch.int32, device=weight.device)
+    qzeros = torch.empty((G, N // pf), dtype=torch.int32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = lib.gptqhip_pack_gptq(_ptr(w), _ptr(s), _ptr(z), _ptr(gi), _ptr(qweight), _ptr(qzeros), K, N, G, bits,
+                                   _stream(weight.device))
+    _lib.check(rc, "gptqhip_pack_gptq")
+    return qweight, qzeros
+
+
 def gather_cols(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     _require_cuda(x, perm)

@@ -15,6 +15,11 @@ from .backend import BACKEND, normalize_backend
 from .const import DEVICE, FORMAT, METHOD, normalize_device
 
 
+def _supports_pack_api(cls: Type[BaseQuantLinear]) -> bool:
+    """upstream importer.py:37-42: a kernel can be chosen with pack=True iff it exposes pack()/pack_block()."""
+    return callable(getattr(cls, "pack", None)) or callable(getattr(cls, "pack_block", None))
+
+
 def _import_all_qlinear_kernels() -> None:
     from ..nn_modules.qlinear import hip_awq, hip_gptq  # noqa: F401
 
@@ -88,8 +93,6 @@ def select_quant_linear(bits: int, group_size: int, desc_act: bool, sym: bool,
         raise ValueError(f"Unsupported quantization method: `{quant_method}`")
     if format not in supported:
         raise ValueError(f"Unsupported format: `{format}` for quantization method `{quant_method}`")
-    if pack:
-        raise ValueError("gptqmodel_amd kernels are inference-only and cannot pack quantized weights")
     trainable = backend == BACKEND.AUTO_TRAINABLE
 
     if backend in (BACKEND.AUTO, BACKEND.AUTO_TRAINABLE):
@@ -105,6 +108,8 @@ def select_quant_linear(bits: int, group_size: int, desc_act: bool, sym: bool,
             if not ok:
                 last_err = err
                 continue
+            if pack and not _supports_pack_api(cls):
+                continue
             if not multi_select:
                 return cls
             validated.append(cls)
@@ -119,6 +124,9 @@ def select_quant_linear(bits: int, group_size: int, desc_act: bool, sym: bool,
                                dtype=dtype, dynamic=dynamic, device=device, trainable=trainable)
     if not ok:
         raise ValueError(err)
+    if pack and not _supports_pack_api(qlinear):
+        raise ValueError(f"Selected backend `{backend}` with kernel `{qlinear.__name__}` cannot pack quantized weights "
+                         f"for format `{format}`.")
     return [qlinear] if multi_select else qlinear
 
 

@@ -128,6 +128,14 @@ int gptqhip_repack_awq(const int32_t* qweight_awq, const int32_t* qzeros_awq,
                        int32_t* qweight_out, int32_t* qzeros_out, int K, int N, int G,
                        gptqhip_stream_t stream);
 
+/* Quantise-and-pack on the device: weight fp32 [N,K] (nn.Linear layout), scales fp32 [G,N], zeros
+ * int32 [G,N], g_idx int32 [K] (negative entries wrap by +G) -> checkpoint-layout qweight int32 [K*bits/32, N] and
+ * qzeros int32 [G, N*bits/32].  q = clamp(rint((w + zero*scale)/scale), 0, maxq) in fp32, scale == 0 -> 1e-6:
+ * bit-exact with the reference packer pack_block_cpu (gptqmodel_ext/pack_block_cpu.cpp:105-190) and
+ * PackableQuantLinear.pack_block (gptqmodel/nn_modules/qlinear/__init__.py:1036-1323).  K % 32 == 0, N % 32 == 0. */
+int gptqhip_pack_gptq(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
+                      int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, gptqhip_stream_t stream);
+
 /* out[m, k'] = x[m, perm[k']]  (16-bit elements).  Used by gptqhip_gemm internally and exported for tests
  * (ExllamaV2 gathers A through q_perm: gptqmodel_ext/exllamav2/cuda/q_gemm_kernel_gptq.cuh:79-90). */
 int gptqhip_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, gptqhip_stream_t stream);

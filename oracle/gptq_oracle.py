@@ -225,6 +225,24 @@ def pack_awq_cols(vals: np.ndarray) -> np.ndarray:
     return np.bitwise_or.reduce(v << shifts, axis=2).astype(np.uint32).view(np.int32)
 
 
+def quantize_pack_gptq(weight_f32: np.ndarray, scales_f32: np.ndarray, zeros: np.ndarray, g_idx: np.ndarray, bits: int):
+    """The reference packer's quantise-and-pack step: weight [N,K] fp32, scales [G,N] fp32, zeros [G,N] ints, g_idx [K]
+    -> (qweight int32 [K*bits/32, N], qzeros int32 [G, N*bits/32]).
+    q = clamp(rint((w + zero*scale) / scale), 0, maxq) in fp32, scale==0 -> 1e-6, negative g_idx wraps by +G
+    (gptqmodel_ext/pack_block_cpu.cpp:105-143; python path qlinear/__init__.py:1197-1228).  rint = round-half-even
+    like std::nearbyint / torch.round."""
+    w = np.ascontiguousarray(weight_f32, dtype=np.float32)
+    s = np.ascontiguousarray(scales_f32, dtype=np.float32)
+    z = np.asarray(zeros).astype(np.float32)
+    g = normalize_g_idx(g_idx, s.shape[0])
+    off = (z * s).astype(np.float32)                       # scale_zeros = zeros * scales   (fp32)
+    sk = s[g].T.astype(np.float32)                         # [N, K]
+    sk = np.where(sk == 0.0, np.float32(1e-6), sk)
+    q = np.rint(((w + off[g].T) / sk).astype(np.float32))
+    q = np.clip(q, 0, (1 << bits) - 1).astype(np.uint8)    # [N, K]
+    return pack_rows(q.T.copy(), bits), pack_cols(np.asarray(zeros).astype(np.uint8), bits)
+
+
 def act_order_perm(g_idx: np.ndarray) -> np.ndarray:
     """Stable argsort of g_idx: the row order in which the backend stores act-order weights
     (semantics of torch_fused.py:121-151 / utils/marlin.py:368-372)."""

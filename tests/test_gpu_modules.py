@@ -182,3 +182,41 @@ def test_row_parallel_partials_on_one_gpu():
     assert rel_err(torch_to_f32(y_tp), ref) <= 1e-3
     row = tp.RowParallelQuantLinear(shards[0], bias=None)  # world size 1 / no process group: no collective
     assert row(xt[:, :K // 2].contiguous()).dtype == torch.float16
+
+
+def test_device_packer_bit_exact_and_roundtrip():
+    """gptqhip_pack_gptq == the reference packer (golden from pack_block) bit for bit; and a module packed on the
+    device then run through post_init/forward reproduces x @ W_quantised."""
+    from gptqmodel_amd import ops
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    g = load_golden("ref_pack.npz")
+    tags = sorted({k.rsplit("_", 1)[0] for k in g.files if k.endswith("_qweight")})
+    for t in tags:
+        bits = int(t.split("_")[0][1:])
+        qw, qz = ops.pack_gptq(torch.from_numpy(g[t + "_weight"]).to(DEV), torch.from_numpy(g[t + "_scales"]).to(DEV),
+                               torch.from_numpy(g[t + "_zeros"]).to(DEV), torch.from_numpy(g[t + "_g_idx"]).to(DEV), bits)
+        assert np.array_equal(qw.cpu().numpy(), g[t + "_qweight"]), t
+        assert np.array_equal(qz.cpu().numpy(), g[t + "_qzeros"]), t
+    # larger random problem vs the oracle packer + end-to-end through the module API
+    K, N, gs, bits = 1024, 256, 128, 4
+    rng = np.random.RandomState(3)
+    lin = nn.Linear(K, N, bias=True)
+    scales = torch.rand(N, K // gs) * 0.01 + 0.005
+    zeros = torch.randint(0, 16, (N, K // gs)).float()
+    g_idx = torch.arange(K, dtype=torch.int32) // gs
+    mod = HipGptqLinear(bits=bits, group_size=gs, sym=False, desc_act=False, in_features=K, out_features=N, bias=True,
+                        register_buffers=False)
+    mod.pack_block(lin, scales.clone(), zeros.clone(), g_idx.clone())
+    e_qw, e_qz = O.quantize_pack_gptq(lin.weight.detach().numpy(), scales.T.contiguous().numpy(),
+                                      zeros.T.contiguous().numpy().astype(np.int32), g_idx.numpy(), bits)
+    assert np.array_equal(mod.qweight.cpu().numpy(), e_qw) and np.array_equal(mod.qzeros.cpu().numpy(), e_qz)
+    mod.eval()
+    mod.post_init()
+    x = O.round_to(rng.randn(3, K).astype(np.float32) * 0.5, "fp16")
+    out = mod(f32_to_torch(x, "fp16", DEV))
+    ref = O.forward_gptq(x, e_qw, e_qz, torch_to_f32(mod.scales), g_idx.numpy(), bits,
+                         torch_to_f32(mod.bias))
+    assert rel_err(torch_to_f32(out), ref) <= 1e-3
+    with pytest.raises(IndexError):
+        ops.pack_gptq(lin.weight.detach().to(DEV), scales.T.contiguous().to(DEV), zeros.T.contiguous().to(DEV),
+                      torch.full((K,), 99, dtype=torch.int32, device=DEV), bits)

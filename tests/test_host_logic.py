@@ -109,8 +109,9 @@ def test_selection_with_kernels_available(kernels_available):
         sel(4, 128, False, True, device="cpu")
     with pytest.raises(ValueError, match="Unsupported format"):
         sel(4, 128, False, True, device=DEVICE.ROCM, format=FORMAT.GEMM)  # AWQ layout under METHOD.GPTQ
-    with pytest.raises(ValueError):
-        sel(4, 128, False, True, device=DEVICE.ROCM, pack=True)
+    assert sel(4, 128, False, True, device=DEVICE.ROCM, pack=True) is HipGptqLinear   # device packer (pack_block)
+    with pytest.raises(ValueError):                                                  # the AWQ class cannot pack
+        sel(4, 128, False, False, device=DEVICE.ROCM, format=FORMAT.GEMM, quant_method=METHOD.AWQ, pack=True)
 
 
 @pytest.mark.parametrize("kw,ok", [
