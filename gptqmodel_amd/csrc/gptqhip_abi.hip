@@ -211,7 +211,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         a.x = xin;
         a.out = out;
         a.M = M;
-        const TiledPlan tp = plan_tiled(M, K, N, group_size);
+        const TiledPlan tp = plan_tiled(M, K, N, group_size, g_force_waves);  // force_waves doubles as tiled variant
         return launch_tiled(a, tp, stream);
     }
     // skinny kernel, 64 rows at a time

@@ -31,6 +31,7 @@ struct SkinnyPlan {
 struct TiledPlan {
     int gpc;  // meta words per chunk (1 or 4)
     int bm;   // rows per block tile (256 or 128)
+    int waves;  // waves per block (8: 2 column tiles each, 4: 4 column tiles each)
 };
 
 void set_error(const char* fmt, ...);
@@ -39,7 +40,7 @@ int check_hip(hipError_t e, const char* what);
 SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves);
 int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* counters, hipStream_t stream);
 
-TiledPlan plan_tiled(int M, int K, int N, int group_size);
+TiledPlan plan_tiled(int M, int K, int N, int group_size, int force_variant);
 int launch_tiled(const GemmArgs& a, const TiledPlan& pl, hipStream_t stream);
 
 int launch_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* g_idx, void* out,

@@ -22,9 +22,7 @@
 
 namespace gptqhip {
 
-constexpr int kTiledBN = 256;     // columns per block = 8 waves x 2 tiles x 16
-constexpr int kTiledWaves = 8;  // block = 512 threads
-constexpr int kTilesPerWave = 2;
+constexpr int kTiledBN = 256;  // columns per block = WAVES x TPW x 16
 
 struct TiledParams {
     const void* x;
@@ -49,17 +47,17 @@ __device__ __forceinline__ int tiled_group_of(const TiledParams& p, int k) {
     return g < p.G ? g : p.G - 1;
 }
 
-template <int BITS, int GPC>
+template <int BITS, int GPC, int TPW>
 struct BStage {
-    u4_t w[kTilesPerWave][BITS == 4 ? 1 : 2];
-    uint32_t meta[kTilesPerWave][GPC];
+    u4_t w[TPW][BITS == 4 ? 1 : 2];
+    uint32_t meta[TPW][GPC];
 };
 
-template <int BITS, int GPC>
-__device__ __forceinline__ void load_b(BStage<BITS, GPC>& st, const TiledParams& p, int tile0, int chunk, int lane) {
+template <int BITS, int GPC, int TPW>
+__device__ __forceinline__ void load_b(BStage<BITS, GPC, TPW>& st, const TiledParams& p, int tile0, int chunk, int lane) {
     constexpr int WPC = BITS == 4 ? 1 : 2;
 #pragma unroll
-    for (int t = 0; t < kTilesPerWave; ++t) {
+    for (int t = 0; t < TPW; ++t) {
         int tile = tile0 + t;
         tile = tile < p.tiles ? tile : p.tiles - 1;  // ragged N: clamp (those columns are never stored)
         const u4_t* src = reinterpret_cast<const u4_t*>(p.qw) + ((size_t)tile * p.chunks + chunk) * (WPC * 64) + lane;
@@ -71,13 +69,13 @@ __device__ __forceinline__ void load_b(BStage<BITS, GPC>& st, const TiledParams&
     }
 }
 
-// A tile: BM rows x 128 halves (256 B per row), thread t moves 16-byte segments idx = i*512 + t, i < BM/32.
-template <int BM>
-__device__ __forceinline__ void load_a(u4_t (&stage)[BM / 32], const TiledParams& p, int m0, int chunk, int tid) {
+// A tile: BM rows x 128 halves (256 B per row), thread t moves 16-byte segments idx = i*NT + t, i < BM*16/NT.
+template <int BM, int NT>
+__device__ __forceinline__ void load_a(u4_t (&stage)[BM * 16 / NT], const TiledParams& p, int m0, int chunk, int tid) {
     const uint16_t* xs = reinterpret_cast<const uint16_t*>(p.x);
 #pragma unroll
-    for (int i = 0; i < BM / 32; ++i) {
-        const int idx = i * 512 + tid;
+    for (int i = 0; i < BM * 16 / NT; ++i) {
+        const int idx = i * NT + tid;
         int row = m0 + (idx >> 4);
         row = row < p.M ? row : p.M - 1;  // ragged M: duplicate the last row (its outputs are never stored)
         int k = chunk * kChunkK + (idx & 15) * 8;
@@ -86,20 +84,22 @@ __device__ __forceinline__ void load_a(u4_t (&stage)[BM / 32], const TiledParams
     }
 }
 
-template <int BM>
-__device__ __forceinline__ void store_a(const u4_t (&stage)[BM / 32], char* lds, int tid) {
+template <int BM, int NT>
+__device__ __forceinline__ void store_a(const u4_t (&stage)[BM * 16 / NT], char* lds, int tid) {
 #pragma unroll
-    for (int i = 0; i < BM / 32; ++i) {
-        const int idx = i * 512 + tid;
+    for (int i = 0; i < BM * 16 / NT; ++i) {
+        const int idx = i * NT + tid;
         const int row = idx >> 4;
         const int off = row * 256 + (((idx & 15) << 4) ^ ((row & 15) << 4));
         *reinterpret_cast<u4_t*>(lds + off) = stage[i];
     }
 }
 
-template <int BITS, int ACT, int SCL, int GPC, int BM>
-__global__ __launch_bounds__(64 * kTiledWaves) void tiled_kernel(TiledParams p) {
+template <int BITS, int ACT, int SCL, int GPC, int BM, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     constexpr int MT = BM / 16;
+    constexpr int NT = 64 * WAVES;
+    constexpr int TPW = kTiledBN / kTileN / WAVES;  // column tiles per wave
     // two A-tile buffers: the next tile is written while slower waves may still read the current one -> ONE barrier
     // per 128-deep tile
     __shared__ __attribute__((aligned(16))) char lds_all[2 * BM * 256];
@@ -121,21 +121,21 @@ __global__ __launch_bounds__(64 * kTiledWaves) void tiled_kernel(TiledParams p) 
     const int bm = lin / nbx;
     const int bn = lin - bm * nbx;
     const int m0 = bm * BM;
-    const int tile0 = bn * (kTiledBN / kTileN) + wave * kTilesPerWave;
+    const int tile0 = bn * (kTiledBN / kTileN) + wave * TPW;
 
-    f4_t acc[MT][kTilesPerWave];
+    f4_t acc[MT][TPW];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int t = 0; t < kTilesPerWave; ++t) acc[mt][t] = f4_t{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TPW; ++t) acc[mt][t] = f4_t{0.f, 0.f, 0.f, 0.f};
 
     const DequantConsts dk = make_dequant_consts<BITS>();
-    u4_t astage[BM / 32];
-    BStage<BITS, GPC> bcur, bnxt;
+    u4_t astage[BM * 16 / NT];
+    BStage<BITS, GPC, TPW> bcur, bnxt;
 
-    load_a<BM>(astage, p, m0, 0, tid);
-    load_b<BITS, GPC>(bcur, p, tile0, 0, lane);
-    store_a<BM>(astage, lds_all, tid);
+    load_a<BM, NT>(astage, p, m0, 0, tid);
+    load_b<BITS, GPC, TPW>(bcur, p, tile0, 0, lane);
+    store_a<BM, NT>(astage, lds_all, tid);
     __syncthreads();
 
     for (int chunk = 0; chunk < p.chunks; ++chunk) {
@@ -143,14 +143,14 @@ __global__ __launch_bounds__(64 * kTiledWaves) void tiled_kernel(TiledParams p) 
         char* lds = lds_all + (chunk & 1) * (BM * 256);
         char* lds_next = lds_all + ((chunk + 1) & 1) * (BM * 256);
         if (more) {
-            load_a<BM>(astage, p, m0, chunk + 1, tid);       // in flight during the MFMA phase
-            load_b<BITS, GPC>(bnxt, p, tile0, chunk + 1, lane);
+            load_a<BM, NT>(astage, p, m0, chunk + 1, tid);       // in flight during the MFMA phase
+            load_b<BITS, GPC, TPW>(bnxt, p, tile0, chunk + 1, lane);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            u4_t b[kTilesPerWave];
+            u4_t b[TPW];
 #pragma unroll
-            for (int t = 0; t < kTilesPerWave; ++t) {
+            for (int t = 0; t < TPW; ++t) {
                 const ColConst cc = expand_meta<BITS, SCL>(bcur.meta[t][GPC == 4 ? j : 0]);
                 if constexpr (BITS == 4) {
                     b[t] = dequant_word4<ACT, SCL>(bcur.w[t][0][j], cc, dk);
@@ -164,11 +164,11 @@ __global__ __launch_bounds__(64 * kTiledWaves) void tiled_kernel(TiledParams p) 
                 const int off = row * 256 + ((j * 64 + rq * 16) ^ (c << 4));  // (row & 15) == c
                 const u4_t a = *reinterpret_cast<const u4_t*>(lds + off);
 #pragma unroll
-                for (int t = 0; t < kTilesPerWave; ++t) acc[mt][t] = mfma16<ACT>(a, b[t], acc[mt][t]);
+                for (int t = 0; t < TPW; ++t) acc[mt][t] = mfma16<ACT>(a, b[t], acc[mt][t]);
             }
         }
         if (more) {
-            store_a<BM>(astage, lds_next, tid);  // the other buffer: its readers passed the previous barrier
+            store_a<BM, NT>(astage, lds_next, tid);  // the other buffer: its readers passed the previous barrier
             bcur = bnxt;
         }
         __syncthreads();
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64 * kTiledWaves) void tiled_kernel(TiledParams p) 
 
     // ---- epilogue ------------------------------------------------------------------------------------
 #pragma unroll
-    for (int t = 0; t < kTilesPerWave; ++t) {
+    for (int t = 0; t < TPW; ++t) {
         const int n = (tile0 + t) * kTileN + c;
         if (n >= p.N) continue;
         float bias = 0.f;
@@ -203,28 +203,33 @@ __global__ __launch_bounds__(64 * kTiledWaves) void tiled_kernel(TiledParams p) 
 
 // ------------------------------------------------------------------------------------------------
 template <int BITS, int ACT, int SCL, int GPC>
-static int launch_tiled_bm(const TiledParams& p, int bm, hipStream_t stream) {
+static int launch_tiled_bm(const TiledParams& p, int bm, int waves, hipStream_t stream) {
     const dim3 grid(ceil_div(p.N, kTiledBN), ceil_div(p.M, bm));
     if (bm == 256) {
-        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 256>), grid, dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 256, 8>), grid, dim3(512), 0, stream, p);
     } else {
-        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 128>), grid, dim3(512), 0, stream, p);
+        // (a 4-wave x 4-tile variant with two independent blocks per CU was measured 25-30 % slower: 660 vs 950 TF)
+        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 128, 8>), grid, dim3(512), 0, stream, p);
     }
+    (void)waves;
     return check_hip(hipGetLastError(), "tiled_kernel launch");
 }
 
 template <int BITS, int ACT, int SCL>
-static int launch_tiled_gpc(const TiledParams& p, int gpc, int bm, hipStream_t stream) {
-    if (gpc == 1) return launch_tiled_bm<BITS, ACT, SCL, 1>(p, bm, stream);
-    return launch_tiled_bm<BITS, ACT, SCL, 4>(p, bm, stream);
+static int launch_tiled_gpc(const TiledParams& p, int gpc, int bm, int waves, hipStream_t stream) {
+    if (gpc == 1) return launch_tiled_bm<BITS, ACT, SCL, 1>(p, bm, waves, stream);
+    return launch_tiled_bm<BITS, ACT, SCL, 4>(p, bm, waves, stream);
 }
 
-TiledPlan plan_tiled(int M, int K, int N, int group_size) {
+TiledPlan plan_tiled(int M, int K, int N, int group_size, int force_variant) {
     TiledPlan pl;
     pl.gpc = (group_size % kChunkK == 0) ? 1 : 4;
     // 256-row tiles when they alone fill the chip, else 128-row tiles (twice the blocks)
     const long blocks256 = (long)ceil_div(M, 256) * ceil_div(N, kTiledBN);
     pl.bm = blocks256 >= 256 ? 256 : 128;
+    pl.waves = 8;
+    if (force_variant == 1) { pl.bm = 256; pl.waves = 8; }
+    if (force_variant == 2) { pl.bm = 128; pl.waves = 8; }
     (void)K;
     return pl;
 }
@@ -253,7 +258,7 @@ int launch_tiled(const GemmArgs& a, const TiledPlan& pl, hipStream_t stream) {
             p.cpg_shift = sh;
         }
     }
-#define GPTQHIP_TDISPATCH(B, A_, S_) return launch_tiled_gpc<B, A_, S_>(p, pl.gpc, pl.bm, stream)
+#define GPTQHIP_TDISPATCH(B, A_, S_) return launch_tiled_gpc<B, A_, S_>(p, pl.gpc, pl.bm, pl.waves, stream)
     if (a.bits == 4) {
         if (a.act_dtype == kFP16 && a.scale_dtype == kFP16) GPTQHIP_TDISPATCH(4, kFP16, kFP16);
         if (a.act_dtype == kBF16 && a.scale_dtype == kFP16) GPTQHIP_TDISPATCH(4, kBF16, kFP16);

@@ -19,6 +19,12 @@ def run(M, K, N, gs=128, iters=20):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     return ms, 2.0 * M * K * N / ms / 1e9
+variants = [0] if len(sys.argv) < 2 else [int(v) for v in sys.argv[1].split(",")]
 for (M, K, N) in [(128,4096,4096),(512,4096,4096),(2048,4096,4096),(8192,4096,4096),(2048,4096,14336),(2048,14336,4096),(8192,4096,28672),(65536,4096,4096)]:
-    ms, tf = run(M, K, N)
-    print(f"M={M} K={K} N={N}: {ms:.3f} ms  {tf:.1f} TFLOPS", flush=True)
+    res = []
+    for v in variants:
+        ops.set_tuning(0, 0, v)
+        ms, tf = run(M, K, N)
+        res.append(f"v{v}: {ms:.3f} ms {tf:.1f} TFLOPS")
+    ops.set_tuning(0, 0, 0)
+    print(f"M={M} K={K} N={N}: " + " | ".join(res), flush=True)
