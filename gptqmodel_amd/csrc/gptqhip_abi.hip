@@ -31,7 +31,7 @@ int check_hip(hipError_t e, const char* what) {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-constexpr int kSkinnyMaxM = 64;
+constexpr int kSkinnyMaxM = 32;  // above: the MFMA-tiled kernel (split-K when its grid is small)
 constexpr bool kHaveTiled = true;
 constexpr size_t kCounterBytes = 64 * 1024;  // 16384 arrival counters
 
@@ -58,6 +58,10 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
         if (gs <= 0 || K % gs != 0) continue;
         const SkinnyPlan pl = plan_skinny(mchunk, K, N, gs, g_force_split, g_force_waves);
         if (pl.slab_floats > floats) floats = pl.slab_floats;
+    }
+    if (M > kSkinnyMaxM || g_force_kernel == 2) {
+        const TiledPlan tp = plan_tiled(M, K, N, group_size > 0 ? group_size : 128, g_force_waves, g_force_split);
+        if (tp.slab_floats > floats) floats = tp.slab_floats;
     }
     L.slabs_bytes = align_up(floats * sizeof(float), 256);
     L.total = L.slabs_off + L.slabs_bytes;
@@ -211,8 +215,8 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         a.x = xin;
         a.out = out;
         a.M = M;
-        const TiledPlan tp = plan_tiled(M, K, N, group_size, g_force_waves);  // force_waves doubles as tiled variant
-        return launch_tiled(a, tp, stream);
+        const TiledPlan tp = plan_tiled(M, K, N, group_size, g_force_waves, g_force_split);  // force_waves doubles as tiled variant
+        return launch_tiled(a, tp, slabs, stream);
     }
     // skinny kernel, 64 rows at a time
     for (int m0 = 0; m0 < M; m0 += kSkinnyMaxM) {

@@ -32,6 +32,9 @@ struct TiledPlan {
     int gpc;  // meta words per chunk (1 or 4)
     int bm;   // rows per block tile (256 or 128)
     int waves;  // waves per block (8: 2 column tiles each, 4: 4 column tiles each)
+    int splits;            // grid.z (split-K through fp32 slabs + reduce kernel)
+    int chunks_per_split;
+    size_t slab_floats;
 };
 
 void set_error(const char* fmt, ...);
@@ -40,8 +43,8 @@ int check_hip(hipError_t e, const char* what);
 SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves);
 int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* counters, hipStream_t stream);
 
-TiledPlan plan_tiled(int M, int K, int N, int group_size, int force_variant);
-int launch_tiled(const GemmArgs& a, const TiledPlan& pl, hipStream_t stream);
+TiledPlan plan_tiled(int M, int K, int N, int group_size, int force_variant, int force_split);
+int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, hipStream_t stream);
 
 int launch_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* g_idx, void* out,
                    int K, int N, int group_size, int bits, int scale_dtype, int out_dtype, hipStream_t stream);

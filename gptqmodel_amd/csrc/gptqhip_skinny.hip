@@ -46,10 +46,31 @@ struct SkinnyParams {
 //                       and reads the four MFMA A fragments back with broadcast ds_read_b128 (all 16 fragment rows
 //                       see row 0: rows >= M feed output rows nobody stores).
 //   AM_ROW4  (M <= 4):  the same with 16 bytes per lane (lane = row*16 + segment: 4 rows x 256 B).
-//   AM_FRAG  (M <= 16*MT): fragment-shaped loads, 4*MT x 16 B per lane per chunk, prefetched with the weights.
+//   AM_ROWS  (M <= 32): 4*MT loads of 16 B per lane, each covering 4 rows x 256 B in FULL cache lines; the wave
+//                       parks the 16*MT x 128 tile in its LDS slot with rows padded to 272 B so the fragment
+//                       ds_read_b128 (16 rows, same 16-B column) is bank-conflict free.  (Fragment-shaped global
+//                       loads touch 16 half-used lines per instruction and made M=8 2.6x slower than M=1.)
+//   AM_FRAG  (M <= 64): fragment-shaped loads, 4*MT x 16 B per lane per chunk, straight to registers.
 constexpr int AM_ROW4 = 0;
 constexpr int AM_FRAG = 1;
 constexpr int AM_ROW1 = 2;
+constexpr int AM_ROWS = 3;
+constexpr int AM_ROWSH = 4;  // AM_ROWS with the last two (unused) row quads skipped: M <= 16*MT - 8
+constexpr int kRowsPitch = 17;  // u4 per padded LDS row (272 B)
+
+template <int AM, int MT>
+__host__ __device__ constexpr int slot_bytes() {
+    return AM == AM_ROW1 ? 256
+                         : (AM == AM_ROW4 ? 1024 : ((AM == AM_ROWS || AM == AM_ROWSH) ? 16 * MT * kRowsPitch * 16 : 0));
+}
+template <int AM>
+__host__ __device__ constexpr bool is_rows() {
+    return AM == AM_ROWS || AM == AM_ROWSH;
+}
+template <int AM, int MT>
+__host__ __device__ constexpr int row_quads() {  // 4-row groups actually loaded per chunk
+    return AM == AM_ROWSH ? 4 * MT - 2 : 4 * MT;
+}
 
 template <int AM, int MT>
 struct AStage {
@@ -114,6 +135,15 @@ __device__ __forceinline__ void load_stage(Stage<BITS, GPC, MT, AM>& st, const S
         int k0 = chunk * kChunkK + 8 * (lane & 15);
         k0 = k0 < p.K ? k0 : 0;
         st.x.a[0] = *reinterpret_cast<const u4_t*>(tb.x + ((size_t)row * p.K + k0) * 2);
+    } else if constexpr (is_rows<AM>()) {
+        int k0 = chunk * kChunkK + 8 * (lane & 15);
+        k0 = k0 < p.K ? k0 : 0;
+#pragma unroll
+        for (int i = 0; i < row_quads<AM, MT>(); ++i) {
+            int row = 4 * i + (lane >> 4);
+            row = row < p.M ? row : 0;
+            st.x.a[i] = *reinterpret_cast<const u4_t*>(tb.x + ((size_t)row * p.K + k0) * 2);
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -140,7 +170,7 @@ struct Cursor {
 
 template <int MT, int AM>
 struct LaneOffs {
-    uint32_t x[AM == AM_FRAG ? MT : 1];  // byte offset of this lane's activation load(s) inside the chunk's columns
+    uint32_t x[AM == AM_FRAG ? MT : (is_rows<AM>() ? 4 * MT : 1)];  // byte offsets of this lane's activation loads
 };
 
 template <int BITS, int GPC, int MT, int AM>
@@ -156,6 +186,9 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
         st.x.a[0] = *reinterpret_cast<const uint32_t*>(cu.x + lo.x[0]);
     } else if constexpr (AM == AM_ROW4) {
         st.x.a[0] = *reinterpret_cast<const u4_t*>(cu.x + lo.x[0]);
+    } else if constexpr (is_rows<AM>()) {
+#pragma unroll
+        for (int i = 0; i < row_quads<AM, MT>(); ++i) st.x.a[i] = *reinterpret_cast<const u4_t*>(cu.x + lo.x[i]);
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -179,6 +212,10 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
     } else if constexpr (AM == AM_ROW4) {
         aslot[lane] = st.x.a[0];
         abase = (c < p.M ? c : 0) << 4;  // lanes of unused rows re-read row 0: a broadcast, no extra bank traffic
+    } else if constexpr (is_rows<AM>()) {
+        // rows of skipped quads keep whatever the slot held: they only feed output rows >= M, which nobody stores
+#pragma unroll
+        for (int i = 0; i < row_quads<AM, MT>(); ++i) aslot[(4 * i + rq) * kRowsPitch + c] = st.x.a[i];
     }
     ColConst cc = expand_meta<BITS, SCL>(st.meta[0]);
 #pragma unroll
@@ -192,11 +229,17 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
         } else {
             b = dequant_word8<ACT, SCL>(st.w[j >> 1][(j & 1) * 2], st.w[j >> 1][(j & 1) * 2 + 1], cc, dk);
         }
-        if constexpr (AM != AM_FRAG) {
+        if constexpr (AM == AM_ROW1 || AM == AM_ROW4) {
             // fragment of lane (m = c, rq) = the 16 bytes at segment 4*j + rq of row m (same-wave LDS accesses
             // execute in order, so the read needs no barrier after the write above)
             const u4_t av = aslot[abase + 4 * j + rq];
             acc[0] = mfma16<ACT>(av, b, acc[0]);
+        } else if constexpr (is_rows<AM>()) {
+#pragma unroll
+            for (int mtile = 0; mtile < MT; ++mtile) {
+                const u4_t av = aslot[(16 * mtile + c) * kRowsPitch + 4 * j + rq];
+                acc[mtile] = mfma16<ACT>(av, b, acc[mtile]);
+            }
         } else {
 #pragma unroll
             for (int mtile = 0; mtile < MT; ++mtile) acc[mtile] = mfma16<ACT>(st.x.a[j * MT + mtile], b, acc[mtile]);
@@ -206,11 +249,12 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
 
 template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int D>
 __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
-    // one LDS array: per-wave activation slots (AM_ROW4, 16 x 1 KiB) during the K loop, then the split-K
-    // reduction buffer red[16][MT*4][64]
-    __shared__ __attribute__((aligned(16))) float lds[16 * MT * 4 * 64 + 4];
+    // ONE dynamic LDS array (16-B aligned base, no statics in front of it): per-wave activation slots during the K
+    // loop, then the split-K reduction buffer red[W][MT*4][64]; the last 16 bytes hold the "last arriver" flag.
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     float(*red)[MT * 4][64] = reinterpret_cast<float(*)[MT * 4][64]>(lds);
-    int* s_last = reinterpret_cast<int*>(lds + 16 * MT * 4 * 64);
+    constexpr int kSlot = slot_bytes<AM, MT>() > MT * 1024 ? slot_bytes<AM, MT>() : MT * 1024;  // bytes per wave
+    int* s_last = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + (blockDim.x >> 6) * kSlot);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform -> scalar branches
@@ -233,7 +277,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     tb.x = reinterpret_cast<const char*>(p.x);
     tb.lane16 = (uint32_t)lane * 16u;
     tb.c4 = (uint32_t)c * 4u;
-    u4_t* aslot = reinterpret_cast<u4_t*>(lds) + wave * 64;
+    u4_t* aslot = reinterpret_cast<u4_t*>(reinterpret_cast<char*>(lds) + wave * slot_bytes<AM, MT>());
     const DequantConsts dk = make_dequant_consts<BITS>();
 
     // D-deep register ring: every load of a chunk (weights, constants, activations) is issued D chunks ahead,
@@ -252,6 +296,13 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
             } else if constexpr (AM == AM_ROW4) {
                 const int row = rq < p.M ? rq : 0;
                 lo.x[0] = (uint32_t)row * (uint32_t)p.K * 2u + (uint32_t)c * 16u;
+            } else if constexpr (is_rows<AM>()) {
+#pragma unroll
+                for (int i = 0; i < row_quads<AM, MT>(); ++i) {
+                    int row = 4 * i + rq;
+                    row = row < p.M ? row : 0;
+                    lo.x[i] = (uint32_t)row * (uint32_t)p.K * 2u + (uint32_t)c * 16u;
+                }
             } else {
 #pragma unroll
                 for (int mtile = 0; mtile < MT; ++mtile) {
@@ -366,10 +417,12 @@ template <int BITS, int ACT, int SCL, int MT, int AM, int D>
 static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
     const dim3 grid(ceil_div(p.N, kTileN), p.splits);
     const dim3 block(64 * pl.waves);
+    constexpr int kSlot = slot_bytes<AM, MT>() > MT * 1024 ? slot_bytes<AM, MT>() : MT * 1024;
+    const size_t lds_bytes = (size_t)pl.waves * kSlot + 16;
     if (pl.gpc == 1) {
-        hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D>), grid, block, lds_bytes, stream, p);
     } else {
-        hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 4, AM, D>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 4, AM, D>), grid, block, lds_bytes, stream, p);
     }
     return check_hip(hipGetLastError(), "skinny_kernel launch");
 }
@@ -378,8 +431,10 @@ template <int BITS, int ACT, int SCL>
 static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
     if (pl.mt == 1 && p.M == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1, 4>(p, pl, stream);
     if (pl.mt == 1 && p.M <= 4) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW4, 4>(p, pl, stream);
-    if (pl.mt == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_FRAG, 2>(p, pl, stream);
-    if (pl.mt == 2) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_FRAG, 2>(p, pl, stream);
+    if (pl.mt == 1 && p.M <= 8) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROWSH, 2>(p, pl, stream);
+    if (pl.mt == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROWS, 2>(p, pl, stream);
+    if (pl.mt == 2 && p.M <= 24) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWSH, 2>(p, pl, stream);
+    if (pl.mt == 2) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWS, 2>(p, pl, stream);
     return launch_skinny_gpc<BITS, ACT, SCL, 4, AM_FRAG, 1>(p, pl, stream);
 }
 
@@ -404,6 +459,7 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
         }
         if (best > 0 && (best >= waves || pl.chunks / (waves * pl.depth) * (waves * pl.depth) != pl.chunks)) waves = best;
     }
+    if (pl.mt == 2 && waves > 8) waves = 8;  // 8.5 KiB of LDS per wave for the padded activation tile
     if (waves < 4 * pl.mt) waves = 4 * pl.mt;
     if (force_waves > 0) waves = force_waves < 4 * pl.mt ? 4 * pl.mt : force_waves;
     pl.waves = waves;

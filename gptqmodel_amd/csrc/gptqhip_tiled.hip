@@ -35,6 +35,9 @@ struct TiledParams {
     int tiles;  // ceil(N/16)
     int out_f32;
     int cpg_shift;
+    int splits;            // grid.z: K split across blocks (small grids); partials go to `slabs`
+    int chunks_per_split;
+    float* slabs;          // [splits][M][N] fp32 when splits > 1
 };
 
 __device__ __forceinline__ int tiled_group_of(const TiledParams& p, int k) {
@@ -133,15 +136,18 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     u4_t astage[BM * 16 / NT];
     BStage<BITS, GPC, TPW> bcur, bnxt;
 
-    load_a<BM, NT>(astage, p, m0, 0, tid);
-    load_b<BITS, GPC, TPW>(bcur, p, tile0, 0, lane);
+    const int c_begin = blockIdx.z * p.chunks_per_split;
+    const int c_end = min(p.chunks, c_begin + p.chunks_per_split);
+
+    load_a<BM, NT>(astage, p, m0, c_begin, tid);
+    load_b<BITS, GPC, TPW>(bcur, p, tile0, c_begin, lane);
     store_a<BM, NT>(astage, lds_all, tid);
     __syncthreads();
 
-    for (int chunk = 0; chunk < p.chunks; ++chunk) {
-        const bool more = chunk + 1 < p.chunks;
-        char* lds = lds_all + (chunk & 1) * (BM * 256);
-        char* lds_next = lds_all + ((chunk + 1) & 1) * (BM * 256);
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const bool more = chunk + 1 < c_end;
+        char* lds = lds_all + ((chunk - c_begin) & 1) * (BM * 256);
+        char* lds_next = lds_all + ((chunk - c_begin + 1) & 1) * (BM * 256);
         if (more) {
             load_a<BM, NT>(astage, p, m0, chunk + 1, tid);       // in flight during the MFMA phase
             load_b<BITS, GPC, TPW>(bnxt, p, tile0, chunk + 1, lane);
@@ -189,7 +195,9 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
                 const int m = m0 + mt * 16 + 4 * rq + i;
                 if (m >= p.M) continue;
                 const float v = acc[mt][t][i];
-                if (p.out_f32) {
+                if (p.splits > 1) {  // split-K partial: summed, rounded and biased by splitk_reduce_kernel
+                    p.slabs[((size_t)blockIdx.z * p.M + m) * p.N + n] = v;
+                } else if (p.out_f32) {
                     reinterpret_cast<float*>(p.out)[(size_t)m * p.N + n] = v;
                 } else {
                     float y = round_through<ACT>(v);
@@ -201,10 +209,39 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     }
 }
 
+// Sum the split-K slabs in a fixed order (deterministic), then the reference's rounding chain.  One thread per 4
+// consecutive columns (16-byte slab loads).
+template <int ACT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, const void* __restrict__ bias,
+                                                            void* __restrict__ out, int M, int N, int splits, int out_f32) {
+    const size_t quads = (size_t)M * N / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= quads) return;
+    const size_t stride = (size_t)M * N;
+    f4_t s = *reinterpret_cast<const f4_t*>(slabs + 4 * i);
+    for (int sp = 1; sp < splits; ++sp) s += *reinterpret_cast<const f4_t*>(slabs + sp * stride + 4 * i);
+    if (out_f32) {
+        *reinterpret_cast<f4_t*>(reinterpret_cast<float*>(out) + 4 * i) = s;
+        return;
+    }
+    const int n = (int)((4 * i) % N);
+    uint16_t r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float y = round_through<ACT>(s[j]);
+        if (bias != nullptr) y = y + load16_as_f32<ACT>(bias, (size_t)n + j);
+        r[j] = f32_to_16<ACT>(y);
+    }
+    u2_t o;
+    o.x = (uint32_t)r[0] | ((uint32_t)r[1] << 16);
+    o.y = (uint32_t)r[2] | ((uint32_t)r[3] << 16);
+    *reinterpret_cast<u2_t*>(reinterpret_cast<uint16_t*>(out) + 4 * i) = o;
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int BITS, int ACT, int SCL, int GPC>
 static int launch_tiled_bm(const TiledParams& p, int bm, int waves, hipStream_t stream) {
-    const dim3 grid(ceil_div(p.N, kTiledBN), ceil_div(p.M, bm));
+    const dim3 grid(ceil_div(p.N, kTiledBN), ceil_div(p.M, bm), p.splits);
     if (bm == 256) {
         hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 256, 8>), grid, dim3(512), 0, stream, p);
     } else {
@@ -221,7 +258,7 @@ static int launch_tiled_gpc(const TiledParams& p, int gpc, int bm, int waves, hi
     return launch_tiled_bm<BITS, ACT, SCL, 4>(p, bm, waves, stream);
 }
 
-TiledPlan plan_tiled(int M, int K, int N, int group_size, int force_variant) {
+TiledPlan plan_tiled(int M, int K, int N, int group_size, int force_variant, int force_split) {
     TiledPlan pl;
     pl.gpc = (group_size % kChunkK == 0) ? 1 : 4;
     // 256-row tiles when they alone fill the chip, else 128-row tiles (twice the blocks)
@@ -230,11 +267,27 @@ TiledPlan plan_tiled(int M, int K, int N, int group_size, int force_variant) {
     pl.waves = 8;
     if (force_variant == 1) { pl.bm = 256; pl.waves = 8; }
     if (force_variant == 2) { pl.bm = 128; pl.waves = 8; }
-    (void)K;
+    // split K across blocks when the (M, N) grid alone leaves most CUs idle (mid-size M, or K-heavy layers):
+    // fp32 partial slabs + a tiny reduce kernel (a kernel boundary is cheaper than re-reading 100s of KB of slabs
+    // through a last-arriver block -- MI355X_MICROARCH.md "handoff-payload")
+    const int chunks = ceil_div(K, kChunkK);
+    const long blocks = (long)ceil_div(M, pl.bm) * ceil_div(N, kTiledBN);
+    int s = 1;
+    if (blocks <= 128 && chunks >= 8) {
+        s = (int)(256 / blocks);  // measured: splitting grids that already have > 128 blocks loses to the reduce pass
+        if (s > chunks / 4) s = chunks / 4;           // at least 4 chunks (512 rows of K) per block
+        const size_t cap_floats = (size_t)16 << 20;  // 64 MiB of slabs at most
+        while (s > 1 && (size_t)s * M * N > cap_floats) --s;
+        if (s < 1) s = 1;
+    }
+    if (force_split > 0) s = force_split < chunks ? force_split : chunks;
+    pl.chunks_per_split = ceil_div(chunks, s);
+    pl.splits = ceil_div(chunks, pl.chunks_per_split);
+    pl.slab_floats = pl.splits > 1 ? (size_t)pl.splits * M * N : 0;
     return pl;
 }
 
-int launch_tiled(const GemmArgs& a, const TiledPlan& pl, hipStream_t stream) {
+int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, hipStream_t stream) {
     TiledParams p;
     p.x = a.x;
     p.qw = a.qweight;
@@ -249,6 +302,9 @@ int launch_tiled(const GemmArgs& a, const TiledPlan& pl, hipStream_t stream) {
     p.chunks = ceil_div(a.K, kChunkK);
     p.tiles = ceil_div(a.N, kTileN);
     p.out_f32 = a.out_f32;
+    p.splits = pl.splits;
+    p.chunks_per_split = pl.chunks_per_split;
+    p.slabs = slabs;
     p.cpg_shift = -1;
     if (a.group_size % kChunkK == 0) {
         const int cpg = a.group_size / kChunkK;
@@ -258,6 +314,7 @@ int launch_tiled(const GemmArgs& a, const TiledPlan& pl, hipStream_t stream) {
             p.cpg_shift = sh;
         }
     }
+    const int rc_main = [&]() -> int {
 #define GPTQHIP_TDISPATCH(B, A_, S_) return launch_tiled_gpc<B, A_, S_>(p, pl.gpc, pl.bm, pl.waves, stream)
     if (a.bits == 4) {
         if (a.act_dtype == kFP16 && a.scale_dtype == kFP16) GPTQHIP_TDISPATCH(4, kFP16, kFP16);
@@ -271,6 +328,16 @@ int launch_tiled(const GemmArgs& a, const TiledPlan& pl, hipStream_t stream) {
         GPTQHIP_TDISPATCH(8, kBF16, kBF16);
     }
 #undef GPTQHIP_TDISPATCH
+    }();
+    if (rc_main != 0 || pl.splits <= 1) return rc_main;
+    const size_t quads = (size_t)a.M * a.N / 4;
+    const dim3 grid((unsigned)((quads + 255) / 256));
+    if (a.act_dtype == kFP16) {
+        hipLaunchKernelGGL(splitk_reduce_kernel<kFP16>, grid, dim3(256), 0, stream, slabs, a.bias, a.out, a.M, a.N, pl.splits, a.out_f32);
+    } else {
+        hipLaunchKernelGGL(splitk_reduce_kernel<kBF16>, grid, dim3(256), 0, stream, slabs, a.bias, a.out, a.M, a.N, pl.splits, a.out_f32);
+    }
+    return check_hip(hipGetLastError(), "splitk_reduce_kernel launch");
 }
 
 }  // namespace gptqhip

@@ -283,6 +283,24 @@ def test_tiled_prefill_kernel_vs_oracle(ops, bits, K, N, gs, M, act, desc_act):
     assert rel_err(torch_to_f32(out), ref) <= tol(act)
 
 
+@pytest.mark.parametrize("M,K,N,split", [(100, 4096, 1024, 0), (64, 2048, 512, 4), (257, 1024, 1000, 3), (40, 14336, 4096, 0)])
+def test_tiled_split_k(ops, M, K, N, split):
+    """Small (M, N) grids split K across blocks: fp32 slabs + reduce kernel, fixed order => deterministic."""
+    gs = 128 if K % 128 == 0 else 64
+    qweight, qzeros, scales, g_idx = synth_gptq(555, 4, K, N, gs)
+    rng = np.random.RandomState(23)
+    x = O.round_to(rng.randn(M, K).astype(np.float32) * 0.5, "fp16")
+    bias = O.round_to(rng.randn(N).astype(np.float32) * 0.1, "fp16")
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, bias, "fp16", "fp16")
+    try:
+        ops.set_tuning(split, 2, 0)
+        outs = [torch_to_bits(run_gptq(ops, x, qweight, qzeros, scales, g_idx, 4, gs, bias, "fp16", "fp16")) for _ in range(2)]
+    finally:
+        ops.set_tuning(0, 0, 0)
+    assert np.array_equal(outs[0], outs[1])
+    assert rel_err(outs[0].view(np.float16).astype(np.float32), ref) <= 1e-3
+
+
 def test_tiled_and_skinny_kernels_agree(ops):
     """Same problem through both kernel families: identical weight rounding, only the accumulation order differs."""
     K, N, gs, M = 2048, 768, 128, 48
