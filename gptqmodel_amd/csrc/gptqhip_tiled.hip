@@ -98,6 +98,30 @@ __device__ __forceinline__ void store_a(const u4_t (&stage)[BM * 16 / NT], char*
     }
 }
 
+// LDS-DMA staging (global_load_lds_dwordx4): the A tile goes HBM/L2 -> LDS without passing through VGPRs (frees the 32
+// staging registers of the BM=256 variant and the ds_write pass).  The hardware writes wave-uniform base + lane*16,
+// i.e. the LDS image is lane-linear: one instruction fills 4 rows x 256 B.  The XOR swizzle therefore moves to the
+// SOURCE address (lane (r, pos) fetches segment pos ^ (row & 15)) and the fragment reads apply the same XOR
+// (cdna_hip_programming.md rule 21: linear destination + swizzled source + swizzled read).
+template <int BM, int NT>
+__device__ __forceinline__ void stage_a_glds(const TiledParams& p, char* lds_buf, int m0, int chunk, int wave, int lane) {
+    const char* xs = reinterpret_cast<const char*>(p.x);
+#pragma unroll
+    for (int i = 0; i < BM * 16 / NT; ++i) {
+        const int r0 = (i * (NT / 64) + wave) * 4;  // wave-uniform first row of this 1 KiB piece
+        const int rl = r0 + (lane >> 4);
+        int row = m0 + rl;
+        row = row < p.M ? row : p.M - 1;
+        const int seg = (lane & 15) ^ (rl & 15);
+        int k = chunk * kChunkK + seg * 8;
+        k = k < p.K ? k : 0;
+        const char* src = xs + ((size_t)row * p.K + k) * 2;
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_buf + r0 * 256), 16, 0, 0);
+    }
+}
+
 template <int BITS, int ACT, int SCL, int GPC, int BM, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     constexpr int MT = BM / 16;
@@ -133,28 +157,32 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         for (int t = 0; t < TPW; ++t) acc[mt][t] = f4_t{0.f, 0.f, 0.f, 0.f};
 
     const DequantConsts dk = make_dequant_consts<BITS>();
-    u4_t astage[BM * 16 / NT];
     BStage<BITS, GPC, TPW> bcur, bnxt;
 
     const int c_begin = blockIdx.z * p.chunks_per_split;
     const int c_end = min(p.chunks, c_begin + p.chunks_per_split);
 
-    load_a<BM, NT>(astage, p, m0, c_begin, tid);
+    stage_a_glds<BM, NT>(p, lds_all, m0, c_begin, wave, lane);
     load_b<BITS, GPC, TPW>(bcur, p, tile0, c_begin, lane);
-    store_a<BM, NT>(astage, lds_all, tid);
-    __syncthreads();
+    __syncthreads();  // (hipcc drains vmcnt before a barrier while LDS-DMA is in flight: the tile has landed)
 
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         const bool more = chunk + 1 < c_end;
         char* lds = lds_all + ((chunk - c_begin) & 1) * (BM * 256);
         char* lds_next = lds_all + ((chunk - c_begin + 1) & 1) * (BM * 256);
         if (more) {
-            load_a<BM, NT>(astage, p, m0, chunk + 1, tid);       // in flight during the MFMA phase
+            stage_a_glds<BM, NT>(p, lds_next, m0, chunk + 1, wave, lane);  // in flight during the MFMA phase
             load_b<BITS, GPC, TPW>(bnxt, p, tile0, chunk + 1, lane);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            u4_t b[TPW];
+        // Software pipeline inside the chunk (everything is compile-time unrolled, all indices static):
+        //   * A fragments: a ring of PF ds_read_b128 stays in flight ahead of the MFMAs that consume them (the
+        //     compiler otherwise issues 2 reads, waits, 4 MFMAs, ... and exposes the LDS latency every 64 pipe cycles);
+        //   * B fragments of K-step j+1 are dequantised in the middle of step j's MFMA stream (VALU work hides under
+        //     the matrix pipe instead of forming a VALU-only phase).
+        constexpr int PF = 4;
+        u4_t aring[PF];
+        u4_t bnow[TPW], bnext[TPW];
+        auto dequant_step = [&](int j, u4_t (&b)[TPW]) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const ColConst cc = expand_meta<BITS, SCL>(bcur.meta[t][GPC == 4 ? j : 0]);
@@ -164,20 +192,46 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
                     b[t] = dequant_word8<ACT, SCL>(bcur.w[t][j >> 1][(j & 1) * 2], bcur.w[t][j >> 1][(j & 1) * 2 + 1], cc, dk);
                 }
             }
+        };
+        auto a_read = [&](int idx) {  // idx = j * MT + mt
+            const int j = idx / MT, mt = idx % MT;
+            return *reinterpret_cast<const u4_t*>(lds + (mt * 16 + c) * 256 + ((j * 64 + rq * 16) ^ (c << 4)));
+        };
+        // Groups of PF fragments: the reads of group g+1 are issued, then a scheduling fence, then the MFMAs of group g
+        // (PF*TPW of them, >= 128 matrix-pipe cycles) under which those reads land; sched_barrier(0) keeps hipcc from
+        // sinking the reads back next to their consumers.  The next K-step's dequant rides in the MFMA blocks.
+        constexpr int NG = 4 * MT / PF;  // fragment groups per chunk
+        u4_t anext[PF];
+        dequant_step(0, bnow);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int row = mt * 16 + c;
-                const int off = row * 256 + ((j * 64 + rq * 16) ^ (c << 4));  // (row & 15) == c
-                const u4_t a = *reinterpret_cast<const u4_t*>(lds + off);
+        for (int i = 0; i < PF; ++i) aring[i] = a_read(i);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) acc[mt][t] = mfma16<ACT>(a, b[t], acc[mt][t]);
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
+#pragma unroll
+                for (int i = 0; i < PF; ++i) anext[i] = a_read((g + 1) * PF + i);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            const int j = (g * PF) / MT;            // K-step of this group (PF divides MT)
+            const bool last_of_step = ((g + 1) * PF) % MT == 0;
+            if ((g * PF) % MT == 0 && j < 3) dequant_step(j + 1, bnext);   // VALU under this group's MFMAs
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int mt = (g * PF + i) % MT;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) acc[mt][t] = mfma16<ACT>(aring[i], bnow[t], acc[mt][t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (last_of_step && j < 3) {
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) bnow[t] = bnext[t];
+            }
+#pragma unroll
+            for (int i = 0; i < PF; ++i) aring[i] = anext[i];
         }
-        if (more) {
-            store_a<BM, NT>(astage, lds_next, tid);  // the other buffer: its readers passed the previous barrier
-            bcur = bnxt;
-        }
-        __syncthreads();
+        if (more) bcur = bnxt;
+        __syncthreads();  // next tile landed (vmcnt drained by the barrier) and everyone is done with this one
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------
