@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         //     compiler otherwise issues 2 reads, waits, 4 MFMAs, ... and exposes the LDS latency every 64 pipe cycles);
         //   * B fragments of K-step j+1 are dequantised in the middle of step j's MFMA stream (VALU work hides under
         //     the matrix pipe instead of forming a VALU-only phase).
-        constexpr int PF = 4;
+        constexpr int PF = BM == 256 ? 4 : 8;  // measured: deeper spills at BM=256, helps at BM=128
         u4_t aring[PF];
         u4_t bnow[TPW], bnext[TPW];
         auto dequant_step = [&](int j, u4_t (&b)[TPW]) {
@@ -235,13 +235,42 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------
+    if (p.splits == 1 && !p.out_f32) {
+        // 16-bit output: round like the reference, transpose through LDS (the A buffers are free now) and store whole
+        // 16-byte row pieces instead of 2-byte scattered elements.  Wave w owns columns [32w, 32w+32) of the tile:
+        // its LDS slab is BM rows x 64 B.
+        __syncthreads();  // every wave has finished reading the last A tile
+        uint16_t* slab = reinterpret_cast<uint16_t*>(lds_all + wave * (BM * 64));
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int n = (tile0 + t) * kTileN + c;
+            float bias = 0.f;
+            if (p.bias != nullptr && n < p.N) bias = load16_as_f32<ACT>(p.bias, (size_t)n);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float y = round_through<ACT>(acc[mt][t][i]);
+                    if (p.bias != nullptr) y = y + bias;
+                    slab[(mt * 16 + 4 * rq + i) * 32 + t * 16 + c] = f32_to_16<ACT>(y);
+                }
+            }
+        }
+        // same-wave LDS accesses execute in order: no barrier needed between this wave's writes and reads
+        const int n0 = tile0 * kTileN + (lane & 3) * 8;
+#pragma unroll
+        for (int pass = 0; pass < BM / 16; ++pass) {
+            const int row = pass * 16 + (lane >> 2);
+            const u4_t v = *reinterpret_cast<const u4_t*>(slab + row * 32 + (lane & 3) * 8);
+            const int m = m0 + row;
+            if (m < p.M && n0 < p.N) *reinterpret_cast<u4_t*>(reinterpret_cast<uint16_t*>(p.out) + (size_t)m * p.N + n0) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int n = (tile0 + t) * kTileN + c;
         if (n >= p.N) continue;
-        float bias = 0.f;
-        const bool has_bias = p.bias != nullptr;
-        if (has_bias) bias = load16_as_f32<ACT>(p.bias, (size_t)n);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -251,12 +280,8 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
                 const float v = acc[mt][t][i];
                 if (p.splits > 1) {  // split-K partial: summed, rounded and biased by splitk_reduce_kernel
                     p.slabs[((size_t)blockIdx.z * p.M + m) * p.N + n] = v;
-                } else if (p.out_f32) {
-                    reinterpret_cast<float*>(p.out)[(size_t)m * p.N + n] = v;
                 } else {
-                    float y = round_through<ACT>(v);
-                    if (has_bias) y = y + bias;
-                    reinterpret_cast<uint16_t*>(p.out)[(size_t)m * p.N + n] = f32_to_16<ACT>(y);
+                    reinterpret_cast<float*>(p.out)[(size_t)m * p.N + n] = v;
                 }
             }
         }
