@@ -216,12 +216,14 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
             const int j = (g * PF) / MT;            // K-step of this group (PF divides MT)
             const bool last_of_step = ((g + 1) * PF) % MT == 0;
             if ((g * PF) % MT == 0 && j < 3) dequant_step(j + 1, bnext);   // VALU under this group's MFMAs
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int mt = (g * PF + i) % MT;
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) acc[mt][t] = mfma16<ACT>(aring[i], bnow[t], acc[mt][t]);
             }
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (last_of_step && j < 3) {
 #pragma unroll
