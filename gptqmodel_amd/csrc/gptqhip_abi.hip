@@ -59,7 +59,7 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
         const SkinnyPlan pl = plan_skinny(mchunk, K, N, gs, g_force_split, g_force_waves);
         if (pl.slab_floats > floats) floats = pl.slab_floats;
     }
-    if (M > kSkinnyMaxM || g_force_kernel == 2) {
+    if (M > 16 || g_force_kernel == 2) {
         const TiledPlan tp = plan_tiled(M, K, N, group_size > 0 ? group_size : 128, g_force_waves, g_force_split);
         if (tp.slab_floats > floats) floats = tp.slab_floats;
     }
@@ -210,7 +210,10 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     a.scale_dtype = scale_dtype;
     a.out_f32 = partial_f32 ? 1 : 0;
 
-    const bool use_tiled = kHaveTiled && ((g_force_kernel == 2) || (g_force_kernel == 0 && M > kSkinnyMaxM));
+    // measured crossover (profiles/r01_m_sweep.txt): the MFMA-tiled kernel wins above 32 rows, and already above 16
+    // rows on wide layers (N >= 8192, e.g. fused gate_up) where its grid fills the chip without split-K
+    const bool wide = N >= 8192 && M > 16;
+    const bool use_tiled = kHaveTiled && ((g_force_kernel == 2) || (g_force_kernel == 0 && (M > kSkinnyMaxM || wide)));
     if (use_tiled) {
         a.x = xin;
         a.out = out;

@@ -4,13 +4,14 @@ import sys, torch
 sys.path.insert(0, "/root/repo")
 from gptqmodel_amd import ops
 dev = "cuda"
+DT = torch.bfloat16 if "bf16" in sys.argv else torch.float16
 def run(M, K, N, gs=128, iters=20):
     qw = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=dev)
     qz = torch.randint(-2**31, 2**31 - 1, (K // gs, N // 8), dtype=torch.int32, device=dev)
     sc = (torch.rand((K // gs, N), device=dev) * 0.01 + 0.005).half()
     qw_t, meta = ops.repack_tiled(qw, qz, sc, None, gs, 4)
-    x = (torch.randn(M, K, device=dev) * 0.5).half()
-    out = torch.empty((M, N), dtype=torch.float16, device=dev)
+    x = (torch.randn(M, K, device=dev) * 0.5).to(DT)
+    out = torch.empty((M, N), dtype=DT, device=dev)
     for _ in range(3): ops.gemm(x, qw_t, meta, None, None, N, gs, 4, torch.float16, out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -19,7 +20,7 @@ def run(M, K, N, gs=128, iters=20):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     return ms, 2.0 * M * K * N / ms / 1e9
-variants = [0] if len(sys.argv) < 2 else [int(v) for v in sys.argv[1].split(",")]
+variants = [0] if len(sys.argv) < 2 or not sys.argv[1][0].isdigit() else [int(v) for v in sys.argv[1].split(",")]
 for (M, K, N) in [(128,4096,4096),(512,4096,4096),(2048,4096,4096),(8192,4096,4096),(2048,4096,14336),(2048,14336,4096),(8192,4096,28672),(65536,4096,4096)]:
     res = []
     for v in variants:
