@@ -280,6 +280,20 @@ int gptqhip_dequant_tiled(const uint32_t* qweight_t, const uint32_t* meta, const
                                 reinterpret_cast<hipStream_t>(stream));
 }
 
+int gptqhip_embedding(const int64_t* ids, const uint32_t* qweight_t, const uint32_t* meta, const int32_t* inv_perm,
+                      void* out, int32_t* status, int T, int K, int N, int group_size, int bits, int scale_dtype,
+                      gptqhip_stream_t stream) {
+    if (T == 0) return GPTQHIP_OK;
+    if (!ids || !qweight_t || !meta || !out || !status || T < 0 || T > 65535) {
+        set_error("gptqhip_embedding: bad arguments (T=%d, at most 65535 ids per call)", T);
+        return GPTQHIP_EINVAL;
+    }
+    int rc = validate_common("gptqhip_embedding", K, N, group_size, bits);
+    if (rc) return rc;
+    return launch_embedding(ids, qweight_t, meta, inv_perm, out, status, T, K, N, group_size, bits, scale_dtype,
+                            reinterpret_cast<hipStream_t>(stream));
+}
+
 int gptqhip_pack_gptq(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
                       int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, gptqhip_stream_t stream) {
     if (!weight || !scales || !zeros || !g_idx || !qweight || !qzeros) {

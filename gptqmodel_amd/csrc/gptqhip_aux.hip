@@ -338,6 +338,63 @@ int launch_gather_cols(const void* x, const int32_t* perm, void* out, int M, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// embedding gather-dequant from the tiled layout: one thread per (token, column).  Reads one packed word per output
+// element (8x read amplification on a tokens x dim problem that is tiny next to the table itself) instead of
+// materialising the whole [vocab, dim] table like the reference does.
+// ---------------------------------------------------------------------------------------------
+template <int BITS, int SCL>
+__global__ __launch_bounds__(256) void embedding_kernel(const int64_t* __restrict__ ids, const uint32_t* __restrict__ qw,
+                                                        const uint32_t* __restrict__ meta,
+                                                        const int32_t* __restrict__ inv_perm, uint16_t* __restrict__ out,
+                                                        int32_t* __restrict__ status, int T, int K, int N, int G,
+                                                        int group_size, int chunks) {
+    constexpr uint32_t MASK = (1u << BITS) - 1u;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.y;
+    if (n >= N) return;
+    const int64_t id = ids[t];
+    if (id < 0 || id >= K) {
+        if (n == 0) atomicExch(status, 1);
+        out[(size_t)t * N + n] = 0;
+        return;
+    }
+    const int k = inv_perm ? inv_perm[id] : (int)id;  // row in the (group-sorted) tiled matrix
+    const int tile = n >> 4, c = n & 15, chunk = k >> 7, r = k & 127;
+    const int j = r >> 5, rq = (r >> 3) & 3;
+    uint32_t code;
+    if constexpr (BITS == 4) {
+        const uint32_t w = qw[(((size_t)tile * chunks + chunk) * 64 + (rq << 4 | c)) * 4 + j];
+        code = (w >> tiled_shift4(r & 7)) & MASK;
+    } else {
+        const int e8 = r & 7, half = e8 >> 2, h = j >> 1, jj = (j & 1) * 2 + half;
+        const uint32_t w = qw[((((size_t)tile * chunks + chunk) * 2 + h) * 64 + (rq << 4 | c)) * 4 + jj];
+        code = (w >> tiled_shift8(e8 & 3)) & MASK;
+    }
+    const uint32_t mw = meta[((size_t)tile * G + k / group_size) * 16 + c];
+    const int zero = (int)((mw >> 16) & 0x3FFu);
+    const float s = bits16_to_f32<SCL>((uint16_t)(mw & 0xffffu));
+    out[(size_t)t * N + n] = f32_to_16<SCL>(s * (float)((int)code - zero));  // exact product, one rounding
+}
+
+int launch_embedding(const int64_t* ids, const uint32_t* qw, const uint32_t* meta, const int32_t* inv_perm, void* out,
+                     int32_t* status, int T, int K, int N, int group_size, int bits, int scale_dtype,
+                     hipStream_t stream) {
+    const int chunks = ceil_div(K, kChunkK);
+    const int G = K / group_size;
+    const dim3 grid((N + 255) / 256, T);
+    uint16_t* o = reinterpret_cast<uint16_t*>(out);
+#define GPTQHIP_EMB(B, S_) \
+    hipLaunchKernelGGL((embedding_kernel<B, S_>), grid, dim3(256), 0, stream, ids, qw, meta, inv_perm, o, status, T, K, N, G, group_size, chunks)
+    if (bits == 4) {
+        if (scale_dtype == kFP16) GPTQHIP_EMB(4, kFP16); else GPTQHIP_EMB(4, kBF16);
+    } else {
+        if (scale_dtype == kFP16) GPTQHIP_EMB(8, kFP16); else GPTQHIP_EMB(8, kBF16);
+    }
+#undef GPTQHIP_EMB
+    return check_hip(hipGetLastError(), "embedding_kernel launch");
+}
+
+// ---------------------------------------------------------------------------------------------
 // quantise-and-pack (reference: gptqmodel_ext/pack_block_cpu.cpp:105-190).  Thread (r, n) packs the pf codes of
 // packed row r, column n.  __fdiv_rn / rintf keep the IEEE fp32 semantics of the CPU packer (no fast-math).
 // ---------------------------------------------------------------------------------------------

@@ -55,6 +55,9 @@ int launch_repack_awq(const int32_t* qw_awq, const int32_t* qz_awq, int32_t* qw_
 int launch_repack_tiled(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* perm,
                         uint32_t* qweight_t, uint32_t* meta, int K, int N, int group_size, int bits,
                         hipStream_t stream);
+int launch_embedding(const int64_t* ids, const uint32_t* qw, const uint32_t* meta, const int32_t* inv_perm, void* out,
+                     int32_t* status, int T, int K, int N, int group_size, int bits, int scale_dtype,
+                     hipStream_t stream);
 int launch_pack_gptq(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
                      int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, hipStream_t stream);
 int launch_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, hipStream_t stream);

@@ -157,4 +157,48 @@ class HipGptqLinear(GPTQQuantLinear):
                                  self.group_size, self.bits, self._scale_dtype)
 
 
-__all__ = ["HipGptqLinear"]
+class HipQuantEmbeddings(HipGptqLinear):
+    """Quantised embedding table on the HIP backend: the mirror of TorchQuantEmbeddings
+    (gptqmodel/nn_modules/qlinear/torch.py:764-797).  in_features = num_embeddings, out_features = embedding dim; forward
+    takes integer token ids.  Selected by module role, never by backend discovery (SUPPORTS_BACKEND_SELECTION False).
+    Unlike the reference, which dequantises the whole table per call, only the requested rows are decoded."""
+
+    # every SUPPORTS_* must be declared on the class itself (verify_supports_params, like upstream's
+    # TorchQuantEmbeddings which restates them all)
+    SUPPORTS_BACKENDS = [BACKEND.GPTQ_HIP]
+    SUPPORTS_BACKEND_SELECTION = False
+    SUPPORTS_METHODS = [METHOD.GPTQ]
+    SUPPORTS_FORMATS = {FORMAT.GPTQ: 120, FORMAT.GPTQ_V2: 120}
+    SUPPORTS_BITS = [4, 8]
+    SUPPORTS_GROUP_SIZE = [-1, 32, 64, 128, 256, 512, 1024]
+    SUPPORTS_DESC_ACT = [True, False]
+    SUPPORTS_SYM = [True, False]
+    SUPPORTS_SHARDS = True
+    SUPPORTS_TRAINING = False
+    SUPPORTS_AUTO_PADDING = False
+    SUPPORTS_IN_FEATURES_DIVISIBLE_BY = [32]
+    SUPPORTS_OUT_FEATURES_DIVISIBLE_BY = [8]
+    SUPPORTS_DEVICES = [DEVICE.ROCM]
+    SUPPORTS_PLATFORM = [PLATFORM.LINUX]
+    SUPPORTS_PACK_DTYPES = [torch.int32]
+    SUPPORTS_ADAPTERS = []
+    SUPPORTS_DTYPES = [torch.float16, torch.bfloat16]
+    QUANT_TYPE = "hip_gptq_embedding"
+
+    def post_init(self):
+        super().post_init()
+        self._inv_perm = None
+        if self.perm is not None:
+            inv = torch.empty_like(self.perm)
+            inv[self.perm.long()] = torch.arange(self.perm.numel(), dtype=torch.int32, device=self.perm.device)
+            self._inv_perm = inv
+
+    def forward(self, input_ids: torch.Tensor) -> torch.Tensor:
+        if not self._ready:
+            raise RuntimeError("HipQuantEmbeddings.forward called before post_init()")
+        from gptqmodel_amd import ops
+        return ops.embedding(input_ids, self.qweight, self.meta, self._inv_perm, self.in_features, self.out_features,
+                             self.group_size, self.bits, self._scale_dtype)
+
+
+__all__ = ["HipGptqLinear", "HipQuantEmbeddings"]

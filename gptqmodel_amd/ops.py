@@ -157,6 +157,28 @@ def repack_awq(qweight_awq: torch.Tensor, qzeros_awq: torch.Tensor):
     return qw, qz
 
 
+def embedding(ids: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, inv_perm: Optional[torch.Tensor],
+              K: int, N: int, group_size: int, bits: int, scale_dtype: torch.dtype) -> torch.Tensor:
+    """Rows ids[...] of the dequantised [K,N] matrix (tiled layout) in the scales dtype; raises IndexError on ids
+    outside [0, K) like torch.nn.functional.embedding."""
+    lib = _lib.load()
+    _require_cuda(ids, qweight_t, meta, inv_perm)
+    flat = ids.reshape(-1).to(torch.int64).contiguous()
+    T = flat.numel()
+    out = torch.empty((T, N), dtype=scale_dtype, device=qweight_t.device)
+    status = torch.zeros(1, dtype=torch.int32, device=qweight_t.device)
+    with torch.cuda.device(qweight_t.device):
+        for t0 in range(0, T, 65535):
+            t1 = min(T, t0 + 65535)
+            rc = lib.gptqhip_embedding(_ptr(flat[t0:t1]), _ptr(qweight_t), _ptr(meta), _ptr(inv_perm), _ptr(out[t0:t1]),
+                                       _ptr(status), t1 - t0, K, N, group_size, bits, _DT[scale_dtype],
+                                       _stream(qweight_t.device))
+            _lib.check(rc, "gptqhip_embedding")
+    if int(status.item()) != 0:
+        raise IndexError("index out of range in quantised embedding lookup")
+    return out.reshape(tuple(ids.shape) + (N,))
+
+
 def pack_gptq(weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, g_idx: torch.Tensor, bits: int):
     """Device quantise-and-pack: weight [N,K], scales [G,N], zeros [G,N], g_idx [K] -> (qweight, qzeros) in the
     checkpoint layout, bit-exact with the reference's pack_block."""

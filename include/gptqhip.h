@@ -128,6 +128,15 @@ int gptqhip_repack_awq(const int32_t* qweight_awq, const int32_t* qzeros_awq,
                        int32_t* qweight_out, int32_t* qzeros_out, int K, int N, int G,
                        gptqhip_stream_t stream);
 
+/* Quantised embedding lookup: out[t, :] = dequantised row ids[t] of the [K = num_embeddings, N = dim]
+ * matrix held in the TILED layout, in the scales dtype -- replaces TorchQuantEmbeddings.forward
+ * (gptqmodel/nn_modules/qlinear/torch.py:764-797), which dequantises the WHOLE table on every call and then runs
+ * F.embedding.  ids int64 [T]; inv_perm [K] int32 or NULL (act-order: tiled row of checkpoint row k); out [T,N] 16-bit.
+ * Ids outside [0, K) are an error reported through `status` (device int32, set to 1) like torch's index check. */
+int gptqhip_embedding(const int64_t* ids, const uint32_t* qweight_t, const uint32_t* meta, const int32_t* inv_perm,
+                      void* out, int32_t* status, int T, int K, int N, int group_size, int bits, int scale_dtype,
+                      gptqhip_stream_t stream);
+
 /* Quantise-and-pack on the device: weight fp32 [N,K] (nn.Linear layout), scales fp32 [G,N], zeros
  * int32 [G,N], g_idx int32 [K] (negative entries wrap by +G) -> checkpoint-layout qweight int32 [K*bits/32, N] and
  * qzeros int32 [G, N*bits/32].  q = clamp(rint((w + zero*scale)/scale), 0, maxq) in fp32, scale == 0 -> 1e-6:

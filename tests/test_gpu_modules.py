@@ -220,3 +220,27 @@ def test_device_packer_bit_exact_and_roundtrip():
     with pytest.raises(IndexError):
         ops.pack_gptq(lin.weight.detach().to(DEV), scales.T.contiguous().to(DEV), zeros.T.contiguous().to(DEV),
                       torch.full((K,), 99, dtype=torch.int32, device=DEV), bits)
+
+
+@pytest.mark.parametrize("bits,desc_act", [(4, False), (4, True), (8, False)])
+def test_quant_embeddings_match_reference_semantics(bits, desc_act):
+    """HipQuantEmbeddings.forward(ids) == F.embedding(ids, dequantize_weight()) -- the reference's TorchQuantEmbeddings
+    (torch.py:764-797) -- bit for bit, without materialising the table."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipQuantEmbeddings
+    V, D, gs = 1024, 256, 128   # in_features = num_embeddings, out_features = dim
+    qweight, qzeros, scales, g_idx = synth_gptq(64 + bits, bits, V, D, gs, desc_act=desc_act)
+    emb = HipQuantEmbeddings(bits=bits, group_size=gs, sym=False, desc_act=desc_act, in_features=V, out_features=D, bias=False)
+    emb.qweight, emb.qzeros = torch.from_numpy(qweight), torch.from_numpy(qzeros)
+    emb.scales, emb.g_idx = f32_to_torch(scales, "fp16"), torch.from_numpy(g_idx)
+    emb.qzero_format(format=2)
+    emb = emb.to(DEV).eval()
+    emb.post_init()
+    ids = torch.tensor([[0, 1, 127, 128], [1023, 512, 5, 5]], device=DEV)
+    out = emb(ids)
+    assert out.shape == (2, 4, D) and out.dtype == torch.float16
+    table = O.dequant_gptq(qweight, qzeros, scales, g_idx, bits)           # [V, D], bit-exact with the reference
+    exp = table[ids.cpu().numpy()]
+    assert np.array_equal(torch_to_f32(out), exp)
+    assert np.array_equal(torch_to_bits(emb.dequantize_weight()), table.astype(np.float16).view(np.uint16))
+    with pytest.raises(IndexError):
+        emb(torch.tensor([V], device=DEV))

@@ -314,3 +314,22 @@ def test_tiled_and_skinny_kernels_agree(ops):
         finally:
             ops.set_tuning(0, 0, 0)
     assert rel_err(outs[0], outs[1]) <= 5e-4
+
+
+def test_lm_head_sized_layer_column_slices(ops):
+    """N = 128256 (Llama-3 lm_head): 8016 column tiles in one launch.  The full oracle product
+    would need GBs, so the first / last / a middle 256-column slice are checked against the oracle on sliced tensors
+    (columns are independent: a size-independent property of the path)."""
+    K, N, gs = 4096, 128256, 128
+    rng = np.random.RandomState(77)
+    qweight = rng.randint(-2**31, 2**31, size=(K // 8, N), dtype=np.int64).astype(np.int32)
+    qzeros = rng.randint(-2**31, 2**31, size=(K // gs, N // 8), dtype=np.int64).astype(np.int32)
+    scales = O.round_to(rng.rand(K // gs, N).astype(np.float32) * 0.01 + 0.005, "fp16")
+    g_idx = (np.arange(K) // gs).astype(np.int32)
+    x = O.round_to(rng.randn(2, K).astype(np.float32) * 0.5, "fp16")
+    out = torch_to_f32(run_gptq(ops, x, qweight, qzeros, scales, g_idx, 4, gs, None, "fp16", "fp16"))
+    assert out.shape == (2, N)
+    for n0 in (0, 64000, N - 256):
+        sl = slice(n0, n0 + 256)
+        ref = O.forward_gptq(x, qweight[:, sl], qzeros[:, n0 // 8:(n0 + 256) // 8], scales[:, sl], g_idx, 4)
+        assert rel_err(out[:, sl], ref) <= 1e-3
