@@ -1,4 +1,4 @@
-// Skinny fused dequant-GEMM for decode / small batch (M <= 64): HBM-bound streaming of the packed
+// Skinny fused dequant-GEMM for decode / small batch (M <= 32): HBM-bound streaming of the packed
 // weights with the dequantisation fused into the MFMA contraction.
 //
 // Replaces the reference hot loop TorchLinear._forward_eager (gptqmodel/nn_modules/qlinear/torch.py:326-347)
@@ -7,17 +7,20 @@
 // Mapping (wave64, mfma_f32_16x16x32, tile-major layout of gptqhip_device.h):
 //   * A block owns ONE 16-column tile; its W waves (4..16) split the tile's K range chunk by chunk
 //     (chunk = 128 rows).  One dwordx4 per lane = one (tile, chunk) block = 1 KiB contiguous; wave w reads
-//     chunk c0+w, c0+w+W, ... so the block streams one linear address range with 16 KiB in flight per
-//     "round" and every byte is fetched exactly once (non-temporal: no reuse).
+//     chunk c0+w, c0+w+W, ... so the block streams one linear address range and every byte is fetched exactly
+//     once (non-temporal: no reuse).
 //   * Each int32 word is one lane's B fragment (8 consecutive k of its column): HBM -> VGPR ->
 //     (and_or magic, pk_add/pk_fma, pk_mul) -> MFMA operand.  No LDS, no cross-lane traffic for weights.
-//   * Activations (x is M*K*2 bytes, L2 resident; natural k order matches the tiled nibble order): for M <= 4
-//     ONE 16-byte load per lane per chunk + ds_bpermute to build the A fragments; otherwise fragment-shaped
-//     loads x[m = l&15][k0 + 8*(l>>4) .. +7].  Both are prefetched in the same register ring as the weights.
-//   * Reduction: the W partial 16xMT*16 accumulators meet in LDS (in-block split-K).  Only when N/16 tiles
-//     cannot fill the 256 CUs does K also split across blocks (grid.y): fp32 slabs published with
-//     write-through (sc1) stores + one relaxed agent-scope ticket, reduced by the last arriver in a fixed
-//     order (deterministic, no float atomics) -- cdna_hip_programming.md §5 "in-launch split-K reduction".
+//   * A D-deep register ring per wave keeps D chunks (weights + constants + activations) in flight; in the
+//     "regular" case (the planner picks W so every wave owns a multiple of D chunks) the loop is straight-line with
+//     unconditional loads so hipcc emits COUNTED s_waitcnt vmcnt(N) instead of draining the queue.
+//   * Activations (x is M*K*2 bytes, L2 resident; natural k order matches the tiled nibble order) are loaded in
+//     full cache lines with the ring, parked in the wave's private LDS slot and read back as MFMA A fragments
+//     (AM_ROW1 / AM_ROW4 / AM_ROWS below).  Rows >= M only feed output rows nobody stores: no masking.
+//   * Reduction: the W partial accumulators meet in LDS (in-block split-K).  Only when N/16 tiles cannot occupy
+//     the chip does K also split across blocks (grid.y): fp32 slabs published with write-through (sc1) stores + one
+//     relaxed agent-scope ticket, reduced by the last arriver in a fixed order (deterministic, no float atomics)
+//     -- cdna_hip_programming.md §5 "in-launch split-K reduction".
 #include "gptqhip_device.h"
 #include "gptqhip_host.h"
 
@@ -50,9 +53,7 @@ struct SkinnyParams {
 //                       parks the 16*MT x 128 tile in its LDS slot with rows padded to 272 B so the fragment
 //                       ds_read_b128 (16 rows, same 16-B column) is bank-conflict free.  (Fragment-shaped global
 //                       loads touch 16 half-used lines per instruction and made M=8 2.6x slower than M=1.)
-//   AM_FRAG  (M <= 64): fragment-shaped loads, 4*MT x 16 B per lane per chunk, straight to registers.
 constexpr int AM_ROW4 = 0;
-constexpr int AM_FRAG = 1;
 constexpr int AM_ROW1 = 2;
 constexpr int AM_ROWS = 3;
 constexpr int AM_ROWSH = 4;  // AM_ROWS with the last two (unused) row quads skipped: M <= 16*MT - 8
@@ -144,18 +145,6 @@ __device__ __forceinline__ void load_stage(Stage<BITS, GPC, MT, AM>& st, const S
             row = row < p.M ? row : 0;
             st.x.a[i] = *reinterpret_cast<const u4_t*>(tb.x + ((size_t)row * p.K + k0) * 2);
         }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int k0 = chunk * kChunkK + 32 * j + 8 * (lane >> 4);
-            k0 = k0 < p.K ? k0 : 0;
-#pragma unroll
-            for (int mtile = 0; mtile < MT; ++mtile) {
-                int m = mtile * 16 + (lane & 15);
-                m = m < p.M ? m : 0;
-                st.x.a[j * MT + mtile] = *reinterpret_cast<const u4_t*>(tb.x + ((size_t)m * p.K + k0) * 2);
-            }
-        }
     }
 }
 
@@ -170,7 +159,7 @@ struct Cursor {
 
 template <int MT, int AM>
 struct LaneOffs {
-    uint32_t x[AM == AM_FRAG ? MT : (is_rows<AM>() ? 4 * MT : 1)];  // byte offsets of this lane's activation loads
+    uint32_t x[is_rows<AM>() ? 4 * MT : 1];  // byte offsets of this lane's activation loads
 };
 
 template <int BITS, int GPC, int MT, int AM>
@@ -189,12 +178,6 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
     } else if constexpr (is_rows<AM>()) {
 #pragma unroll
         for (int i = 0; i < row_quads<AM, MT>(); ++i) st.x.a[i] = *reinterpret_cast<const u4_t*>(cu.x + lo.x[i]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mtile = 0; mtile < MT; ++mtile)
-                st.x.a[j * MT + mtile] = *reinterpret_cast<const u4_t*>(cu.x + lo.x[mtile] + j * 64);
     }
     cu.w += (size_t)stride_chunks * (WPC * 1024);
     cu.x += (size_t)stride_chunks * 256;
@@ -240,9 +223,6 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
                 const u4_t av = aslot[(16 * mtile + c) * kRowsPitch + 4 * j + rq];
                 acc[mtile] = mfma16<ACT>(av, b, acc[mtile]);
             }
-        } else {
-#pragma unroll
-            for (int mtile = 0; mtile < MT; ++mtile) acc[mtile] = mfma16<ACT>(st.x.a[j * MT + mtile], b, acc[mtile]);
         }
     }
 }
@@ -303,13 +283,6 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
                     row = row < p.M ? row : 0;
                     lo.x[i] = (uint32_t)row * (uint32_t)p.K * 2u + (uint32_t)c * 16u;
                 }
-            } else {
-#pragma unroll
-                for (int mtile = 0; mtile < MT; ++mtile) {
-                    int m = mtile * 16 + c;
-                    m = m < p.M ? m : 0;
-                    lo.x[mtile] = (uint32_t)m * (uint32_t)p.K * 2u + (uint32_t)rq * 16u;
-                }
             }
             int cur = c_begin + wave;
             Cursor cu;
@@ -356,7 +329,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     }
 
     // ---- in-block split-K reduction through LDS -------------------------------------------------
-    if constexpr (AM != AM_FRAG) __syncthreads();  // activation slots alias the reduction buffer
+    __syncthreads();  // the activation slots alias the reduction buffer
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -435,13 +408,13 @@ static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStre
     if (pl.mt == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROWS, 2>(p, pl, stream);
     if (pl.mt == 2 && p.M <= 24) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWSH, 2>(p, pl, stream);
     if (pl.mt == 2) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWS, 2>(p, pl, stream);
-    return launch_skinny_gpc<BITS, ACT, SCL, 4, AM_FRAG, 1>(p, pl, stream);
+    return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWS, 2>(p, pl, stream);  // (callers chunk M to <= 32 rows)
 }
 
 SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves) {
     SkinnyPlan pl;
     const int mtiles = ceil_div(M, 16);
-    pl.mt = mtiles <= 1 ? 1 : (mtiles <= 2 ? 2 : 4);
+    pl.mt = mtiles <= 1 ? 1 : 2;  // gptqhip_gemm feeds at most 32 rows per launch
     pl.gpc = (group_size % kChunkK == 0) ? 1 : 4;
     pl.chunks = ceil_div(K, kChunkK);
     const int tiles = ceil_div(N, kTileN);
@@ -451,7 +424,7 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     if (tiles <= 256 && pl.chunks >= 16) waves = 16;  // few tiles: one block per CU, go wide on K
     // prefer a wave count that gives every wave a multiple of the ring depth (regular pipeline, counted waits):
     // e.g. K=14336 -> 112 chunks -> 14 waves x 8 chunks
-    pl.depth = (pl.mt == 1 && M <= 4) ? 4 : (pl.mt <= 2 ? 2 : 1);
+    pl.depth = (pl.mt == 1 && M <= 4) ? 4 : 2;
     {
         int best = 0;
         for (int w = 16; w >= 4; --w) {
