@@ -36,6 +36,7 @@ SIGNATURES = {
     "gptqhip_repack_awq": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "gptqhip_embedding": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_pack_gptq": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "gptqhip_pack_gptq_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gptqhip_gather_cols": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "gptqhip_set_tuning": (_i, [_i, _i, _i]),
 }

@@ -1,9 +1,14 @@
 // C ABI of libgptqhip.so (declared in include/gptqhip.h): argument validation, workspace carving,
 // kernel selection.  No torch types, no global mutable state besides the thread-local error string and
 // the process-wide tuning overrides used by benchmarks.
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+
+#include <algorithm>
+#include <thread>
+#include <vector>
 
 #include "../../include/gptqhip.h"
 #include "gptqhip_device.h"
@@ -306,6 +311,63 @@ int gptqhip_pack_gptq(const float* weight, const float* scales, const int32_t* z
     }
     return launch_pack_gptq(weight, scales, zeros, g_idx, qweight, qzeros, K, N, G, bits,
                             reinterpret_cast<hipStream_t>(stream));
+}
+
+int gptqhip_pack_gptq_host(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
+                           int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, int threads) {
+    if (!weight || !scales || !zeros || !g_idx || !qweight || !qzeros) {
+        set_error("gptqhip_pack_gptq_host: null pointer");
+        return GPTQHIP_EINVAL;
+    }
+    if ((bits != 4 && bits != 8) || K <= 0 || N <= 0 || G <= 0 || K % 32 != 0 || N % 32 != 0) {
+        set_error("gptqhip_pack_gptq_host: bad args K=%d N=%d G=%d bits=%d (K, N multiples of 32)", K, N, G, bits);
+        return GPTQHIP_EINVAL;
+    }
+    for (int k = 0; k < K; ++k) {
+        const int g = g_idx[k] < 0 ? g_idx[k] + G : g_idx[k];
+        if (g < 0 || g >= G) {
+            set_error("gptqhip_pack_gptq_host: g_idx[%d]=%d is out of range for groups=%d", k, g_idx[k], G);
+            return GPTQHIP_EINVAL;
+        }
+    }
+    const int pf = 32 / bits;
+    const int rows = K / pf;
+    const float maxq = (float)((1 << bits) - 1);
+    auto work = [&](int r0, int r1) {
+        for (int r = r0; r < r1; ++r) {
+            for (int n = 0; n < N; ++n) {
+                uint32_t w = 0;
+                for (int j = 0; j < pf; ++j) {
+                    const int k = r * pf + j;
+                    const int g = g_idx[k] < 0 ? g_idx[k] + G : g_idx[k];
+                    float scale = scales[(size_t)g * N + n];
+                    const float offset = (float)zeros[(size_t)g * N + n] * scale;
+                    if (scale == 0.0f) scale = 1e-6f;
+                    float q = nearbyintf((weight[(size_t)n * K + k] + offset) / scale);
+                    q = std::max(0.0f, std::min(q, maxq));
+                    w |= ((uint32_t)(int)q) << (bits * j);
+                }
+                qweight[(size_t)r * N + n] = (int32_t)w;
+            }
+        }
+    };
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    nt = std::max(1, std::min(nt, rows));
+    std::vector<std::thread> pool;
+    const int per = (rows + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        const int r0 = t * per, r1 = std::min(rows, r0 + per);
+        if (r0 < r1) pool.emplace_back(work, r0, r1);
+    }
+    for (auto& th : pool) th.join();
+    const uint32_t mask = (1u << bits) - 1u;
+    for (int g = 0; g < G; ++g)
+        for (int c = 0; c < N / pf; ++c) {
+            uint32_t w = 0;
+            for (int j = 0; j < pf; ++j) w |= ((uint32_t)zeros[(size_t)g * N + c * pf + j] & mask) << (bits * j);
+            qzeros[(size_t)g * (N / pf) + c] = (int32_t)w;
+        }
+    return GPTQHIP_OK;
 }
 
 int gptqhip_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, gptqhip_stream_t stream) {

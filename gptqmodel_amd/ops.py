@@ -205,6 +205,31 @@ def pack_gptq(weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, g
     return qweight, qzeros
 
 
+def pack_gptq_host(weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, g_idx: torch.Tensor, bits: int,
+                   threads: int = 0):
+    """Host (CPU tensors) quantise-and-pack through the library's threaded C++ packer -- the equivalent of the
+    reference's native pack_block_cpu.  Same contract as pack_gptq; needs no GPU."""
+    lib = _lib.load()
+    for t in (weight, scales, zeros, g_idx):
+        if t.is_cuda:
+            raise RuntimeError("pack_gptq_host takes CPU tensors (use pack_gptq on the device)")
+    N, K = weight.shape
+    G = scales.shape[0]
+    pf = 32 // bits
+    w = weight.to(torch.float32).contiguous()
+    s = scales.to(torch.float32).contiguous()
+    z = zeros.to(torch.int32).contiguous()
+    gi = g_idx.to(torch.int32).contiguous()
+    if gi.numel() != K:
+        raise ValueError(f"g_idx length {gi.numel()} != in_features {K}")
+    qweight = torch.empty((K // pf, N), dtype=torch.int32)
+    qzeros = torch.empty((G, N // pf), dtype=torch.int32)
+    rc = lib.gptqhip_pack_gptq_host(_ptr(w), _ptr(s), _ptr(z), _ptr(gi), _ptr(qweight), _ptr(qzeros), K, N, G, bits,
+                                    threads)
+    _lib.check(rc, "gptqhip_pack_gptq_host")
+    return qweight, qzeros
+
+
 def gather_cols(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     _require_cuda(x, perm)

@@ -145,6 +145,12 @@ int gptqhip_embedding(const int64_t* ids, const uint32_t* qweight_t, const uint3
 int gptqhip_pack_gptq(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
                       int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, gptqhip_stream_t stream);
 
+/* The same quantise-and-pack on the HOST (all pointers are CPU memory): the C++ equivalent of the reference's native
+ * packer gptqmodel::pack_block_cpu (gptqmodel_ext/pack_block_cpu.cpp:230-239, at::parallel_for over K/32 blocks :100),
+ * threaded over packed rows with `threads` std::threads (<= 0: hardware concurrency).  Needs no GPU. */
+int gptqhip_pack_gptq_host(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
+                           int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, int threads);
+
 /* out[m, k'] = x[m, perm[k']]  (16-bit elements).  Used by gptqhip_gemm internally and exported for tests
  * (ExllamaV2 gathers A through q_perm: gptqmodel_ext/exllamav2/cuda/q_gemm_kernel_gptq.cuh:79-90). */
 int gptqhip_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, gptqhip_stream_t stream);

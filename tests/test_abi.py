@@ -93,3 +93,21 @@ def test_ops_refuse_cpu_tensors(lib):
     w = torch.zeros(256, dtype=torch.int32)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.gemm(x, w, w, None, None, 16, 128, 4, torch.float16)
+
+
+def test_host_packer_bit_exact_with_reference_pack_block(lib):
+    """gptqhip_pack_gptq_host (threaded C++, no GPU) vs the golden produced by the reference's pack_block."""
+    import numpy as np
+    import torch
+    from conftest import load_golden
+    from gptqmodel_amd import ops
+    g = load_golden("ref_pack.npz")
+    tags = sorted({k.rsplit("_", 1)[0] for k in g.files if k.endswith("_qweight")})
+    for t in tags:
+        bits = int(t.split("_")[0][1:])
+        for threads in (1, 3):
+            qw, qz = ops.pack_gptq_host(torch.from_numpy(g[t + "_weight"]), torch.from_numpy(g[t + "_scales"]),
+                                        torch.from_numpy(g[t + "_zeros"]), torch.from_numpy(g[t + "_g_idx"]), bits, threads)
+            assert np.array_equal(qw.numpy(), g[t + "_qweight"]) and np.array_equal(qz.numpy(), g[t + "_qzeros"]), t
+    with pytest.raises(RuntimeError, match="out of range"):
+        ops.pack_gptq_host(torch.zeros(32, 32), torch.ones(1, 32), torch.zeros(1, 32), torch.full((32,), 5), 4)
