@@ -146,7 +146,7 @@ int gptqhip_pack_gptq(const float* weight, const float* scales, const int32_t* z
                       int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, gptqhip_stream_t stream);
 
 /* The same quantise-and-pack on the HOST (all pointers are CPU memory): the C++ equivalent of the reference's native
- * packer gptqmodel::pack_block_cpu (gptqmodel_ext/pack_block_cpu.cpp:230-239, at::parallel_for over K/32 blocks :100),
+ * packer gptqmodel::pack_block_cpu (gptqmodel_ext/pack_block_cpu.cpp:17, at::parallel_for over blocks :100),
  * threaded over packed rows with `threads` std::threads (<= 0: hardware concurrency).  Needs no GPU. */
 int gptqhip_pack_gptq_host(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
                            int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, int threads);
