@@ -20,6 +20,8 @@
 #include "gptqhip_device.h"
 #include "gptqhip_host.h"
 
+#include <utility>
+
 namespace gptqhip {
 
 constexpr int kTiledBN = 256;  // columns per block = WAVES x TPW x 16
@@ -122,6 +124,28 @@ __device__ __forceinline__ void stage_a_glds(const TiledParams& p, char* lds_buf
     }
 }
 
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// ds_read_b128 the compiler does not track: completion is awaited by lds_wait<CNT>, whose "+v" operands make every
+// consumer of the fragments depend on the wait.
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(u4_t& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int CNT, int N>
+__device__ __forceinline__ void lds_wait(u4_t (&frag)[N]) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag[0]) : "n"(CNT));
+#pragma unroll
+    for (int i = 1; i < N; ++i) asm volatile("" : "+v"(frag[i]));
+}
+
 template <int BITS, int ACT, int SCL, int GPC, int BM, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     constexpr int MT = BM / 16;
@@ -162,13 +186,15 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     const int c_begin = blockIdx.z * p.chunks_per_split;
     const int c_end = min(p.chunks, c_begin + p.chunks_per_split);
 
+    // LDS byte address of this lane's fragment row (the low 32 bits of a generic LDS pointer are the LDS offset)
+    const uint32_t lds_row_base = (uint32_t)(uintptr_t)lds_all + (uint32_t)(c * 256);
+
     stage_a_glds<BM, NT>(p, lds_all, m0, c_begin, wave, lane);
     load_b<BITS, GPC, TPW>(bcur, p, tile0, c_begin, lane);
     __syncthreads();  // (hipcc drains vmcnt before a barrier while LDS-DMA is in flight: the tile has landed)
 
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
         const bool more = chunk + 1 < c_end;
-        char* lds = lds_all + ((chunk - c_begin) & 1) * (BM * 256);
         char* lds_next = lds_all + ((chunk - c_begin + 1) & 1) * (BM * 256);
         if (more) {
             stage_a_glds<BM, NT>(p, lds_next, m0, chunk + 1, wave, lane);  // in flight during the MFMA phase
@@ -180,7 +206,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         //   * B fragments of K-step j+1 are dequantised in the middle of step j's MFMA stream (VALU work hides under
         //     the matrix pipe instead of forming a VALU-only phase).
         constexpr int PF = BM == 256 ? 4 : 8;  // measured: deeper spills at BM=256, helps at BM=128
-        u4_t aring[PF];
+        u4_t abuf[2][PF];
         u4_t bnow[TPW], bnext[TPW];
         auto dequant_step = [&](int j, u4_t (&b)[TPW]) {
 #pragma unroll
@@ -193,45 +219,50 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
                 }
             }
         };
-        auto a_read = [&](int idx) {  // idx = j * MT + mt
-            const int j = idx / MT, mt = idx % MT;
-            return *reinterpret_cast<const u4_t*>(lds + (mt * 16 + c) * 256 + ((j * 64 + rq * 16) ^ (c << 4)));
-        };
-        // Groups of PF fragments: the reads of group g+1 are issued, then a scheduling fence, then the MFMAs of group g
-        // (PF*TPW of them, >= 128 matrix-pipe cycles) under which those reads land; sched_barrier(0) keeps hipcc from
-        // sinking the reads back next to their consumers.  The next K-step's dequant rides in the MFMA blocks.
+        // A fragment idx = j * MT + mt lives at row mt*16 + c, 16-byte segment (4j + rq) ^ c of this buffer.  The reads
+        // are inline asm with counted waits: with LDS-DMA in the kernel hipcc turns every LDS wait into lgkmcnt(0),
+        // which drains the reads just issued for the NEXT group and exposes the LDS latency every other group.
+        const uint32_t abase = lds_row_base + (uint32_t)(((chunk - c_begin) & 1) * (BM * 256));
+        uint32_t aaddr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aaddr[j] = abase + (uint32_t)((j * 64 + rq * 16) ^ (c << 4));
         constexpr int NG = 4 * MT / PF;  // fragment groups per chunk
-        u4_t anext[PF];
+        // Groups of PF fragments: the reads of group g+1 are issued, then the wait for group g only (lgkmcnt(PF)), then
+        // the MFMAs of group g (PF*TPW of them, >= 128 matrix-pipe cycles) under which the newer reads land;
+        // sched_barrier(0) keeps hipcc from moving anything across the phases.  The next K-step's dequant rides along.
         dequant_step(0, bnow);
-#pragma unroll
-        for (int i = 0; i < PF; ++i) aring[i] = a_read(i);
+        static_for<PF>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            lds_read_b128<(i % MT) * 4096>(abuf[0][i], aaddr[i / MT]);
+        });
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) {
-#pragma unroll
-                for (int i = 0; i < PF; ++i) anext[i] = a_read((g + 1) * PF + i);
+        static_for<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g + 1 < NG) {
+                static_for<PF>([&](auto ic) {
+                    constexpr int idx = (g + 1) * PF + decltype(ic)::value;
+                    lds_read_b128<(idx % MT) * 4096>(abuf[(g + 1) & 1][decltype(ic)::value], aaddr[idx / MT]);
+                });
             }
             __builtin_amdgcn_sched_barrier(0);
-            const int j = (g * PF) / MT;            // K-step of this group (PF divides MT)
-            const bool last_of_step = ((g + 1) * PF) % MT == 0;
-            if ((g * PF) % MT == 0 && j < 3) dequant_step(j + 1, bnext);   // VALU under this group's MFMAs
+            constexpr int j = (g * PF) / MT;            // K-step of this group (PF divides MT)
+            constexpr bool last_of_step = ((g + 1) * PF) % MT == 0;
+            if constexpr ((g * PF) % MT == 0 && j < 3) dequant_step(j + 1, bnext);   // VALU under this group's MFMAs
+            lds_wait<(g + 1 < NG) ? PF : 0, PF>(abuf[g & 1]);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int mt = (g * PF + i) % MT;
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) acc[mt][t] = mfma16<ACT>(aring[i], bnow[t], acc[mt][t]);
+                for (int t = 0; t < TPW; ++t) acc[mt][t] = mfma16<ACT>(abuf[g & 1][i], bnow[t], acc[mt][t]);
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (last_of_step && j < 3) {
+            if constexpr (last_of_step && j < 3) {
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) bnow[t] = bnext[t];
             }
-#pragma unroll
-            for (int i = 0; i < PF; ++i) aring[i] = anext[i];
-        }
+        });
         if (more) bcur = bnxt;
         __syncthreads();  // next tile landed (vmcnt drained by the barrier) and everyone is done with this one
     }

@@ -1,0 +1,110 @@
+"""End-to-end drop-in check on the GPU: a random-init Hugging Face Llama is quantised (RTN, packed on the device),
+its decoder nn.Linear modules are swapped for the HIP QuantLinear through the reference-style make_quant /
+gptqmodel_post_init flow (gptqmodel/utils/model.py:398, :1281) and compared, prefill and KV-cache decode, with the same
+model running dense fp16 weights = the dequantised checkpoint (what BACKEND.TORCH computes, torch.py:326-347)."""
+import copy
+import zlib
+
+import pytest
+import torch
+import torch.nn as nn
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+transformers = pytest.importorskip("transformers")
+
+
+def _rtn(weight: torch.Tensor, group_size: int, bits: int):
+    """Asymmetric round-to-nearest per (output row, K-group): scales/zeros as [out, G] like the reference quantiser hands
+    them to pack()."""
+    n, k = weight.shape
+    w = weight.float().reshape(n, k // group_size, group_size)
+    wmax, wmin = w.amax(dim=2), w.amin(dim=2)
+    maxq = (1 << bits) - 1
+    scales = ((wmax - wmin).clamp(min=1e-5) / maxq).half().float()
+    zeros = torch.round(-wmin / scales).clamp(0, maxq)
+    return scales, zeros
+
+
+def _get(model, name):
+    mod = model
+    for part in name.split("."):
+        mod = getattr(mod, part)
+    return mod
+
+
+def _build(desc_act: bool, fuse: bool, dtype):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from gptqmodel_amd import ops
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    from gptqmodel_amd.utils.backend import BACKEND
+    from gptqmodel_amd.utils.const import FORMAT
+    from gptqmodel_amd.utils.model import fuse_siblings, gptqmodel_post_init, make_quant
+
+    torch.manual_seed(7)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=8,
+                      num_key_value_heads=2, vocab_size=2048, max_position_embeddings=128, tie_word_embeddings=False)
+    dense = LlamaForCausalLM(cfg).to(dtype).cuda().eval()
+    quant = copy.deepcopy(dense)
+    names = [n for n, m in dense.named_modules() if isinstance(m, nn.Linear) and ".layers." in n]
+    assert len(names) == 14
+    gs, bits = 128, 4
+    make_quant(quant, names, bits=bits, group_size=gs, desc_act=desc_act, sym=False, backend=BACKEND.AUTO,
+               format=FORMAT.GPTQ, dtype=dtype)
+    for name in names:
+        lin, qm = _get(dense, name), _get(quant, name)
+        assert isinstance(qm, HipGptqLinear)
+        k = lin.in_features
+        if desc_act:
+            # one act-order permutation per input tensor: q/k/v (and gate/up) of a layer share it, as in real checkpoints
+            gen_l = torch.Generator().manual_seed(zlib.crc32((name.rsplit(".", 1)[0] + str(k)).encode()))
+            g_idx = (torch.randperm(k, generator=gen_l) // gs).to(torch.int32)
+        else:
+            g_idx = (torch.arange(k) // gs).to(torch.int32)
+        # quantise the weight with its columns grouped by g_idx (group g = the columns whose g_idx == g)
+        order = torch.argsort(g_idx.long(), stable=True).cuda()
+        scales, zeros = _rtn(lin.weight.data[:, order], gs, bits)
+        qm.pack(lin, scales, zeros, g_idx)
+        w = ops.dequant(qm.qweight, qm.qzeros, qm.scales, qm.g_idx, gs, bits, dtype)       # [K, N]
+        lin.weight.data.copy_(w.T)
+    if fuse:
+        for layer in quant.model.layers:
+            assert fuse_siblings(layer.self_attn, ["q_proj", "k_proj", "v_proj"]) is not None
+            assert fuse_siblings(layer.mlp, ["gate_proj", "up_proj"]) is not None
+    gptqmodel_post_init(quant)
+    return dense, quant
+
+
+@pytest.mark.parametrize("desc_act,fuse,dtype", [(False, False, torch.float16), (False, True, torch.float16),
+                                                  (True, True, torch.float16), (False, True, torch.bfloat16)])
+def test_llama_prefill_and_decode_match_dense_dequantised_model(desc_act, fuse, dtype):
+    dense, quant = _build(desc_act, fuse, dtype)
+    tol = 2e-2 if dtype == torch.float16 else 6e-2
+    torch.manual_seed(11)
+    ids = torch.randint(0, 2048, (2, 24), device="cuda")
+    with torch.no_grad():
+        o_d = dense(input_ids=ids, use_cache=True)
+        o_q = quant(input_ids=ids, use_cache=True)
+        assert o_q.logits.dtype == dtype and o_q.logits.shape == o_d.logits.shape
+        assert rel_err(o_q.logits.float().cpu().numpy(), o_d.logits.float().cpu().numpy()) < tol
+        # teacher-forced KV-cache decode (M = batch = 2 rows per launch), both models fed the same tokens
+        pk_d, pk_q = o_d.past_key_values, o_q.past_key_values
+        tok = o_d.logits[:, -1].argmax(-1, keepdim=True)
+        for _ in range(6):
+            s_d = dense(input_ids=tok, past_key_values=pk_d, use_cache=True)
+            s_q = quant(input_ids=tok, past_key_values=pk_q, use_cache=True)
+            assert rel_err(s_q.logits.float().cpu().numpy(), s_d.logits.float().cpu().numpy()) < tol
+            pk_d, pk_q = s_d.past_key_values, s_q.past_key_values
+            tok = s_d.logits[:, -1].argmax(-1, keepdim=True)
+
+
+def test_llama_generate_runs_on_quantised_model():
+    dense, quant = _build(False, True, torch.float16)
+    ids = torch.randint(0, 2048, (1, 8), device="cuda")
+    with torch.no_grad():
+        out = quant.generate(input_ids=ids, max_new_tokens=8, do_sample=False, pad_token_id=0)
+    assert out.shape == (1, 16)
+    n_launch_modules = sum(1 for m in quant.modules() if type(m).__name__ == "HipGptqLinear")
+    assert n_launch_modules == 2 * 4  # fused qkv, o, fused gate_up, down per layer
