@@ -224,6 +224,31 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         a.out = out;
         a.M = M;
         const TiledPlan tp = plan_tiled(M, K, N, group_size, g_force_waves, g_force_split);  // force_waves doubles as tiled variant
+        if (tp.tail_cols > 0) {
+            // two launches (plan_tiled): 256-row tiles over the leading block columns, 128-row tiles over the trailing
+            // ones.  The tile-major weight layout makes a column sub-range a plain pointer offset; the output keeps its
+            // row stride (ldo).
+            const int n_a = (ceil_div(N, kTiledBN) - tp.tail_cols) * kTiledBN;
+            GemmArgs a1 = a;
+            a1.N = n_a;
+            a1.ldo = N;
+            TiledPlan t1 = tp;
+            t1.tail_cols = 0;
+            rc = launch_tiled(a1, t1, slabs, stream);
+            if (rc) return rc;
+            const size_t tile_off = (size_t)n_a / kTileN;
+            const size_t chunks = (size_t)ceil_div(K, kChunkK);
+            GemmArgs a2 = a;
+            a2.N = N - n_a;
+            a2.ldo = N;
+            a2.qweight = a.qweight + tile_off * chunks * (bits == 4 ? 1 : 2) * 256;
+            a2.meta = a.meta + tile_off * (size_t)(K / group_size) * 16;
+            a2.bias = a.bias ? reinterpret_cast<const char*>(a.bias) + (size_t)n_a * 2 : nullptr;
+            a2.out = reinterpret_cast<char*>(out) + (size_t)n_a * (partial_f32 ? 4 : 2);
+            TiledPlan t2 = t1;
+            t2.bm = 128;
+            return launch_tiled(a2, t2, slabs, stream);
+        }
         return launch_tiled(a, tp, slabs, stream);
     }
     // skinny kernel, 64 rows at a time

@@ -6,6 +6,8 @@
 
 namespace gptqhip {
 
+constexpr int kTiledBN = 256;  // columns per block of the prefill kernel = WAVES x TPW x 16
+
 struct GemmArgs {
     const void* x;
     const uint32_t* qweight;  // tile-major words (gptqhip_device.h)
@@ -14,6 +16,7 @@ struct GemmArgs {
     void* out;
     int M, K, N, group_size, bits, act_dtype, scale_dtype;
     int out_f32;  // write unrounded fp32 accumulators (tensor-parallel partial sums)
+    int ldo = 0;  // output row stride in elements (0: N) -- lets a launch cover a column sub-range of a wider output
 };
 
 struct SkinnyPlan {
@@ -35,6 +38,7 @@ struct TiledPlan {
     int splits;            // grid.z (split-K through fp32 slabs + reduce kernel)
     int chunks_per_split;
     size_t slab_floats;
+    int tail_cols = 0;  // trailing block columns (256 wide) handed to a second launch with 128-row tiles; 0: none
 };
 
 void set_error(const char* fmt, ...);

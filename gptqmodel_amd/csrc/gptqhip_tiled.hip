@@ -24,7 +24,6 @@
 
 namespace gptqhip {
 
-constexpr int kTiledBN = 256;  // columns per block = WAVES x TPW x 16
 
 struct TiledParams {
     const void* x;
@@ -33,6 +32,7 @@ struct TiledParams {
     const void* bias;
     void* out;
     int M, K, N, G, group_size;
+    int ldo;    // output row stride (elements)
     int chunks;
     int tiles;  // ceil(N/16)
     int out_f32;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
             const int row = pass * 16 + (lane >> 2);
             const u4_t v = *reinterpret_cast<const u4_t*>(slab + row * 32 + (lane & 3) * 8);
             const int m = m0 + row;
-            if (m < p.M && n0 < p.N) *reinterpret_cast<u4_t*>(reinterpret_cast<uint16_t*>(p.out) + (size_t)m * p.N + n0) = v;
+            if (m < p.M && n0 < p.N) *reinterpret_cast<u4_t*>(reinterpret_cast<uint16_t*>(p.out) + (size_t)m * p.ldo + n0) = v;
         }
         return;
     }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
                 if (p.splits > 1) {  // split-K partial: summed, rounded and biased by splitk_reduce_kernel
                     p.slabs[((size_t)blockIdx.z * p.M + m) * p.N + n] = v;
                 } else {
-                    reinterpret_cast<float*>(p.out)[(size_t)m * p.N + n] = v;
+                    reinterpret_cast<float*>(p.out)[(size_t)m * p.ldo + n] = v;
                 }
             }
         }
@@ -325,18 +325,19 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
 // consecutive columns (16-byte slab loads).
 template <int ACT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, const void* __restrict__ bias,
-                                                            void* __restrict__ out, int M, int N, int splits, int out_f32) {
+                                                            void* __restrict__ out, int M, int N, int ldo, int splits, int out_f32) {
     const size_t quads = (size_t)M * N / 4;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= quads) return;
     const size_t stride = (size_t)M * N;
     f4_t s = *reinterpret_cast<const f4_t*>(slabs + 4 * i);
     for (int sp = 1; sp < splits; ++sp) s += *reinterpret_cast<const f4_t*>(slabs + sp * stride + 4 * i);
+    const int n = (int)((4 * i) % N);
+    const size_t o = (4 * i) / N * (size_t)ldo + n;  // N % 4 == 0: the quad stays inside one row
     if (out_f32) {
-        *reinterpret_cast<f4_t*>(reinterpret_cast<float*>(out) + 4 * i) = s;
+        *reinterpret_cast<f4_t*>(reinterpret_cast<float*>(out) + o) = s;
         return;
     }
-    const int n = (int)((4 * i) % N);
     uint16_t r[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -344,10 +345,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         if (bias != nullptr) y = y + load16_as_f32<ACT>(bias, (size_t)n + j);
         r[j] = f32_to_16<ACT>(y);
     }
-    u2_t o;
-    o.x = (uint32_t)r[0] | ((uint32_t)r[1] << 16);
-    o.y = (uint32_t)r[2] | ((uint32_t)r[3] << 16);
-    *reinterpret_cast<u2_t*>(reinterpret_cast<uint16_t*>(out) + 4 * i) = o;
+    u2_t ov;
+    ov.x = (uint32_t)r[0] | ((uint32_t)r[1] << 16);
+    ov.y = (uint32_t)r[2] | ((uint32_t)r[3] << 16);
+    *reinterpret_cast<u2_t*>(reinterpret_cast<uint16_t*>(out) + o) = ov;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -373,9 +374,32 @@ static int launch_tiled_gpc(const TiledParams& p, int gpc, int bm, int waves, hi
 TiledPlan plan_tiled(int M, int K, int N, int group_size, int force_variant, int force_split) {
     TiledPlan pl;
     pl.gpc = (group_size % kChunkK == 0) ? 1 : 4;
-    // 256-row tiles when they alone fill the chip, else 128-row tiles (twice the blocks)
-    const long blocks256 = (long)ceil_div(M, 256) * ceil_div(N, kTiledBN);
-    pl.bm = blocks256 >= 256 ? 256 : 128;
+    // Tile height from a small measured cost model (unit = one full round of 256 blocks with 256-row tiles on 256 CUs).
+    // The chip is power-bound in this kernel: a partly filled round runs at higher clocks, partial(b) ~ 0.45 + 0.55 b/256
+    // (K=4096: 128 / 192 / 256 blocks take 81 / 99 / 113 us), and a round of 128-row tiles costs ~0.61.  Candidates:
+    // all 256-row, all 128-row, or 256-row tiles for the full rounds plus ONE launch of 128-row tiles for the block
+    // columns of a last round that would be at most half full (M=4096, N=6144: 207 / 198 / 186 us).
+    const int cus = 256;
+    const int nbx = ceil_div(N, kTiledBN), nby256 = ceil_div(M, 256), nby128 = ceil_div(M, 128);
+    auto cost = [&](long blocks, double unit) {
+        const long full = blocks / cus, rem = blocks % cus;
+        return unit * ((double)full + (rem ? 0.45 + 0.55 * (double)rem / cus : 0.0));
+    };
+    const long blocks256 = (long)nbx * nby256, blocks128 = (long)nbx * nby128;
+    const double t256 = cost(blocks256, 1.0), t128 = cost(blocks128, 0.61);
+    pl.bm = (blocks256 > 128 && t256 <= t128) ? 256 : 128;
+    pl.tail_cols = 0;
+    if (blocks256 > cus && force_variant == 0 && force_split == 0) {
+        const int rem = (int)(blocks256 % cus);
+        const int nbx_b = rem > 0 && rem <= cus / 2 ? ceil_div(rem, nby256) : 0;
+        if (nbx_b > 0 && nbx_b < nbx) {
+            const double ttail = cost((long)(nbx - nbx_b) * nby256, 1.0) + cost((long)nbx_b * nby128, 0.61) + 0.03;
+            if (ttail < t256 && ttail < t128) {
+                pl.bm = 256;
+                pl.tail_cols = nbx_b;
+            }
+        }
+    }
     pl.waves = 8;
     if (force_variant == 1) { pl.bm = 256; pl.waves = 8; }
     if (force_variant == 2) { pl.bm = 128; pl.waves = 8; }
@@ -409,6 +433,7 @@ int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, hipStream
     p.M = a.M;
     p.K = a.K;
     p.N = a.N;
+    p.ldo = a.ldo > 0 ? a.ldo : a.N;
     p.G = a.K / a.group_size;
     p.group_size = a.group_size;
     p.chunks = ceil_div(a.K, kChunkK);
@@ -445,9 +470,9 @@ int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, hipStream
     const size_t quads = (size_t)a.M * a.N / 4;
     const dim3 grid((unsigned)((quads + 255) / 256));
     if (a.act_dtype == kFP16) {
-        hipLaunchKernelGGL(splitk_reduce_kernel<kFP16>, grid, dim3(256), 0, stream, slabs, a.bias, a.out, a.M, a.N, pl.splits, a.out_f32);
+        hipLaunchKernelGGL(splitk_reduce_kernel<kFP16>, grid, dim3(256), 0, stream, slabs, a.bias, a.out, a.M, a.N, p.ldo, pl.splits, a.out_f32);
     } else {
-        hipLaunchKernelGGL(splitk_reduce_kernel<kBF16>, grid, dim3(256), 0, stream, slabs, a.bias, a.out, a.M, a.N, pl.splits, a.out_f32);
+        hipLaunchKernelGGL(splitk_reduce_kernel<kBF16>, grid, dim3(256), 0, stream, slabs, a.bias, a.out, a.M, a.N, p.ldo, pl.splits, a.out_f32);
     }
     return check_hip(hipGetLastError(), "splitk_reduce_kernel launch");
 }

@@ -12,7 +12,7 @@ def run(M, K, N, gs=128, iters=20):
     qw_t, meta = ops.repack_tiled(qw, qz, sc, None, gs, 4)
     x = (torch.randn(M, K, device=dev) * 0.5).to(DT)
     out = torch.empty((M, N), dtype=DT, device=dev)
-    for _ in range(3): ops.gemm(x, qw_t, meta, None, None, N, gs, 4, torch.float16, out=out)
+    for _ in range(25): ops.gemm(x, qw_t, meta, None, None, N, gs, 4, torch.float16, out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -20,8 +20,8 @@ def run(M, K, N, gs=128, iters=20):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     return ms, 2.0 * M * K * N / ms / 1e9
-variants = [0] if len(sys.argv) < 2 or not sys.argv[1][0].isdigit() else [int(v) for v in sys.argv[1].split(",")]
-for (M, K, N) in [(128,4096,4096),(512,4096,4096),(2048,4096,4096),(8192,4096,4096),(2048,4096,14336),(2048,14336,4096),(8192,4096,28672),(65536,4096,4096)]:
+variants = [0] if len(sys.argv) < 2 or not sys.argv[1][0].isdigit() else [int(v) for v in sys.argv[1].split(",")]  # 1 / 2 force 256- / 128-row tiles
+for (M, K, N) in [(128,4096,4096),(512,4096,4096),(2048,4096,4096),(8192,4096,4096),(2048,4096,14336),(2048,14336,4096),(8192,4096,28672),(65536,4096,4096),(2048,4096,6144),(4096,4096,6144),(2048,4096,28672),(4096,4096,28672),(2560,4096,4096),(3072,4096,4096),(1024,4096,14336),(1024,4096,28672),(1536,4096,6144)]:
     res = []
     for v in variants:
         ops.set_tuning(0, 0, v)

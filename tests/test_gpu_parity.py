@@ -333,3 +333,33 @@ def test_lm_head_sized_layer_column_slices(ops):
         sl = slice(n0, n0 + 256)
         ref = O.forward_gptq(x, qweight[:, sl], qzeros[:, n0 // 8:(n0 + 256) // 8], scales[:, sl], g_idx, 4)
         assert rel_err(out[:, sl], ref) <= 1e-3
+
+
+@pytest.mark.parametrize("K,N,desc_act", [(4096, 14336, True), (14336, 4096, False)])
+def test_prefill_full_size_sampled_rows(ops, K, N, desc_act):
+    """BASELINE config C3 shapes at M = 8192 (Llama-3-8B gate/up and down projections, act-order): the oracle cannot
+    form the full product in seconds, so rows are sampled -- every output row depends only on its own input row (a
+    size-independent property of the path), including rows at block-tile boundaries and the ragged last tile."""
+    gs, M = 128, 8192 + 40
+    qweight, qzeros, scales, g_idx = synth_gptq(2024, 4, K, N, gs, desc_act=desc_act)
+    rng = np.random.RandomState(5)
+    x = O.round_to(rng.randn(M, K).astype(np.float32) * 0.5, "fp16")
+    out = run_gptq(ops, x, qweight, qzeros, scales, g_idx, 4, gs, None, "fp16", "fp16")
+    rows = np.array([0, 1, 127, 128, 255, 256, 4095, 4096, 8191, 8192, M - 1] + list(rng.randint(0, M, size=5)))
+    got = torch_to_f32(out[torch.from_numpy(rows).to(out.device)])
+    ref = O.forward_gptq(x[rows], qweight, qzeros, scales, g_idx, 4)
+    assert rel_err(got, ref) <= 1e-3
+
+
+@pytest.mark.parametrize("act", ["fp16", "bf16"])
+def test_tiled_tail_launch_column_split(ops, act):
+    """288 block tiles on 256 CUs: the last 32 block columns' worth of work goes to a second launch with half-height
+    tiles writing a column sub-range of the same output (row stride = N); ragged M and N, bias."""
+    K, N, gs, M = 256, 9208, 128, 2048 + 13
+    qweight, qzeros, scales, g_idx = synth_gptq(31, 4, K, N, gs)
+    rng = np.random.RandomState(8)
+    x = O.round_to(rng.randn(M, K).astype(np.float32) * 0.5, act)
+    bias = O.round_to(rng.randn(N).astype(np.float32), act)
+    got = torch_to_f32(run_gptq(ops, x, qweight, qzeros, scales, g_idx, 4, gs, bias, act, "fp16"))
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, bias_f32=bias, act_dtype=act)
+    assert rel_err(got, ref) <= (1e-3 if act == "fp16" else 8e-3)
