@@ -74,53 +74,40 @@ __device__ __forceinline__ void load_b(BStage<BITS, GPC, TPW>& st, const TiledPa
     }
 }
 
-// A tile: BM rows x 128 halves (256 B per row), thread t moves 16-byte segments idx = i*NT + t, i < BM*16/NT.
+// LDS-DMA staging (buffer_load_dwordx4 ... lds): the A tile goes HBM/L2 -> LDS without passing through VGPRs.  The
+// hardware writes wave-uniform base + lane*16, i.e. the LDS image is lane-linear: one instruction fills 4 rows x 256 B.
+// The XOR swizzle therefore moves to the SOURCE address (lane (r, pos) fetches segment pos ^ (row & 15)) and the
+// fragment reads apply the same XOR (cdna_hip_programming.md rule 21: linear destination + swizzled source + swizzled
+// read).  MUBUF rather than global_load_lds on purpose: hipcc treats the FLAT-encoded global_load_lds as touching both
+// VMEM and LDS and then turns EVERY later vmcnt/lgkmcnt wait into a full drain, which defeats the multi-stage pipeline.
+// The buffer descriptor covers exactly this block's valid rows, so rows >= M and columns >= K come back as zeros
+// (no clamps, no address VALU: the lane offset is chunk-invariant, the chunk advances through the scalar offset).
+struct ATileSrc {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t voff;        // this lane's byte offset inside a 32-row piece: row * K * 2 + swizzled segment * 16
+    uint32_t piece_step;  // bytes between consecutive pieces of one wave (NT/64 * 4 rows)
+};
+
 template <int BM, int NT>
-__device__ __forceinline__ void load_a(u4_t (&stage)[BM * 16 / NT], const TiledParams& p, int m0, int chunk, int tid) {
-    const uint16_t* xs = reinterpret_cast<const uint16_t*>(p.x);
-#pragma unroll
-    for (int i = 0; i < BM * 16 / NT; ++i) {
-        const int idx = i * NT + tid;
-        int row = m0 + (idx >> 4);
-        row = row < p.M ? row : p.M - 1;  // ragged M: duplicate the last row (its outputs are never stored)
-        int k = chunk * kChunkK + (idx & 15) * 8;
-        k = k < p.K ? k : 0;  // ragged K: the padded weights dequantise to exactly 0, any finite x will do
-        stage[i] = *reinterpret_cast<const u4_t*>(xs + (size_t)row * p.K + k);
-    }
+__device__ __forceinline__ ATileSrc make_a_src(const TiledParams& p, int m0, int wave, int lane) {
+    ATileSrc a;
+    const int rows = min(p.M - m0, BM);
+    const char* base = reinterpret_cast<const char*>(p.x) + (size_t)m0 * p.K * 2;
+    a.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, rows * p.K * 2, 0x00020000);
+    const int rl = wave * 4 + (lane >> 4);
+    a.voff = (uint32_t)(rl * p.K * 2 + (((lane & 15) ^ (rl & 15)) << 4));
+    a.piece_step = (uint32_t)((NT / 64) * 4 * p.K * 2);
+    return a;
 }
 
 template <int BM, int NT>
-__device__ __forceinline__ void store_a(const u4_t (&stage)[BM * 16 / NT], char* lds, int tid) {
+__device__ __forceinline__ void stage_a_dma(const ATileSrc& a, char* lds_buf, int chunk, int wave) {
+    typedef __attribute__((address_space(3))) void* lptr_t;
 #pragma unroll
     for (int i = 0; i < BM * 16 / NT; ++i) {
-        const int idx = i * NT + tid;
-        const int row = idx >> 4;
-        const int off = row * 256 + (((idx & 15) << 4) ^ ((row & 15) << 4));
-        *reinterpret_cast<u4_t*>(lds + off) = stage[i];
-    }
-}
-
-// LDS-DMA staging (global_load_lds_dwordx4): the A tile goes HBM/L2 -> LDS without passing through VGPRs (frees the 32
-// staging registers of the BM=256 variant and the ds_write pass).  The hardware writes wave-uniform base + lane*16,
-// i.e. the LDS image is lane-linear: one instruction fills 4 rows x 256 B.  The XOR swizzle therefore moves to the
-// SOURCE address (lane (r, pos) fetches segment pos ^ (row & 15)) and the fragment reads apply the same XOR
-// (cdna_hip_programming.md rule 21: linear destination + swizzled source + swizzled read).
-template <int BM, int NT>
-__device__ __forceinline__ void stage_a_glds(const TiledParams& p, char* lds_buf, int m0, int chunk, int wave, int lane) {
-    const char* xs = reinterpret_cast<const char*>(p.x);
-#pragma unroll
-    for (int i = 0; i < BM * 16 / NT; ++i) {
-        const int r0 = (i * (NT / 64) + wave) * 4;  // wave-uniform first row of this 1 KiB piece
-        const int rl = r0 + (lane >> 4);
-        int row = m0 + rl;
-        row = row < p.M ? row : p.M - 1;
-        const int seg = (lane & 15) ^ (rl & 15);
-        int k = chunk * kChunkK + seg * 8;
-        k = k < p.K ? k : 0;
-        const char* src = xs + ((size_t)row * p.K + k) * 2;
-        typedef const __attribute__((address_space(1))) void* gptr_t;
-        typedef __attribute__((address_space(3))) void* lptr_t;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_buf + r0 * 256), 16, 0, 0);
+        const int r0 = (i * (NT / 64) + wave) * 4;  // wave-uniform first row of this 1 KiB piece (r0 & 15 == 4*wave & 15)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a.rsrc, (lptr_t)(lds_buf + r0 * 256), 16, a.voff + i * a.piece_step,
+                                                 chunk * (kChunkK * 2), 0, 0);
     }
 }
 
@@ -146,14 +133,33 @@ __device__ __forceinline__ void lds_wait(u4_t (&frag)[N]) {
     for (int i = 1; i < N; ++i) asm volatile("" : "+v"(frag[i]));
 }
 
-template <int BITS, int ACT, int SCL, int GPC, int BM, int WAVES>
+// s_waitcnt vmcnt(stages * OPS) for a block-uniform run-time `stages` in [0, MAXS] (the immediate must be a constant)
+template <int OPS, int MAXS>
+__device__ __forceinline__ void vm_wait_stages(int stages) {
+    static_assert(MAXS * OPS <= 63, "vmcnt is a 6-bit field");
+    if constexpr (MAXS >= 2) {
+        if (stages >= 2) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
+            return;
+        }
+    }
+    if constexpr (MAXS >= 1) {
+        if (stages >= 1) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+            return;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int BITS, int ACT, int SCL, int GPC, int BM, int WAVES, int D>
 __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     constexpr int MT = BM / 16;
     constexpr int NT = 64 * WAVES;
     constexpr int TPW = kTiledBN / kTileN / WAVES;  // column tiles per wave
     // two A-tile buffers: the next tile is written while slower waves may still read the current one -> ONE barrier
     // per 128-deep tile
-    __shared__ __attribute__((aligned(16))) char lds_all[2 * BM * 256];
+    __shared__ __attribute__((aligned(16))) char lds_all[D * BM * 256];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         for (int t = 0; t < TPW; ++t) acc[mt][t] = f4_t{0.f, 0.f, 0.f, 0.f};
 
     const DequantConsts dk = make_dequant_consts<BITS>();
-    BStage<BITS, GPC, TPW> bcur, bnxt;
+    BStage<BITS, GPC, TPW> bst[D];
 
     const int c_begin = blockIdx.z * p.chunks_per_split;
     const int c_end = min(p.chunks, c_begin + p.chunks_per_split);
@@ -189,26 +195,29 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     // LDS byte address of this lane's fragment row (the low 32 bits of a generic LDS pointer are the LDS offset)
     const uint32_t lds_row_base = (uint32_t)(uintptr_t)lds_all + (uint32_t)(c * 256);
 
-    stage_a_glds<BM, NT>(p, lds_all, m0, c_begin, wave, lane);
-    load_b<BITS, GPC, TPW>(bcur, p, tile0, c_begin, lane);
-    __syncthreads();  // (hipcc drains vmcnt before a barrier while LDS-DMA is in flight: the tile has landed)
+    // D-stage pipeline over the 128-deep K chunks: chunk i lives in LDS buffer / register stage i % D, the loads of
+    // chunks i+1 .. i+D-1 are in flight while chunk i is multiplied.  One chunk of a 128-row tile is only ~1000
+    // matrix-pipe cycles per wave -- shorter than an HBM round trip -- so D = 4 there (a 2-deep pipe measured 15 us
+    // for FOUR chunks at M=64); 256-row tiles (2 x 64 KiB of LDS) keep D = 2.
+    const ATileSrc asrc = make_a_src<BM, NT>(p, m0, wave, lane);
+    constexpr int OPS = BM * 16 / NT + TPW * ((BITS == 4 ? 1 : 2) + GPC);  // VMEM instructions per stage and wave
+    auto issue = [&](auto sc, int chunk) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        stage_a_dma<BM, NT>(asrc, lds_all + s * (BM * 256), chunk, wave);
+        load_b<BITS, GPC, TPW>(bst[s], p, tile0, chunk, lane);
+    };
 
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-        const bool more = chunk + 1 < c_end;
-        char* lds_next = lds_all + ((chunk - c_begin + 1) & 1) * (BM * 256);
-        if (more) {
-            stage_a_glds<BM, NT>(p, lds_next, m0, chunk + 1, wave, lane);  // in flight during the MFMA phase
-            load_b<BITS, GPC, TPW>(bnxt, p, tile0, chunk + 1, lane);
-        }
+    auto compute = [&](auto sc) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        BStage<BITS, GPC, TPW>& bcur = bst[s];
         // Software pipeline inside the chunk (everything is compile-time unrolled, all indices static):
-        //   * A fragments: a ring of PF ds_read_b128 stays in flight ahead of the MFMAs that consume them (the
-        //     compiler otherwise issues 2 reads, waits, 4 MFMAs, ... and exposes the LDS latency every 64 pipe cycles);
+        //   * A fragments: a ring of PF ds_read_b128 stays in flight ahead of the MFMAs that consume them;
         //   * B fragments of K-step j+1 are dequantised in the middle of step j's MFMA stream (VALU work hides under
         //     the matrix pipe instead of forming a VALU-only phase).
         constexpr int PF = BM == 256 ? 4 : 8;  // measured: deeper spills at BM=256, helps at BM=128
         u4_t abuf[2][PF];
         u4_t bnow[TPW], bnext[TPW];
-        auto dequant_step = [&](int j, u4_t (&b)[TPW]) {
+        auto dequant_step = [&](int j, u4_t (&b)[TPW]) __attribute__((always_inline)) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const ColConst cc = expand_meta<BITS, SCL>(bcur.meta[t][GPC == 4 ? j : 0]);
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         // A fragment idx = j * MT + mt lives at row mt*16 + c, 16-byte segment (4j + rq) ^ c of this buffer.  The reads
         // are inline asm with counted waits: with LDS-DMA in the kernel hipcc turns every LDS wait into lgkmcnt(0),
         // which drains the reads just issued for the NEXT group and exposes the LDS latency every other group.
-        const uint32_t abase = lds_row_base + (uint32_t)(((chunk - c_begin) & 1) * (BM * 256));
+        const uint32_t abase = lds_row_base + (uint32_t)(s * (BM * 256));
         uint32_t aaddr[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) aaddr[j] = abase + (uint32_t)((j * 64 + rq * 16) ^ (c << 4));
@@ -263,8 +272,53 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
                 for (int t = 0; t < TPW; ++t) bnow[t] = bnext[t];
             }
         });
-        if (more) bcur = bnxt;
-        __syncthreads();  // next tile landed (vmcnt drained by the barrier) and everyone is done with this one
+    };
+
+    // One pipeline stage = wait for chunk's own loads, barrier, issue chunk + D - 1, multiply chunk.
+    //   wait: chunk's loads have landed once at most `ahead` younger stages are still in flight;
+    //   barrier: the same holds for every wave's pieces of the A tile AND every wave is done reading buffer (s-1) % D,
+    //   which the next issue overwrites.  (Plain s_barrier: __syncthreads() would make hipcc drain vmcnt to 0.)
+    // STEADY stages issue unconditionally: hipcc's own wait for the B registers is then a counted vmcnt as well (with
+    // a conditional issue on the path it falls back to vmcnt(0), draining the whole prefetch once per round).
+    auto stage = [&](auto sc, int chunk, auto steady) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (decltype(steady)::value) {
+            vm_wait_stages<OPS, D - 2>(D - 2);
+            __builtin_amdgcn_s_barrier();
+            issue(std::integral_constant<int, (s + D - 1) % D>{}, chunk + D - 1);
+        } else {
+            vm_wait_stages<OPS, D - 2>(min(D - 2, c_end - 1 - chunk));
+            __builtin_amdgcn_s_barrier();
+            if (chunk + D - 1 < c_end) issue(std::integral_constant<int, (s + D - 1) % D>{}, chunk + D - 1);
+        }
+        compute(sc);
+    };
+    int chunk0 = c_begin;
+    if constexpr (D == 2) {
+        // two stages: the wait is vmcnt(0) either way, so no separate steady state (its extra code copies cost
+        // registers the 256-row tile does not have)
+        if (c_begin < c_end) issue(std::integral_constant<int, 0>{}, c_begin);
+        for (; chunk0 < c_end; chunk0 += 2) {
+            stage(std::integral_constant<int, 0>{}, chunk0, std::false_type{});
+            if (chunk0 + 1 < c_end) stage(std::integral_constant<int, 1>{}, chunk0 + 1, std::false_type{});
+        }
+    } else {
+        if (c_end - c_begin >= 2 * D - 1) {
+            static_for<D - 1>([&](auto dc) { issue(dc, c_begin + decltype(dc)::value); });
+            while (chunk0 + 2 * D - 2 < c_end) {  // every stage of this round still has a chunk + D - 1 to issue
+                static_for<D>([&](auto sc) { stage(sc, chunk0 + decltype(sc)::value, std::true_type{}); });
+                chunk0 += D;
+            }
+        } else {
+            static_for<D - 1>([&](auto dc) {
+                if (c_begin + decltype(dc)::value < c_end) issue(dc, c_begin + decltype(dc)::value);
+            });
+        }
+        // drain: the last (up to 2D - 2) chunks; chunk0 - c_begin is a multiple of D, so chunk0 + i uses stage i % D
+        static_for<2 * D - 2>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (chunk0 + i < c_end) stage(std::integral_constant<int, i % D>{}, chunk0 + i, std::false_type{});
+        });
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------
@@ -356,10 +410,13 @@ template <int BITS, int ACT, int SCL, int GPC>
 static int launch_tiled_bm(const TiledParams& p, int bm, int waves, hipStream_t stream) {
     const dim3 grid(ceil_div(p.N, kTiledBN), ceil_div(p.M, bm), p.splits);
     if (bm == 256) {
-        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 256, 8>), grid, dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 256, 8, 2>), grid, dim3(512), 0, stream, p);
     } else {
         // (a 4-wave x 4-tile variant with two independent blocks per CU was measured 25-30 % slower: 660 vs 950 TF)
-        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 128, 8>), grid, dim3(512), 0, stream, p);
+        // 4 stages in flight for 4-bit weights; the 8-bit register stages are twice as large (2 stages fit without spills)
+        // 3 stages in flight (measured on 128-row tiles, M=2048 4096^2: 951 / 1061 / 984 TF for 2 / 3 / 4 stages -- the
+        // fourth only lengthens the start-up burst); the 8-bit register stages are twice as large: 2 stages there
+        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 128, 8, BITS == 4 ? 3 : 2>), grid, dim3(512), 0, stream, p);
     }
     (void)waves;
     return check_hip(hipGetLastError(), "tiled_kernel launch");
@@ -376,24 +433,25 @@ TiledPlan plan_tiled(int M, int K, int N, int group_size, int force_variant, int
     pl.gpc = (group_size % kChunkK == 0) ? 1 : 4;
     // Tile height from a small measured cost model (unit = one full round of 256 blocks with 256-row tiles on 256 CUs).
     // The chip is power-bound in this kernel: a partly filled round runs at higher clocks, partial(b) ~ 0.45 + 0.55 b/256
-    // (K=4096: 128 / 192 / 256 blocks take 81 / 99 / 113 us), and a round of 128-row tiles costs ~0.61.  Candidates:
+    // (K=4096: 128 / 192 / 256 blocks take 81 / 99 / 113 us), and a round of 128-row tiles costs ~0.56.  Candidates:
     // all 256-row, all 128-row, or 256-row tiles for the full rounds plus ONE launch of 128-row tiles for the block
     // columns of a last round that would be at most half full (M=4096, N=6144: 207 / 198 / 186 us).
     const int cus = 256;
+    const double kHalf = 0.56;  // one round of 128-row tiles relative to one round of 256-row tiles
     const int nbx = ceil_div(N, kTiledBN), nby256 = ceil_div(M, 256), nby128 = ceil_div(M, 128);
     auto cost = [&](long blocks, double unit) {
         const long full = blocks / cus, rem = blocks % cus;
         return unit * ((double)full + (rem ? 0.45 + 0.55 * (double)rem / cus : 0.0));
     };
     const long blocks256 = (long)nbx * nby256, blocks128 = (long)nbx * nby128;
-    const double t256 = cost(blocks256, 1.0), t128 = cost(blocks128, 0.61);
+    const double t256 = cost(blocks256, 1.0), t128 = cost(blocks128, kHalf);
     pl.bm = (blocks256 > 128 && t256 <= t128) ? 256 : 128;
     pl.tail_cols = 0;
     if (blocks256 > cus && force_variant == 0 && force_split == 0) {
         const int rem = (int)(blocks256 % cus);
         const int nbx_b = rem > 0 && rem <= cus / 2 ? ceil_div(rem, nby256) : 0;
         if (nbx_b > 0 && nbx_b < nbx) {
-            const double ttail = cost((long)(nbx - nbx_b) * nby256, 1.0) + cost((long)nbx_b * nby128, 0.61) + 0.03;
+            const double ttail = cost((long)(nbx - nbx_b) * nby256, 1.0) + cost((long)nbx_b * nby128, kHalf) + 0.03;
             if (ttail < t256 && ttail < t128) {
                 pl.bm = 256;
                 pl.tail_cols = nbx_b;
