@@ -354,22 +354,30 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         }
         return;
     }
+    // fp32 accumulators (split-K partials or tensor-parallel partial sums): same LDS transpose, in two passes of MT/2
+    // row tiles so a wave's staging area stays BM x 64 bytes: rows of 32 floats (128 B) leave as 16-byte pieces
+    // instead of 4-byte scattered elements.
+    {
+        __syncthreads();  // every wave has finished reading the last A tile
+        float* slab = reinterpret_cast<float*>(lds_all + wave * (BM * 64));
+        float* dst = p.splits > 1 ? p.slabs + (size_t)blockIdx.z * p.M * p.N : reinterpret_cast<float*>(p.out);
+        const size_t ld = p.splits > 1 ? (size_t)p.N : (size_t)p.ldo;
+        const int n0 = tile0 * kTileN + (lane & 7) * 4;
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int n = (tile0 + t) * kTileN + c;
-        if (n >= p.N) continue;
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+            for (int t = 0; t < TPW; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + mt * 16 + 4 * rq + i;
-                if (m >= p.M) continue;
-                const float v = acc[mt][t][i];
-                if (p.splits > 1) {  // split-K partial: summed, rounded and biased by splitk_reduce_kernel
-                    p.slabs[((size_t)blockIdx.z * p.M + m) * p.N + n] = v;
-                } else {
-                    reinterpret_cast<float*>(p.out)[(size_t)m * p.ldo + n] = v;
-                }
+                for (int mh = 0; mh < MT / 2; ++mh)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) slab[(mh * 16 + 4 * rq + i) * 32 + t * 16 + c] = acc[h * (MT / 2) + mh][t][i];
+            // same-wave LDS accesses execute in order: no barrier between this wave's writes and reads
+#pragma unroll
+            for (int pass = 0; pass < BM / 16; ++pass) {
+                const int row = pass * 8 + (lane >> 3);
+                const f4_t v = *reinterpret_cast<const f4_t*>(slab + row * 32 + (lane & 7) * 4);
+                const int m = m0 + h * (BM / 2) + row;
+                if (m < p.M && n0 < p.N) *reinterpret_cast<f4_t*>(dst + (size_t)m * ld + n0) = v;
             }
         }
     }
@@ -384,8 +392,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= quads) return;
     const size_t stride = (size_t)M * N;
-    f4_t s = *reinterpret_cast<const f4_t*>(slabs + 4 * i);
-    for (int sp = 1; sp < splits; ++sp) s += *reinterpret_cast<const f4_t*>(slabs + sp * stride + 4 * i);
+    // loads four slabs ahead (independent 16-byte loads in flight), additions stay in slab order
+    const float* src = slabs + 4 * i;
+    f4_t s = *reinterpret_cast<const f4_t*>(src);
+    int sp = 1;
+    for (; sp + 4 <= splits; sp += 4) {
+        const f4_t a = *reinterpret_cast<const f4_t*>(src + (size_t)sp * stride);
+        const f4_t b = *reinterpret_cast<const f4_t*>(src + (size_t)(sp + 1) * stride);
+        const f4_t c = *reinterpret_cast<const f4_t*>(src + (size_t)(sp + 2) * stride);
+        const f4_t d = *reinterpret_cast<const f4_t*>(src + (size_t)(sp + 3) * stride);
+        s += a;
+        s += b;
+        s += c;
+        s += d;
+    }
+    for (; sp < splits; ++sp) s += *reinterpret_cast<const f4_t*>(src + (size_t)sp * stride);
     const int n = (int)((4 * i) % N);
     const size_t o = (4 * i) / N * (size_t)ldo + n;  // N % 4 == 0: the quad stays inside one row
     if (out_f32) {
