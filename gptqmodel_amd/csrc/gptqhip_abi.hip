@@ -65,8 +65,10 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
         if (pl.slab_floats > floats) floats = pl.slab_floats;
     }
     if (M > 16 || g_force_kernel == 2) {
-        const TiledPlan tp = plan_tiled(M, K, N, group_size > 0 ? group_size : 128, g_force_waves, g_force_split);
-        if (tp.slab_floats > floats) floats = tp.slab_floats;
+        for (int b : {4, 8}) {  // the 8-bit plan uses 128-row tiles only and may split K further
+            const TiledPlan tp = plan_tiled(M, K, N, group_size > 0 ? group_size : 128, b, g_force_waves, g_force_split);
+            if (tp.slab_floats > floats) floats = tp.slab_floats;
+        }
     }
     L.slabs_bytes = align_up(floats * sizeof(float), 256);
     L.total = L.slabs_off + L.slabs_bytes;
@@ -223,7 +225,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         a.x = xin;
         a.out = out;
         a.M = M;
-        const TiledPlan tp = plan_tiled(M, K, N, group_size, g_force_waves, g_force_split);  // force_waves doubles as tiled variant
+        const TiledPlan tp = plan_tiled(M, K, N, group_size, bits, g_force_waves, g_force_split);  // force_waves doubles as tiled variant
         if (tp.tail_cols > 0) {
             // two launches (plan_tiled): 256-row tiles over the leading block columns, 128-row tiles over the trailing
             // ones.  The tile-major weight layout makes a column sub-range a plain pointer offset; the output keeps its

@@ -47,7 +47,7 @@ int check_hip(hipError_t e, const char* what);
 SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves);
 int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* counters, hipStream_t stream);
 
-TiledPlan plan_tiled(int M, int K, int N, int group_size, int force_variant, int force_split);
+TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_variant, int force_split);
 int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, hipStream_t stream);
 
 int launch_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* g_idx, void* out,

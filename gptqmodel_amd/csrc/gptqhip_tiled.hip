@@ -133,59 +133,73 @@ __device__ __forceinline__ void lds_wait(u4_t (&frag)[N]) {
     for (int i = 1; i < N; ++i) asm volatile("" : "+v"(frag[i]));
 }
 
-// s_waitcnt vmcnt(stages * OPS) for a block-uniform run-time `stages` in [0, MAXS] (the immediate must be a constant)
-template <int OPS, int MAXS>
-__device__ __forceinline__ void vm_wait_stages(int stages) {
-    static_assert(MAXS * OPS <= 63, "vmcnt is a 6-bit field");
-    if constexpr (MAXS >= 2) {
-        if (stages >= 2) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
-            return;
+// s_waitcnt vmcnt(stages * OPS + (plus_stores ? S : 0)) for block-uniform run-time arguments, stages in [0, MAXS]
+// (the immediate must be a constant)
+template <int OPS, int S, int MAXS>
+__device__ __forceinline__ void vm_wait(int stages, bool plus_stores) {
+    static_assert(MAXS <= 1, "at most 3 pipeline stages");
+    static_assert(MAXS * OPS + S <= 63, "vmcnt is a 6-bit field");
+    if (plus_stores) {
+        if (MAXS >= 1 && stages >= 1) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXS * OPS + S) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
+        }
+    } else {
+        if (MAXS >= 1 && stages >= 1) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXS * OPS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
-    if constexpr (MAXS >= 1) {
-        if (stages >= 1) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
-            return;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int BITS, int ACT, int SCL, int GPC, int BM, int WAVES, int D>
+// Per-tile context of the persistent tile loop
+struct TileCtx {
+    int m0;     // first row of the tile
+    int tile0;  // this wave's first 16-column weight tile
+    ATileSrc a;
+};
+
+// OUTF = 0: 16-bit output with the reference's rounding chain; 1: fp32 accumulators (split-K slabs, TP partial sums).  A
+// template parameter rather than a run-time branch: the two epilogues issue different numbers of stores, and a branch
+// between them inside the tile loop makes hipcc assume the smaller count (zero, after its CFG lowering) in every wait.
+template <int BITS, int ACT, int SCL, int GPC, int BM, int WAVES, int D, int OUTF>
 __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     constexpr int MT = BM / 16;
     constexpr int NT = 64 * WAVES;
     constexpr int TPW = kTiledBN / kTileN / WAVES;  // column tiles per wave
-    // two A-tile buffers: the next tile is written while slower waves may still read the current one -> ONE barrier
-    // per 128-deep tile
+    // D stage buffers for the A tile + a separate staging area for the epilogue transposes (BM x 16 B per wave), so a
+    // tile's output can leave while the NEXT tile's first stages are already landing in the stage buffers
     __shared__ __attribute__((aligned(16))) char lds_all[D * BM * 256];
+    __shared__ __attribute__((aligned(16))) char lds_epi[WAVES * BM * 16];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15;
     const int rq = lane >> 4;
-    // XCD-aware block order (cdna_hip_programming.md T1): hardware places linear block b on XCD b % 8; remap so each
-    // XCD works on a contiguous run of (bm, bn) pairs -> the blocks sharing one A row-panel reuse it from ONE L2.
-    const int nbx = gridDim.x;
-    const int nwg = nbx * gridDim.y;
-    int lin = blockIdx.y * nbx + blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, idx = lin >> 3;
-        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective for any nwg
-    }
-    const int bm = lin / nbx;
-    const int bn = lin - bm * nbx;
-    const int m0 = bm * BM;
-    const int tile0 = bn * (kTiledBN / kTileN) + wave * TPW;
+
+    // Persistent tile loop: block b works on virtual blocks b, b + G, b + 2G, ... (G = gridDim.x, one block per CU).
+    // XCD-aware order (cdna_hip_programming.md T1): hardware places block b on XCD b % 8 and G % 8 == 0 or G == ntiles,
+    // so virtual block v also runs on XCD v % 8; remap so each XCD works on a contiguous run of (bm, bn) pairs -> the
+    // blocks sharing one A row-panel reuse it from ONE L2.
+    const int nbx = ceil_div(p.N, kTiledBN);
+    const int ntiles = nbx * ceil_div(p.M, BM);
+    const int G = gridDim.x;
+    auto make_ctx = [&](int v) __attribute__((always_inline)) {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, idx = v >> 3;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective for any ntiles
+        const int bm = lin / nbx;
+        const int bn = lin - bm * nbx;
+        TileCtx t;
+        t.m0 = bm * BM;
+        t.tile0 = bn * (kTiledBN / kTileN) + wave * TPW;
+        t.a = make_a_src<BM, NT>(p, t.m0, wave, lane);
+        return t;
+    };
 
     f4_t acc[MT][TPW];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[mt][t] = f4_t{0.f, 0.f, 0.f, 0.f};
-
     const DequantConsts dk = make_dequant_consts<BITS>();
     BStage<BITS, GPC, TPW> bst[D];
 
@@ -197,18 +211,26 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
 
     // D-stage pipeline over the 128-deep K chunks: chunk i lives in LDS buffer / register stage i % D, the loads of
     // chunks i+1 .. i+D-1 are in flight while chunk i is multiplied.  One chunk of a 128-row tile is only ~1000
-    // matrix-pipe cycles per wave -- shorter than an HBM round trip -- so D = 4 there (a 2-deep pipe measured 15 us
-    // for FOUR chunks at M=64); 256-row tiles (2 x 64 KiB of LDS) keep D = 2.
-    const ATileSrc asrc = make_a_src<BM, NT>(p, m0, wave, lane);
+    // matrix-pipe cycles per wave -- shorter than a loaded HBM round trip -- so D = 3 there; 256-row tiles (2 x 64 KiB
+    // of LDS) keep D = 2.
     constexpr int OPS = BM * 16 / NT + TPW * ((BITS == 4 ? 1 : 2) + GPC);  // VMEM instructions per stage and wave
-    auto issue = [&](auto sc, int chunk) __attribute__((always_inline)) {
+    constexpr int NST = OUTF ? BM / 8 : BM / 16;  // 16-byte store instructions per wave and tile in the epilogue
+    // Every issue is UNCONDITIONAL (a chunk index past the end is clamped and re-fetches the last chunk into a stage
+    // nobody reads): the instruction stream between any load and its use is then the same on every path, which is what
+    // lets both the hand-written and hipcc's own vmcnt waits be exact counts instead of full drains.
+    auto issue = [&](auto sc, const TileCtx& t, int chunk) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
-        stage_a_dma<BM, NT>(asrc, lds_all + s * (BM * 256), chunk, wave);
-        load_b<BITS, GPC, TPW>(bst[s], p, tile0, chunk, lane);
+        const int ck = min(chunk, c_end - 1);
+        stage_a_dma<BM, NT>(t.a, lds_all + s * (BM * 256), ck, wave);
+        load_b<BITS, GPC, TPW>(bst[s], p, t.tile0, ck, lane);
+    };
+    auto prologue = [&](const TileCtx& t) __attribute__((always_inline)) {
+        static_for<D - 1>([&](auto dc) { issue(dc, t, c_begin + decltype(dc)::value); });
     };
 
-    auto compute = [&](auto sc) __attribute__((always_inline)) {
+    auto compute = [&](auto sc, auto first_c) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
+        constexpr bool kFirst = decltype(first_c)::value;  // first chunk of a tile: K-step 0 starts from C = 0
         BStage<BITS, GPC, TPW>& bcur = bst[s];
         // Software pipeline inside the chunk (everything is compile-time unrolled, all indices static):
         //   * A fragments: a ring of PF ds_read_b128 stays in flight ahead of the MFMAs that consume them;
@@ -229,8 +251,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
             }
         };
         // A fragment idx = j * MT + mt lives at row mt*16 + c, 16-byte segment (4j + rq) ^ c of this buffer.  The reads
-        // are inline asm with counted waits: with LDS-DMA in the kernel hipcc turns every LDS wait into lgkmcnt(0),
-        // which drains the reads just issued for the NEXT group and exposes the LDS latency every other group.
+        // are inline asm with counted waits (hipcc does not track them; lds_wait ties the consumers to the wait).
         const uint32_t abase = lds_row_base + (uint32_t)(s * (BM * 256));
         uint32_t aaddr[4];
 #pragma unroll
@@ -263,7 +284,13 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
             for (int i = 0; i < PF; ++i) {
                 const int mt = (g * PF + i) % MT;
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) acc[mt][t] = mfma16<ACT>(abuf[g & 1][i], bnow[t], acc[mt][t]);
+                for (int t = 0; t < TPW; ++t) {
+                    if constexpr (kFirst && j == 0) {
+                        acc[mt][t] = mfma16<ACT>(abuf[g & 1][i], bnow[t], f4_t{0.f, 0.f, 0.f, 0.f});
+                    } else {
+                        acc[mt][t] = mfma16<ACT>(abuf[g & 1][i], bnow[t], acc[mt][t]);
+                    }
+                }
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
@@ -274,112 +301,162 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         });
     };
 
-    // One pipeline stage = wait for chunk's own loads, barrier, issue chunk + D - 1, multiply chunk.
-    //   wait: chunk's loads have landed once at most `ahead` younger stages are still in flight;
+    // One pipeline stage = wait for the chunk's own loads, barrier, issue chunk + D - 1, multiply the chunk.
+    //   wait: the issue order per tile is [prologue stages 0..D-2] [NST output stores of the previous tile] [one stage per
+    //   executed pipeline stage] and vmcnt retires in issue order, so the chunk in stage slot s has landed once at most
+    //   AHEAD younger stages (+ the stores, for prologue chunks) are outstanding;
     //   barrier: the same holds for every wave's pieces of the A tile AND every wave is done reading buffer (s-1) % D,
     //   which the next issue overwrites.  (Plain s_barrier: __syncthreads() would make hipcc drain vmcnt to 0.)
-    // STEADY stages issue unconditionally: hipcc's own wait for the B registers is then a counted vmcnt as well (with
-    // a conditional issue on the path it falls back to vmcnt(0), draining the whole prefetch once per round).
-    auto stage = [&](auto sc, int chunk, auto steady) __attribute__((always_inline)) {
+    // KIND 0: first round of a tile (prologue chunks: the stores count; stage 0 starts the accumulators from C = 0),
+    //      1: steady round, 2: drain (no issue; fewer stages in flight).
+    auto stage = [&](auto sc, const TileCtx& t, int chunk, auto kind_c, auto pos_c) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
-        if constexpr (decltype(steady)::value) {
-            vm_wait_stages<OPS, D - 2>(D - 2);
+        constexpr int kind = decltype(kind_c)::value;
+        constexpr int pos = decltype(pos_c)::value;  // position inside the round / the drain
+        if constexpr (kind == 2) {
+            // drain stage `pos`: the younger stages still in flight are the D - 2 - pos issued by the last round
+            vm_wait<OPS, NST, D - 2>(D - 2 - pos, chunk - c_begin <= D - 2);
             __builtin_amdgcn_s_barrier();
-            issue(std::integral_constant<int, (s + D - 1) % D>{}, chunk + D - 1);
+            compute(sc, std::false_type{});
         } else {
-            vm_wait_stages<OPS, D - 2>(min(D - 2, c_end - 1 - chunk));
+            vm_wait<OPS, NST, D - 2>(D - 2, kind == 0 && pos <= D - 2);
             __builtin_amdgcn_s_barrier();
-            if (chunk + D - 1 < c_end) issue(std::integral_constant<int, (s + D - 1) % D>{}, chunk + D - 1);
+            issue(std::integral_constant<int, (s + D - 1) % D>{}, t, chunk + D - 1);
+            compute(sc, std::integral_constant<bool, kind == 0 && pos == 0>{});
         }
-        compute(sc);
     };
-    int chunk0 = c_begin;
-    if constexpr (D == 2) {
-        // two stages: the wait is vmcnt(0) either way, so no separate steady state (its extra code copies cost
-        // registers the 256-row tile does not have)
-        if (c_begin < c_end) issue(std::integral_constant<int, 0>{}, c_begin);
-        for (; chunk0 < c_end; chunk0 += 2) {
-            stage(std::integral_constant<int, 0>{}, chunk0, std::false_type{});
-            if (chunk0 + 1 < c_end) stage(std::integral_constant<int, 1>{}, chunk0 + 1, std::false_type{});
+
+    // ---- epilogue pieces: buffer stores (hardware bounds check drops rows >= M, the lane offset of columns >= N is
+    // pushed out of range) so that EVERY tile issues exactly the same number of store instructions -- the counted
+    // waits above rely on it.
+    // bias of the tile's columns: fetched BEFORE the next tile's prologue is issued (the wait for these few bytes would
+    // otherwise sit behind that prologue's loads)
+    auto load_bias = [&](const TileCtx& t, float (&bias)[TPW]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            const int n = (t.tile0 + tt) * kTileN + c;
+            bias[tt] = (p.bias != nullptr && n < p.N) ? load16_as_f32<ACT>(p.bias, (size_t)n) : 0.f;
         }
-    } else {
-        if (c_end - c_begin >= 2 * D - 1) {
-            static_for<D - 1>([&](auto dc) { issue(dc, c_begin + decltype(dc)::value); });
-            while (chunk0 + 2 * D - 2 < c_end) {  // every stage of this round still has a chunk + D - 1 to issue
-                static_for<D>([&](auto sc) { stage(sc, chunk0 + decltype(sc)::value, std::true_type{}); });
-                chunk0 += D;
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) asm volatile("" : "+v"(bias[tt]));  // loaded (and waited for) here, not later
+    };
+    auto store_tile = [&](const TileCtx& t, const float (&bias)[TPW]) __attribute__((always_inline)) {
+        const int rows = min(p.M - t.m0, BM);
+        // opaque copy of the lane id: keeps hipcc from hoisting the epilogue's address arithmetic out of the tile loop,
+        // where it would occupy registers all through the main loop
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int c_e = lane_e & 15, rq_e = lane_e >> 4;
+        if constexpr (OUTF == 0) {
+            // 16-bit output: round like the reference, transpose through this wave's staging area (4 passes of MT/4
+            // row tiles) and store whole 16-byte row pieces instead of 2-byte scattered elements
+            uint16_t* slab = reinterpret_cast<uint16_t*>(lds_epi + wave * (BM * 16));
+            char* base = reinterpret_cast<char*>(p.out) + (size_t)t.m0 * p.ldo * 2;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, rows * p.ldo * 2, 0x00020000);
+            const int n0 = t.tile0 * kTileN + (lane_e & 3) * 8;
+            const uint32_t lane_off = n0 < p.N ? (uint32_t)((lane_e >> 2) * p.ldo * 2 + n0 * 2) : 0xFFFFFF00u;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt)
+#pragma unroll
+                    for (int mh = 0; mh < MT / 4; ++mh)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float y = round_through<ACT>(acc[h * (MT / 4) + mh][tt][i]);
+                            if (p.bias != nullptr) y = y + bias[tt];
+                            slab[(mh * 16 + 4 * rq_e + i) * 32 + tt * 16 + c_e] = f32_to_16<ACT>(y);
+                        }
+                // same-wave LDS accesses execute in order: no barrier between this wave's writes and reads
+#pragma unroll
+                for (int pass = 0; pass < BM / 64; ++pass) {
+                    const int row = pass * 16 + (lane_e >> 2);
+                    const u4_t v = *reinterpret_cast<const u4_t*>(slab + row * 32 + (lane_e & 3) * 8);
+                    const uint32_t off = lane_off + (uint32_t)((h * (BM / 4) + pass * 16) * p.ldo * 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane_off >= 0xFFFFFF00u ? lane_off : off, 0, 0);
+                }
             }
         } else {
-            static_for<D - 1>([&](auto dc) {
-                if (c_begin + decltype(dc)::value < c_end) issue(dc, c_begin + decltype(dc)::value);
-            });
-        }
-        // drain: the last (up to 2D - 2) chunks; chunk0 - c_begin is a multiple of D, so chunk0 + i uses stage i % D
-        static_for<2 * D - 2>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            if (chunk0 + i < c_end) stage(std::integral_constant<int, i % D>{}, chunk0 + i, std::false_type{});
-        });
-    }
-
-    // ---- epilogue ------------------------------------------------------------------------------------
-    if (p.splits == 1 && !p.out_f32) {
-        // 16-bit output: round like the reference, transpose through LDS (the A buffers are free now) and store whole
-        // 16-byte row pieces instead of 2-byte scattered elements.  Wave w owns columns [32w, 32w+32) of the tile:
-        // its LDS slab is BM rows x 64 B.
-        __syncthreads();  // every wave has finished reading the last A tile
-        uint16_t* slab = reinterpret_cast<uint16_t*>(lds_all + wave * (BM * 64));
+            // fp32 accumulators (split-K partials or tensor-parallel partial sums): 8 passes of MT/8 row tiles, rows
+            // of 32 floats (128 B) leave as 16-byte pieces
+            float* slab = reinterpret_cast<float*>(lds_epi + wave * (BM * 16));
+            const size_t ld = p.splits > 1 ? (size_t)p.N : (size_t)p.ldo;
+            char* base = p.splits > 1 ? reinterpret_cast<char*>(p.slabs + ((size_t)blockIdx.z * p.M + t.m0) * p.N)
+                                      : reinterpret_cast<char*>(p.out) + (size_t)t.m0 * p.ldo * 4;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(rows * ld * 4), 0x00020000);
+            const int n0 = t.tile0 * kTileN + (lane_e & 7) * 4;
+            const uint32_t lane_off = n0 < p.N ? (uint32_t)((lane_e >> 3) * ld * 4 + n0 * 4) : 0xFFFFFF00u;
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            const int n = (tile0 + t) * kTileN + c;
-            float bias = 0.f;
-            if (p.bias != nullptr && n < p.N) bias = load16_as_f32<ACT>(p.bias, (size_t)n);
+            for (int h = 0; h < 8; ++h) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+                for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float y = round_through<ACT>(acc[mt][t][i]);
-                    if (p.bias != nullptr) y = y + bias;
-                    slab[(mt * 16 + 4 * rq + i) * 32 + t * 16 + c] = f32_to_16<ACT>(y);
+                    for (int mh = 0; mh < MT / 8; ++mh)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) slab[(mh * 16 + 4 * rq_e + i) * 32 + tt * 16 + c_e] = acc[h * (MT / 8) + mh][tt][i];
+#pragma unroll
+                for (int pass = 0; pass < BM / 64; ++pass) {
+                    const int row = pass * 8 + (lane_e >> 3);
+                    const f4_t v = *reinterpret_cast<const f4_t*>(slab + row * 32 + (lane_e & 7) * 4);
+                    const uint32_t off = lane_off + (uint32_t)((h * (BM / 8) + pass * 8) * ld * 4);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs,
+                                                           lane_off >= 0xFFFFFF00u ? lane_off : off, 0, 0);
                 }
             }
         }
-        // same-wave LDS accesses execute in order: no barrier needed between this wave's writes and reads
-        const int n0 = tile0 * kTileN + (lane & 3) * 8;
-#pragma unroll
-        for (int pass = 0; pass < BM / 16; ++pass) {
-            const int row = pass * 16 + (lane >> 2);
-            const u4_t v = *reinterpret_cast<const u4_t*>(slab + row * 32 + (lane & 3) * 8);
-            const int m = m0 + row;
-            if (m < p.M && n0 < p.N) *reinterpret_cast<u4_t*>(reinterpret_cast<uint16_t*>(p.out) + (size_t)m * p.ldo + n0) = v;
-        }
-        return;
-    }
-    // fp32 accumulators (split-K partials or tensor-parallel partial sums): same LDS transpose, in two passes of MT/2
-    // row tiles so a wave's staging area stays BM x 64 bytes: rows of 32 floats (128 B) leave as 16-byte pieces
-    // instead of 4-byte scattered elements.
+    };
+
+    TileCtx cur = make_ctx(blockIdx.x);
+    prologue(cur);
     {
-        __syncthreads();  // every wave has finished reading the last A tile
-        float* slab = reinterpret_cast<float*>(lds_all + wave * (BM * 64));
-        float* dst = p.splits > 1 ? p.slabs + (size_t)blockIdx.z * p.M * p.N : reinterpret_cast<float*>(p.out);
-        const size_t ld = p.splits > 1 ? (size_t)p.N : (size_t)p.ldo;
-        const int n0 = tile0 * kTileN + (lane & 7) * 4;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int t = 0; t < TPW; ++t)
-#pragma unroll
-                for (int mh = 0; mh < MT / 2; ++mh)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) slab[(mh * 16 + 4 * rq + i) * 32 + t * 16 + c] = acc[h * (MT / 2) + mh][t][i];
-            // same-wave LDS accesses execute in order: no barrier between this wave's writes and reads
-#pragma unroll
-            for (int pass = 0; pass < BM / 16; ++pass) {
-                const int row = pass * 8 + (lane >> 3);
-                const f4_t v = *reinterpret_cast<const f4_t*>(slab + row * 32 + (lane & 7) * 4);
-                const int m = m0 + h * (BM / 2) + row;
-                if (m < p.M && n0 < p.N) *reinterpret_cast<f4_t*>(dst + (size_t)m * ld + n0) = v;
+        // the first tile has no predecessor whose stores sit between its prologue and its later stages: issue the same
+        // number of (out-of-range, dropped) stores so that every tile sees the same instruction sequence
+        const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0, 0x00020000);
+        const u4_t z = {0u, 0u, 0u, 0u};
+        static_for<NST>([&](auto ic) {  // NST distinct instructions (a rolled-up loop would hide their count from hipcc)
+            __builtin_amdgcn_raw_buffer_store_b128(z, none, 16 * decltype(ic)::value, 0, 0);
+        });
+    }
+    for (int v = blockIdx.x;; v += G) {
+        int chunk0 = c_begin;
+        if (c_end - c_begin >= D) {
+            static_for<D>([&](auto sc) {
+                stage(sc, cur, chunk0 + decltype(sc)::value, std::integral_constant<int, 0>{}, sc);
+            });
+            chunk0 += D;
+            while (chunk0 + D <= c_end) {
+                static_for<D>([&](auto sc) {
+                    stage(sc, cur, chunk0 + decltype(sc)::value, std::integral_constant<int, 1>{}, sc);
+                });
+                chunk0 += D;
             }
+        } else {
+            f4_t zero = {0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+v"(zero));  // fewer than D chunks (tiny K): rare path, plain zeroing
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) acc[mt][t] = zero;
         }
+        // drain: the last c_end - chunk0 < D chunks; chunk0 - c_begin is a multiple of D, so chunk0 + i uses stage i
+        static_for<D - 1>([&](auto ic) {
+            if (chunk0 + decltype(ic)::value < c_end) {
+                stage(ic, cur, chunk0 + decltype(ic)::value, std::integral_constant<int, 2>{}, ic);
+            }
+        });
+        // every wave is done reading the stage buffers -> the next tile's first stages may land in them while this
+        // tile's output is rounded, transposed and stored; those stores then drain under the next tile's first chunks
+        __builtin_amdgcn_s_barrier();
+        float bias[TPW];
+        load_bias(cur, bias);
+        if (v + G >= ntiles) {
+            store_tile(cur, bias);
+            break;
+        }
+        const TileCtx nxt = make_ctx(v + G);
+        prologue(nxt);
+        store_tile(cur, bias);
+        cur = nxt;
     }
 }
 
@@ -427,20 +504,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+template <int BITS, int ACT, int SCL, int GPC, int OUTF>
+static int launch_tiled_out(const TiledParams& p, int bm, hipStream_t stream) {
+    // one block per CU; with more tiles than CUs the blocks loop over tiles (persistent), keeping the next tile's first
+    // loads in flight across the epilogue.  Split-K launches have few tiles by construction: one tile per block.
+    const int ntiles = ceil_div(p.N, kTiledBN) * ceil_div(p.M, bm);
+    const dim3 grid(p.splits == 1 && ntiles > 256 ? 256 : ntiles, 1, p.splits);
+    if constexpr (BITS == 4 && GPC == 1) {
+        if (bm == 256) {
+            hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 256, 8, 2, OUTF>), grid, dim3(512), 0, stream, p);
+            return check_hip(hipGetLastError(), "tiled_kernel launch");
+        }
+    }
+    if (bm != 128) {
+        set_error("tiled kernel: no %d-row tile for bits=%d gpc=%d", bm, BITS, GPC);
+        return -22;  // GPTQHIP_EINVAL
+    }
+    // (a 4-wave x 4-tile variant with two independent blocks per CU was measured 25-30 % slower: 660 vs 950 TF)
+    // 3 stages in flight (measured on 128-row tiles, M=2048 4096^2: 951 / 1061 / 984 TF for 2 / 3 / 4 stages -- the
+    // fourth only lengthens the start-up burst); the 8-bit register stages are twice as large: 2 stages there
+    hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 128, 8, BITS == 4 ? 3 : 2, OUTF>), grid, dim3(512), 0, stream, p);
+    return check_hip(hipGetLastError(), "tiled_kernel launch");
+}
+
 template <int BITS, int ACT, int SCL, int GPC>
 static int launch_tiled_bm(const TiledParams& p, int bm, int waves, hipStream_t stream) {
-    const dim3 grid(ceil_div(p.N, kTiledBN), ceil_div(p.M, bm), p.splits);
-    if (bm == 256) {
-        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 256, 8, 2>), grid, dim3(512), 0, stream, p);
-    } else {
-        // (a 4-wave x 4-tile variant with two independent blocks per CU was measured 25-30 % slower: 660 vs 950 TF)
-        // 4 stages in flight for 4-bit weights; the 8-bit register stages are twice as large (2 stages fit without spills)
-        // 3 stages in flight (measured on 128-row tiles, M=2048 4096^2: 951 / 1061 / 984 TF for 2 / 3 / 4 stages -- the
-        // fourth only lengthens the start-up burst); the 8-bit register stages are twice as large: 2 stages there
-        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 128, 8, BITS == 4 ? 3 : 2>), grid, dim3(512), 0, stream, p);
-    }
     (void)waves;
-    return check_hip(hipGetLastError(), "tiled_kernel launch");
+    if (p.splits > 1 || p.out_f32) return launch_tiled_out<BITS, ACT, SCL, GPC, 1>(p, bm, stream);
+    return launch_tiled_out<BITS, ACT, SCL, GPC, 0>(p, bm, stream);
 }
 
 template <int BITS, int ACT, int SCL>
@@ -449,7 +540,7 @@ static int launch_tiled_gpc(const TiledParams& p, int gpc, int bm, int waves, hi
     return launch_tiled_bm<BITS, ACT, SCL, 4>(p, bm, waves, stream);
 }
 
-TiledPlan plan_tiled(int M, int K, int N, int group_size, int force_variant, int force_split) {
+TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_variant, int force_split) {
     TiledPlan pl;
     pl.gpc = (group_size % kChunkK == 0) ? 1 : 4;
     // Tile height from a small measured cost model (unit = one full round of 256 blocks with 256-row tiles on 256 CUs).
@@ -482,6 +573,12 @@ TiledPlan plan_tiled(int M, int K, int N, int group_size, int force_variant, int
     pl.waves = 8;
     if (force_variant == 1) { pl.bm = 256; pl.waves = 8; }
     if (force_variant == 2) { pl.bm = 128; pl.waves = 8; }
+    // 256-row tiles exist for 4-bit weights with one scale row per chunk only: the 8-bit and small-group register
+    // stages do not fit beside 128 accumulator registers (they spilled 10-25 VGPRs into the main loop)
+    if (bits != 4 || pl.gpc != 1) {
+        pl.bm = 128;
+        pl.tail_cols = 0;
+    }
     // split K across blocks when the (M, N) grid alone leaves most CUs idle (mid-size M, or K-heavy layers):
     // fp32 partial slabs + a tiny reduce kernel (a kernel boundary is cheaper than re-reading 100s of KB of slabs
     // through a last-arriver block -- MI355X_MICROARCH.md "handoff-payload")
