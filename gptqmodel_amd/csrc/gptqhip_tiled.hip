@@ -74,6 +74,15 @@ __device__ __forceinline__ void load_b(BStage<BITS, GPC, TPW>& st, const TiledPa
     }
 }
 
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // LDS-DMA staging (buffer_load_dwordx4 ... lds): the A tile goes HBM/L2 -> LDS without passing through VGPRs.  The
 // hardware writes wave-uniform base + lane*16, i.e. the LDS image is lane-linear: one instruction fills 4 rows x 256 B.
 // The XOR swizzle therefore moves to the SOURCE address (lane (r, pos) fetches segment pos ^ (row & 15)) and the
@@ -100,24 +109,17 @@ __device__ __forceinline__ ATileSrc make_a_src(const TiledParams& p, int m0, int
     return a;
 }
 
-template <int BM, int NT>
-__device__ __forceinline__ void stage_a_dma(const ATileSrc& a, char* lds_buf, int chunk, int wave) {
+template <int BM, int NT, int I>
+__device__ __forceinline__ void stage_a_piece(const ATileSrc& a, char* lds_buf, int chunk, int wave) {
     typedef __attribute__((address_space(3))) void* lptr_t;
-#pragma unroll
-    for (int i = 0; i < BM * 16 / NT; ++i) {
-        const int r0 = (i * (NT / 64) + wave) * 4;  // wave-uniform first row of this 1 KiB piece (r0 & 15 == 4*wave & 15)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(a.rsrc, (lptr_t)(lds_buf + r0 * 256), 16, a.voff + i * a.piece_step,
-                                                 chunk * (kChunkK * 2), 0, 0);
-    }
+    const int r0 = (I * (NT / 64) + wave) * 4;  // wave-uniform first row of this 1 KiB piece (r0 & 15 == 4*wave & 15)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a.rsrc, (lptr_t)(lds_buf + r0 * 256), 16, a.voff + I * a.piece_step,
+                                             chunk * (kChunkK * 2), 0, 0);
 }
 
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
+template <int BM, int NT>
+__device__ __forceinline__ void stage_a_dma(const ATileSrc& a, char* lds_buf, int chunk, int wave) {
+    static_for<BM * 16 / NT>([&](auto ic) { stage_a_piece<BM, NT, decltype(ic)::value>(a, lds_buf, chunk, wave); });
 }
 
 // ds_read_b128 the compiler does not track: completion is awaited by lds_wait<CNT>, whose "+v" operands make every
@@ -228,43 +230,66 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         static_for<D - 1>([&](auto dc) { issue(dc, t, c_begin + decltype(dc)::value); });
     };
 
-    auto compute = [&](auto sc, auto first_c) __attribute__((always_inline)) {
-        constexpr int s = decltype(sc)::value;
-        constexpr bool kFirst = decltype(first_c)::value;  // first chunk of a tile: K-step 0 starts from C = 0
-        BStage<BITS, GPC, TPW>& bcur = bst[s];
-        // Software pipeline inside the chunk (everything is compile-time unrolled, all indices static):
-        //   * A fragments: a ring of PF ds_read_b128 stays in flight ahead of the MFMAs that consume them;
-        //   * B fragments of K-step j+1 are dequantised in the middle of step j's MFMA stream (VALU work hides under
-        //     the matrix pipe instead of forming a VALU-only phase).
-        constexpr int PF = BM == 256 ? 4 : 8;  // measured: deeper spills at BM=256, helps at BM=128
-        u4_t abuf[2][PF];
-        u4_t bnow[TPW], bnext[TPW];
-        auto dequant_step = [&](int j, u4_t (&b)[TPW]) __attribute__((always_inline)) {
+    // K-step fragments of B: bnow is carried ACROSS chunks -- K-step 0 of the next chunk is dequantised under the last
+    // K-step's MFMAs of the current one, so that after the barrier the matrix pipe restarts after one LDS round trip
+    // instead of after a VMEM issue burst + a dequant pass (all 8 waves leave the barrier together: nobody covers).
+    u4_t bnow[TPW], bnext[TPW];
+    auto dequant_step = [&](const BStage<BITS, GPC, TPW>& bs, int j, u4_t (&b)[TPW]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const ColConst cc = expand_meta<BITS, SCL>(bcur.meta[t][GPC == 4 ? j : 0]);
-                if constexpr (BITS == 4) {
-                    b[t] = dequant_word4<ACT, SCL>(bcur.w[t][0][j], cc, dk);
-                } else {
-                    b[t] = dequant_word8<ACT, SCL>(bcur.w[t][j >> 1][(j & 1) * 2], bcur.w[t][j >> 1][(j & 1) * 2 + 1], cc, dk);
-                }
+        for (int t = 0; t < TPW; ++t) {
+            const ColConst cc = expand_meta<BITS, SCL>(bs.meta[t][GPC == 4 ? j : 0]);
+            if constexpr (BITS == 4) {
+                b[t] = dequant_word4<ACT, SCL>(bs.w[t][0][j], cc, dk);
+            } else {
+                b[t] = dequant_word8<ACT, SCL>(bs.w[t][j >> 1][(j & 1) * 2], bs.w[t][j >> 1][(j & 1) * 2 + 1], cc, dk);
             }
-        };
-        // A fragment idx = j * MT + mt lives at row mt*16 + c, 16-byte segment (4j + rq) ^ c of this buffer.  The reads
-        // are inline asm with counted waits (hipcc does not track them; lds_wait ties the consumers to the wait).
+        }
+    };
+    // tile start: chunk 0's loads (a prologue stage: the previous tile's stores are younger) have landed -> K-step 0
+    auto pre_first = [&]() __attribute__((always_inline)) {
+        vm_wait<OPS, NST, D - 2>(D - 2, true);
+        dequant_step(bst[0], 0, bnow);
+    };
+
+    // One pipeline stage = barrier, multiply chunk (stage slot s) while issuing chunk + D - 1 and preparing chunk + 1.
+    //   barrier: every wave's pieces of this chunk's A tile have landed (each wave waited for its own loads before it
+    //   got here) AND every wave is done reading buffer (s-1) % D, which this stage's DMA overwrites.  (Plain s_barrier:
+    //   __syncthreads() would make hipcc drain vmcnt to 0.)
+    //   issue: B loads right after the first fragment reads, the A-tile DMA pieces one per MFMA group (an LDS-DMA issue
+    //   costs 60-185 cycles, MI355X_MICROARCH.md -- as one burst after the barrier it kept the matrix pipe idle).
+    //   wait for chunk + 1, at the start of the last K-step: issue order per tile is [prologue stages 0..D-2] [NST output
+    //   stores of the previous tile] [one stage per executed pipeline stage] and vmcnt retires in issue order, so chunk + 1
+    //   has landed once at most AHEAD younger stages (+ the stores, if chunk + 1 is a prologue stage) are outstanding.
+    // KIND 0: first round of a tile (stage 0 starts the accumulators from C = 0), 1: steady round, 2: drain (no issue).
+    // Everything is compile-time unrolled with sched_barrier(0) fences; A fragments: groups of PF ds_read_b128 (inline
+    // asm hipcc does not track; lds_wait ties the consumers to the counted wait), the reads of group g+1 in flight
+    // under the MFMAs of group g; the next K-step's dequant VALU rides in the MFMA stream.
+    auto stage = [&](auto sc, const TileCtx& t, int chunk, auto kind_c, auto pos_c) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int kind = decltype(kind_c)::value;
+        constexpr int pos = decltype(pos_c)::value;  // position inside the round / the drain
+        constexpr bool kFirst = kind == 0 && pos == 0;
+        constexpr bool kIssue = kind != 2;
+        constexpr bool kNext = !(kind == 2 && pos == D - 2);  // loads of a next chunk exist (clamped past the end)
+        constexpr int sn = (s + 1) % D, si = (s + D - 1) % D;
+        constexpr int PF = BM == 256 ? 4 : 8;  // measured: deeper spills at BM=256, helps at BM=128
+        constexpr int NG = 4 * MT / PF;        // fragment groups per chunk
+        constexpr int NPIECE = BM * 16 / NT;
+        static_assert(NPIECE <= NG, "one DMA piece per fragment group");
+        u4_t abuf[2][PF];
+
+        __builtin_amdgcn_s_barrier();
+        // A fragment idx = j * MT + mt lives at row mt*16 + c, 16-byte segment (4j + rq) ^ c of this buffer
         const uint32_t abase = lds_row_base + (uint32_t)(s * (BM * 256));
         uint32_t aaddr[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) aaddr[j] = abase + (uint32_t)((j * 64 + rq * 16) ^ (c << 4));
-        constexpr int NG = 4 * MT / PF;  // fragment groups per chunk
-        // Groups of PF fragments: the reads of group g+1 are issued, then the wait for group g only (lgkmcnt(PF)), then
-        // the MFMAs of group g (PF*TPW of them, >= 128 matrix-pipe cycles) under which the newer reads land;
-        // sched_barrier(0) keeps hipcc from moving anything across the phases.  The next K-step's dequant rides along.
-        dequant_step(0, bnow);
         static_for<PF>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             lds_read_b128<(i % MT) * 4096>(abuf[0][i], aaddr[i / MT]);
         });
+        const int ck = min(chunk + D - 1, c_end - 1);
+        if constexpr (kIssue) load_b<BITS, GPC, TPW>(bst[si], p, t.tile0, ck, lane);
         __builtin_amdgcn_sched_barrier(0);
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -275,55 +300,42 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
                 });
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (kIssue && g < NPIECE) stage_a_piece<BM, NT, g>(t.a, lds_all + si * (BM * 256), ck, wave);
             constexpr int j = (g * PF) / MT;            // K-step of this group (PF divides MT)
             constexpr bool last_of_step = ((g + 1) * PF) % MT == 0;
-            if constexpr ((g * PF) % MT == 0 && j < 3) dequant_step(j + 1, bnext);   // VALU under this group's MFMAs
+            if constexpr ((g * PF) % MT == 0) {  // VALU under this group's MFMAs
+                if constexpr (j < 3) {
+                    dequant_step(bst[s], j + 1, bnext);
+                } else if constexpr (kNext) {
+                    if constexpr (kind == 2) {
+                        vm_wait<OPS, NST, D - 2>(D - 3 - pos, chunk + 1 - c_begin <= D - 2);
+                    } else {
+                        vm_wait<OPS, NST, D - 2>(D - 2, kind == 0 && pos + 1 <= D - 2);
+                    }
+                    dequant_step(bst[sn], 0, bnext);
+                }
+            }
             lds_wait<(g + 1 < NG) ? PF : 0, PF>(abuf[g & 1]);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int mt = (g * PF + i) % MT;
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) {
+                for (int tt = 0; tt < TPW; ++tt) {
                     if constexpr (kFirst && j == 0) {
-                        acc[mt][t] = mfma16<ACT>(abuf[g & 1][i], bnow[t], f4_t{0.f, 0.f, 0.f, 0.f});
+                        acc[mt][tt] = mfma16<ACT>(abuf[g & 1][i], bnow[tt], f4_t{0.f, 0.f, 0.f, 0.f});
                     } else {
-                        acc[mt][t] = mfma16<ACT>(abuf[g & 1][i], bnow[t], acc[mt][t]);
+                        acc[mt][tt] = mfma16<ACT>(abuf[g & 1][i], bnow[tt], acc[mt][tt]);
                     }
                 }
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (last_of_step && j < 3) {
+            if constexpr (last_of_step && (j < 3 || kNext)) {
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) bnow[t] = bnext[t];
+                for (int tt = 0; tt < TPW; ++tt) bnow[tt] = bnext[tt];
             }
         });
-    };
-
-    // One pipeline stage = wait for the chunk's own loads, barrier, issue chunk + D - 1, multiply the chunk.
-    //   wait: the issue order per tile is [prologue stages 0..D-2] [NST output stores of the previous tile] [one stage per
-    //   executed pipeline stage] and vmcnt retires in issue order, so the chunk in stage slot s has landed once at most
-    //   AHEAD younger stages (+ the stores, for prologue chunks) are outstanding;
-    //   barrier: the same holds for every wave's pieces of the A tile AND every wave is done reading buffer (s-1) % D,
-    //   which the next issue overwrites.  (Plain s_barrier: __syncthreads() would make hipcc drain vmcnt to 0.)
-    // KIND 0: first round of a tile (prologue chunks: the stores count; stage 0 starts the accumulators from C = 0),
-    //      1: steady round, 2: drain (no issue; fewer stages in flight).
-    auto stage = [&](auto sc, const TileCtx& t, int chunk, auto kind_c, auto pos_c) __attribute__((always_inline)) {
-        constexpr int s = decltype(sc)::value;
-        constexpr int kind = decltype(kind_c)::value;
-        constexpr int pos = decltype(pos_c)::value;  // position inside the round / the drain
-        if constexpr (kind == 2) {
-            // drain stage `pos`: the younger stages still in flight are the D - 2 - pos issued by the last round
-            vm_wait<OPS, NST, D - 2>(D - 2 - pos, chunk - c_begin <= D - 2);
-            __builtin_amdgcn_s_barrier();
-            compute(sc, std::false_type{});
-        } else {
-            vm_wait<OPS, NST, D - 2>(D - 2, kind == 0 && pos <= D - 2);
-            __builtin_amdgcn_s_barrier();
-            issue(std::integral_constant<int, (s + D - 1) % D>{}, t, chunk + D - 1);
-            compute(sc, std::integral_constant<bool, kind == 0 && pos == 0>{});
-        }
     };
 
     // ---- epilogue pieces: buffer stores (hardware bounds check drops rows >= M, the lane offset of columns >= N is
@@ -419,6 +431,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     }
     for (int v = blockIdx.x;; v += G) {
         int chunk0 = c_begin;
+        pre_first();
         if (c_end - c_begin >= D) {
             static_for<D>([&](auto sc) {
                 stage(sc, cur, chunk0 + decltype(sc)::value, std::integral_constant<int, 0>{}, sc);
