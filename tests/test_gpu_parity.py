@@ -363,3 +363,32 @@ def test_tiled_tail_launch_column_split(ops, act):
     got = torch_to_f32(run_gptq(ops, x, qweight, qzeros, scales, g_idx, 4, gs, bias, act, "fp16"))
     ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, bias_f32=bias, act_dtype=act)
     assert rel_err(got, ref) <= (1e-3 if act == "fp16" else 8e-3)
+
+
+@pytest.mark.parametrize("K,variant,partial", [(128, 1, False), (256, 1, False), (384, 1, True), (384, 2, False),
+                                                (640, 2, True), (128, 2, False)])
+def test_persistent_tile_loop_short_k(ops, K, variant, partial):
+    """More output tiles than CUs with only 1-5 K chunks per tile: every block runs several tiles back to back through
+    the first-round / drain code paths (fewer chunks than pipeline stages included), 16-bit and fp32-partial epilogues,
+    ragged M and N."""
+    N, gs, M = 4096 + 8, 128, 4096 + 7
+    qweight, qzeros, scales, g_idx = synth_gptq(70 + K, 4, K, N, gs)
+    rng = np.random.RandomState(K)
+    x = O.round_to(rng.randn(M, K).astype(np.float32) * 0.5, "fp16")
+    qw_t, meta = ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV),
+                                  f32_to_torch(scales, "fp16", DEV), None, gs, 4)
+    xt = f32_to_torch(x, "fp16", DEV)
+    try:
+        ops.set_tuning(0, 2, variant)  # tiled kernel, 256- / 128-row tiles
+        out = ops.gemm(xt, qw_t, meta, None, None, N, gs, 4, torch.float16, partial_f32=partial)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_tuning(0, 0, 0)
+    if partial:
+        w = O.dequant_gptq(qweight, qzeros, scales, g_idx, 4, "fp16").astype(np.float64)
+        ref = (x.astype(np.float64) @ w).astype(np.float32)
+        assert out.dtype == torch.float32
+        assert rel_err(out.cpu().numpy(), ref) <= 1e-5
+    else:
+        ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4)
+        assert rel_err(torch_to_f32(out), ref) <= 1e-3
