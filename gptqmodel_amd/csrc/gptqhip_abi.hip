@@ -198,7 +198,14 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     float* slabs = reinterpret_cast<float*>(ws + L.slabs_off);
 
     const void* xin = x;
-    if (perm) {
+    // act-order: batch-1 decode applies the permutation inside the kernel (no extra launch per linear) when the plan is
+    // the regular straight-line pipeline; everything else gathers x once into the workspace first
+    bool fused_perm = false;
+    if (perm && M == 1 && g_force_kernel != 2) {
+        const SkinnyPlan pl1 = plan_skinny(1, K, N, group_size, g_force_split, g_force_waves);
+        fused_perm = pl1.regular && pl1.gpc == 1;
+    }
+    if (perm && !fused_perm) {
         void* gbuf = ws + L.gather_off;
         rc = launch_gather_cols(x, perm, gbuf, M, K, stream);
         if (rc) return rc;
@@ -216,6 +223,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     a.act_dtype = act_dtype;
     a.scale_dtype = scale_dtype;
     a.out_f32 = partial_f32 ? 1 : 0;
+    a.perm = fused_perm ? perm : nullptr;
 
     // measured crossover (profiles/r01_m_sweep.txt): the MFMA-tiled kernel wins above 32 rows, and already above 16
     // rows on wide layers (N >= 8192, e.g. fused gate_up) where its grid fills the chip without split-K

@@ -291,24 +291,53 @@ int launch_dequant_tiled(const uint32_t* qweight_t, const uint32_t* meta, const 
 // kernel.
 constexpr int kGatherMaxK = 16384;  // 32 KiB of LDS per staged row
 
+// R rows per pass: all R*IT 16-byte loads of a pass are issued before the first LDS write (R * K * 2 bytes in flight per
+// block instead of one row's latency per row), the permutation is read once per pass and reused for the R rows.
+template <int R, int IT>
 __global__ __launch_bounds__(256) void gather_cols_lds_kernel(const uint16_t* __restrict__ x,
                                                               const int32_t* __restrict__ perm,
                                                               uint16_t* __restrict__ out, int M, int K) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t row[];
-    for (int m = blockIdx.x; m < M; m += gridDim.x) {
-        const u4_t* src = reinterpret_cast<const u4_t*>(x + (size_t)m * K);
-        for (int i = threadIdx.x; i < K / 8; i += blockDim.x) reinterpret_cast<u4_t*>(row)[i] = src[i];
+    extern __shared__ __attribute__((aligned(16))) uint16_t rows[];  // [R][K]
+    const int k8 = K / 8;
+    for (int m0 = blockIdx.x * R; m0 < M; m0 += gridDim.x * R) {
+        u4_t stage[R][IT];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int m = m0 + r < M ? m0 + r : M - 1;
+            const u4_t* src = reinterpret_cast<const u4_t*>(x + (size_t)m * K);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int i = threadIdx.x + it * 256;
+                if (i < k8) stage[r][it] = src[i];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int i = threadIdx.x + it * 256;
+                if (i < k8) reinterpret_cast<u4_t*>(rows + (size_t)r * K)[i] = stage[r][it];
+            }
         __syncthreads();
-        u4_t* dst = reinterpret_cast<u4_t*>(out + (size_t)m * K);
-        for (int i = threadIdx.x; i < K / 8; i += blockDim.x) {
-            const u4_t p0 = *reinterpret_cast<const u4_t*>(perm + 8 * i);
-            const u4_t p1 = *reinterpret_cast<const u4_t*>(perm + 8 * i + 4);
-            u4_t v;
-            v.x = (uint32_t)row[p0.x] | ((uint32_t)row[p0.y] << 16);
-            v.y = (uint32_t)row[p0.z] | ((uint32_t)row[p0.w] << 16);
-            v.z = (uint32_t)row[p1.x] | ((uint32_t)row[p1.y] << 16);
-            v.w = (uint32_t)row[p1.z] | ((uint32_t)row[p1.w] << 16);
-            dst[i] = v;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = threadIdx.x + it * 256;
+            if (i < k8) {
+                const u4_t p0 = *reinterpret_cast<const u4_t*>(perm + 8 * i);
+                const u4_t p1 = *reinterpret_cast<const u4_t*>(perm + 8 * i + 4);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (m0 + r < M) {
+                        const uint16_t* row = rows + (size_t)r * K;
+                        u4_t v;
+                        v.x = (uint32_t)row[p0.x] | ((uint32_t)row[p0.y] << 16);
+                        v.y = (uint32_t)row[p0.z] | ((uint32_t)row[p0.w] << 16);
+                        v.z = (uint32_t)row[p1.x] | ((uint32_t)row[p1.y] << 16);
+                        v.w = (uint32_t)row[p1.z] | ((uint32_t)row[p1.w] << 16);
+                        reinterpret_cast<u4_t*>(out + (size_t)(m0 + r) * K)[i] = v;
+                    }
+                }
+            }
         }
         __syncthreads();
     }
@@ -327,8 +356,21 @@ int launch_gather_cols(const void* x, const int32_t* perm, void* out, int M, int
     const uint16_t* xs = reinterpret_cast<const uint16_t*>(x);
     uint16_t* os = reinterpret_cast<uint16_t*>(out);
     if (K % 8 == 0 && K <= kGatherMaxK && M >= 8) {
-        const int blocks = M < 2048 ? M : 2048;
-        hipLaunchKernelGGL(gather_cols_lds_kernel, dim3(blocks), dim3(256), (size_t)K * 2, stream, xs, perm, os, M, K);
+        const int it = ceil_div(K / 8, 256);  // 16-byte pieces per thread and row
+        const int r = K <= 8192 ? 4 : 2;      // rows per pass (<= 64 KiB of LDS)
+        const int passes = ceil_div(M, r);
+        const dim3 grid(passes < 2048 ? passes : 2048);
+        const size_t lds = (size_t)r * K * 2;
+#define GPTQHIP_GATHER(R_, IT_) hipLaunchKernelGGL((gather_cols_lds_kernel<R_, IT_>), grid, dim3(256), lds, stream, xs, perm, os, M, K)
+        if (r == 4) {
+            if (it <= 1) GPTQHIP_GATHER(4, 1);
+            else if (it <= 2) GPTQHIP_GATHER(4, 2);
+            else GPTQHIP_GATHER(4, 4);
+        } else {
+            if (it <= 6) GPTQHIP_GATHER(2, 6);
+            else GPTQHIP_GATHER(2, 8);
+        }
+#undef GPTQHIP_GATHER
     } else {
         const int gy = M < 1024 ? M : 1024;
         const dim3 grid((K + 255) / 256, gy);

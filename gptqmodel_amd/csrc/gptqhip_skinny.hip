@@ -28,6 +28,7 @@ namespace gptqhip {
 
 struct SkinnyParams {
     const void* x;
+    const int32_t* perm;   // act-order row permutation applied to x inside the kernel (AM_ROW1P), else nullptr
     const uint32_t* qw;    // tiled words
     const uint32_t* meta;  // [tiles][G][16]
     const void* bias;
@@ -57,11 +58,15 @@ constexpr int AM_ROW4 = 0;
 constexpr int AM_ROW1 = 2;
 constexpr int AM_ROWS = 3;
 constexpr int AM_ROWSH = 4;  // AM_ROWS with the last two (unused) row quads skipped: M <= 16*MT - 8
+constexpr int AM_ROW1P = 5;  // AM_ROW1 for act-order checkpoints (no separate gather launch per linear): the block copies the
+                             // x row into LDS once (coalesced), the ring carries the chunk's permutation pair per lane and the
+                             // two halves are gathered from LDS at compute time (2-byte gathers straight from global memory
+                             // were measured 1.4-1.9x slower than the un-permuted kernel: 64 distinct lines per wave load)
 constexpr int kRowsPitch = 17;  // u4 per padded LDS row (272 B)
 
 template <int AM, int MT>
 __host__ __device__ constexpr int slot_bytes() {
-    return AM == AM_ROW1 ? 256
+    return (AM == AM_ROW1 || AM == AM_ROW1P) ? 256
                          : (AM == AM_ROW4 ? 1024 : ((AM == AM_ROWS || AM == AM_ROWSH) ? 16 * MT * kRowsPitch * 16 : 0));
 }
 template <int AM>
@@ -80,6 +85,10 @@ struct AStage {
 template <int MT>
 struct AStage<AM_ROW1, MT> {
     uint32_t a[1];
+};
+template <int MT>
+struct AStage<AM_ROW1P, MT> {
+    uint32_t a[2];  // perm[k], perm[k+1] of this lane's pair in the chunk
 };
 
 template <int BITS, int GPC, int MT, int AM>
@@ -126,7 +135,12 @@ __device__ __forceinline__ void load_stage(Stage<BITS, GPC, MT, AM>& st, const S
     // activations: no masking anywhere.  Rows >= M only feed output rows nobody stores (address clamped to row 0);
     // k >= K happens only in the zero-padded tail chunk of a ragged K, whose weights dequantise to exactly 0
     // (repack_tiled stores code == zero-point there), so the clamped address may read any finite x.
-    if constexpr (AM == AM_ROW1) {
+    if constexpr (AM == AM_ROW1P) {
+        int k0 = chunk * kChunkK + 2 * lane;
+        k0 = k0 + 1 < p.K ? k0 : 0;
+        st.x.a[0] = p.perm[k0];
+        st.x.a[1] = p.perm[k0 + 1];
+    } else if constexpr (AM == AM_ROW1) {
         uint32_t off = (uint32_t)chunk * 256u + (uint32_t)lane * 4u;       // bytes into row 0
         off = off < (uint32_t)p.K * 2u ? off : 0u;
         st.x.a[0] = *reinterpret_cast<const uint32_t*>(tb.x + off);
@@ -173,6 +187,10 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
     st.meta[0] = *reinterpret_cast<const uint32_t*>(mrow + tb.c4);
     if constexpr (AM == AM_ROW1) {
         st.x.a[0] = *reinterpret_cast<const uint32_t*>(cu.x + lo.x[0]);
+    } else if constexpr (AM == AM_ROW1P) {
+        const u2_t pr = *reinterpret_cast<const u2_t*>(reinterpret_cast<const char*>(p.perm) + (size_t)cu.chunk * 512 + lo.x[0]);
+        st.x.a[0] = pr.x;
+        st.x.a[1] = pr.y;
     } else if constexpr (AM == AM_ROW4) {
         st.x.a[0] = *reinterpret_cast<const u4_t*>(cu.x + lo.x[0]);
     } else if constexpr (is_rows<AM>()) {
@@ -186,12 +204,15 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
 
 template <int BITS, int ACT, int SCL, int MT, int GPC, int AM>
 __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st, const SkinnyParams& p, int chunk,
-                                              int lane, u4_t* aslot, const DequantConsts& dk, f4_t (&acc)[MT]) {
+                                              int lane, u4_t* aslot, const DequantConsts& dk, f4_t (&acc)[MT],
+                                              const uint16_t* xbuf = nullptr) {
     const int c = lane & 15;
     const int rq = lane >> 4;
     int abase = 0;  // u4 index of this lane's fragment row inside the wave's LDS slot
     if constexpr (AM == AM_ROW1) {
         reinterpret_cast<uint32_t*>(aslot)[lane] = st.x.a[0];
+    } else if constexpr (AM == AM_ROW1P) {
+        reinterpret_cast<uint32_t*>(aslot)[lane] = (uint32_t)xbuf[st.x.a[0]] | ((uint32_t)xbuf[st.x.a[1]] << 16);
     } else if constexpr (AM == AM_ROW4) {
         aslot[lane] = st.x.a[0];
         abase = (c < p.M ? c : 0) << 4;  // lanes of unused rows re-read row 0: a broadcast, no extra bank traffic
@@ -212,7 +233,7 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
         } else {
             b = dequant_word8<ACT, SCL>(st.w[j >> 1][(j & 1) * 2], st.w[j >> 1][(j & 1) * 2 + 1], cc, dk);
         }
-        if constexpr (AM == AM_ROW1 || AM == AM_ROW4) {
+        if constexpr (AM == AM_ROW1 || AM == AM_ROW1P || AM == AM_ROW4) {
             // fragment of lane (m = c, rq) = the 16 bytes at segment 4*j + rq of row m (same-wave LDS accesses
             // execute in order, so the read needs no barrier after the write above)
             const u4_t av = aslot[abase + 4 * j + rq];
@@ -235,6 +256,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     float(*red)[MT * 4][64] = reinterpret_cast<float(*)[MT * 4][64]>(lds);
     constexpr int kSlot = slot_bytes<AM, MT>() > MT * 1024 ? slot_bytes<AM, MT>() : MT * 1024;  // bytes per wave
     int* s_last = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + (blockDim.x >> 6) * kSlot);
+    uint16_t* xbuf = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(lds) + (blockDim.x >> 6) * kSlot + 16);  // AM_ROW1P
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform -> scalar branches
@@ -273,6 +295,8 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
             LaneOffs<MT, AM> lo;
             if constexpr (AM == AM_ROW1) {
                 lo.x[0] = (uint32_t)lane * 4u;
+            } else if constexpr (AM == AM_ROW1P) {
+                lo.x[0] = (uint32_t)lane * 8u;  // this lane's (perm[k], perm[k+1]) pair inside a chunk's 512 bytes
             } else if constexpr (AM == AM_ROW4) {
                 const int row = rq < p.M ? rq : 0;
                 lo.x[0] = (uint32_t)row * (uint32_t)p.K * 2u + (uint32_t)c * 16u;
@@ -289,24 +313,52 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
             cu.w = tb.w + (size_t)cur * (BITS == 4 ? 1024 : 2048);
             cu.x = tb.x + (size_t)cur * 256;
             cu.chunk = cur;
+            if constexpr (AM == AM_ROW1P) {
+                // the x row goes to LDS once per block: its (L2-hit) loads are issued BEFORE the weight ring so that
+                // waiting for them does not wait for the HBM stream behind them (vmcnt retires in issue order)
+                const u4_t* xs = reinterpret_cast<const u4_t*>(p.x);
+                const int n16 = p.K / 8;
+                u4_t xr[2];
 #pragma unroll
-            for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM>(st[d], p, tb, lo, cu, W);
+                for (int i = 0; i < 2; ++i) {
+                    const int idx = (int)threadIdx.x + i * (int)blockDim.x;
+                    xr[i] = xs[idx < n16 ? idx : 0];
+                }
+#pragma unroll
+                for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM>(st[d], p, tb, lo, cu, W);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int idx = (int)threadIdx.x + i * (int)blockDim.x;
+                    if (idx < n16) reinterpret_cast<u4_t*>(xbuf)[idx] = xr[i];
+                }
+                for (int idx = (int)threadIdx.x + 2 * (int)blockDim.x; idx < n16; idx += (int)blockDim.x)
+                    reinterpret_cast<u4_t*>(xbuf)[idx] = xs[idx];  // (rows longer than 32 B x threads: rare, plain copy)
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM>(st[d], p, tb, lo, cu, W);
+            }
             for (int it = D; it < n_mine; it += D) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc);
+                    compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc, xbuf);
                     load_stage_fast<BITS, GPC, MT, AM>(st[d], p, tb, lo, cu, W);
                     cur += W;
                 }
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc);
+                compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc, xbuf);
                 cur += W;
             }
         }
     } else {
         // generic: any chunk count per wave (ragged K, forced geometry); conservative waits
+        if constexpr (AM == AM_ROW1P) {
+            for (int idx = (int)threadIdx.x; idx < p.K / 8; idx += (int)blockDim.x)
+                reinterpret_cast<u4_t*>(xbuf)[idx] = reinterpret_cast<const u4_t*>(p.x)[idx];
+            __syncthreads();
+        }
         {
             int nxt = c_begin + wave;
 #pragma unroll
@@ -319,7 +371,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 if (cur < c_end) {
-                    compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc);
+                    compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc, xbuf);
                     const int nxt = cur + D * W;
                     if (nxt < c_end) load_stage<BITS, GPC, MT, AM>(st[d], p, tb, nxt, lane);
                     cur += W;
@@ -391,7 +443,7 @@ static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStr
     const dim3 grid(ceil_div(p.N, kTileN), p.splits);
     const dim3 block(64 * pl.waves);
     constexpr int kSlot = slot_bytes<AM, MT>() > MT * 1024 ? slot_bytes<AM, MT>() : MT * 1024;
-    const size_t lds_bytes = (size_t)pl.waves * kSlot + 16;
+    const size_t lds_bytes = (size_t)pl.waves * kSlot + 16 + (AM == AM_ROW1P ? (size_t)p.K * 2 : 0);
     if (pl.gpc == 1) {
         hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D>), grid, block, lds_bytes, stream, p);
     } else {
@@ -402,6 +454,7 @@ static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStr
 
 template <int BITS, int ACT, int SCL>
 static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
+    if (pl.mt == 1 && p.M == 1 && p.perm != nullptr) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1P, 4>(p, pl, stream);
     if (pl.mt == 1 && p.M == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1, 4>(p, pl, stream);
     if (pl.mt == 1 && p.M <= 4) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW4, 4>(p, pl, stream);
     if (pl.mt == 1 && p.M <= 8) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROWSH, 2>(p, pl, stream);
@@ -458,6 +511,7 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
 int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* counters, hipStream_t stream) {
     SkinnyParams p;
     p.x = a.x;
+    p.perm = a.perm;
     p.qw = a.qweight;
     p.meta = a.meta;
     p.bias = a.bias;

@@ -39,6 +39,24 @@ for act, sdt in ((torch.float16, torch.float16), (torch.bfloat16, torch.float16)
     ms = graph_time(step)
     print(f"decode M=1 {K}x{N} act={act} scales={sdt}: {ms*1e3/len(sets):.2f} us/launch  {K*N/2/(ms*1e-3/len(sets))/1e12:.2f} TB/s", flush=True)
     del sets
+# decode with act-order (desc_act=True): the permutation is applied inside the kernel at M == 1
+for (K2, N2) in ((4096, 28672), (14336, 4096), (4096, 6144)):
+    sets, perms = [], []
+    for _ in range(10):
+        qw = torch.randint(-2**31, 2**31 - 1, (K2 // 8, N2), dtype=torch.int32, device=dev)
+        qz = torch.randint(-2**31, 2**31 - 1, (K2 // gs, N2 // 8), dtype=torch.int32, device=dev)
+        sc = (torch.rand((K2 // gs, N2), device=dev) * 0.01 + 0.005).half()
+        g_idx = (torch.randperm(K2, device=dev) // gs).int()
+        pm = torch.argsort(g_idx.long(), stable=True).int()
+        sets.append(ops.repack_tiled(qw, qz, sc, pm, gs, 4) + (pm,))
+    x = torch.randn(1, K2, device=dev).half()
+    def step_p():
+        for qw_t, meta, pm in sets: ops.gemm(x, qw_t, meta, None, pm, N2, gs, 4, torch.float16)
+    def step_n():
+        for qw_t, meta, pm in sets: ops.gemm(x, qw_t, meta, None, None, N2, gs, 4, torch.float16)
+    tp, tn = graph_time(step_p), graph_time(step_n)
+    print(f"decode M=1 {K2}x{N2} fp16: desc_act=True {tp*1e3/len(sets):.2f} us/launch | desc_act=False {tn*1e3/len(sets):.2f} us/launch", flush=True)
+    del sets
 # prefill with act-order gather (C3): M = 2048 and 8192, 4096x4096
 K, N = 4096, 4096
 qw = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=dev)

@@ -392,3 +392,17 @@ def test_persistent_tile_loop_short_k(ops, K, variant, partial):
     else:
         ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4)
         assert rel_err(torch_to_f32(out), ref) <= 1e-3
+
+
+@pytest.mark.parametrize("K,N,act", [(4096, 4096, "fp16"), (4096, 512, "bf16"), (14336, 1024, "fp16")])
+def test_decode_act_order_fused_gather(ops, K, N, act):
+    """Batch-1 decode of an act-order checkpoint: regular plans apply the permutation inside the kernel (no gather
+    launch); K=4096 x 512 columns also takes the cross-block split-K path."""
+    gs = 128
+    qweight, qzeros, scales, g_idx = synth_gptq(91, 4, K, N, gs, desc_act=True)
+    rng = np.random.RandomState(12)
+    x = O.round_to(rng.randn(1, K).astype(np.float32) * 0.5, act)
+    bias = O.round_to(rng.randn(N).astype(np.float32) * 0.1, act)
+    got = torch_to_f32(run_gptq(ops, x, qweight, qzeros, scales, g_idx, 4, gs, bias, act, "fp16"))
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, bias, act, "fp16")
+    assert rel_err(got, ref) <= tol(act)
