@@ -1,29 +1,30 @@
-// Prefill / large-batch fused dequant-GEMM (M > 64): MFMA-bound.
+// Prefill / large-batch fused dequant-GEMM (M > 32): MFMA-bound.
 //
 // Replaces, for large M, the reference's "dequantise the whole [K,N] weight to fp16, then aten matmul"
 // (gptqmodel/nn_modules/qlinear/torch.py:326-347) and plays the role Marlin / ExllamaV2's reconstruct+GEMM play
 // on NVIDIA (gptqmodel_ext/marlin/gptq_marlin.cu, gptqmodel_ext/exllamav2/cuda/q_gemm.cu:118-137) -- designed
 // for CDNA4 instead of translated:
 //
-//   block = 8 waves, output tile BM x 256 (BM = 256 or 128), K advanced one 128-row chunk at a time.
+//   block = 8 waves (2 per SIMD), output tile BM x 256 (BM = 256 or 128), K advanced one 128-row chunk at a time;
+//   one block per CU loops over the output tiles (persistent).
 //   * B (weights) never touches LDS: wave w owns column tiles 2w, 2w+1 of the block (32 columns) for ALL BM rows,
 //     so every packed word is fetched (one dwordx4 per lane per tile-chunk, 1 KiB contiguous) and dequantised
 //     exactly once per block, in registers, straight into mfma_f32_16x16x32 B fragments.
-//   * A (activations) is the shared operand: the BM x 128 tile is staged global -> registers -> LDS in full 256-byte
-//     rows (coalesced dwordx4), XOR-swizzled ((row&15)<<4) so the column-slice ds_read_b128 of the A fragments is
-//     bank-conflict free (cdna_hip_programming.md T2).  The next tile's global loads are issued before the MFMA
-//     phase and written to LDS after it (T14 async-stage split): one LDS buffer, two barriers per 128-deep tile
-//     (amortised over 4*BM/16*2 MFMAs per wave).
-//   * per K-step (32 rows) a wave issues 2 dequants (~24 VALU) + BM/16 ds_read_b128 + 2*BM/16 MFMAs: the VALU and
-//     LDS work hides under the matrix pipe.
-//   * epilogue rounds like the reference (round(acc), + bias, round) or writes fp32 partials for tensor parallel.
+//   * A (activations) is the shared operand: the BM x 128 tile goes HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds) in
+//     full 256-byte rows, XOR-swizzled on the source side ((row&15)<<4) so the column-slice ds_read_b128 of the A
+//     fragments is bank-conflict free (cdna_hip_programming.md T2 / rule 21).
+//   * D-stage chunk pipeline (D = 2 on 256-row tiles, 3 on 128-row tiles): one s_barrier per chunk, counted vmcnt
+//     waits, the next chunk's first K-step dequantised before the barrier, DMA pieces issued between MFMA groups.
+//   * per K-step (32 rows) a wave issues 2 dequants (~26 VALU) + BM/16 ds_read_b128 + 2*BM/16 MFMAs.
+//   * epilogue: round like the reference (round(acc), + bias, round) or keep fp32 (split-K slabs, tensor-parallel
+//     partial sums), transposed through LDS into 16-byte buffer stores; it overlaps the next tile's first loads.
+// DESIGN.md section 4.2 has the measurements behind each of these choices.
 #include "gptqhip_device.h"
 #include "gptqhip_host.h"
 
 #include <utility>
 
 namespace gptqhip {
-
 
 struct TiledParams {
     const void* x;
