@@ -13,6 +13,8 @@ Extra objects on the JSON line (tier contract):
   roofline      dominant kernel = skinny fused dequant-GEMM; achieved = algorithmic bytes per launch
                 (K*N/2 + G*N*2 + G*N/2 + M*(K+N)*2, averaged over the 224 launches) / average
                 launch duration measured with HIP events on the launch stream over the timed region.
+  prefill       the TFLOPS half of BASELINE.json's metric: one decoder layer's launches of the same modules at M=8192
+                tokens through the MFMA-bound prefill kernel (outside the timed region), vs the dense fp16 MFMA peak.
   cpu_baseline  the oracle's torch-CPU port of BACKEND.TORCH (oracle/gptq_oracle.py:torch_cpu_forward_gptq)
                 timed on this host's cores on a bounded sample (one decoder layer), rank 0, N=1 only.
 """
@@ -70,6 +72,36 @@ def make_linear(k, n, gs, device, gen, dtype=torch.float16):
     lin.eval()
     lin.post_init()
     return lin
+
+
+def prefill_tflops(layer, dtype, dev, m=8192, iters=5):
+    """The TFLOPS half of BASELINE.json's metric (methodology of scripts/benchmark_marlin_a100.py: 2*M*K*N / t): one
+    decoder layer's launches of the SAME modules at M = 8192 tokens (4 x 2048-token sequences), MFMA-bound prefill
+    kernel, reported next to the dense fp16/bf16 MFMA peak.  Not part of the timed decode region."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99)
+    xs = {}
+    for lin, _ in layer:
+        if lin.in_features not in xs:
+            xs[lin.in_features] = (torch.randn((m, lin.in_features), device=dev, generator=gen) * 0.5).to(dtype)
+    def run():
+        for lin, _ in layer:
+            lin(xs[lin.in_features])
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = sum(2.0 * m * lin.in_features * lin.out_features for lin, _ in layer)
+    tf = flops / ms / 1e9
+    return {"workload": f"one Llama-3-8B decoder layer's quantised linears ({len(layer)} launches) at M={m} tokens",
+            "tflops": tf, "ms": ms, "bound": "mfma", "peak": MFMA_PEAK_TFLOPS, "frac": tf / MFMA_PEAK_TFLOPS,
+            "kernel": "gptqhip::tiled_kernel<BITS=4,...,BM=256,D=2>"}
 
 
 def cpu_baseline(cfg, gs=128, budget_s=20.0):
@@ -263,6 +295,8 @@ def main():
         }
         if args.model != "llama3-8b":
             out["roofline"]["traffic"] = None
+        if world == 1 and tp == 1:
+            out["prefill"] = prefill_tflops(layers[0], dtype, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, gs)
         print(json.dumps(out), flush=True)
