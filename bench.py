@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="7 launches per layer instead of fused qkv / gate_up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--exact-bf16", action="store_true",
+                    help="opt in to GPTQHIP_GEMM_EXACT_BF16 (bf16 only; leaves the reference's per-weight rounding)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,6 +176,9 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     fuse = not args.no_fuse
+    if args.exact_bf16:
+        from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+        HipGptqLinear.EXACT_BF16_DECODE = True
     lshapes = launch_shapes(cfg, fuse)
     if tp > 1:
         # Megatron split of every launch: column-parallel (N / tp) when K == hidden, row-parallel (K / tp) otherwise

@@ -184,7 +184,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         return GPTQHIP_EINVAL;
     }
     const bool partial_f32 = (flags & GPTQHIP_GEMM_PARTIAL_F32) != 0;
-    if ((flags & ~GPTQHIP_GEMM_PARTIAL_F32) != 0 || (partial_f32 && bias != nullptr)) {
+    if ((flags & ~(GPTQHIP_GEMM_PARTIAL_F32 | GPTQHIP_GEMM_EXACT_BF16)) != 0 || (partial_f32 && bias != nullptr)) {
         set_error("gptqhip_gemm: bad flags 0x%x (PARTIAL_F32 excludes bias)", flags);
         return GPTQHIP_EINVAL;
     }
@@ -224,6 +224,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     a.scale_dtype = scale_dtype;
     a.out_f32 = partial_f32 ? 1 : 0;
     a.perm = fused_perm ? perm : nullptr;
+    a.exact_bf16 = (flags & GPTQHIP_GEMM_EXACT_BF16) ? 1 : 0;
 
     // measured crossover (profiles/r01_m_sweep.txt): the MFMA-tiled kernel wins above 32 rows, and already above 16
     // rows on wide layers (N >= 8192, e.g. fused gate_up) where its grid fills the chip without split-K

@@ -109,6 +109,7 @@ struct ColConst {
     uint32_t s;    // SCL fp16: half2(scale,scale);  SCL bf16: fp32 scale bits
     uint32_t zlo;  // half2(-(1024+z), -(1024+z))
     uint32_t zhi;  // half2(-(64+z),   -(64+z))      (4-bit high nibbles only)
+    float nzs;     // SCL bf16 only: -zero * scale (exact in fp32: 8 x 8 significant bits)
 };
 
 template <int BITS, int SCL>
@@ -120,6 +121,7 @@ __device__ __forceinline__ ColConst expand_meta(uint32_t meta) {
     } else {
         c.s = sb << 16;
     }
+    c.nzs = SCL == kBF16 ? -(float)((meta >> 16) & 0x3FFu) * __builtin_bit_cast(float, sb << 16) : 0.f;
     const uint32_t zc = meta >> 16;  // 0xE400 | zero
     c.zlo = zc | (zc << 16);
     if constexpr (BITS == 4) {
@@ -157,6 +159,7 @@ __device__ __forceinline__ uint32_t scale_pair(h2_t d, const ColConst& c) {
 // the magic in a VGPR, made opaque once per kernel so they stay in registers, and the pattern then selects itself.
 struct DequantConsts {
     uint32_t magic;      // 0x64006400 in a VGPR
+    uint32_t magic_bf;   // 0x43004300 in a VGPR: (nibble | magic_bf) = bf16 pair (128 + q) exactly
     uint32_t lo, hi;     // nibble (or byte) masks in SGPRs
     uint32_t sixteenth;  // half2(1/16, 1/16)
 };
@@ -164,10 +167,12 @@ template <int BITS>
 __device__ __forceinline__ DequantConsts make_dequant_consts() {
     DequantConsts k;
     k.magic = 0x64006400u;
+    k.magic_bf = 0x43004300u;
     k.lo = BITS == 4 ? 0x000F000Fu : 0x00FF00FFu;
     k.hi = 0x00F000F0u;
     k.sixteenth = 0x2C002C00u;
     asm volatile("" : "+v"(k.magic));
+    asm volatile("" : "+v"(k.magic_bf));
     asm volatile("" : "+s"(k.lo));
     asm volatile("" : "+s"(k.hi));
     return k;
@@ -179,6 +184,34 @@ __device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask_sgpr, uint3
 // One tiled int32 word of 4-bit codes -> MFMA B fragment (8 x 16-bit, natural k order).
 template <int ACT, int SCL>
 __device__ __forceinline__ u4_t dequant_word4(uint32_t w, const ColConst& c, const DequantConsts& k) {
+    if constexpr (ACT == kBF16 && SCL == kBF16) {
+        // bf16 scales and activations: W = bf16(s * (q - z)), ONE rounding of the exact product (torch bf16 mul).  No
+        // packed bf16 VALU on gfx950, so go through fp32 with the byte converts: two masks put the 8 codes into the 8
+        // bytes of two dwords, v_cvt_f32_ubyteN + one fma(q, s, -z*s) each (exact: 12 significant bits), cvt_pk.
+        // 23 VALU per word instead of 28 for the half2 route + converts.
+        const float s = __builtin_bit_cast(float, c.s);
+        const uint32_t a = w & 0x0F0F0F0Fu;         // bytes: e0, e4, e1, e5   (code e sits at bit 4*(e>>1) + 16*(e&1))
+        const uint32_t b = (w >> 4) & 0x0F0F0F0Fu;  // bytes: e2, e6, e3, e7
+        // (inline asm: hipcc only selects v_cvt_f32_ubyte0 and isolates the other bytes with extra shifts / bfe)
+#define GPTQHIP_UBYTE(N, dst, src) asm("v_cvt_f32_ubyte" #N " %0, %1" : "=v"(dst) : "v"(src))
+        float q0, q1, q2, q3, q4, q5, q6, q7;
+        GPTQHIP_UBYTE(0, q0, a);
+        GPTQHIP_UBYTE(2, q1, a);
+        GPTQHIP_UBYTE(0, q2, b);
+        GPTQHIP_UBYTE(2, q3, b);
+        GPTQHIP_UBYTE(1, q4, a);
+        GPTQHIP_UBYTE(3, q5, a);
+        GPTQHIP_UBYTE(1, q6, b);
+        GPTQHIP_UBYTE(3, q7, b);
+#undef GPTQHIP_UBYTE
+        auto f = [&](float q) { return __builtin_fmaf(q, s, c.nzs); };
+        u4_t r;
+        r.x = pack_bf16(f(q0), f(q1));
+        r.y = pack_bf16(f(q2), f(q3));
+        r.z = pack_bf16(f(q4), f(q5));
+        r.w = pack_bf16(f(q6), f(q7));
+        return r;
+    }
     const uint32_t LO = k.lo, HI = k.hi;
     const h2_t sixteenth = as_h2(k.sixteenth);
     const uint32_t w8 = w >> 8;

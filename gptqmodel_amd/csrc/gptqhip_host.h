@@ -17,6 +17,7 @@ struct GemmArgs {
     int M, K, N, group_size, bits, act_dtype, scale_dtype;
     int out_f32;  // write unrounded fp32 accumulators (tensor-parallel partial sums)
     const int32_t* perm = nullptr;  // act-order permutation the kernel applies to x itself (decode, M == 1), else nullptr
+    int exact_bf16 = 0;  // GPTQHIP_GEMM_EXACT_BF16 (decode kernel, bf16 activations)
     int ldo = 0;  // output row stride in elements (0: N) -- lets a launch cover a column sub-range of a wider output
 };
 

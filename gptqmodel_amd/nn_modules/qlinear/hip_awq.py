@@ -39,6 +39,7 @@ class HipAwqLinear(AWQuantLinear):
 
     REQUIRES_FORMAT_V2 = False
     QUANT_TYPE = "hip_awq"
+    EXACT_BF16_DECODE = False  # opt-in, see HipGptqLinear.EXACT_BF16_DECODE
 
     def __init__(self, bits: int, group_size: int, sym: bool, desc_act: bool, in_features: int, out_features: int,
                  bias: bool = False, pack_dtype: torch.dtype = torch.int32, adapter: Adapter = None,
@@ -95,7 +96,8 @@ class HipAwqLinear(AWQuantLinear):
         out_shape = x.shape[:-1] + (self.out_features,)
         x2, in_dtype = flatten_input(x, self.in_features)
         meta, bias = self._runtime(x2.dtype)
-        out = ops.gemm(x2, self.qweight, meta, bias, None, self.out_features, self.group_size, self.bits, x2.dtype)
+        out = ops.gemm(x2, self.qweight, meta, bias, None, self.out_features, self.group_size, self.bits, x2.dtype,
+                       exact_bf16=self.EXACT_BF16_DECODE)
         if self.adapter:
             out = self.adapter.apply(x=x2, out=out)
         if out.dtype != in_dtype:

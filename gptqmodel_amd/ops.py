@@ -87,9 +87,11 @@ def repack_tiled(qweight: Optional[torch.Tensor], qzeros: torch.Tensor, scales: 
 
 def gemm(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Optional[torch.Tensor],
          perm: Optional[torch.Tensor], N: int, group_size: int, bits: int, scale_dtype: torch.dtype,
-         out: Optional[torch.Tensor] = None, partial_f32: bool = False) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, partial_f32: bool = False, exact_bf16: bool = False) -> torch.Tensor:
     """out[M,N] = x[M,K] @ dequant(qweight_t, meta) (+bias)  via gptqhip_gemm (tiled layout).
-    partial_f32=True returns the unrounded float32 accumulators (tensor-parallel partial sums, no bias)."""
+    partial_f32=True returns the unrounded float32 accumulators (tensor-parallel partial sums, no bias).
+    exact_bf16=True opts in to GPTQHIP_GEMM_EXACT_BF16 (bf16 decode without the per-weight bf16 rounding; see
+    include/gptqhip.h)."""
     lib = _lib.load()
     _require_cuda(x, qweight_t, meta, bias, perm)
     if x.dim() != 2 or not x.is_contiguous():
@@ -110,7 +112,7 @@ def gemm(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Opt
         ws = workspace_for(x.device, need)
         rc = lib.gptqhip_gemm(_ptr(x), _ptr(qweight_t), _ptr(meta), _ptr(perm), _ptr(bias), _ptr(out), _ptr(ws),
                               ws.numel(), M, K, N, group_size, bits, _DT[x.dtype], _DT[scale_dtype],
-                              1 if partial_f32 else 0, _stream(x.device))
+                              (1 if partial_f32 else 0) | (2 if exact_bf16 else 0), _stream(x.device))
     _lib.check(rc, "gptqhip_gemm")
     return out
 

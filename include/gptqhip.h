@@ -101,8 +101,13 @@ int gptqhip_repack_tiled(const int32_t* qweight, const int32_t* qzeros, const vo
  *   scale_dtype: dtype of the scale bits inside meta
  *   flags    GPTQHIP_GEMM_PARTIAL_F32: `out` is float32 [M,N] and receives the UNROUNDED fp32 accumulators (bias
  *            must be NULL) -- the partial sums a row-parallel (K-sharded) tensor-parallel layer all-reduces before
- *            rounding once, so TP reproduces the single-GPU rounding chain. */
+ *            rounding once, so TP reproduces the single-GPU rounding chain.
+ *            GPTQHIP_GEMM_EXACT_BF16 (opt-in, default off): bf16 activations, 4-bit weights, group_size % 128 == 0,
+ *            M <= 4: accumulate the exact products s*(q-z)*x instead of first rounding every weight to bf16 like
+ *            torch.py:326-335 does (gfx950 has no packed bf16 VALU; decode is ~20 % faster).  The result is the
+ *            exact-arithmetic value, up to 2 output ulps away from the reference's chain; ignored elsewhere. */
 #define GPTQHIP_GEMM_PARTIAL_F32 1
+#define GPTQHIP_GEMM_EXACT_BF16 2
 int gptqhip_gemm(const void* x, const uint32_t* qweight_t, const uint32_t* meta,
                  const int32_t* perm, const void* bias, void* out,
                  void* workspace, size_t workspace_bytes,

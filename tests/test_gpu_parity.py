@@ -406,3 +406,25 @@ def test_decode_act_order_fused_gather(ops, K, N, act):
     got = torch_to_f32(run_gptq(ops, x, qweight, qzeros, scales, g_idx, 4, gs, bias, act, "fp16"))
     ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, bias, act, "fp16")
     assert rel_err(got, ref) <= tol(act)
+
+
+@pytest.mark.parametrize("M", [1, 3])
+def test_exact_bf16_flag_is_opt_in_and_exact(ops, M):
+    """GPTQHIP_GEMM_EXACT_BF16: default off (the default result follows the reference's rounding chain); when on, the
+    result is the exact-arithmetic product (unrounded weights, one output rounding) to within one bf16 output ulp."""
+    K, N, gs = 4096, 2048, 128
+    qweight, qzeros, scales, g_idx = synth_gptq(5, 4, K, N, gs)
+    x = O.round_to(np.random.RandomState(6).randn(M, K).astype(np.float32) * 0.5, "bf16")
+    qw_t, meta = ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV),
+                                  f32_to_torch(scales, "fp16", DEV), None, gs, 4)
+    xt = f32_to_torch(x, "bf16", DEV)
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, None, "bf16", "fp16")
+    codes = O.unpack_rows(qweight, 4).astype(np.int32)
+    zeros = O.unpack_cols(qzeros, 4).astype(np.int32)
+    w_exact = scales[g_idx].astype(np.float64) * (codes - zeros[g_idx])
+    exact = O.round_to((x.astype(np.float64) @ w_exact).astype(np.float32), "bf16")
+    default = torch_to_f32(ops.gemm(xt, qw_t, meta, None, None, N, gs, 4, torch.float16))
+    fast = torch_to_f32(ops.gemm(xt, qw_t, meta, None, None, N, gs, 4, torch.float16, exact_bf16=True))
+    assert rel_err(default, ref) <= 8e-3
+    assert rel_err(fast, exact) <= 4e-3          # one bf16 ulp of the largest output
+    assert rel_err(fast, ref) <= 2.5e-2          # the reference's own weight-rounding noise
