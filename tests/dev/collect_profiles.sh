@@ -15,6 +15,7 @@ cd $R
 timeout 240 python bench.py 2>&1 | tail -1 > $O/${TAG}_bench.json
 timeout 240 python bench.py --model llama3-70b --steps 30 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > $O/${TAG}_bench_70b_tp1.json
 timeout 240 python bench.py --dtype bf16 --steps 100 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 > $O/${TAG}_bench_bf16.json
+timeout 240 python bench.py --dtype bf16 --exact-bf16 --steps 100 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 > $O/${TAG}_bench_bf16_exact_optin.json
 timeout 240 python tests/dev/gemm_tflops.py 2>&1 | grep "^M=" > $O/${TAG}_gemm_tflops.txt
 timeout 240 python tests/dev/gemm_tflops.py bf16 2>&1 | grep "^M=" > $O/${TAG}_gemm_tflops_bf16.txt
 timeout 240 python tests/dev/midm.py 1,8,32,128,512,2048 2>&1 | grep "^K=" > $O/${TAG}_m_sweep.txt

@@ -42,7 +42,7 @@ try:
 except Exception as e:
     summ["tiled_kernel_M8192_4096x4096"] = str(e)
 json.dump(summ, open(f"{dst}{tag}_pmc_summary.json", "w"), indent=1)
-for f in ("bench.json", "bench_70b_tp1.json", "bench_bf16.json", "gemm_tflops.txt", "gemm_tflops_bf16.txt", "m_sweep.txt", "configs.txt", "stream_probe.txt"):
+for f in ("bench.json", "bench_70b_tp1.json", "bench_bf16.json", "bench_bf16_exact_optin.json", "torch_gpu_baseline.txt", "gemm_tflops.txt", "gemm_tflops_bf16.txt", "m_sweep.txt", "configs.txt", "stream_probe.txt"):
     if os.path.exists(f"{src}{tag}_{f}"): shutil.copy(f"{src}{tag}_{f}", f"{dst}{tag}_{f}")
 print(json.dumps({k: summ[k] for k in ("avg_kernel_us_rocprof", "avg_launch_us_bench_events", "traffic_over_algorithmic")}, indent=1))
 print(open(f"{dst}{tag}_bench.json").read()[:400])
