@@ -1,0 +1,126 @@
+#!/usr/bin/env python
+"""End-to-end drop-in demo on a random-init Hugging Face Llama (no checkpoint / network needed):
+
+  1. build the model (Llama-3-8B shapes with --size 8b, a small one by default), weights created on the GPU;
+  2. quantise every decoder nn.Linear to 4-bit g128 (RTN) and pack it ON THE DEVICE through the module's pack()
+     (reference API: PackableQuantLinear.pack_block, qlinear/__init__.py:1036);
+  3. swap the modules with make_quant (BACKEND.AUTO -> HipGptqLinear), fuse q/k/v and gate/up, gptqmodel_post_init;
+  4. greedy-decode with HF generate (eager; Python-bound) and with ONE captured HIP graph per decode step over a static
+     KV cache (what a serving stack would do), and report tokens/s for both.
+
+The numbers here include attention, norms, rotary, lm_head ... (plain PyTorch ops); bench.py isolates the quantised
+linears, which is the path this repository owns."""
+import argparse
+import sys
+import time
+import os
+
+import torch
+import torch.nn as nn
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+SIZES = {
+    "tiny": dict(hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2,
+                 vocab_size=2048),
+    "1b": dict(hidden_size=2048, intermediate_size=8192, num_hidden_layers=16, num_attention_heads=32, num_key_value_heads=8,
+               vocab_size=128256),
+    "8b": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=8,
+               vocab_size=128256),
+}
+
+
+def rtn(weight, group_size, bits):
+    n, k = weight.shape
+    w = weight.float().reshape(n, k // group_size, group_size)
+    wmax, wmin = w.amax(dim=2), w.amin(dim=2)
+    maxq = (1 << bits) - 1
+    scales = ((wmax - wmin).clamp(min=1e-5) / maxq).half().float()
+    zeros = torch.round(-wmin / scales).clamp(0, maxq)
+    return scales, zeros
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", default="tiny", choices=list(SIZES))
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--new-tokens", type=int, default=64)
+    ap.add_argument("--no-fuse", action="store_true")
+    args = ap.parse_args()
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from gptqmodel_amd.utils.backend import BACKEND
+    from gptqmodel_amd.utils.const import FORMAT
+    from gptqmodel_amd.utils.model import fuse_siblings, gptqmodel_post_init, make_quant
+
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    dev = torch.device("cuda", 0)
+    cfg = LlamaConfig(max_position_embeddings=2048, tie_word_embeddings=False, **SIZES[args.size])
+    torch.manual_seed(0)
+    t0 = time.time()
+    with torch.device(dev):
+        model = LlamaForCausalLM(cfg).to(dtype).eval()
+    names = [n for n, m in model.named_modules() if isinstance(m, nn.Linear) and ".layers." in n]
+    mods = dict(model.named_modules())
+    floats = {n: mods[n] for n in names}
+    make_quant(model, names, bits=4, group_size=128, desc_act=False, sym=False, backend=BACKEND.AUTO, format=FORMAT.GPTQ,
+               dtype=dtype)
+    mods = dict(model.named_modules())
+    for n in names:
+        lin, qm = floats[n], mods[n]
+        scales, zeros = rtn(lin.weight.data, 128, 4)
+        qm.pack(lin, scales, zeros, (torch.arange(lin.in_features) // 128).to(torch.int32))
+    del floats
+    if not args.no_fuse:
+        for layer in model.model.layers:
+            fuse_siblings(layer.self_attn, ["q_proj", "k_proj", "v_proj"])
+            fuse_siblings(layer.mlp, ["gate_proj", "up_proj"])
+    gptqmodel_post_init(model)
+    torch.cuda.synchronize()
+    nq = sum(1 for m in model.modules() if type(m).__name__ == "HipGptqLinear")
+    print(f"built + quantised + packed + repacked {len(names)} linears ({nq} launches/token) in {time.time() - t0:.1f} s; "
+          f"GPU memory {torch.cuda.memory_allocated() / 2**30:.2f} GiB")
+
+    ids = torch.randint(0, cfg.vocab_size, (1, 16), device=dev)
+    with torch.no_grad():
+        model.generate(input_ids=ids, max_new_tokens=4, do_sample=False, pad_token_id=0)  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.time()
+        out = model.generate(input_ids=ids, max_new_tokens=args.new_tokens, do_sample=False, pad_token_id=0)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+    print(f"HF generate (eager, Python-bound): {args.new_tokens / dt:.1f} tokens/s")
+
+    # one HIP graph per decode step over a static KV cache
+    try:
+        from transformers import StaticCache
+        with torch.no_grad():
+            cache = StaticCache(config=cfg, max_cache_len=256)
+            pos = torch.arange(ids.shape[1], device=dev)
+            o = model(input_ids=ids, past_key_values=cache, cache_position=pos, use_cache=True)
+            tok = o.logits[:, -1:].argmax(-1)
+            s_tok = tok.clone()
+            s_pos = torch.tensor([ids.shape[1]], device=dev)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for _ in range(2):  # warm-up outside capture
+                    model(input_ids=s_tok, past_key_values=cache, cache_position=s_pos, use_cache=True)
+                stream.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    lo = model(input_ids=s_tok, past_key_values=cache, cache_position=s_pos, use_cache=True).logits
+                    nxt = lo[:, -1:].argmax(-1)
+                torch.cuda.synchronize()
+                t0 = time.time()
+                for i in range(args.new_tokens):
+                    g.replay()
+                    s_tok.copy_(nxt)
+                    s_pos.add_(1)
+                stream.synchronize()
+                dt = time.time() - t0
+        print(f"graph-replayed decode step (static KV cache): {args.new_tokens / dt:.1f} tokens/s")
+    except Exception as e:  # transformers API drift must not hide the eager result above
+        print(f"graph-replayed decode skipped: {type(e).__name__}: {e}")
+
+
+if __name__ == "__main__":
+    main()
