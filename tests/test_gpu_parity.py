@@ -428,3 +428,51 @@ def test_exact_bf16_flag_is_opt_in_and_exact(ops, M):
     assert rel_err(default, ref) <= 8e-3
     assert rel_err(fast, exact) <= 4e-3          # one bf16 ulp of the largest output
     assert rel_err(fast, ref) <= 2.5e-2          # the reference's own weight-rounding noise
+
+
+def test_tiled_random_shape_stress(ops):
+    """Random problems forced through the prefill kernel back to back: both tile heights, 4/8 bit, group sizes with one
+    or four scale rows per chunk, ragged M/N/K, act-order, bias, fp32 partials, more tiles than CUs and fewer chunks
+    than pipeline stages -- the persistent tile loop's waits are exact counts, so any path-dependent miscount shows up
+    as wrong numbers here."""
+    rng = np.random.RandomState(4242)
+    done = 0
+    for it in range(60):
+        bits = int(rng.choice([4, 4, 8]))
+        gs = int(rng.choice([32, 64, 128, 128, 256]))
+        K = gs * int(rng.randint(1, 12))
+        if K % 32 or K > 2048:
+            continue
+        N = 8 * int(rng.randint(1, 300))
+        M = int(rng.choice([33, 70, 129, 257, 600, 1500, 2900]))
+        if M * N > 3_000_000:
+            M = 257
+        act = str(rng.choice(["fp16", "bf16"]))
+        desc = bool(rng.randint(0, 2)) and (K // gs) > 1
+        variant = int(rng.choice([0, 1, 2]))
+        partial = bool(rng.randint(0, 4) == 0)
+        qweight, qzeros, scales, g_idx = synth_gptq(3000 + it, bits, K, N, gs, desc_act=desc)
+        x = O.round_to(rng.randn(M, K).astype(np.float32) * 0.5, act)
+        bias = None if partial or rng.randint(0, 2) else O.round_to(rng.randn(N).astype(np.float32) * 0.1, act)
+        perm = torch.from_numpy(O.act_order_perm(g_idx)).to(DEV) if desc else None
+        qw_t, meta = ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV),
+                                      f32_to_torch(scales, "fp16", DEV), perm, gs, bits)
+        try:
+            ops.set_tuning(0, 2, variant)
+            out = ops.gemm(f32_to_torch(x, act, DEV), qw_t, meta, None if bias is None else f32_to_torch(bias, act, DEV),
+                           perm, N, gs, bits, torch.float16, partial_f32=partial)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_tuning(0, 0, 0)
+        tag = (it, bits, gs, K, N, M, act, desc, variant, partial)
+        if partial:
+            w = O.dequant_gptq(qweight, qzeros, scales, g_idx, bits, "fp16")
+            if act == "bf16":
+                w = O.round_to(w, "bf16")
+            ref = (x.astype(np.float64) @ w.astype(np.float64)).astype(np.float32)
+            assert rel_err(out.cpu().numpy(), ref) <= 1e-5, tag
+        else:
+            ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, bits, bias, act, "fp16")
+            assert rel_err(torch_to_f32(out), ref) <= tol(act), tag
+        done += 1
+    assert done >= 40
