@@ -37,7 +37,6 @@ int check_hip(hipError_t e, const char* what) {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 constexpr int kSkinnyMaxM = 32;  // above: the MFMA-tiled kernel (split-K when its grid is small)
-constexpr bool kHaveTiled = true;
 constexpr size_t kCounterBytes = 64 * 1024;  // 16384 arrival counters
 
 struct WorkspaceLayout {
@@ -229,7 +228,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     // measured crossover (profiles/r01_m_sweep.txt): the MFMA-tiled kernel wins above 32 rows, and already above 16
     // rows on wide layers (N >= 8192, e.g. fused gate_up) where its grid fills the chip without split-K
     const bool wide = N >= 8192 && M > 16;
-    const bool use_tiled = kHaveTiled && ((g_force_kernel == 2) || (g_force_kernel == 0 && (M > kSkinnyMaxM || wide)));
+    const bool use_tiled = (g_force_kernel == 2) || (g_force_kernel == 0 && (M > kSkinnyMaxM || wide));
     if (use_tiled) {
         a.x = xin;
         a.out = out;
@@ -262,7 +261,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         }
         return launch_tiled(a, tp, slabs, stream);
     }
-    // skinny kernel, 64 rows at a time
+    // skinny kernel, kSkinnyMaxM rows per launch
     for (int m0 = 0; m0 < M; m0 += kSkinnyMaxM) {
         const int mc = (M - m0) < kSkinnyMaxM ? (M - m0) : kSkinnyMaxM;
         a.x = reinterpret_cast<const char*>(xin) + (size_t)m0 * K * 2;

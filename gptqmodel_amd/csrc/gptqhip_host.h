@@ -36,7 +36,6 @@ struct SkinnyPlan {
 struct TiledPlan {
     int gpc;  // meta words per chunk (1 or 4)
     int bm;   // rows per block tile (256 or 128)
-    int waves;  // waves per block (8: 2 column tiles each, 4: 4 column tiles each)
     int splits;            // grid.z (split-K through fp32 slabs + reduce kernel)
     int chunks_per_split;
     size_t slab_floats;

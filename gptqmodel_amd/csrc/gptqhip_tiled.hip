@@ -81,9 +81,8 @@ TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_va
             }
         }
     }
-    pl.waves = 8;
-    if (force_variant == 1) { pl.bm = 256; pl.waves = 8; }
-    if (force_variant == 2) { pl.bm = 128; pl.waves = 8; }
+    if (force_variant == 1) pl.bm = 256;
+    if (force_variant == 2) pl.bm = 128;
     // 256-row tiles exist for 4-bit weights with one scale row per chunk only: the 8-bit and small-group register
     // stages do not fit beside 128 accumulator registers (they spilled 10-25 VGPRs into the main loop)
     if (bits != 4 || pl.gpc != 1) {

@@ -501,16 +501,15 @@ inline int launch_tiled_out(const TiledParams& p, int bm, hipStream_t stream) {
 }
 
 template <int BITS, int ACT, int SCL, int GPC>
-inline int launch_tiled_bm(const TiledParams& p, int bm, int waves, hipStream_t stream) {
-    (void)waves;
+inline int launch_tiled_bm(const TiledParams& p, int bm, hipStream_t stream) {
     if (p.splits > 1 || p.out_f32) return launch_tiled_out<BITS, ACT, SCL, GPC, 1>(p, bm, stream);
     return launch_tiled_out<BITS, ACT, SCL, GPC, 0>(p, bm, stream);
 }
 
 template <int BITS, int ACT, int SCL>
-inline int launch_tiled_gpc(const TiledParams& p, int gpc, int bm, int waves, hipStream_t stream) {
-    if (gpc == 1) return launch_tiled_bm<BITS, ACT, SCL, 1>(p, bm, waves, stream);
-    return launch_tiled_bm<BITS, ACT, SCL, 4>(p, bm, waves, stream);
+inline int launch_tiled_gpc(const TiledParams& p, int gpc, int bm, hipStream_t stream) {
+    if (gpc == 1) return launch_tiled_bm<BITS, ACT, SCL, 1>(p, bm, stream);
+    return launch_tiled_bm<BITS, ACT, SCL, 4>(p, bm, stream);
 }
 
 // one translation unit per bit width (defined in gptqhip_tiled.hip / gptqhip_tiled8.hip)
@@ -519,10 +518,10 @@ int launch_tiled_w8(const TiledParams& p, int act_dtype, int scale_dtype, int gp
 
 template <int BITS>
 inline int launch_tiled_bits(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int bm, hipStream_t stream) {
-    if (act_dtype == kFP16 && scale_dtype == kFP16) return launch_tiled_gpc<BITS, kFP16, kFP16>(p, gpc, bm, 8, stream);
-    if (act_dtype == kBF16 && scale_dtype == kFP16) return launch_tiled_gpc<BITS, kBF16, kFP16>(p, gpc, bm, 8, stream);
-    if (act_dtype == kFP16 && scale_dtype == kBF16) return launch_tiled_gpc<BITS, kFP16, kBF16>(p, gpc, bm, 8, stream);
-    return launch_tiled_gpc<BITS, kBF16, kBF16>(p, gpc, bm, 8, stream);
+    if (act_dtype == kFP16 && scale_dtype == kFP16) return launch_tiled_gpc<BITS, kFP16, kFP16>(p, gpc, bm, stream);
+    if (act_dtype == kBF16 && scale_dtype == kFP16) return launch_tiled_gpc<BITS, kBF16, kFP16>(p, gpc, bm, stream);
+    if (act_dtype == kFP16 && scale_dtype == kBF16) return launch_tiled_gpc<BITS, kFP16, kBF16>(p, gpc, bm, stream);
+    return launch_tiled_gpc<BITS, kBF16, kBF16>(p, gpc, bm, stream);
 }
 
 }  // namespace gptqhip

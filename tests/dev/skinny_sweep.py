@@ -2,7 +2,7 @@
 back-to-back launches over ROTATING weight copies (> 512 MB total, defeats the 256 MB Infinity Cache)."""
 import sys, itertools, json
 import numpy as np, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+sys.path.insert(0, "/root/repo"); 
 from gptqmodel_amd import ops
 
 def bytes_alg(m, k, n, gs=128):
