@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--new-tokens", type=int, default=64)
     ap.add_argument("--no-fuse", action="store_true")
+    ap.add_argument("--quant-lm-head", action="store_true", help="also quantise lm_head (qcfg.lm_head upstream, loader.py:1376)")
     args = ap.parse_args()
     from transformers import LlamaConfig, LlamaForCausalLM
     from gptqmodel_amd.utils.backend import BACKEND
@@ -59,7 +60,8 @@ def main():
     t0 = time.time()
     with torch.device(dev):
         model = LlamaForCausalLM(cfg).to(dtype).eval()
-    names = [n for n, m in model.named_modules() if isinstance(m, nn.Linear) and ".layers." in n]
+    names = [n for n, m in model.named_modules() if isinstance(m, nn.Linear) and
+             (".layers." in n or (args.quant_lm_head and n == "lm_head"))]
     mods = dict(model.named_modules())
     floats = {n: mods[n] for n in names}
     make_quant(model, names, bits=4, group_size=128, desc_act=False, sym=False, backend=BACKEND.AUTO, format=FORMAT.GPTQ,
