@@ -1,11 +1,11 @@
-// Prefill kernel, host side: planner, launcher, split-K reduce, and the 4-bit instantiations of the kernel template
-// (gptqhip_tiled_kernel.h; the 8-bit ones live in gptqhip_tiled8.hip).
+// Prefill kernel, host side: planner, launcher, split-K reduce, and the 4-bit / 16-bit-output instantiations of the kernel
+// template (gptqhip_tiled_kernel.h; fp32-output ones in gptqhip_tiled_f32.hip, 8-bit ones in gptqhip_tiled8.hip).
 #include "gptqhip_tiled_kernel.h"
 
 namespace gptqhip {
 
 int launch_tiled_w4(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int bm, hipStream_t stream) {
-    return launch_tiled_bits<4>(p, act_dtype, scale_dtype, gpc, bm, stream);
+    return launch_tiled_bits<4, 0>(p, act_dtype, scale_dtype, gpc, bm, stream);
 }
 
 // Sum the split-K slabs in a fixed order (deterministic), then the reference's rounding chain.  One thread per 4
@@ -137,8 +137,11 @@ int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, hipStream
             p.cpg_shift = sh;
         }
     }
-    const int rc_main = a.bits == 4 ? launch_tiled_w4(p, a.act_dtype, a.scale_dtype, pl.gpc, pl.bm, stream)
-                                    : launch_tiled_w8(p, a.act_dtype, a.scale_dtype, pl.gpc, pl.bm, stream);
+    // fp32 epilogue (split-K slabs, tensor-parallel partial sums) or the 16-bit rounding epilogue
+    const bool f32 = p.splits > 1 || p.out_f32;
+    const int rc_main = a.bits != 4 ? launch_tiled_w8(p, a.act_dtype, a.scale_dtype, pl.gpc, pl.bm, stream)
+                        : f32   ? launch_tiled_w4_f32(p, a.act_dtype, a.scale_dtype, pl.gpc, pl.bm, stream)
+                                : launch_tiled_w4(p, a.act_dtype, a.scale_dtype, pl.gpc, pl.bm, stream);
     if (rc_main != 0 || pl.splits <= 1) return rc_main;
     const size_t quads = (size_t)a.M * a.N / 4;
     const dim3 grid((unsigned)((quads + 255) / 256));

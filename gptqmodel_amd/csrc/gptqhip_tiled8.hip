@@ -4,7 +4,8 @@
 namespace gptqhip {
 
 int launch_tiled_w8(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int bm, hipStream_t stream) {
-    return launch_tiled_bits<8>(p, act_dtype, scale_dtype, gpc, bm, stream);
+    if (p.splits > 1 || p.out_f32) return launch_tiled_bits<8, 1>(p, act_dtype, scale_dtype, gpc, bm, stream);
+    return launch_tiled_bits<8, 0>(p, act_dtype, scale_dtype, gpc, bm, stream);
 }
 
 }  // namespace gptqhip

@@ -500,28 +500,24 @@ inline int launch_tiled_out(const TiledParams& p, int bm, hipStream_t stream) {
     return check_hip(hipGetLastError(), "tiled_kernel launch");
 }
 
-template <int BITS, int ACT, int SCL, int GPC>
-inline int launch_tiled_bm(const TiledParams& p, int bm, hipStream_t stream) {
-    if (p.splits > 1 || p.out_f32) return launch_tiled_out<BITS, ACT, SCL, GPC, 1>(p, bm, stream);
-    return launch_tiled_out<BITS, ACT, SCL, GPC, 0>(p, bm, stream);
-}
-
-template <int BITS, int ACT, int SCL>
+template <int BITS, int ACT, int SCL, int OUTF>
 inline int launch_tiled_gpc(const TiledParams& p, int gpc, int bm, hipStream_t stream) {
-    if (gpc == 1) return launch_tiled_bm<BITS, ACT, SCL, 1>(p, bm, stream);
-    return launch_tiled_bm<BITS, ACT, SCL, 4>(p, bm, stream);
+    if (gpc == 1) return launch_tiled_out<BITS, ACT, SCL, 1, OUTF>(p, bm, stream);
+    return launch_tiled_out<BITS, ACT, SCL, 4, OUTF>(p, bm, stream);
 }
 
-// one translation unit per bit width (defined in gptqhip_tiled.hip / gptqhip_tiled8.hip)
+// one translation unit per (bit width, epilogue) so the instantiations compile in parallel:
+// gptqhip_tiled.hip (4-bit, 16-bit output), gptqhip_tiled_f32.hip (4-bit, fp32 output), gptqhip_tiled8.hip (8-bit)
 int launch_tiled_w4(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int bm, hipStream_t stream);
+int launch_tiled_w4_f32(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int bm, hipStream_t stream);
 int launch_tiled_w8(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int bm, hipStream_t stream);
 
-template <int BITS>
+template <int BITS, int OUTF>
 inline int launch_tiled_bits(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int bm, hipStream_t stream) {
-    if (act_dtype == kFP16 && scale_dtype == kFP16) return launch_tiled_gpc<BITS, kFP16, kFP16>(p, gpc, bm, stream);
-    if (act_dtype == kBF16 && scale_dtype == kFP16) return launch_tiled_gpc<BITS, kBF16, kFP16>(p, gpc, bm, stream);
-    if (act_dtype == kFP16 && scale_dtype == kBF16) return launch_tiled_gpc<BITS, kFP16, kBF16>(p, gpc, bm, stream);
-    return launch_tiled_gpc<BITS, kBF16, kBF16>(p, gpc, bm, stream);
+    if (act_dtype == kFP16 && scale_dtype == kFP16) return launch_tiled_gpc<BITS, kFP16, kFP16, OUTF>(p, gpc, bm, stream);
+    if (act_dtype == kBF16 && scale_dtype == kFP16) return launch_tiled_gpc<BITS, kBF16, kFP16, OUTF>(p, gpc, bm, stream);
+    if (act_dtype == kFP16 && scale_dtype == kBF16) return launch_tiled_gpc<BITS, kFP16, kBF16, OUTF>(p, gpc, bm, stream);
+    return launch_tiled_gpc<BITS, kBF16, kBF16, OUTF>(p, gpc, bm, stream);
 }
 
 }  // namespace gptqhip
