@@ -50,15 +50,41 @@ def create_quant_module(parent: nn.Module, child_name: str, linear_cls: Type[Bas
     return new
 
 
+def dynamic_get(dynamic: Optional[Dict[str, Dict]], module_name: str):
+    """Per-module override lookup of `QuantizeConfig.dynamic` (quantization/config.py:1614-1652, 1822-1854): patterns are
+    tried in dict order and matched with re.match at the start of the qualified module name; "-:" prefix = negative
+    match (returns False: leave the module unquantised), "+:" or no prefix = positive (returns a copy of the override
+    dict); no match returns None."""
+    if not dynamic:
+        return None
+    import re
+    for pattern, overrides in dynamic.items():
+        negative = pattern.startswith("-:")
+        raw = pattern[2:] if pattern.startswith(("-:", "+:")) else pattern
+        if re.match(raw, module_name):
+            return False if negative else dict(overrides or {})
+    return None
+
+
 def make_quant(model: nn.Module, names: Iterable[str], bits: int, group_size: int, desc_act: bool, sym: bool,
                backend: BACKEND = BACKEND.AUTO, format: FORMAT = FORMAT.GPTQ, quant_method: METHOD = METHOD.GPTQ,
-               device=DEVICE.ROCM, dtype: Optional[torch.dtype] = None) -> List[Type[BaseQuantLinear]]:
+               device=DEVICE.ROCM, dtype: Optional[torch.dtype] = None,
+               dynamic: Optional[Dict[str, Dict]] = None) -> List[Type[BaseQuantLinear]]:
     """Replace every nn.Linear whose qualified name is in `names` by the selected QuantLinear class
-    (utils/model.py:398-472, 651-727).  NotImplementedError from a candidate => try the next one (AUTO)."""
+    (utils/model.py:398-472, 651-727).  NotImplementedError from a candidate => try the next one (AUTO).
+    `dynamic`: per-module overrides of bits / group_size / desc_act / sym, or exclusion (utils/model.py:545-564)."""
     wanted = set(names)
-    candidates = select_quant_linear(bits=bits, group_size=group_size, desc_act=desc_act, sym=sym, device=device,
-                                     backend=backend, format=format, quant_method=quant_method, dtype=dtype,
-                                     multi_select=True)
+    base = (bits, group_size, desc_act, sym)
+    cache: Dict[tuple, List[Type[BaseQuantLinear]]] = {}
+
+    def candidates_for(cfg):
+        if cfg not in cache:
+            cache[cfg] = select_quant_linear(bits=cfg[0], group_size=cfg[1], desc_act=cfg[2], sym=cfg[3], device=device,
+                                             backend=backend, format=format, quant_method=quant_method, dtype=dtype,
+                                             multi_select=True)
+        return cache[cfg]
+
+    candidates = candidates_for(base)
     modules: Dict[str, nn.Module] = dict(model.named_modules())
     for full_name in sorted(wanted):
         sub = modules.get(full_name)
@@ -66,12 +92,19 @@ def make_quant(model: nn.Module, names: Iterable[str], bits: int, group_size: in
             continue
         if not isinstance(sub, nn.Linear):
             raise ValueError(f"make_quant: `{full_name}` is {type(sub).__name__}, expected nn.Linear")
+        cfg = base
+        overrides = dynamic_get(dynamic, full_name)
+        if overrides is False:  # negative match: this module stays a float nn.Linear
+            continue
+        if overrides:
+            cfg = (overrides.get("bits", bits), overrides.get("group_size", group_size),
+                   overrides.get("desc_act", desc_act), overrides.get("sym", sym))
         parent_name, _, child = full_name.rpartition(".")
         parent = modules[parent_name] if parent_name else model
         last = None
-        for cls in candidates:
+        for cls in candidates_for(cfg):
             try:
-                create_quant_module(parent, child, cls, bits, group_size, desc_act, sym, sub.in_features,
+                create_quant_module(parent, child, cls, cfg[0], cfg[1], cfg[2], cfg[3], sub.in_features,
                                     sub.out_features, sub.bias is not None, full_name, backend, format, dtype)
                 last = None
                 break

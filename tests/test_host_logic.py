@@ -167,6 +167,32 @@ def test_make_quant_swaps_linears(kernels_available):
         make_quant(m, ["layer.norm"], bits=4, group_size=64, desc_act=False, sym=True)
 
 
+def test_make_quant_dynamic_overrides(kernels_available):
+    """QuantizeConfig.dynamic semantics (quantization/config.py:1614-1652; utils/model.py:545-564): first matching pattern
+    in dict order wins, "-:" excludes the module, "+:" / plain patterns override bits / group_size / desc_act / sym."""
+    from gptqmodel_amd.utils.model import dynamic_get
+
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj = nn.Linear(256, 128, bias=False)
+            self.k_proj = nn.Linear(256, 128, bias=False)
+            self.down_proj = nn.Linear(256, 256, bias=False)
+    m = nn.ModuleDict({"layers": nn.ModuleList([Block(), Block()])})
+    dynamic = {r"-:layers\.0\.k_proj": {}, r"+:.*down_proj": {"bits": 8, "group_size": 32}, r"layers\.1\..*": {"desc_act": True}}
+    assert dynamic_get(dynamic, "layers.0.k_proj") is False
+    assert dynamic_get(dynamic, "layers.1.down_proj") == {"bits": 8, "group_size": 32}   # earlier pattern wins
+    assert dynamic_get(dynamic, "layers.1.q_proj") == {"desc_act": True}
+    assert dynamic_get(dynamic, "layers.0.q_proj") is None and dynamic_get(None, "x") is None
+    names = [n for n, mod in m.named_modules() if isinstance(mod, nn.Linear)]
+    make_quant(m, names, bits=4, group_size=128, desc_act=False, sym=True, dynamic=dynamic)
+    l0, l1 = m["layers"][0], m["layers"][1]
+    assert isinstance(l0.k_proj, nn.Linear) and not isinstance(l0.k_proj, HipGptqLinear)
+    assert (l0.q_proj.bits, l0.q_proj.group_size, l0.q_proj.desc_act) == (4, 128, False)
+    assert (l0.down_proj.bits, l0.down_proj.group_size) == (8, 32)
+    assert (l1.q_proj.bits, l1.q_proj.desc_act) == (4, True) and (l1.down_proj.bits, l1.down_proj.desc_act) == (8, False)
+
+
 def test_act_order_permutation_and_bounds():
     gs, k = 4, 16
     seq = torch.arange(k, dtype=torch.int32) // gs
