@@ -140,3 +140,32 @@ def hf_select_quant_linear(bits: int, group_size: int, desc_act: bool, sym: bool
         device = normalize_device(next(iter(device_map.values())))
     return select_quant_linear(bits=bits, group_size=group_size, desc_act=desc_act, sym=sym, device=device,
                                backend=backend or BACKEND.AUTO, format=fmt, quant_method=method, pack=pack)
+
+
+def hf_select_quant_linear_v2(bits: int, group_size: int, desc_act: bool, sym: bool, format, quant_method,
+                              zero_point=None, dtype=None, meta=None, pack: bool = False, device_map=None, backend=None,
+                              **kw):
+    """HF/optimum entry with explicit method / format strings (upstream importer.py:413-470): enum and dtype strings are
+    normalised here, AWQ's `zero_point` is the negation of `sym`."""
+    def _enum(value, cls, field):
+        if isinstance(value, cls):
+            return value
+        try:
+            return cls(str(value).lower())
+        except ValueError as exc:
+            raise ValueError(f"Unsupported {field}: `{value}`") from exc
+
+    method = _enum(quant_method, METHOD, "quant_method")
+    fmt = _enum(format, FORMAT, "format")
+    if isinstance(dtype, str):
+        cand = getattr(torch, dtype.replace("torch.", "").lower(), None)
+        if not isinstance(cand, torch.dtype):
+            raise ValueError(f"Unsupported dtype: `{dtype}`")
+        dtype = cand
+    if method == METHOD.AWQ and zero_point is not None:
+        sym = not bool(zero_point)
+    device = DEVICE.ROCM
+    if isinstance(device_map, dict) and device_map:
+        device = normalize_device(next(iter(device_map.values())))
+    return select_quant_linear(bits=bits, group_size=group_size, desc_act=desc_act, sym=sym, device=device,
+                               backend=backend or BACKEND.AUTO, format=fmt, quant_method=method, pack=pack, dtype=dtype)

@@ -35,6 +35,22 @@ def convert_gptq_v1_to_v2_format(model: nn.Module, bits: int, pack_dtype: torch.
     return model
 
 
+def hf_convert_gptq_v1_to_v2_format(model: nn.Module, bits: int, qlinear_kernel=None, checkpoint_format: str = "gptq",
+                                    meta=None):
+    """HF/optimum entry (utils/model.py:730-748): convert only `gptq` (v1) checkpoints, and only when a loaded module
+    needs v2 zeros.  Returns (model, converted)."""
+    if str(checkpoint_format).lower() != "gptq":
+        return model, False
+    if not any(isinstance(m, BaseQuantLinear) and getattr(m, "REQUIRES_FORMAT_V2", False) for m in model.modules()):
+        return model, False
+    return convert_gptq_v1_to_v2_format(model, bits=bits), True
+
+
+def hf_gptqmodel_post_init(model, use_act_order: bool = False, quantize_config=None, max_input_length=None):
+    """HF/optimum entry (utils/model.py:1276-1278)."""
+    return gptqmodel_post_init(model, use_act_order)
+
+
 def create_quant_module(parent: nn.Module, child_name: str, linear_cls: Type[BaseQuantLinear], bits: int,
                         group_size: int, desc_act: bool, sym: bool, in_features: int, out_features: int, bias: bool,
                         full_name: str, backend: BACKEND, fmt: FORMAT, dtype: Optional[torch.dtype] = None):

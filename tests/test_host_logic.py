@@ -245,3 +245,22 @@ def test_fuse_quant_linears_concatenates_along_n(kernels_available):
     blk = nn.Module()
     blk.a, blk.b = mods[0], mods[1]
     assert fuse_siblings(blk, ["a", "b"]) is None and blk.a is mods[0]
+
+
+def test_hf_entry_points(kernels_available):
+    """The HF/optimum-facing wrappers (upstream importer.py:377-470, utils/model.py:730-748, 1276)."""
+    from gptqmodel_amd.utils.importer import hf_select_quant_linear_v2
+    from gptqmodel_amd.utils.model import hf_convert_gptq_v1_to_v2_format, hf_gptqmodel_post_init
+    from gptqmodel_amd.nn_modules.qlinear.hip_awq import HipAwqLinear
+    assert hf_select_quant_linear_v2(4, 128, False, True, "gptq", "gptq", dtype="torch.float16") is HipGptqLinear
+    assert hf_select_quant_linear_v2(4, 128, False, True, "gemm", "awq", zero_point=True) is HipAwqLinear
+    with pytest.raises(ValueError):
+        hf_select_quant_linear_v2(4, 128, False, True, "nope", "gptq")
+    m = nn.ModuleDict({"a": nn.Linear(64, 32, bias=False)})
+    make_quant(m, ["a"], bits=4, group_size=32, desc_act=False, sym=True)
+    m["a"].qzeros.data.fill_(0x77777777)
+    _, converted = hf_convert_gptq_v1_to_v2_format(m, bits=4, checkpoint_format="gptq")
+    assert converted and int(m["a"].qzeros[0, 0]) == -0x77777778 and m["a"].qzero_format() == 2   # 0x88888888 as int32
+    _, again = hf_convert_gptq_v1_to_v2_format(m, bits=4, checkpoint_format="gptq_v2")
+    assert not again
+    assert callable(hf_gptqmodel_post_init)
