@@ -95,9 +95,34 @@ class BaseQuantLinear(nn.Module):
     # ---- lifecycle ---------------------------------------------------------------------------------
     def post_init(self):
         """Called after weights are on their device (gptqmodel/utils/model.py:1335-1340)."""
+        self.clear_autotune()
         if self.adapter is not None:
             self.adapter.post_init(weight_key=self.name, device=self.runtime_device(),
                                    lora_A=getattr(self, "lora_A", None), lora_B=getattr(self, "lora_B", None))
+
+    # ---- optional per-module autotune hook (qlinear/__init__.py:236-255): one-shot, skipped in training; the HIP kernels
+    # plan their launch geometry per call (plan_skinny / plan_tiled), so the classes here leave `_autotune` unimplemented
+    # and keep autotune disabled
+    autotune_enabled: bool = False
+
+    def clear_autotune(self):
+        self._autotune_complete = False
+        self._autotune_result = None
+
+    def get_autotune_result(self):
+        return getattr(self, "_autotune_result", None)
+
+    def _autotune(self, *args, **kwargs):
+        raise NotImplementedError(f"{self.__class__.__name__} does not implement `_autotune()`.")
+
+    def maybe_autotune(self, *args, **kwargs):
+        if not self.autotune_enabled or self.training:
+            return self.get_autotune_result()
+        if getattr(self, "_autotune_complete", False):
+            return self._autotune_result
+        self._autotune_result = self._autotune(*args, **kwargs)
+        self._autotune_complete = True
+        return self._autotune_result
 
     def optimize(self, backend: str = "inductor", mode: str = None, fullgraph: bool = False):
         self.optimized = True  # nothing to torch.compile: the kernel is native

@@ -264,3 +264,23 @@ def test_hf_entry_points(kernels_available):
     _, again = hf_convert_gptq_v1_to_v2_format(m, bits=4, checkpoint_format="gptq_v2")
     assert not again
     assert callable(hf_gptqmodel_post_init)
+
+
+def test_autotune_hook_contract(kernels_available):
+    """maybe_autotune (qlinear/__init__.py:246-255): off by default; when a subclass enables it, `_autotune` runs once,
+    never in training mode, and post_init() clears the cached result."""
+    calls = []
+
+    class Tuned(HipGptqLinear):
+        autotune_enabled = True
+
+        def _autotune(self, x):
+            calls.append(x)
+            return {"plan": len(calls)}
+
+    lin = HipGptqLinear(bits=4, group_size=32, sym=True, desc_act=False, in_features=64, out_features=32, bias=False)
+    assert lin.maybe_autotune(1) is None and lin.get_autotune_result() is None
+    t = Tuned(bits=4, group_size=32, sym=True, desc_act=False, in_features=64, out_features=32, bias=False).eval()
+    assert t.maybe_autotune("a") == {"plan": 1} and t.maybe_autotune("b") == {"plan": 1} and calls == ["a"]
+    t.clear_autotune()
+    assert t.maybe_autotune("c") == {"plan": 2}
