@@ -267,20 +267,16 @@ def test_hf_entry_points(kernels_available):
 
 
 def test_autotune_hook_contract(kernels_available):
-    """maybe_autotune (qlinear/__init__.py:246-255): off by default; when a subclass enables it, `_autotune` runs once,
-    never in training mode, and post_init() clears the cached result."""
+    """maybe_autotune (qlinear/__init__.py:246-255): off by default; once enabled, `_autotune` runs once, never in
+    training mode, and clear_autotune() (called by post_init) drops the cached result."""
     calls = []
-
-    class Tuned(HipGptqLinear):
-        autotune_enabled = True
-
-        def _autotune(self, x):
-            calls.append(x)
-            return {"plan": len(calls)}
-
     lin = HipGptqLinear(bits=4, group_size=32, sym=True, desc_act=False, in_features=64, out_features=32, bias=False)
     assert lin.maybe_autotune(1) is None and lin.get_autotune_result() is None
-    t = Tuned(bits=4, group_size=32, sym=True, desc_act=False, in_features=64, out_features=32, bias=False).eval()
-    assert t.maybe_autotune("a") == {"plan": 1} and t.maybe_autotune("b") == {"plan": 1} and calls == ["a"]
-    t.clear_autotune()
-    assert t.maybe_autotune("c") == {"plan": 2}
+    with pytest.raises(NotImplementedError):
+        lin._autotune(1)
+    lin.eval()
+    lin.autotune_enabled = True
+    lin._autotune = lambda x: (calls.append(x), {"plan": len(calls)})[1]
+    assert lin.maybe_autotune("a") == {"plan": 1} and lin.maybe_autotune("b") == {"plan": 1} and calls == ["a"]
+    lin.clear_autotune()
+    assert lin.maybe_autotune("c") == {"plan": 2}
