@@ -59,6 +59,12 @@ class BaseQuantLinear(nn.Module):
         self.backend = backend
         self.adapter = copy.deepcopy(adapter)  # adapters hold per-module tensors (qlinear/__init__.py:125)
         self.optimized = False
+        # rotation / online-Hadamard state of SpinQuant / QuaRot checkpoints (qlinear/__init__.py:133-141): off by default
+        self.online_full_had = False
+        self.online_partial_had = False
+        self.had_dim = -1
+        self.K = 1
+        self.had_K = None
 
         _, err = self.validate(bits=bits, group_size=group_size, desc_act=desc_act, sym=sym,
                                in_features=in_features, out_features=out_features, pack_dtype=pack_dtype,
@@ -99,6 +105,30 @@ class BaseQuantLinear(nn.Module):
         if self.adapter is not None:
             self.adapter.post_init(weight_key=self.name, device=self.runtime_device(),
                                    lora_A=getattr(self, "lora_A", None), lora_B=getattr(self, "lora_B", None))
+
+    # ---- rotation hook (qlinear/__init__.py:485-518; torch.py:312 applies it to x before the matmul) -------------------
+    def set_had_K(self, had_K: Optional[torch.Tensor]) -> None:
+        if "had_K" in self._buffers:
+            if had_K is None:
+                del self._buffers["had_K"]
+                self.had_K = None
+            else:
+                self._buffers["had_K"] = had_K
+            return
+        if had_K is None:
+            self.had_K = None
+            return
+        if hasattr(self, "had_K"):
+            del self.had_K
+        self.register_buffer("had_K", had_K, persistent=False)
+
+    def _apply_rotation_to_input(self, x: torch.Tensor) -> torch.Tensor:
+        """Identity unless the checkpoint asks for an online Hadamard transform.  That transform lives in the reference's
+        quantization/rotation package (out of this path's scope): fail loudly instead of returning unrotated results."""
+        if self.online_full_had or self.online_partial_had:
+            raise NotImplementedError(f"{self.__class__.__name__}: online Hadamard rotation (SpinQuant/QuaRot) is not "
+                                      "implemented by the HIP backend")
+        return x
 
     # ---- optional per-module autotune hook (qlinear/__init__.py:236-255): one-shot, skipped in training; the HIP kernels
     # plan their launch geometry per call (plan_skinny / plan_tiled), so the classes here leave `_autotune` unimplemented

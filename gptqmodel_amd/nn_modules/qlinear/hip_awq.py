@@ -94,7 +94,7 @@ class HipAwqLinear(AWQuantLinear):
             raise RuntimeError("HipAwqLinear.forward called before post_init()")
         from gptqmodel_amd import ops
         out_shape = x.shape[:-1] + (self.out_features,)
-        x2, in_dtype = flatten_input(x, self.in_features)
+        x2, in_dtype = flatten_input(self._apply_rotation_to_input(x), self.in_features)
         meta, bias = self._runtime(x2.dtype)
         out = ops.gemm(x2, self.qweight, meta, bias, None, self.out_features, self.group_size, self.bits, x2.dtype,
                        exact_bf16=self.EXACT_BF16_DECODE)

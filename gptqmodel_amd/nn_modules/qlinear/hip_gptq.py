@@ -105,7 +105,7 @@ class HipGptqLinear(GPTQQuantLinear):
             raise RuntimeError("HipGptqLinear.forward called before post_init()")
         from gptqmodel_amd import ops
         out_shape = x.shape[:-1] + (self.out_features,)
-        x2, in_dtype = flatten_input(x, self.in_features)
+        x2, in_dtype = flatten_input(self._apply_rotation_to_input(x), self.in_features)
         out = ops.gemm(x2, self.qweight, self.meta, self._bias_for(x2.dtype, x2.device), self.perm, self.out_features,
                        self.group_size, self.bits, self._scale_dtype, exact_bf16=self.EXACT_BF16_DECODE)
         if self.adapter:

@@ -280,3 +280,16 @@ def test_autotune_hook_contract(kernels_available):
     assert lin.maybe_autotune("a") == {"plan": 1} and lin.maybe_autotune("b") == {"plan": 1} and calls == ["a"]
     lin.clear_autotune()
     assert lin.maybe_autotune("c") == {"plan": 2}
+
+
+def test_rotation_hook_fails_loudly(kernels_available):
+    lin = HipGptqLinear(bits=4, group_size=32, sym=True, desc_act=False, in_features=64, out_features=32, bias=False)
+    x = torch.zeros(2, 64)
+    assert lin._apply_rotation_to_input(x) is x
+    lin.set_had_K(torch.eye(4))
+    assert "had_K" in dict(lin.named_buffers())
+    lin.set_had_K(None)
+    assert lin.had_K is None
+    lin.online_full_had = True
+    with pytest.raises(NotImplementedError, match="Hadamard"):
+        lin._apply_rotation_to_input(x)
