@@ -227,3 +227,45 @@ def fuse_siblings(parent: nn.Module, names: List[str]) -> Optional[_FusedGroup]:
     for i, (n, m) in enumerate(zip(names, mods)):
         setattr(parent, n, FusedSiblingView(group, i, m.in_features, m.out_features))
     return group
+
+
+def dequantize_model(model: nn.Module, device="cpu", dtype: torch.dtype = torch.float16) -> nn.Module:
+    """Replace every HIP QuantLinear by an nn.Linear holding its dequantised weights -- the mirror of the reference's
+    dequantize_model (nn_modules/qlinear/torch.py:736-761, which does this for TorchLinear and moves the weights to CPU
+    fp16).  The [K,N] weights come from the device dequant kernels (bit-exact with dequantize_weight()).  Fused sibling
+    groups (fuse_siblings) are split back into one nn.Linear per original projection."""
+    from ..nn_modules.qlinear.hip_awq import HipAwqLinear
+    from ..nn_modules.qlinear.hip_gptq import HipGptqLinear, HipQuantEmbeddings
+
+    def to_linear(w_kn: torch.Tensor, bias: Optional[torch.Tensor]) -> nn.Linear:
+        lin = nn.Linear(w_kn.shape[0], w_kn.shape[1], bias=bias is not None)
+        lin.weight = nn.Parameter(w_kn.T.detach().to(device=device, dtype=dtype).contiguous(), requires_grad=False)
+        if bias is not None:
+            lin.bias = nn.Parameter(bias.detach().to(device=device, dtype=dtype), requires_grad=False)
+        return lin
+
+    for name, module in list(model.named_modules()):
+        parent_name, _, child = name.rpartition(".")
+        live = dict(model.named_modules())
+        if parent_name and parent_name not in live:
+            continue  # child of a fused group that was already replaced
+        parent = live[parent_name] if parent_name else model
+        if isinstance(module, _FusedGroup):
+            w = module.fused.dequantize_weight()
+            b = module.fused.bias
+            views = {n: v for n, v in parent.named_children() if isinstance(v, FusedSiblingView) and v._group[0] is module}
+            for vname, view in views.items():
+                o, n_out = module.offsets[view.index], module.sizes[view.index]
+                setattr(parent, vname, to_linear(w[:, o:o + n_out], None if b is None else b[o:o + n_out]))
+            delattr(parent, child)
+        elif isinstance(module, HipQuantEmbeddings):
+            continue  # embeddings are not linears; the reference's dequantize_model leaves them alone too
+        elif isinstance(module, (HipGptqLinear, HipAwqLinear)) and not isinstance(parent, _FusedGroup):
+            setattr(parent, child, to_linear(module.dequantize_weight(), module.bias))
+        elif isinstance(module, BaseQuantLinear) and not isinstance(parent, _FusedGroup):
+            raise ValueError(f"dequantize_model: `{name}` is {type(module).__name__}; only HIP QuantLinear modules are "
+                             "supported")
+    cfg = getattr(model, "config", None)
+    if cfg is not None and hasattr(cfg, "quantization_config"):
+        del cfg.quantization_config
+    return model

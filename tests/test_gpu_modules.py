@@ -244,3 +244,41 @@ def test_quant_embeddings_match_reference_semantics(bits, desc_act):
     assert np.array_equal(torch_to_bits(emb.dequantize_weight()), table.astype(np.float16).view(np.uint16))
     with pytest.raises(IndexError):
         emb(torch.tensor([V], device=DEV))
+
+
+def test_dequantize_model_replaces_modules_incl_fused_groups():
+    """dequantize_model (mirror of nn_modules/qlinear/torch.py:736-761): dense nn.Linear twins reproduce the quantised
+    modules' outputs (same dequantised weights), fused q/k/v groups are split back."""
+    import torch.nn as nn
+    from gptqmodel_amd.utils.model import dequantize_model, fuse_siblings, gptqmodel_post_init, make_quant
+
+    class Attn(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj = nn.Linear(256, 128, bias=True)
+            self.k_proj = nn.Linear(256, 64, bias=True)
+            self.v_proj = nn.Linear(256, 64, bias=True)
+            self.o_proj = nn.Linear(128, 256, bias=False)
+    torch.manual_seed(3)
+    blk = Attn().half().cuda()
+    floats = {n: m for n, m in blk.named_children()}
+    make_quant(blk, list(floats), bits=4, group_size=64, desc_act=False, sym=False)
+    for n, lin in floats.items():
+        qm = getattr(blk, n)
+        w = lin.weight.data.float().reshape(lin.out_features, lin.in_features // 64, 64)
+        scales = ((w.amax(2) - w.amin(2)).clamp(min=1e-5) / 15).half().float()
+        zeros = torch.round(-w.amin(2) / scales).clamp(0, 15)
+        qm.pack(lin, scales, zeros, (torch.arange(lin.in_features) // 64).to(torch.int32))
+    assert fuse_siblings(blk, ["q_proj", "k_proj", "v_proj"]) is not None
+    gptqmodel_post_init(blk)
+    x = (torch.randn(5, 256, device="cuda") * 0.5).half()
+    xo = (torch.randn(5, 128, device="cuda") * 0.5).half()
+    ref = {n: getattr(blk, n)(x).float().cpu() for n in ("q_proj", "k_proj", "v_proj")}
+    ref["o_proj"] = blk.o_proj(xo).float().cpu()
+    dequantize_model(blk, device="cuda")
+    assert all(type(getattr(blk, n)) is nn.Linear for n in ("q_proj", "k_proj", "v_proj", "o_proj"))
+    assert not any("fused" in n for n, _ in blk.named_children())
+    for n in ("q_proj", "k_proj", "v_proj"):
+        got = getattr(blk, n)(x).float().cpu()
+        assert (got - ref[n]).abs().max() <= 2e-3 * ref[n].abs().max() + 1e-3
+    assert (blk.o_proj(xo).float().cpu() - ref["o_proj"]).abs().max() <= 2e-3 * ref["o_proj"].abs().max() + 1e-3
