@@ -282,3 +282,36 @@ def test_dequantize_model_replaces_modules_incl_fused_groups():
         got = getattr(blk, n)(x).float().cpu()
         assert (got - ref[n]).abs().max() <= 2e-3 * ref[n].abs().max() + 1e-3
     assert (blk.o_proj(xo).float().cpu() - ref["o_proj"]).abs().max() <= 2e-3 * ref["o_proj"].abs().max() + 1e-3
+
+
+def test_lora_adapter_hook_adds_low_rank_update():
+    """The adapter hook of the reference forward (torch.py:344-345; adapter/adapter.py:148-173): out += (x @ A) @ B on top
+    of the kernel's result, for 2-D and batched inputs."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    from gptqmodel_amd.utils.adapter import Lora
+    K, N, gs, r = 256, 128, 64, 8
+    qweight, qzeros, scales, g_idx = synth_gptq(21, 4, K, N, gs)
+    torch.manual_seed(1)
+    A = (torch.randn(K, r) * 0.05).half()
+    B = (torch.randn(r, N) * 0.05).half()
+
+    def build(adapter):
+        lin = HipGptqLinear(bits=4, group_size=gs, sym=False, desc_act=False, in_features=K, out_features=N, bias=False,
+                            adapter=adapter, register_buffers=False)
+        lin.qweight = torch.from_numpy(qweight).cuda()
+        lin.qzeros = torch.from_numpy(qzeros).cuda()
+        lin.scales = f32_to_torch(scales, "fp16", "cuda")
+        lin.g_idx = torch.from_numpy(g_idx).cuda()
+        lin.bias = None
+        lin.qzero_format(format=2)
+        lin.eval()
+        lin.post_init()
+        return lin
+
+    plain, lora = build(None), build(Lora(rank=r, lora_A=A, lora_B=B))
+    for shape in ((3, K), (2, 5, K)):
+        x = (torch.randn(*shape, device="cuda") * 0.5).half()
+        want = plain(x).float() + ((x.reshape(-1, K) @ A.cuda()) @ B.cuda()).float().reshape(*shape[:-1], N)
+        got = lora(x).float()
+        assert got.shape == want.shape
+        assert (got - want).abs().max() <= 2e-3 * want.abs().max() + 2e-3
