@@ -89,6 +89,8 @@ TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_va
         pl.bm = 128;
         pl.tail_cols = 0;
     }
+    if (M <= 64 && force_variant == 0) pl.bm = 64;  // one block row either way: 64-row tiles halve the per-chunk work
+    if (force_variant == 3) pl.bm = 64;
     // split K across blocks when the (M, N) grid alone leaves most CUs idle (mid-size M, or K-heavy layers):
     // fp32 partial slabs + a tiny reduce kernel (a kernel boundary is cheaper than re-reading 100s of KB of slabs
     // through a last-arriver block -- MI355X_MICROARCH.md "handoff-payload")

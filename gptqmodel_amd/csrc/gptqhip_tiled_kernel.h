@@ -177,7 +177,10 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     // D stage buffers for the A tile + a separate staging area for the epilogue transposes (BM x 16 B per wave), so a
     // tile's output can leave while the NEXT tile's first stages are already landing in the stage buffers
     __shared__ __attribute__((aligned(16))) char lds_all[D * BM * 256];
-    __shared__ __attribute__((aligned(16))) char lds_epi[WAVES * BM * 16];
+    // staging per wave: TG row tiles per epilogue pass (16-bit: 64 B per row; fp32: 128 B per row)
+    constexpr int TG16 = MT >= 4 ? MT / 4 : 1, TG32 = MT >= 8 ? MT / 8 : 1;
+    constexpr int kEpi = OUTF ? TG32 * 16 * 128 : TG16 * 16 * 64;  // bytes per wave
+    __shared__ __attribute__((aligned(16))) char lds_epi[WAVES * kEpi];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         constexpr bool kIssue = kind != 2;
         constexpr bool kNext = !(kind == 2 && pos == D - 2);  // loads of a next chunk exist (clamped past the end)
         constexpr int sn = (s + 1) % D, si = (s + D - 1) % D;
-        constexpr int PF = BM == 256 ? 4 : 8;  // measured: deeper spills at BM=256, helps at BM=128
+        constexpr int PF = BM == 128 ? 8 : 4;  // measured: deeper spills at BM=256, helps at BM=128; 64-row tiles: MT = 4
         constexpr int NG = 4 * MT / PF;        // fragment groups per chunk
         constexpr int NPIECE = BM * 16 / NT;
         static_assert(NPIECE <= NG, "one DMA piece per fragment group");
@@ -363,38 +366,38 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         asm volatile("" : "+v"(lane_e));
         const int c_e = lane_e & 15, rq_e = lane_e >> 4;
         if constexpr (OUTF == 0) {
-            // 16-bit output: round like the reference, transpose through this wave's staging area (4 passes of MT/4
-            // row tiles) and store whole 16-byte row pieces instead of 2-byte scattered elements
-            uint16_t* slab = reinterpret_cast<uint16_t*>(lds_epi + wave * (BM * 16));
+            // 16-bit output: round like the reference, transpose through this wave's staging area (passes of TG16 row
+            // tiles) and store whole 16-byte row pieces instead of 2-byte scattered elements
+            uint16_t* slab = reinterpret_cast<uint16_t*>(lds_epi + wave * kEpi);
             char* base = reinterpret_cast<char*>(p.out) + (size_t)t.m0 * p.ldo * 2;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, rows * p.ldo * 2, 0x00020000);
             const int n0 = t.tile0 * kTileN + (lane_e & 3) * 8;
             const uint32_t lane_off = n0 < p.N ? (uint32_t)((lane_e >> 2) * p.ldo * 2 + n0 * 2) : 0xFFFFFF00u;
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {
+            for (int h = 0; h < MT / TG16; ++h) {
 #pragma unroll
                 for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
-                    for (int mh = 0; mh < MT / 4; ++mh)
+                    for (int mh = 0; mh < TG16; ++mh)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            float y = round_through<ACT>(acc[h * (MT / 4) + mh][tt][i]);
+                            float y = round_through<ACT>(acc[h * TG16 + mh][tt][i]);
                             if (p.bias != nullptr) y = y + bias[tt];
                             slab[(mh * 16 + 4 * rq_e + i) * 32 + tt * 16 + c_e] = f32_to_16<ACT>(y);
                         }
                 // same-wave LDS accesses execute in order: no barrier between this wave's writes and reads
 #pragma unroll
-                for (int pass = 0; pass < BM / 64; ++pass) {
+                for (int pass = 0; pass < TG16; ++pass) {
                     const int row = pass * 16 + (lane_e >> 2);
                     const u4_t v = *reinterpret_cast<const u4_t*>(slab + row * 32 + (lane_e & 3) * 8);
-                    const uint32_t off = lane_off + (uint32_t)((h * (BM / 4) + pass * 16) * p.ldo * 2);
+                    const uint32_t off = lane_off + (uint32_t)((h * (TG16 * 16) + pass * 16) * p.ldo * 2);
                     __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane_off >= 0xFFFFFF00u ? lane_off : off, 0, 0);
                 }
             }
         } else {
-            // fp32 accumulators (split-K partials or tensor-parallel partial sums): 8 passes of MT/8 row tiles, rows
-            // of 32 floats (128 B) leave as 16-byte pieces
-            float* slab = reinterpret_cast<float*>(lds_epi + wave * (BM * 16));
+            // fp32 accumulators (split-K partials or tensor-parallel partial sums): passes of TG32 row tiles, rows of 32
+            // floats (128 B) leave as 16-byte pieces
+            float* slab = reinterpret_cast<float*>(lds_epi + wave * kEpi);
             const size_t ld = p.splits > 1 ? (size_t)p.N : (size_t)p.ldo;
             char* base = p.splits > 1 ? reinterpret_cast<char*>(p.slabs + ((size_t)blockIdx.z * p.M + t.m0) * p.N)
                                       : reinterpret_cast<char*>(p.out) + (size_t)t.m0 * p.ldo * 4;
@@ -402,18 +405,18 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
             const int n0 = t.tile0 * kTileN + (lane_e & 7) * 4;
             const uint32_t lane_off = n0 < p.N ? (uint32_t)((lane_e >> 3) * ld * 4 + n0 * 4) : 0xFFFFFF00u;
 #pragma unroll
-            for (int h = 0; h < 8; ++h) {
+            for (int h = 0; h < MT / TG32; ++h) {
 #pragma unroll
                 for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
-                    for (int mh = 0; mh < MT / 8; ++mh)
+                    for (int mh = 0; mh < TG32; ++mh)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) slab[(mh * 16 + 4 * rq_e + i) * 32 + tt * 16 + c_e] = acc[h * (MT / 8) + mh][tt][i];
+                        for (int i = 0; i < 4; ++i) slab[(mh * 16 + 4 * rq_e + i) * 32 + tt * 16 + c_e] = acc[h * TG32 + mh][tt][i];
 #pragma unroll
-                for (int pass = 0; pass < BM / 64; ++pass) {
+                for (int pass = 0; pass < TG32 * 2; ++pass) {
                     const int row = pass * 8 + (lane_e >> 3);
                     const f4_t v = *reinterpret_cast<const f4_t*>(slab + row * 32 + (lane_e & 7) * 4);
-                    const uint32_t off = lane_off + (uint32_t)((h * (BM / 8) + pass * 8) * ld * 4);
+                    const uint32_t off = lane_off + (uint32_t)((h * (TG32 * 16) + pass * 8) * ld * 4);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs,
                                                            lane_off >= 0xFFFFFF00u ? lane_off : off, 0, 0);
                 }
@@ -488,6 +491,10 @@ inline int launch_tiled_out(const TiledParams& p, int bm, hipStream_t stream) {
             hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 256, 8, 2, OUTF>), grid, dim3(512), 0, stream, p);
             return check_hip(hipGetLastError(), "tiled_kernel launch");
         }
+    }
+    if (bm == 64) {  // M <= 64: half the MFMA work and staging of a 128-row tile
+        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 64, 8, BITS == 4 ? 3 : 2, OUTF>), grid, dim3(512), 0, stream, p);
+        return check_hip(hipGetLastError(), "tiled_kernel launch");
     }
     if (bm != 128) {
         set_error("tiled kernel: no %d-row tile for bits=%d gpc=%d", bm, BITS, GPC);

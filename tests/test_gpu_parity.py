@@ -366,7 +366,7 @@ def test_tiled_tail_launch_column_split(ops, act):
 
 
 @pytest.mark.parametrize("K,variant,partial", [(128, 1, False), (256, 1, False), (384, 1, True), (384, 2, False),
-                                                (640, 2, True), (128, 2, False)])
+                                                (640, 2, True), (128, 2, False), (384, 3, False), (256, 3, True)])
 def test_persistent_tile_loop_short_k(ops, K, variant, partial):
     """More output tiles than CUs with only 1-5 K chunks per tile: every block runs several tiles back to back through
     the first-round / drain code paths (fewer chunks than pipeline stages included), 16-bit and fp32-partial epilogues,
@@ -379,7 +379,7 @@ def test_persistent_tile_loop_short_k(ops, K, variant, partial):
                                   f32_to_torch(scales, "fp16", DEV), None, gs, 4)
     xt = f32_to_torch(x, "fp16", DEV)
     try:
-        ops.set_tuning(0, 2, variant)  # tiled kernel, 256- / 128-row tiles
+        ops.set_tuning(0, 2, variant)  # tiled kernel, 256- / 128- / 64-row tiles
         out = ops.gemm(xt, qw_t, meta, None, None, N, gs, 4, torch.float16, partial_f32=partial)
         torch.cuda.synchronize()
     finally:
@@ -449,7 +449,7 @@ def test_tiled_random_shape_stress(ops):
             M = 257
         act = str(rng.choice(["fp16", "bf16"]))
         desc = bool(rng.randint(0, 2)) and (K // gs) > 1
-        variant = int(rng.choice([0, 1, 2]))
+        variant = int(rng.choice([0, 1, 2, 3]))
         partial = bool(rng.randint(0, 4) == 0)
         qweight, qzeros, scales, g_idx = synth_gptq(3000 + it, bits, K, N, gs, desc_act=desc)
         x = O.round_to(rng.randn(M, K).astype(np.float32) * 0.5, act)
