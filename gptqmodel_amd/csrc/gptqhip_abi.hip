@@ -63,7 +63,7 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
         const SkinnyPlan pl = plan_skinny(mchunk, K, N, gs, g_force_split, g_force_waves);
         if (pl.slab_floats > floats) floats = pl.slab_floats;
     }
-    if (M > 16 || g_force_kernel == 2) {
+    if (M > 8 || g_force_kernel == 2) {
         for (int b : {4, 8}) {  // the 8-bit plan uses 128-row tiles only and may split K further
             const TiledPlan tp = plan_tiled(M, K, N, group_size > 0 ? group_size : 128, b, g_force_waves, g_force_split);
             if (tp.slab_floats > floats) floats = tp.slab_floats;
@@ -225,9 +225,10 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     a.perm = fused_perm ? perm : nullptr;
     a.exact_bf16 = (flags & GPTQHIP_GEMM_EXACT_BF16) ? 1 : 0;
 
-    // measured crossover (profiles/r01_m_sweep.txt): the MFMA-tiled kernel wins above 32 rows, and already above 16
-    // rows on wide layers (N >= 8192, e.g. fused gate_up) where its grid fills the chip without split-K
-    const bool wide = N >= 8192 && M > 16;
+    // measured crossover (profiles/r01_m_sweep.txt): the MFMA-tiled kernel (64-row tiles, split-K) wins above 32 rows,
+    // and already above 8 rows on wide layers (N >= 8192, e.g. fused gate_up: 23.7 vs 26.0 us at M=9) where every 16-column
+    // block of the skinny kernel would re-stage the whole activation tile
+    const bool wide = N >= 8192 && M > 8;
     const bool use_tiled = (g_force_kernel == 2) || (g_force_kernel == 0 && (M > kSkinnyMaxM || wide));
     if (use_tiled) {
         a.x = xin;
