@@ -13,5 +13,5 @@ x = (torch.randn(M, K, device=dev) * 0.5).half()
 out = torch.empty((M, N), dtype=torch.float16, device=dev)
 for it in range(40):
     qw_t, meta = sets[it % 8]
-    ops.gemm(x, qw_t, meta, None, None, N, 128, 4, torch.float16, out=out)
+    ops.gemm(x, qw_t, meta, None, None, N, 128, 4, torch.float16, out=out)  # default dispatch
 torch.cuda.synchronize()

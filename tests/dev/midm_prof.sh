@@ -2,7 +2,7 @@
 # Run ON THE GPU BOX: per-kernel durations (main + split-K reduce) of mid-M shapes.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-for cfg in "64 4096 4096" "128 4096 4096" "512 4096 4096" "1024 4096 4096" "128 4096 28672" "128 14336 4096"; do
+for cfg in "16 4096 28672" "64 4096 28672" "16 4096 4096"; do
   tag=$(echo $cfg | tr ' ' '_')
   timeout 90 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/midm_$tag -o p -- python $R/tests/dev/midm_prof.py $cfg > /dev/null 2>&1
   f=$(find $R/gpurun_out/midm_$tag -name "*kernel_stats.csv" | head -1)
