@@ -476,3 +476,14 @@ def test_tiled_random_shape_stress(ops):
             assert rel_err(torch_to_f32(out), ref) <= tol(act), tag
         done += 1
     assert done >= 40
+
+
+def test_decode_act_order_long_k_falls_back_to_gather(ops):
+    """K = 28672 (Llama-3-70B down_proj): the x row no longer fits the in-kernel LDS staging of the fused act-order path,
+    so batch-1 decode gathers x first -- same result either way."""
+    K, N, gs = 28672, 256, 128
+    qweight, qzeros, scales, g_idx = synth_gptq(17, 4, K, N, gs, desc_act=True)
+    x = O.round_to(np.random.RandomState(2).randn(1, K).astype(np.float32) * 0.5, "fp16")
+    got = torch_to_f32(run_gptq(ops, x, qweight, qzeros, scales, g_idx, 4, gs, None, "fp16", "fp16"))
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, None, "fp16", "fp16")
+    assert rel_err(got, ref) <= 1e-3
