@@ -11,6 +11,9 @@ import torch
 def hip_validate_once() -> Tuple[bool, Optional[Exception]]:
     """validate_once() contract (reference qlinear/__init__.py:257-270): (False, ImportError) when the native
     library or a gfx950 device is unusable, so that BACKEND.AUTO falls through to the next candidate."""
+    import os
+    if os.environ.get("GPTQHIP_DISABLE", "").strip() not in ("", "0"):
+        return False, ImportError("gptqmodel_amd HIP kernels disabled by GPTQHIP_DISABLE")
     try:
         from gptqmodel_amd import ops
         if not torch.cuda.is_available():

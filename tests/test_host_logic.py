@@ -293,3 +293,18 @@ def test_rotation_hook_fails_loudly(kernels_available):
     lin.online_full_had = True
     with pytest.raises(NotImplementedError, match="Hadamard"):
         lin._apply_rotation_to_input(x)
+
+
+def test_env_switches(monkeypatch):
+    """GPTQHIP_DISABLE makes validate_once() report the kernels unavailable (AUTO then falls through, like a missing
+    .so); the tuning variables must be integers."""
+    from gptqmodel_amd import _lib
+    from gptqmodel_amd.nn_modules.qlinear.hip_common import hip_validate_once
+    monkeypatch.setenv("GPTQHIP_DISABLE", "1")
+    ok, err = hip_validate_once()
+    assert ok is False and isinstance(err, ImportError) and "GPTQHIP_DISABLE" in str(err)
+    monkeypatch.setenv("GPTQHIP_FORCE_KERNEL", "two")
+    with pytest.raises(RuntimeError, match="not an integer"):
+        _lib._env_int("GPTQHIP_FORCE_KERNEL")
+    monkeypatch.setenv("GPTQHIP_FORCE_KERNEL", "2")
+    assert _lib._env_int("GPTQHIP_FORCE_KERNEL") == 2 and _lib._env_int("GPTQHIP_NOT_SET") == 0
