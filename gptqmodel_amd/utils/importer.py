@@ -5,6 +5,7 @@ SUPPORTS_FORMATS and SUPPORTS_BACKEND_SELECTION is truthy); AUTO orders candidat
 SUPPORTS_FORMATS (higher wins) and filters by device exactly like upstream (importer.py:553-556)."""
 from __future__ import annotations
 
+import logging
 from typing import Dict, List, Optional, Type, Union
 
 import torch
@@ -13,6 +14,17 @@ from ..nn_modules.qlinear import BaseQuantLinear
 from .adapter import Adapter
 from .backend import BACKEND, normalize_backend
 from .const import DEVICE, FORMAT, METHOD, normalize_device
+
+log = logging.getLogger("gptqmodel_amd")
+_logged_selection = set()
+
+
+def _log_selected(cls, backend, method, fmt):
+    """One line per distinct selection (upstream logs the chosen kernel too, importer.py:602-611)."""
+    key = (cls.__name__, str(backend), str(method), str(fmt))
+    if key not in _logged_selection:
+        _logged_selection.add(key)
+        log.info("Kernel: selected `%s` for backend=%s method=%s format=%s", cls.__name__, backend, method, fmt)
 
 
 def _supports_pack_api(cls: Type[BaseQuantLinear]) -> bool:
@@ -111,12 +123,14 @@ def select_quant_linear(bits: int, group_size: int, desc_act: bool, sym: bool,
             if pack and not _supports_pack_api(cls):
                 continue
             if not multi_select:
+                _log_selected(cls, backend, quant_method, format)
                 return cls
             validated.append(cls)
         if not validated:
             if last_err:
                 raise last_err
             raise ValueError("No valid quant linear")
+        _log_selected(validated[0], backend, quant_method, format)
         return validated
 
     qlinear = get_kernel_for_backend(backend, quant_method, format)
@@ -127,6 +141,7 @@ def select_quant_linear(bits: int, group_size: int, desc_act: bool, sym: bool,
     if pack and not _supports_pack_api(qlinear):
         raise ValueError(f"Selected backend `{backend}` with kernel `{qlinear.__name__}` cannot pack quantized weights "
                          f"for format `{format}`.")
+    _log_selected(qlinear, backend, quant_method, format)
     return [qlinear] if multi_select else qlinear
 
 
