@@ -17,7 +17,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libgptqhip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/gptqhip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -26,7 +26,7 @@ SIGNATURES = {
     "gptqhip_abi_version": (_i, []),
     "gptqhip_last_error": (_c.c_char_p, []),
     "gptqhip_device_info": (_i, [_i, _c.POINTER(_i), _c.POINTER(_sz), _c.c_char_p, _i]),
-    "gptqhip_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "gptqhip_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "gptqhip_tiled_words": (_sz, [_i, _i, _i]),
     "gptqhip_meta_words": (_sz, [_i, _i, _i]),
     "gptqhip_repack_tiled": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -82,30 +82,8 @@ def load() -> ctypes.CDLL:
         got = lib.gptqhip_abi_version()
         if got != ABI_VERSION:
             raise RuntimeError(f"libgptqhip.so ABI version {got} != expected {ABI_VERSION}; rebuild it")
-        _apply_env_tuning(lib)
         _lib = lib
     return _lib
-
-
-def _env_int(name: str) -> int:
-    v = os.environ.get(name, "").strip()
-    if not v:
-        return 0
-    try:
-        return int(v)
-    except ValueError as e:
-        raise RuntimeError(f"{name}={v!r} is not an integer") from e
-
-
-def _apply_env_tuning(lib) -> None:
-    """Debug / triage switches (the reference steers its kernels through env flags too, torch.py:172-190):
-      GPTQHIP_FORCE_KERNEL=1|2   always the decode (skinny) / prefill (tiled) kernel
-      GPTQHIP_FORCE_SPLIT_K=n    fixed cross-block split-K
-      GPTQHIP_FORCE_VARIANT=n    decode: waves per block; prefill: 1/2/3 = 256/128/64-row tiles
-    (GPTQHIP_DISABLE=1 is read by validate_once(): the HIP classes report themselves unavailable so AUTO falls through.)"""
-    fk, fs, fv = _env_int("GPTQHIP_FORCE_KERNEL"), _env_int("GPTQHIP_FORCE_SPLIT_K"), _env_int("GPTQHIP_FORCE_VARIANT")
-    if fk or fs or fv:
-        lib.gptqhip_set_tuning(fs, fk, fv)
 
 
 def check(rc: int, what: str) -> None:

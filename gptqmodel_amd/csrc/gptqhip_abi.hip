@@ -1,9 +1,11 @@
 // C ABI of libgptqhip.so (declared in include/gptqhip.h): argument validation, workspace carving,
-// kernel selection.  No torch types, no global mutable state besides the thread-local error string and
-// the process-wide tuning overrides used by benchmarks.
+// kernel selection.  No torch types and no process-global mutable state: the error string and the tuning
+// overrides (benchmarks / tests) are THREAD-LOCAL, so concurrent callers on different threads, devices or
+// streams never observe each other's settings.
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -17,9 +19,29 @@
 namespace gptqhip {
 
 static thread_local char g_err[512] = "";
-static int g_force_split = 0;
-static int g_force_kernel = 0;
-static int g_force_waves = 0;
+// per-thread overrides (gptqhip_set_tuning); 0 = not overridden by this thread
+static thread_local int t_force_split = 0;
+static thread_local int t_force_kernel = 0;
+static thread_local int t_force_waves = 0;
+
+// process-wide DEFAULTS from the environment, read once and immutable afterwards (triage switches, like the env flags
+// the reference steers its kernels with, torch.py:172-190):
+//   GPTQHIP_FORCE_KERNEL=1|2  always the decode (skinny) / prefill (tiled) kernel;  GPTQHIP_FORCE_SPLIT_K=n;
+//   GPTQHIP_FORCE_VARIANT=n   decode: waves per block; prefill: 1/2/3 = 256/128/64-row tiles
+struct EnvTuning {
+    int split, kernel, waves;
+};
+static int env_int(const char* name) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : 0;
+}
+static const EnvTuning& env_tuning() {
+    static const EnvTuning e = {env_int("GPTQHIP_FORCE_SPLIT_K"), env_int("GPTQHIP_FORCE_KERNEL"), env_int("GPTQHIP_FORCE_VARIANT")};
+    return e;
+}
+#define g_force_split (t_force_split ? t_force_split : env_tuning().split)
+#define g_force_kernel (t_force_kernel ? t_force_kernel : env_tuning().kernel)
+#define g_force_waves (t_force_waves ? t_force_waves : env_tuning().waves)
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -46,7 +68,7 @@ struct WorkspaceLayout {
     size_t total;
 };
 
-static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int has_perm) {
+static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int bits, int has_perm) {
     WorkspaceLayout L;
     L.counters_off = 0;
     // FIXED-size counter region: it must stay zero between calls, so no other data may ever alias it
@@ -57,17 +79,12 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
     L.slabs_off = L.gather_off + L.gather_bytes;
     const int mchunk = M < kSkinnyMaxM ? M : kSkinnyMaxM;
     // worst case over the split heuristics: the skinny plan for one row-chunk
-    size_t floats = 0;
-    for (int gs : {group_size, 128, 32}) {
-        if (gs <= 0 || K % gs != 0) continue;
-        const SkinnyPlan pl = plan_skinny(mchunk, K, N, gs, g_force_split, g_force_waves);
-        if (pl.slab_floats > floats) floats = pl.slab_floats;
-    }
+    // the SAME plans gptqhip_gemm will make for this (shape, group_size, bits): both sides call these planners with
+    // identical arguments, so the layout cannot drift from the launch
+    size_t floats = plan_skinny(mchunk, K, N, group_size, g_force_split, g_force_waves).slab_floats;
     if (M > 8 || g_force_kernel == 2) {
-        for (int b : {4, 8}) {  // the 8-bit plan uses 128-row tiles only and may split K further
-            const TiledPlan tp = plan_tiled(M, K, N, group_size > 0 ? group_size : 128, b, g_force_waves, g_force_split);
-            if (tp.slab_floats > floats) floats = tp.slab_floats;
-        }
+        const TiledPlan tp = plan_tiled(M, K, N, group_size, bits, g_force_waves, g_force_split);
+        if (tp.slab_floats > floats) floats = tp.slab_floats;
     }
     L.slabs_bytes = align_up(floats * sizeof(float), 256);
     L.total = L.slabs_off + L.slabs_bytes;
@@ -85,9 +102,9 @@ int gptqhip_abi_version(void) { return GPTQHIP_ABI_VERSION; }
 const char* gptqhip_last_error(void) { return g_err; }
 
 int gptqhip_set_tuning(int force_split_k, int force_kernel, int force_waves) {
-    g_force_split = force_split_k;
-    g_force_kernel = force_kernel;
-    g_force_waves = force_waves;
+    t_force_split = force_split_k;
+    t_force_kernel = force_kernel;
+    t_force_waves = force_waves;
     return GPTQHIP_OK;
 }
 
@@ -113,9 +130,9 @@ int gptqhip_device_info(int device, int* cu_count, size_t* hbm_bytes, char* arch
     return GPTQHIP_OK;
 }
 
-size_t gptqhip_workspace_bytes(int M, int K, int N, int has_perm) {
-    if (M <= 0 || K <= 0 || N <= 0) return 0;
-    return layout_workspace(M, K, N, 0, has_perm).total;
+size_t gptqhip_workspace_bytes(int M, int K, int N, int group_size, int bits, int has_perm) {
+    if (M <= 0 || K <= 0 || N <= 0 || group_size <= 0 || K % group_size != 0 || (bits != 4 && bits != 8)) return 0;
+    return layout_workspace(M, K, N, group_size, bits, has_perm).total;
 }
 
 static int validate_common(const char* fn, int K, int N, int group_size, int bits) {
@@ -187,7 +204,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         set_error("gptqhip_gemm: bad flags 0x%x (PARTIAL_F32 excludes bias)", flags);
         return GPTQHIP_EINVAL;
     }
-    const WorkspaceLayout L = layout_workspace(M, K, N, group_size, perm != nullptr);
+    const WorkspaceLayout L = layout_workspace(M, K, N, group_size, bits, perm != nullptr);
     if (!workspace || workspace_bytes < L.total) {
         set_error("gptqhip_gemm: workspace %zu bytes < required %zu", workspace_bytes, L.total);
         return GPTQHIP_ENOMEM;

@@ -61,6 +61,8 @@ class HipAwqLinear(AWQuantLinear):
         if self.bias is not None and self.bias.dtype not in (torch.float16, torch.bfloat16):
             self.bias = self.bias.to(torch.float16)
         super().post_init()
+        if self._ready:
+            return
         from gptqmodel_amd import ops
         if not self.qweight.is_cuda:
             raise RuntimeError("HipAwqLinear.post_init: buffers must be on the ROCm device (no CPU fallback)")
@@ -78,6 +80,8 @@ class HipAwqLinear(AWQuantLinear):
         """AwqTorchLinear._ensure_runtime_dtype (torch_awq.py:149-155): scales and bias are cast to the compute
         dtype BEFORE the dequant multiply."""
         hit = self._rt.get(dtype)
+        if hit is not None and hit[0].device != self.qweight.device:
+            hit = None  # the module was moved (.to(device)) after post_init: rebuild the constants next to the weights
         if hit is None:
             from gptqmodel_amd import ops
             sc = self.scales if self.scales.dtype == dtype else self.scales.to(dtype).contiguous()
@@ -103,6 +107,24 @@ class HipAwqLinear(AWQuantLinear):
         if out.dtype != in_dtype:
             out = out.to(in_dtype)
         return out.reshape(out_shape)
+
+    def forward_partial(self, x: torch.Tensor) -> torch.Tensor:
+        """float32 [.., N] unrounded accumulators without bias (row-parallel tensor-parallel shards all-reduce these
+        before the single final rounding, gptqmodel_amd/utils/tp.py) -- same contract as HipGptqLinear.forward_partial."""
+        if not self._ready:
+            raise RuntimeError("HipAwqLinear.forward_partial called before post_init()")
+        from gptqmodel_amd import ops
+        x2, _ = flatten_input(x, self.in_features)
+        meta, _ = self._runtime(x2.dtype)
+        out = ops.gemm(x2, self.qweight, meta, None, None, self.out_features, self.group_size, self.bits, x2.dtype,
+                       partial_f32=True)
+        return out.reshape(x.shape[:-1] + (self.out_features,))
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if self._ready:
+            raise RuntimeError(f"{self.__class__.__name__} `{self.name}`: state_dict() after post_init() would save the "
+                               "kernel (tile-major) layout; save from the original checkpoint instead")
+        super()._save_to_state_dict(destination, prefix, keep_vars)
 
     def dequantize_weight(self) -> torch.Tensor:
         from gptqmodel_amd import ops

@@ -50,8 +50,10 @@ class HipGptqLinear(GPTQQuantLinear):
                          out_features=out_features, bias=bias, pack_dtype=pack_dtype,
                          backend=kwargs.pop("backend", BACKEND.GPTQ_HIP), adapter=adapter,
                          register_buffers=register_buffers, format=format, **kwargs)
-        self.perm: Optional[torch.Tensor] = None  # act-order row permutation (device int32 [K]) after post_init
-        self.meta: Optional[torch.Tensor] = None  # pre-baked per-(group, column) constants after post_init
+        # derived device tensors, filled by post_init(): non-persistent BUFFERS so that module.to(device) moves them
+        # with the weights and state_dict() never carries them
+        self.register_buffer("perm", None, persistent=False)  # act-order row permutation (int32 [K])
+        self.register_buffer("meta", None, persistent=False)  # pre-baked per-(group, column) constants
         self._scale_dtype = torch.float16
         self._ready = False
         self._bias_cache = None
@@ -68,8 +70,17 @@ class HipGptqLinear(GPTQQuantLinear):
         from gptqmodel_amd import ops
         if not self.qweight.is_cuda:
             raise RuntimeError("HipGptqLinear.post_init: buffers must be on the ROCm device (no CPU fallback)")
+        if self._ready:
+            return  # already in the kernel layout (post_init is idempotent: HF/optimum and the loader may both call it)
         if self.scales.dtype not in (torch.float16, torch.bfloat16):
             self.scales.data = self.scales.data.to(torch.float16)
+        if self.format == FORMAT.GPTQ and self.qzero_format() == 1:
+            # a v1 checkpoint (zero-1 on disk) that reached post_init unconverted: the reference loader converts before
+            # post_init whenever a loaded module has REQUIRES_FORMAT_V2 (models/loader.py:1658-1675); a caller that goes
+            # make_quant -> load_state_dict -> gptqmodel_post_init directly gets the same result here instead of zeros
+            # that are silently off by one
+            from ...utils.model import convert_gptq_v1_to_v2_format_module
+            convert_gptq_v1_to_v2_format_module(self, bits=self.bits, pack_dtype=self.pack_dtype)
         groups = self.scales.shape[0]
         perm = None
         if self.g_idx is not None and self.g_idx.numel() == self.in_features:
@@ -84,12 +95,14 @@ class HipGptqLinear(GPTQQuantLinear):
         self._scale_dtype = self.scales.dtype
         self._ready = True
 
-    def list_buffers(self):
-        buf = super().list_buffers()
-        for t in (self.perm, getattr(self, "meta", None)):
-            if t is not None:
-                buf.append(t)
-        return buf
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if self._ready:
+            # after post_init `qweight` holds tile-major words under the checkpoint name: writing them out would produce
+            # a checkpoint no loader can read.  The reference saves a loaded quantised model by re-reading the
+            # checkpoint from disk (models/writer.py:681-685), never from the live modules.
+            raise RuntimeError(f"{self.__class__.__name__} `{self.name}`: state_dict() after post_init() would save the "
+                               "kernel (tile-major) layout; save from the original checkpoint instead")
+        super()._save_to_state_dict(destination, prefix, keep_vars)
 
     def _bias_for(self, dtype: torch.dtype, device: torch.device):
         if self.bias is None:

@@ -17,6 +17,11 @@ _DT = {torch.float16: FP16, torch.bfloat16: BF16}
 # per (device index, stream handle) zero-initialised scratch, grown on demand
 # (precedent: ExllamaV2 per-device ScratchSpace, gptqmodel/utils/model.py:1304-1313)
 _workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+# Outgrown workspaces are RETIRED, never freed: a HIP graph captured earlier still holds the old pointer and relies on
+# its arrival counters staying zero, so the allocator must not hand that memory to anyone else.
+_retired: list = []
+# gptqhip_workspace_bytes per problem signature (it re-runs the launch planners: not free on the eager decode path)
+_need_cache: Dict[Tuple[int, int, int, int, int, int], int] = {}
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -49,10 +54,31 @@ def workspace_for(device: torch.device, nbytes: int) -> torch.Tensor:
            torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _retired.append(ws)
         # zero-filled: the split-K arrival counters must start at 0 (kernels reset them after use)
         ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
+
+
+def reserve_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Pre-size the current stream's workspace (e.g. for the largest prefill) BEFORE capturing a HIP graph, so that no
+    later call has to replace the buffer the graph points at."""
+    return workspace_for(device, nbytes)
+
+
+def workspace_bytes(M: int, K: int, N: int, group_size: int, bits: int, has_perm: bool) -> int:
+    key = (M, K, N, group_size, bits, 1 if has_perm else 0)
+    need = _need_cache.get(key)
+    if need is None:
+        need = int(_lib.load().gptqhip_workspace_bytes(*key))
+        if need == 0:
+            raise RuntimeError(f"gptqhip_workspace_bytes: unsupported problem M={M} K={K} N={N} group_size={group_size} bits={bits}")
+        if len(_need_cache) > 4096:
+            _need_cache.clear()
+        _need_cache[key] = need
+    return need
 
 
 def repack_tiled(qweight: Optional[torch.Tensor], qzeros: torch.Tensor, scales: torch.Tensor,
@@ -108,8 +134,7 @@ def gemm(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Opt
     if M == 0:
         return out
     with torch.cuda.device(x.device):
-        need = lib.gptqhip_workspace_bytes(M, K, N, 1 if perm is not None else 0)
-        ws = workspace_for(x.device, need)
+        ws = workspace_for(x.device, workspace_bytes(M, K, N, group_size, bits, perm is not None))
         rc = lib.gptqhip_gemm(_ptr(x), _ptr(qweight_t), _ptr(meta), _ptr(perm), _ptr(bias), _ptr(out), _ptr(ws),
                               ws.numel(), M, K, N, group_size, bits, _DT[x.dtype], _DT[scale_dtype],
                               (1 if partial_f32 else 0) | (2 if exact_bf16 else 0), _stream(x.device))

@@ -149,21 +149,41 @@ def gptqmodel_post_init(model: nn.Module, use_act_order: bool = False, **_kw) ->
 # that returns its column slice of the fused result computed once per distinct input tensor.
 # ---------------------------------------------------------------------------------------------------------
 class _FusedGroup(nn.Module):
+    """One fused launch shared by its sibling views.  The fused output is cached for exactly ONE input tensor, identified
+    by object identity while a strong reference keeps that tensor alive (id()/data_ptr() of a dead tensor get reused by the
+    next decode step's activations), plus its in-place version counter where autograd tracks one.  The cache is dropped as
+    soon as every sibling has been served, so nothing stale or large (a prefill's fused output) stays pinned."""
+
     def __init__(self, fused: BaseQuantLinear, sizes: List[int]):
         super().__init__()
         self.fused = fused
         self.sizes = list(sizes)
         self.offsets = [sum(sizes[:i]) for i in range(len(sizes))]
-        self._key = None
+        self._x = None
+        self._ver = None
         self._out = None
+        self._served = set()
+
+    @staticmethod
+    def _version_of(x: torch.Tensor):
+        try:
+            return x._version
+        except RuntimeError:  # inference tensors (torch.inference_mode) do not track a version counter
+            return None
 
     def slice_for(self, x: torch.Tensor, index: int) -> torch.Tensor:
-        key = (id(x), x.data_ptr(), x._version, tuple(x.shape))
-        if key != self._key or self._out is None:
+        ver = self._version_of(x)
+        if self._out is None or self._x is not x or ver != self._ver or index in self._served:
             self._out = self.fused(x)
-            self._key = key
+            self._x, self._ver = x, ver
+            self._served = set()
         o = self.offsets[index]
-        return self._out[..., o:o + self.sizes[index]]
+        y = self._out[..., o:o + self.sizes[index]]
+        self._served.add(index)
+        if len(self._served) == len(self.sizes):
+            self._x = self._out = self._ver = None
+            self._served = set()
+        return y
 
 
 class FusedSiblingView(nn.Module):
@@ -200,12 +220,18 @@ def fuse_quant_linears(mods: List[BaseQuantLinear]) -> BaseQuantLinear:
     fused = type(m0)(bits=m0.bits, group_size=m0.requested_group_size, sym=m0.sym, desc_act=m0.desc_act,
                      in_features=m0.in_features, out_features=n_total, bias=m0.bias is not None,
                      register_buffers=False, name="+".join(m.name for m in mods), adapter=None)
-    fused.qweight = torch.cat([m.qweight for m in mods], dim=1).contiguous()
-    fused.qzeros = torch.cat([m.qzeros for m in mods], dim=1).contiguous()
-    fused.scales = torch.cat([m.scales for m in mods], dim=1).contiguous()
+    # registered buffers (not plain attributes): model.to(device) / list_buffers() must reach the fused tensors
+    fused.register_buffer("qweight", torch.cat([m.qweight for m in mods], dim=1).contiguous())
+    fused.register_buffer("qzeros", torch.cat([m.qzeros for m in mods], dim=1).contiguous())
+    fused.register_buffer("scales", torch.cat([m.scales for m in mods], dim=1).contiguous())
     if hasattr(m0, "g_idx"):
-        fused.g_idx = m0.g_idx
-    fused.bias = torch.cat([m.bias for m in mods]).contiguous() if m0.bias is not None else None
+        fused.register_buffer("g_idx", m0.g_idx)
+    if m0.bias is not None:
+        fused.register_buffer("bias", torch.cat([m.bias for m in mods]).contiguous())
+    else:
+        fused.bias = None
+    if getattr(m0, "format", None) is not None and hasattr(fused, "format"):
+        fused.format = m0.format
     if hasattr(m0, "qzero_format"):
         fused.qzero_format(format=m0.qzero_format())
     fused.train(m0.training)

@@ -16,7 +16,8 @@
  *     QMatrix* handle of ext_gptq.cpp:73-93).
  *   - work is enqueued on `stream` (the caller passes torch.cuda.current_stream().cuda_stream, as
  *     the reference natives use the current stream: ext_gptq.cpp:108); nothing synchronises.
- *   - re-entrant across devices and streams provided each (device, stream) uses its own workspace.
+ *   - re-entrant across threads, devices and streams provided each (device, stream) uses its own workspace
+ *     (error string and tuning overrides are thread-local; there is no other mutable state).
  *
  * Checkpoint ("canonical", GPTQ v2 K-packed) layout accepted by gptqhip_repack_tiled / gptqhip_dequant:
  *   qweight int32 [K*bits/32, N]   word (r,n) holds codes k = pf*r + j at bits [bits*j, bits*j+bits)
@@ -46,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 1
+#define GPTQHIP_ABI_VERSION 2
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -72,8 +73,9 @@ int gptqhip_device_info(int device, int* cu_count, size_t* hbm_bytes, char* arch
 /* Bytes of zero-initialised device scratch gptqhip_gemm needs for this problem (split-K fp32 slabs +
  * arrival counters + act-order gather buffer).  Precedent: ExllamaV2 per-device ScratchSpace,
  * gptqmodel/utils/model.py:1304-1313.  The workspace must be zero-filled once at allocation; the
- * kernels leave it zeroed where it matters (counters). */
-size_t gptqhip_workspace_bytes(int M, int K, int N, int has_perm);
+ * kernels leave it zeroed where it matters (counters).  Takes the same (group_size, bits) gptqhip_gemm will be
+ * called with: both sides run the same launch planner, so the size can never disagree with the launch.  0 = bad args. */
+size_t gptqhip_workspace_bytes(int M, int K, int N, int group_size, int bits, int has_perm);
 
 /* Sizes (in 32-bit words) of the tiled weight / meta arrays for a [K,N] layer. */
 size_t gptqhip_tiled_words(int K, int N, int bits);
@@ -161,7 +163,9 @@ int gptqhip_pack_gptq_host(const float* weight, const float* scales, const int32
 int gptqhip_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, gptqhip_stream_t stream);
 
 /* Tuning hook (benchmarks / tests): force the cross-block split-K factor and the waves per block of the skinny
- * kernel (0 = heuristic), or the kernel family (0 auto, 1 skinny, 2 tiled-prefill). */
+ * kernel (0 = heuristic), or the kernel family (0 auto, 1 skinny, 2 tiled-prefill).  The overrides are THREAD-LOCAL
+ * (they apply to gptqhip_gemm / gptqhip_workspace_bytes calls made by the calling thread only), so the library keeps
+ * no process-global mutable state and stays re-entrant across threads, devices and streams. */
 int gptqhip_set_tuning(int force_split_k, int force_kernel, int force_waves);
 
 #ifdef __cplusplus

@@ -53,9 +53,9 @@ def test_size_helpers(lib):
     assert lib.gptqhip_meta_words(4096, 4096, 128) == 32 * 4096
     assert lib.gptqhip_meta_words(4096, 4096, 96) == 0  # K % group_size != 0
     assert lib.gptqhip_tiled_words(4096, 4096, 3) == 0
-    assert lib.gptqhip_workspace_bytes(1, 4096, 4096, 0) >= 64 * 1024
-    assert lib.gptqhip_workspace_bytes(8, 4096, 4096, 1) >= lib.gptqhip_workspace_bytes(8, 4096, 4096, 0) + 8 * 4096 * 2
-    assert lib.gptqhip_workspace_bytes(0, 4096, 4096, 0) == 0
+    assert lib.gptqhip_workspace_bytes(1, 4096, 4096, 128, 4, 0) >= 64 * 1024
+    assert lib.gptqhip_workspace_bytes(8, 4096, 4096, 128, 4, 1) >= lib.gptqhip_workspace_bytes(8, 4096, 4096, 128, 4, 0) + 8 * 4096 * 2
+    assert lib.gptqhip_workspace_bytes(0, 4096, 4096, 128, 4, 0) == 0
 
 
 def test_argument_validation_reports_errors_without_a_gpu(lib):

@@ -315,3 +315,77 @@ def test_lora_adapter_hook_adds_low_rank_update():
         got = lora(x).float()
         assert got.shape == want.shape
         assert (got - want).abs().max() <= 2e-3 * want.abs().max() + 2e-3
+
+
+def test_v1_checkpoint_reaching_post_init_unconverted_is_converted_there():
+    """make_quant(format=GPTQ) -> load_state_dict -> gptqmodel_post_init WITHOUT the explicit
+    v1->v2 conversion step must not run with every zero-point off by one: post_init converts (the reference loader
+    always converts before post_init, models/loader.py:1658-1675).  A second post_init is a no-op."""
+    from gptqmodel_amd.utils.backend import BACKEND
+    from gptqmodel_amd.utils.const import FORMAT, METHOD
+    from gptqmodel_amd.utils.model import gptqmodel_post_init, make_quant
+    K, N, gs = 512, 256, 128
+    qweight, qzeros_v2, scales, g_idx = synth_gptq(15, 4, K, N, gs)
+    qzeros_v1 = (qzeros_v2.view(np.uint32) - np.uint32(0x11111111)).view(np.int32)
+
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.proj = nn.Linear(K, N, bias=False)
+
+    model = Block()
+    make_quant(model, ["proj"], bits=4, group_size=gs, desc_act=False, sym=False, backend=BACKEND.AUTO,
+               format=FORMAT.GPTQ, quant_method=METHOD.GPTQ)
+    model.load_state_dict({"proj.qweight": torch.from_numpy(qweight), "proj.qzeros": torch.from_numpy(qzeros_v1),
+                           "proj.scales": f32_to_torch(scales, "fp16"), "proj.g_idx": torch.from_numpy(g_idx)})
+    model = model.to(DEV)
+    gptqmodel_post_init(model)
+    assert model.proj.qzero_format() == 2
+    gptqmodel_post_init(model)  # idempotent
+    x = O.round_to(np.random.RandomState(0).randn(3, K).astype(np.float32) * 0.5, "fp16")
+    ref = O.forward_gptq(x, qweight, qzeros_v2, scales, g_idx, 4)
+    assert rel_err(torch_to_f32(model.proj(f32_to_torch(x, "fp16", DEV))), ref) <= 1e-3
+
+
+def test_derived_tensors_are_buffers_and_state_dict_refuses_kernel_layout():
+    """ADVICE r1 (medium): meta / perm are non-persistent buffers (module.to() moves them, list_buffers() lists them);
+    after post_init `qweight` holds tile-major words, so state_dict() must refuse instead of writing an unloadable
+    checkpoint."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    K, N, gs = 512, 128, 128
+    qweight, qzeros, scales, g_idx = synth_gptq(3, 4, K, N, gs, desc_act=True)
+    lin = HipGptqLinear(bits=4, group_size=gs, sym=False, desc_act=True, in_features=K, out_features=N, bias=False,
+                        register_buffers=True)
+    lin.load_state_dict({"qweight": torch.from_numpy(qweight), "qzeros": torch.from_numpy(qzeros),
+                         "scales": f32_to_torch(scales, "fp16"), "g_idx": torch.from_numpy(g_idx)})
+    assert set(lin.state_dict()) == {"qweight", "qzeros", "scales", "g_idx"}   # checkpoint layout: saving is fine
+    lin.qzero_format(format=2)
+    lin = lin.to(DEV).eval()
+    lin.post_init()
+    bufs = dict(lin.named_buffers())
+    assert bufs["meta"].is_cuda and bufs["perm"].is_cuda and len(lin.list_buffers()) == 6
+    with pytest.raises(RuntimeError, match="tile-major"):
+        lin.state_dict()
+    x = O.round_to(np.random.RandomState(1).randn(2, K).astype(np.float32) * 0.5, "fp16")
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4)
+    assert rel_err(torch_to_f32(lin(f32_to_torch(x, "fp16", DEV))), ref) <= 1e-3
+
+
+def test_awq_forward_partial_matches_unrounded_product():
+    """HipAwqLinear implements forward_partial (row-parallel AWQ shards need it)."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_awq import HipAwqLinear
+    g = load_golden("ref_awq_g128_fp16.npz")
+    K, N = g["qweight"].shape[0], g["qweight"].shape[1] * 8
+    lin = HipAwqLinear(bits=4, group_size=128, sym=False, desc_act=False, in_features=K, out_features=N, bias=False)
+    lin.qweight = torch.from_numpy(g["qweight"])
+    lin.qzeros = torch.from_numpy(g["qzeros"])
+    lin.scales = bits_to_torch(g["scales"], "fp16")
+    lin = lin.to(DEV).eval()
+    lin.post_init()
+    x = bits_to_torch(g["x"], "fp16", DEV)
+    part = lin.forward_partial(x)
+    assert part.dtype == torch.float32
+    w = bits_to_f32(g["w_ref"], "fp16").reshape(K, N).astype(np.float64)
+    ref = bits_to_f32(g["x"], "fp16").astype(np.float64) @ w
+    assert rel_err(part.cpu().numpy(), ref.astype(np.float32)) <= 1e-5
+    assert torch.equal(part.to(torch.float16), lin(x))  # one rounding of the same accumulators

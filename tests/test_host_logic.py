@@ -303,8 +303,75 @@ def test_env_switches(monkeypatch):
     monkeypatch.setenv("GPTQHIP_DISABLE", "1")
     ok, err = hip_validate_once()
     assert ok is False and isinstance(err, ImportError) and "GPTQHIP_DISABLE" in str(err)
-    monkeypatch.setenv("GPTQHIP_FORCE_KERNEL", "two")
-    with pytest.raises(RuntimeError, match="not an integer"):
-        _lib._env_int("GPTQHIP_FORCE_KERNEL")
-    monkeypatch.setenv("GPTQHIP_FORCE_KERNEL", "2")
-    assert _lib._env_int("GPTQHIP_FORCE_KERNEL") == 2 and _lib._env_int("GPTQHIP_NOT_SET") == 0
+
+
+def test_tuning_overrides_are_thread_local():
+    """gptqhip_set_tuning must not leak across threads (the header promises re-entrancy across threads, devices and
+    streams): a forced cross-block split-K on one thread changes that thread's workspace plan only."""
+    import threading
+    from gptqmodel_amd import _lib
+    lib = _lib.load()
+    args = (4, 4096, 512, 128, 4, 0)
+    base = lib.gptqhip_workspace_bytes(*args)
+    seen = {}
+
+    def worker():
+        lib.gptqhip_set_tuning(8, 0, 0)
+        seen["forced"] = lib.gptqhip_workspace_bytes(*args)
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert seen["forced"] > base                       # 8 fp32 slabs planned on the worker thread
+    assert lib.gptqhip_workspace_bytes(*args) == base  # this thread never saw the override
+
+
+def test_fused_group_cache_never_serves_a_stale_input():
+    """the fused-output cache must be keyed on the identity of a LIVE input tensor.  Fresh
+    activations created in a decode loop reuse Python ids / allocator addresses of dead ones; every view call must still
+    see the result for ITS input, also under torch.inference_mode() (no version counter) and after in-place updates."""
+    from gptqmodel_amd.utils.model import FusedSiblingView, _FusedGroup
+
+    class Lin(torch.nn.Module):
+        calls = 0
+
+        def forward(self, x):
+            Lin.calls += 1
+            return torch.cat([x * 2.0, x * 3.0, x * 5.0], dim=-1)
+
+    h = 64
+    group = _FusedGroup(Lin(), [h, h, h])
+    views = [FusedSiblingView(group, i, h, h) for i in range(3)]
+    mult = [2.0, 3.0, 5.0]
+    for mode in (torch.no_grad, torch.inference_mode):
+        with mode():
+            for step in range(400):
+                x = torch.full((1, h), float(step % 97) + 1.0)     # a fresh tensor per step: ids / addresses recycle
+                x = torch.nn.functional.rms_norm(x + step, (h,))
+                for i in (0, 1, 2) if step % 2 else (2, 0, 1):
+                    assert torch.equal(views[i](x), x * mult[i]), (step, i)
+    assert group._x is None and group._out is None                 # nothing pinned once every sibling was served
+    Lin.calls = 0
+    x = torch.ones(1, h)
+    a = views[0](x)
+    x.add_(1.0)                                                     # in-place update bumps the version: recompute
+    b = views[1](x)
+    assert Lin.calls == 2 and torch.equal(a, torch.full((1, h), 2.0)) and torch.equal(b, torch.full((1, h), 6.0))
+    views[2](x)
+    c = views[2](x)                                                 # same sibling asked twice: recomputed, not stale
+    assert torch.equal(c, x * 5.0)
+
+
+def test_fused_module_tensors_are_registered_buffers(kernels_available):
+    """the fused module's tensors must be buffers so .to() / list_buffers() reach them."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    from gptqmodel_amd.utils.const import FORMAT
+    from gptqmodel_amd.utils.model import fuse_quant_linears
+    mods = [HipGptqLinear(bits=4, group_size=128, sym=True, desc_act=False, in_features=256, out_features=n, bias=True,
+                          register_buffers=True, format=FORMAT.GPTQ_V2) for n in (64, 32)]
+    fused = fuse_quant_linears(mods)
+    names = dict(fused.named_buffers())
+    assert {"qweight", "qzeros", "scales", "g_idx", "bias"} <= set(names)
+    assert names["qweight"].shape == (32, 96) and names["bias"].shape == (96,)
+    assert len(fused.list_buffers()) == 5 and fused.format == FORMAT.GPTQ_V2
+    assert "meta" not in fused.state_dict() and "perm" not in fused.state_dict()   # derived tensors are non-persistent
