@@ -31,6 +31,27 @@ def rel_err(a: np.ndarray, b: np.ndarray) -> float:
     return float(np.abs(a - b).max() / max(float(np.abs(b).max()), 1e-12))
 
 
+# element-wise tolerances of the reference's own forward test (tests/test_torch_kernel_accuracy.py:111-125):
+#   torch.allclose(out, ref, atol=5e-3 if fp16 else 3e-2, rtol=1e-2)
+REF_ATOL = {"fp16": 5e-3, "bf16": 3e-2}
+REF_RTOL = 1e-2
+# norm-wise bar: north_star's <= 1e-3 relative fp16 error; bf16: the reference's kernel table (tests/kernels/test_gptq.py:353-360)
+NORM_TOL = {"fp16": 1e-3, "bf16": 8e-3}
+
+
+def assert_forward_close(got: np.ndarray, ref: np.ndarray, act: str, tag=None):
+    """Both gates on a rounded forward output: (1) the norm-wise relative error of the output (north_star), and
+    (2) the reference's own ELEMENT-WISE assertion with its atol/rtol."""
+    got = np.asarray(got, dtype=np.float32)
+    ref = np.asarray(ref, dtype=np.float32)
+    assert got.shape == ref.shape, (got.shape, ref.shape, tag)
+    e = rel_err(got, ref)
+    assert e <= NORM_TOL[act], (f"norm-wise rel err {e:.3e} > {NORM_TOL[act]}", tag)
+    bad = np.abs(got - ref) > REF_ATOL[act] + REF_RTOL * np.abs(ref)
+    assert not bad.any(), (f"{int(bad.sum())} of {bad.size} elements outside atol={REF_ATOL[act]} rtol={REF_RTOL}; "
+                           f"worst |d|={float(np.abs(got - ref).max()):.3e}", tag)
+
+
 def synth_gptq(seed, bits, k, n, gs, desc_act=False, sym=False, scale_dtype="fp16"):
     """Seeded synthetic GPTQ-v2 tensors following BASELINE.md §2 / SURVEY.md §8d."""
     rng = np.random.RandomState(seed)
@@ -45,6 +66,41 @@ def synth_gptq(seed, bits, k, n, gs, desc_act=False, sym=False, scale_dtype="fp1
     scales = O.round_to(rng.rand(g, n).astype(np.float32) * 0.01 + 0.005, scale_dtype)
     g_idx = ((rng.permutation(k) if desc_act else np.arange(k)) // gs).astype(np.int32)
     return qweight, qzeros, scales, g_idx
+
+
+# ----------------------------------------------------------------------------------------------------------
+# FULL-SIZE reference fixtures (tests/golden/full_*.npz, written by oracle/make_golden.py:make_fullsize): the packed
+# tensors of a BASELINE-sized layer are far too big to commit, so a fixture stores the SEED + the reference's outputs
+# (+ a few dequantised rows + a checksum of the regenerated inputs); both the generator and the tests rebuild the
+# inputs with this one function (numpy legacy RandomState: the stream is frozen across numpy versions).
+# ----------------------------------------------------------------------------------------------------------
+def synth_full_case(kind, seed, bits, k, n, gs, desc_act, sym, scale_dtype, act, m):
+    """-> dict(qweight, qzeros, scales (f32, exactly representable in scale_dtype), g_idx | None, x (f32, in act)).
+    kind "gptq": checkpoint-layout v2 tensors; kind "awq": AWQ GEMM-layout tensors (no g_idx, asymmetric zeros)."""
+    rng = np.random.RandomState(seed)
+    g = k // gs
+    if kind == "gptq":
+        qweight, qzeros, scales, g_idx = synth_gptq(seed, bits, k, n, gs, desc_act=desc_act, sym=sym,
+                                                    scale_dtype=scale_dtype)
+        rng = np.random.RandomState(seed + 7919)
+    else:
+        qweight = rng.randint(-2**31, 2**31, size=(k, n // 8), dtype=np.int64).astype(np.int32)
+        qzeros = rng.randint(-2**31, 2**31, size=(g, n // 8), dtype=np.int64).astype(np.int32)
+        scales = O.round_to(rng.rand(g, n).astype(np.float32) * 0.01 + 0.005, scale_dtype)
+        g_idx = None
+    x = O.round_to(rng.randn(m, k).astype(np.float32) * 0.5, act)
+    return {"qweight": qweight, "qzeros": qzeros, "scales": scales, "g_idx": g_idx, "x": x}
+
+
+def inputs_checksum(case) -> np.ndarray:
+    """Cheap order-sensitive checksum of the regenerated inputs (uint64[4]): detects any RNG / rounding drift."""
+    out = []
+    for key in ("qweight", "qzeros", "scales", "x"):
+        a = np.ascontiguousarray(case[key])
+        u = a.view(np.uint32).astype(np.uint64).reshape(-1)
+        w = (np.arange(u.size, dtype=np.uint64) % np.uint64(65521)) + np.uint64(1)
+        out.append(np.uint64((u * w).sum()))
+    return np.array(out, dtype=np.uint64)
 
 
 def f32_to_torch(a: np.ndarray, dtype: str, device="cpu") -> torch.Tensor:

@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from conftest import load_golden
-from helpers import bits_to_f32, bits_to_torch, f32_to_torch, rel_err, synth_gptq, torch_to_bits, torch_to_f32
+from helpers import assert_forward_close, bits_to_f32, bits_to_torch, f32_to_torch, rel_err, synth_gptq, torch_to_bits, torch_to_f32
 from oracle import gptq_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -44,7 +44,7 @@ def test_auto_select_and_forward_gptq_v1_checkpoint():
     out = model.proj(f32_to_torch(x, "fp16", DEV))
     assert out.shape == (2, 3, N)
     ref = O.forward_gptq(x, qweight, qzeros_v2, scales, g_idx, 4)
-    assert rel_err(torch_to_f32(out), ref) <= 1e-3
+    assert_forward_close(torch_to_f32(out), ref, "fp16")
     model.eval()
     with pytest.raises(NotImplementedError):  # inference-only kernel (SUPPORTS_TRAINING=False, qlinear/__init__.py:463-483)
         model.proj.train(True)
@@ -66,7 +66,7 @@ def test_gptq_module_act_order_dequantize_weight_bit_exact():
     w = lin.dequantize_weight()
     assert np.array_equal(torch_to_bits(w), g["w_ref"].reshape(K, N))
     out = lin(bits_to_torch(g["x"], "fp16", DEV))
-    assert rel_err(torch_to_f32(out), bits_to_f32(g["out_ref"], "fp16")) <= 1e-3
+    assert_forward_close(torch_to_f32(out), bits_to_f32(g["out_ref"], "fp16"), "fp16")
 
 
 @pytest.mark.parametrize("name", ["ref_awq_g128_bias_fp16.npz", "ref_awq_g128_bf16.npz"])
@@ -90,7 +90,7 @@ def test_awq_module(name):
     lin = lin.to(DEV).eval()
     lin.post_init()
     out = lin(bits_to_torch(g["x"], act, DEV))
-    assert rel_err(torch_to_f32(out), bits_to_f32(g["out_ref"], act)) <= (1e-3 if act == "fp16" else 8e-3)
+    assert_forward_close(torch_to_f32(out), bits_to_f32(g["out_ref"], act), act)
 
 
 def test_graph_capture_replay_matches_eager():
@@ -179,7 +179,7 @@ def test_row_parallel_partials_on_one_gpu():
     assert partial.dtype == torch.float32
     y_tp = partial.to(torch.float16) + bias
     ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, torch_to_f32(bias))
-    assert rel_err(torch_to_f32(y_tp), ref) <= 1e-3
+    assert_forward_close(torch_to_f32(y_tp), ref, "fp16")
     row = tp.RowParallelQuantLinear(shards[0], bias=None)  # world size 1 / no process group: no collective
     assert row(xt[:, :K // 2].contiguous()).dtype == torch.float16
 
@@ -216,7 +216,7 @@ def test_device_packer_bit_exact_and_roundtrip():
     out = mod(f32_to_torch(x, "fp16", DEV))
     ref = O.forward_gptq(x, e_qw, e_qz, torch_to_f32(mod.scales), g_idx.numpy(), bits,
                          torch_to_f32(mod.bias))
-    assert rel_err(torch_to_f32(out), ref) <= 1e-3
+    assert_forward_close(torch_to_f32(out), ref, "fp16")
     with pytest.raises(IndexError):
         ops.pack_gptq(lin.weight.detach().to(DEV), scales.T.contiguous().to(DEV), zeros.T.contiguous().to(DEV),
                       torch.full((K,), 99, dtype=torch.int32, device=DEV), bits)
@@ -344,7 +344,7 @@ def test_v1_checkpoint_reaching_post_init_unconverted_is_converted_there():
     gptqmodel_post_init(model)  # idempotent
     x = O.round_to(np.random.RandomState(0).randn(3, K).astype(np.float32) * 0.5, "fp16")
     ref = O.forward_gptq(x, qweight, qzeros_v2, scales, g_idx, 4)
-    assert rel_err(torch_to_f32(model.proj(f32_to_torch(x, "fp16", DEV))), ref) <= 1e-3
+    assert_forward_close(torch_to_f32(model.proj(f32_to_torch(x, "fp16", DEV))), ref, "fp16")
 
 
 def test_derived_tensors_are_buffers_and_state_dict_refuses_kernel_layout():
@@ -368,7 +368,7 @@ def test_derived_tensors_are_buffers_and_state_dict_refuses_kernel_layout():
         lin.state_dict()
     x = O.round_to(np.random.RandomState(1).randn(2, K).astype(np.float32) * 0.5, "fp16")
     ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4)
-    assert rel_err(torch_to_f32(lin(f32_to_torch(x, "fp16", DEV))), ref) <= 1e-3
+    assert_forward_close(torch_to_f32(lin(f32_to_torch(x, "fp16", DEV))), ref, "fp16")
 
 
 def test_awq_forward_partial_matches_unrounded_product():
