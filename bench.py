@@ -1,26 +1,34 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X GPTQ/AWQ dequant-matmul backend.
 
-Workload (BASELINE.json configs[1]): Llama-3-8B GPTQ int4 group_size=128 desc_act=False, batch=1 decode.
-One "step" = one pass of the hot path over one token: the 224 quantised linears of the model
-(32 layers x {q,k,v,o,gate,up,down}), M=1, fp16, synthetic random packed weights of the real shapes
-(3.63 GB of distinct packed weight + scale/zero bytes, already resident in HBM), executed through the
-product path (HipGptqLinear.forward -> libgptqhip.so) and replayed as ONE captured HIP graph per token.
-value = tokens/s of that path (whole job; replicas x N for --gpus N: the 8B model fits one GPU so ranks
-are independent replicas, no data-path collective -- SURVEY.md §8e).
+Headline workload (BASELINE.json configs[1], "C2"): Llama-3-8B GPTQ int4 group_size=128 desc_act=False, batch=1 decode.
+One "step" = one pass of the hot path over one token: the 224 quantised linears of the model (32 layers x
+{q,k,v,o,gate,up,down}; q/k/v and gate/up fused along N -> 128 launches), M=1, synthetic random packed weights of the
+real shapes (3.63 GB of distinct packed weight + scale/zero bytes resident in HBM), executed with TRUE DATA DEPENDENCIES:
+every linear consumes the previous one's output through the decoder layer's elementwise glue (RMSNorm, SiLU*mul,
+residual adds -- fused into the decode ops, gptqmodel_amd/utils/decode_chain.py; attention itself is not a quantised
+linear and is replaced by the stand-in "attention output = q").  No attention / KV cache / lm_head / sampling: this
+is the quantised-linear stack of a token, which is what the metric name says.  The step is captured once and replayed
+as ONE HIP graph per token.  value = tokens/s (x N for --gpus N: the 8B model fits one GPU, ranks are independent
+replicas, no data-path collective -- SURVEY.md 8e).
 
 Extra objects on the JSON line (tier contract):
-  roofline      dominant kernel = skinny fused dequant-GEMM; achieved = algorithmic bytes per launch
-                (K*N/2 + G*N*2 + G*N/2 + M*(K+N)*2, averaged over the 224 launches) / average
-                launch duration measured with HIP events on the launch stream over the timed region.
-  prefill       the TFLOPS half of BASELINE.json's metric: one decoder layer's launches of the same modules at M=8192
-                tokens through the MFMA-bound prefill kernel (outside the timed region), vs the dense fp16 MFMA peak.
-  cpu_baseline  the oracle's torch-CPU port of BACKEND.TORCH (oracle/gptq_oracle.py:torch_cpu_forward_gptq)
-                timed on this host's cores on a bounded sample (one decoder layer), rank 0, N=1 only.
+  roofline      dominant kernel = gptqhip::gemv1_kernel (batch-1 fused dequant-GEMV); achieved = algorithmic bytes per
+                launch (K*N/2 + G*N*2 + G*N/2 + M*(K+N)*2, averaged over the launches) / average launch
+                duration measured with HIP events on the launch stream over the timed region.  traffic = HBM bytes per
+                launch from the committed rocprofv3 --pmc passes (traffic_source says which file; it is NOT measured in
+                this run -- PMC counters cannot be read from inside the process).
+  configs       one object per BASELINE.json config with its own workload / value / roofline (outside the timed region):
+                C2 variants (this step without overlap; per-module launches), C3 act-order prefill at M=65536, C4 AWQ
+                decode + M=2048 prefill, C5 Llama-3-70B decode at TP=1.
+  cpu_baseline  the oracle's torch-CPU PORT of BACKEND.TORCH (oracle/gptq_oracle.py:torch_cpu_forward_gptq) on this
+                host's cores, thread count swept, rank 0 at N=1 only: C1 (single 4096x4096 linear, M in {1,32,2048}, fp16 and
+                bf16) and one decoder layer at M=1 extrapolated to tokens/s.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -44,13 +52,10 @@ def layer_shapes(cfg):
             ("gate_proj", h, i), ("up_proj", h, i), ("down_proj", i, h)]
 
 
-def launch_shapes(cfg, fuse):
-    """Kernel launches per decoder layer.  With sibling fusion (gptqmodel_amd.utils.model.
-    fuse_siblings) q/k/v and gate/up -- which read the same x -- are concatenated along N: 7 linears, 4 launches."""
-    if not fuse:
-        return [(k, n, 1) for _, k, n in layer_shapes(cfg)]
+def launch_shapes(cfg):
+    """Kernel launches per decoder layer with sibling fusion: 7 linears, 4 launches."""
     h, i = cfg["hidden"], cfg["inter"]
-    return [(h, cfg["q"] + 2 * cfg["kv"], 3), (cfg["q"], h, 1), (h, 2 * i, 2), (i, h, 1)]
+    return [(h, cfg["q"] + 2 * cfg["kv"]), (cfg["q"], h), (h, 2 * i), (i, h)]
 
 
 def algorithmic_bytes(m, k, n, gs=128):
@@ -58,15 +63,31 @@ def algorithmic_bytes(m, k, n, gs=128):
     return k * n // 2 + g * n * 2 + g * n // 2 + m * (k + n) * 2
 
 
-def make_linear(k, n, gs, device, gen, dtype=torch.float16):
-    """Synthetic GPTQ-v2 tensors: random int32 qweight, scales rand*0.01+0.005, sym zeros 0x88888888."""
+def model_bytes_flops(cfg, m=1, gs=128):
+    b = cfg["layers"] * sum(algorithmic_bytes(m, k, n, gs) for _, k, n in layer_shapes(cfg))
+    f = cfg["layers"] * sum(2 * m * k * n for _, k, n in layer_shapes(cfg))
+    return b, f
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# synthetic modules: random int32 qweight, scales rand*0.01+0.005
+# ---------------------------------------------------------------------------------------------------------------------
+def make_gptq(k, n, gs, dev, gen, dtype, desc_act=False, derive_from=None):
+    """GPTQ-v2 module: sym zeros 0x88888888; desc_act=True uses g_idx = randperm(K)//gs (test_torch_kernel_accuracy.py:55-56).
+    derive_from: reuse another module's random words xor a constant (70B: 34 GB of Philox output would dominate the run)."""
     from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
-    lin = HipGptqLinear(bits=4, group_size=gs, sym=True, desc_act=False, in_features=k, out_features=n, bias=False,
+    lin = HipGptqLinear(bits=4, group_size=gs, sym=True, desc_act=desc_act, in_features=k, out_features=n, bias=False,
                         register_buffers=False)
-    lin.qweight = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=device, generator=gen)
-    lin.qzeros = torch.full((k // gs, n // 8), -2004318072, dtype=torch.int32, device=device)  # 0x88888888
-    lin.scales = (torch.rand((k // gs, n), device=device, generator=gen) * 0.01 + 0.005).to(dtype)
-    lin.g_idx = (torch.arange(k, device=device, dtype=torch.int32) // gs)
+    if derive_from is None:
+        lin.qweight = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=dev, generator=gen)
+    else:
+        lin.qweight = derive_from
+    lin.qzeros = torch.full((k // gs, n // 8), -2004318072, dtype=torch.int32, device=dev)  # 0x88888888
+    lin.scales = (torch.rand((k // gs, n), device=dev, generator=gen) * 0.01 + 0.005).to(dtype)
+    if desc_act:
+        lin.g_idx = (torch.randperm(k, device=dev, generator=gen) // gs).to(torch.int32)
+    else:
+        lin.g_idx = (torch.arange(k, device=dev, dtype=torch.int32) // gs)
     lin.bias = None
     lin.qzero_format(format=2)
     lin.eval()
@@ -74,21 +95,73 @@ def make_linear(k, n, gs, device, gen, dtype=torch.float16):
     return lin
 
 
-def prefill_tflops(layer, dtype, dev, m=8192, iters=5):
-    """The TFLOPS half of BASELINE.json's metric (methodology of scripts/benchmark_marlin_a100.py: 2*M*K*N / t): one
-    decoder layer's launches of the SAME modules at M = 8192 tokens (4 x 2048-token sequences), MFMA-bound prefill
-    kernel, reported next to the dense fp16/bf16 MFMA peak.  Not part of the timed decode region."""
+def make_awq(k, n, gs, dev, gen, dtype):
+    """AWQ GEMM-layout module: random int32 qweight [K,N/8] and qzeros [G,N/8] (asymmetric, all 16 zero values)."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_awq import HipAwqLinear
+    lin = HipAwqLinear(bits=4, group_size=gs, sym=False, desc_act=False, in_features=k, out_features=n, bias=False,
+                       register_buffers=False)
+    lin.qweight = torch.randint(-2**31, 2**31 - 1, (k, n // 8), dtype=torch.int32, device=dev, generator=gen)
+    lin.qzeros = torch.randint(-2**31, 2**31 - 1, (k // gs, n // 8), dtype=torch.int32, device=dev, generator=gen)
+    lin.scales = (torch.rand((k // gs, n), device=dev, generator=gen) * 0.01 + 0.005).to(dtype)
+    lin.bias = None
+    lin.eval()
+    lin.post_init()
+    return lin
+
+
+def build_stack(cfg, maker, dev, gen, dtype, n_layers=None):
+    from gptqmodel_amd.utils.decode_chain import DecodeLayer
+    layers = []
+    for _ in range(n_layers or cfg["layers"]):
+        qkv, o, gu, down = [maker(k, n) for k, n in launch_shapes(cfg)]
+        nw = lambda: (1.0 + 0.1 * torch.randn(cfg["hidden"], device=dev, generator=gen)).to(dtype)
+        layers.append(DecodeLayer(qkv, o, gu, down, nw(), nw()))
+    return layers
+
+
+def time_graph(fn, stream, steps, warmup):
+    """Capture fn() on `stream`, replay: (ms per replay by HIP events on that stream, graph)."""
+    with torch.cuda.stream(stream):
+        fn()
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            fn()
+        for _ in range(warmup):
+            g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(steps):
+            g.replay()
+        e1.record(stream)
+        stream.synchronize()
+    return e0.elapsed_time(e1) / steps, g
+
+
+def decode_entry(name, workload, cfg, ms, n_launch, tp=1, extra=None):
+    b, f = model_bytes_flops(cfg)
+    gbs = b / tp / (ms * 1e-3) / 1e9
+    d = {"config": name, "workload": workload, "value": 1e3 / ms, "unit": "tokens/s", "ms_per_token": ms,
+         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                      "bytes_per_launch": b / tp / n_launch, "avg_launch_us": ms * 1e3 / n_launch},
+         "gemm_tflops_equiv": f / (ms * 1e-3) / 1e12}
+    if extra:
+        d.update(extra)
+    return d
+
+
+def prefill_entry(name, workload, lins, m, dtype, dev, iters=3, kernel="gptqhip::tiled_kernel"):
     gen = torch.Generator(device=dev)
     gen.manual_seed(99)
     xs = {}
-    for lin, _ in layer:
+    for lin in lins:
         if lin.in_features not in xs:
             xs[lin.in_features] = (torch.randn((m, lin.in_features), device=dev, generator=gen) * 0.5).to(dtype)
+
     def run():
-        for lin, _ in layer:
+        for lin in lins:
             lin(xs[lin.in_features])
-    for _ in range(2):
-        run()
+    run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -97,45 +170,97 @@ def prefill_tflops(layer, dtype, dev, m=8192, iters=5):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    flops = sum(2.0 * m * lin.in_features * lin.out_features for lin, _ in layer)
+    flops = sum(2.0 * m * lin.in_features * lin.out_features for lin in lins)
     tf = flops / ms / 1e9
-    return {"workload": f"one Llama-3-8B decoder layer's quantised linears ({len(layer)} launches) at M={m} tokens",
-            "tflops": tf, "ms": ms, "bound": "mfma", "peak": MFMA_PEAK_TFLOPS, "frac": tf / MFMA_PEAK_TFLOPS,
-            "kernel": "gptqhip::tiled_kernel<BITS=4,...,BM=256,D=2>"}
+    del xs
+    torch.cuda.empty_cache()
+    return {"config": name, "workload": workload, "value": tf, "unit": "TFLOP/s", "ms": ms,
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / MFMA_PEAK_TFLOPS, "kernel": kernel}}
 
 
-def cpu_baseline(cfg, gs=128, budget_s=20.0):
-    """Oracle torch-CPU port of the reference BACKEND.TORCH forward on ONE decoder layer's 7 linears, M=1 fp16...
-    timed on all host cores; extrapolated x layers to tokens/s."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle's torch-CPU port of BACKEND.TORCH (kind "port"), thread count swept
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_tensors(k, n, gs, dtype):
+    qw = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32)
+    qz = torch.full((k // gs, n // 8), -2004318072, dtype=torch.int32)
+    sc = (torch.rand((k // gs, n)) * 0.01 + 0.005).to(dtype)
+    gi = (torch.arange(k, dtype=torch.int32) // gs)
+    return qw, qz, sc, gi
+
+
+def _time_cpu(fn, budget_s, max_iters):
+    fn()
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or iters >= max_iters:
+            return el / iters * 1e3, iters
+
+
+def cpu_baseline(cfg, gs=128, budget_s=24.0):
+    """Reference path on the host cores: upstream's CPU test runs bf16 (tests/test_q4_torch.py:27,50) and
+    flags fp16 CPU matmul as slow (:52-53); both are timed.  The torch.compile'd dequant upstream enables in post_init
+    (torch.py:215-216,259) is NOT timed: inductor needs a C++ toolchain run per shape that does not fit this bounded leg."""
     from oracle.gptq_oracle import torch_cpu_forward_gptq
     torch.manual_seed(1234)
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    k = n = 4096
+    t = {dt: _cpu_tensors(k, n, gs, dt) for dt in (torch.bfloat16, torch.float16)}
+    x1 = {dt: (torch.randn(1, k) * 0.5).to(dt) for dt in t}
+    sweep = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu})
+    per_thread = {}
+    t_sweep0 = time.perf_counter()
+    for th in sweep:   # M=1 bf16 on the C1 layer: the op mix the decode token is made of
+        torch.set_num_threads(th)
+        ms, _ = _time_cpu(lambda: torch_cpu_forward_gptq(x1[torch.bfloat16], *t[torch.bfloat16], 4), budget_s * 0.04, 6)
+        per_thread[str(th)] = round(ms, 3)
+    best = int(min(per_thread, key=lambda s: per_thread[s]))
+    torch.set_num_threads(best)
+    c1 = {}
+    for dt, tag in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
+        for m in (1, 32, 2048):
+            x = (torch.randn(m, k) * 0.5).to(dt)
+            ms, it = _time_cpu(lambda: torch_cpu_forward_gptq(x, *t[dt], 4), budget_s * 0.06, 4)
+            c1[f"{tag}_m{m}"] = round(ms, 3)
+    # one decoder layer at M=1 (7 linears, bf16), extrapolated to the model
     mods = []
-    for _, k, n in layer_shapes(cfg):
-        qw = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32)
-        qz = torch.full((k // gs, n // 8), -2004318072, dtype=torch.int32)
-        sc = (torch.rand((k // gs, n)) * 0.01 + 0.005).to(torch.bfloat16)
-        gi = (torch.arange(k, dtype=torch.int32) // gs)
-        x = (torch.randn(1, k) * 0.5).to(torch.bfloat16)  # upstream's CPU test runs bf16 (tests/test_q4_torch.py:27,50)
-        mods.append((x, qw, qz, sc, gi))
+    for _, kk, nn in layer_shapes(cfg):
+        mods.append(((torch.randn(1, kk) * 0.5).to(torch.bfloat16),) + _cpu_tensors(kk, nn, gs, torch.bfloat16))
+
     def one_pass():
         for x, qw, qz, sc, gi in mods:
             torch_cpu_forward_gptq(x, qw, qz, sc, gi, 4)
-    one_pass()
-    iters, t0 = 0, time.perf_counter()
-    while True:
-        one_pass()
-        iters += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or iters >= 50:
-            break
-    per_layer = el / iters
+    per_layer, iters = _time_cpu(one_pass, budget_s * 0.35, 20)
+    torch.set_num_threads(default_threads)
     return {
-        "value": 1.0 / (per_layer * cfg["layers"]), "unit": "tokens/s", "cores": torch.get_num_threads(),
-        "kind": "port",
-        "sample": f"1 of {cfg['layers']} decoder layers (7 linears, M=1, bf16 like upstream's CPU test), {iters} passes "
-                  f"in {el:.1f}s, extrapolated x{cfg['layers']}; host os.cpu_count()={os.cpu_count()}",
-        "ms_per_layer": per_layer * 1e3,
+        "value": 1e3 / (per_layer * cfg["layers"]), "unit": "tokens/s", "cores": best, "kind": "port",
+        "sample": f"1 of {cfg['layers']} decoder layers (7 linears, M=1, bf16 like upstream's CPU test), {iters} passes, "
+                  f"extrapolated x{cfg['layers']}; torch CPU port of BACKEND.TORCH (oracle/gptq_oracle.py), not the reference "
+                  f"module itself; host os.cpu_count()={ncpu}",
+        "ms_per_layer": per_layer, "threads_swept": per_thread, "best_threads": best,
+        "c1_ms": c1, "c1_workload": "single QuantLinear 4096x4096 int4 g128 sym=True, eager dequant + matmul, best_threads",
+        "sweep_s": round(time.perf_counter() - t_sweep0, 1),
     }
+
+
+def latest_pmc():
+    """(traffic bytes per launch | None, source string).  Read from the committed rocprofv3 --pmc summary of the SAME bench
+    command (profiles/*_pmc_summary.json, gfx950 FETCH_SIZE correction applied there); not measured in this run."""
+    try:
+        summ = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+        if not summ:
+            return None, "none (no committed PMC summary)"
+        with open(summ[-1]) as f:
+            pm = json.load(f)
+        tr = pm["hbm_read_bytes_per_launch_corrected"] + 1024.0 * pm.get("WRITE_SIZE_KB_per_launch_raw", 0.0)
+        return tr, f"committed file profiles/{os.path.basename(summ[-1])} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, earlier run of this command; not measured live)"
+    except Exception as e:  # noqa: BLE001
+        return None, f"unavailable ({e})"
 
 
 def main():
@@ -146,13 +271,14 @@ def main():
     ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b"],
                     help="llama3-8b: the headline config, ranks are independent replicas (weak scaling). "
                          "llama3-70b: BASELINE configs[4], tensor parallel over all ranks (strong scaling): column-parallel "
-                         "qkv/gate_up, row-parallel o/down with one fp32 RCCL all-reduce each (gptqmodel_amd/utils/tp.py)")
+                         "qkv/gate_up, row-parallel o/down with one fp32 all-reduce each (gptqmodel_amd/utils/tp.py)")
+    ap.add_argument("--mode", default="chain", choices=["chain", "chain-serial", "modules"],
+                    help="chain: decode ops with fused glue, two-stream overlap with device-side dependency flags (default); "
+                         "chain-serial: the same ops in plain stream order; modules: HipGptqLinear.forward per launch + torch glue")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per token")
-    ap.add_argument("--no-fuse", action="store_true", help="7 launches per layer instead of fused qkv / gate_up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs[] array (C3/C4/C5 legs)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
-    ap.add_argument("--exact-bf16", action="store_true",
-                    help="opt in to GPTQHIP_GEMM_EXACT_BF16 (bf16 only; leaves the reference's per-weight rounding)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,63 +295,53 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    cfg = LLAMA3_8B if args.model == "llama3-8b" else LLAMA3_70B
-    tp = world if args.model == "llama3-70b" else 1   # 8B: replicas only (fits one GPU); 70B: TP over the node
+    if args.model == "llama3-70b":
+        from bench_tp import run_70b   # tensor-parallel 70B leg lives in its own file
+        run_70b(args, rank, local_rank, world, dev, dist)
+        return
+
+    from gptqmodel_amd.utils.decode_chain import DecodeStep
+    cfg = LLAMA3_8B
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     gs = 128
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    fuse = not args.no_fuse
-    if args.exact_bf16:
-        from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
-        HipGptqLinear.EXACT_BF16_DECODE = True
-    lshapes = launch_shapes(cfg, fuse)
-    if tp > 1:
-        # Megatron split of every launch: column-parallel (N / tp) when K == hidden, row-parallel (K / tp) otherwise
-        # (o_proj: K = q dim, down_proj: K = inter).  Shards are generated directly at their sharded shapes.
-        from gptqmodel_amd.utils.tp import _bounds
-        sharded = []
-        for k, n, cnt in lshapes:
-            row_parallel = (n == cfg["hidden"])
-            if row_parallel:
-                _bounds(k, 0, tp, gs, "in_features")
-                sharded.append((k // tp, n, cnt, True))
-            else:
-                _bounds(n, 0, tp, 8, "out_features")
-                sharded.append((k, n // tp, cnt, False))
-    else:
-        sharded = [(k, n, cnt, False) for k, n, cnt in lshapes]
-    layers = []
-    for _ in range(cfg["layers"]):
-        layers.append([(make_linear(k, n, gs, dev, gen, dtype), rowp) for k, n, _, rowp in sharded])
-    xs = {}
-    for k, _, _, _ in sharded:
-        if k not in xs:
-            xs[k] = (torch.randn((1, k), device=dev, generator=gen) * 0.5).to(dtype)
-    n_launch = cfg["layers"] * len(lshapes)
-    n_linear = cfg["layers"] * sum(c for _, _, c in lshapes)
-    step_bytes = cfg["layers"] * sum(algorithmic_bytes(1, k, n, gs) for _, k, n in layer_shapes(cfg))   # whole model
-    step_flops = cfg["layers"] * sum(2 * k * n for _, k, n in layer_shapes(cfg))
+    layers = build_stack(cfg, lambda k, n: make_gptq(k, n, gs, dev, gen, dtype), dev, gen, dtype)
+    n_launch = cfg["layers"] * 4
+    n_linear = cfg["layers"] * 7
+    step_bytes, step_flops = model_bytes_flops(cfg)
+    x0 = (torch.randn(cfg["hidden"], device=dev, generator=gen) * 0.5).to(dtype)
 
-    def token_step():
-        for layer in layers:
-            for lin, rowp in layer:
-                if rowp and tp > 1:
-                    part = lin.forward_partial(xs[lin.in_features])          # fp32 partial sums of this K-shard
-                    dist.all_reduce(part, op=dist.ReduceOp.SUM)               # RCCL over xGMI, 2 per decoder layer
-                    part.to(dtype)                                            # the reference's single rounding
-                else:
-                    lin(xs[lin.in_features])
+    def make_step(mode):
+        if mode == "modules":
+            return ModulesStep(layers, cfg, dtype, x0)
+        st = DecodeStep(layers, cfg["hidden"], cfg["q"], dtype, overlap=(mode == "chain"))
+        st.x_in.copy_(x0)
+        return st
 
+    mode = args.mode
+    step = make_step(mode)
     stream = torch.cuda.Stream(device=dev)
-    graph = None
     with torch.cuda.stream(stream):
-        token_step()  # allocates the workspace for this stream outside of capture
+        step.run()
         stream.synchronize()
-        if not args.no_graph and tp == 1:  # TP>1: eager (RCCL inside graph capture is untested on the 1-GPU dev box)
+    if mode == "chain":
+        # the overlapped chain must reproduce the serial chain bit for bit, else fall back loudly
+        ser = make_step("chain-serial")
+        with torch.cuda.stream(stream):
+            want = ser.run().clone()
+            stream.synchronize()
+        bad = int(step.status.item()) != 0 or not torch.equal(step.out, want)
+        if bad:
+            print("bench.py: overlapped decode chain disagrees with the serial chain or timed out -- using chain-serial",
+                  file=sys.stderr, flush=True)
+            mode, step = "chain-serial", ser
+    graph = None
+    if not args.no_graph:
+        with torch.cuda.stream(stream):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
-                token_step()
+                step.run()
 
     def run(n):
         with torch.cuda.stream(stream):
@@ -233,7 +349,7 @@ def main():
                 if graph is not None:
                     graph.replay()
                 else:
-                    token_step()
+                    step.run()
 
     run(args.warmup)
     torch.cuda.synchronize()
@@ -253,60 +369,167 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
+    if hasattr(step, "check_status"):
+        step.check_status()
 
     tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
     ms_per_step = wall * 1e3 / args.steps
-    value = (world if tp == 1 else 1) * args.steps / wall   # replicas add up; a TP group produces one token stream
+    value = world * args.steps / wall   # replicas add up
 
     if rank == 0:
-        # HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this same command
-        # (profiles/*_pmc_summary.json; gfx950 FETCH_SIZE correction applied there).  PMC cannot be read live here.
-        traffic = None
-        try:
-            import glob
-            summ = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-            if summ and fuse:
-                with open(summ[-1]) as f:
-                    pm = json.load(f)
-                traffic = pm["hbm_read_bytes_per_launch_corrected"] + 1024.0 * pm.get("WRITE_SIZE_KB_per_launch_raw", 0.0)
-        except Exception:
-            traffic = None
-        launch_us = ev_ms * 1e3 / (args.steps * n_launch)  # average launch duration incl. inter-kernel gaps
-        bytes_per_launch = step_bytes / n_launch / tp        # per rank
+        traffic, traffic_source = latest_pmc()
+        launch_us = ev_ms * 1e3 / (args.steps * n_launch)   # average launch duration incl. whatever the ops do not overlap
+        bytes_per_launch = step_bytes / n_launch
         achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
+        kernel = {"chain": "gptqhip::gemv1_kernel<BITS=4,ACT,SCL,D> (two-stream overlap, device-side dependency flags)",
+                  "chain-serial": "gptqhip::gemv1_kernel<BITS=4,ACT,SCL,D> (stream order)",
+                  "modules": "gptqhip::skinny_kernel<BITS=4,ACT,SCL,MT=1,GPC=1,AM_ROW1,D=4>"}[mode]
         out = {
-            "metric": ("llama3_8b" if args.model == "llama3-8b" else "llama3_70b") + "_gptq_int4_g128_decode_tokens_per_s",
+            "metric": "llama3_8b_gptq_int4_g128_decode_linear_stack_tokens_per_s",
             "value": value, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak" if tp == 1 else "strong", "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16",
-            "data": "synthetic",
-            "config": {"workload": ("Llama-3-8B GPTQ int4 g128 desc_act=False batch=1 decode: 224 quantised linears per token "
-                                    "(q,k,v,o,gate,up,down x 32), M=1, random packed weights") if args.model == "llama3-8b" else
-                                   ("Llama-3-70B GPTQ int4 g128 batch=1 decode: 560 quantised linears per token (x 80 layers), M=1, "
-                                    f"tensor parallel TP={tp} (column qkv/gate_up, row o/down + fp32 all-reduce), random packed weights"),
-                       "parallelism": f"replicas x{world}" if tp == 1 else f"tp{tp}",
-                       "linears_per_step": n_linear, "launches_per_step": n_launch, "fused_siblings": fuse,
-                       "graph": graph is not None, "replicas": world,
-                       "weight_bytes_per_token": step_bytes},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if dtype == torch.float16 else "bf16", "data": "synthetic",
+            "config": {"workload": "Llama-3-8B GPTQ int4 g128 desc_act=False batch=1 decode: the 224 quantised linears of a token "
+                                   "(q,k,v,o,gate,up,down x 32) with true data dependencies through the layer glue (RMSNorm, "
+                                   "SiLU*mul, residual adds fused into the ops; attention stand-in = q), M=1, random packed weights",
+                       "parallelism": f"replicas x{world}", "mode": mode,
+                       "linears_per_step": n_linear, "launches_per_step": n_launch, "fused_siblings": True,
+                       "graph": graph is not None, "replicas": world, "weight_bytes_per_token": step_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "gptqhip::skinny_kernel<BITS=4,ACT,SCL,MT=1,GPC=1,AM_ROW1,D=4>",
-                         "bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_us,
-                         "note": "event-timed average over the timed region incl. inter-kernel gaps of the graph"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel, "bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_us,
+                         "note": "event-timed over the timed region; with overlap the launches of consecutive ops run "
+                                 "concurrently, so avg_launch_us is step time / launches, not a single kernel's duration"},
             "gemm_tflops_equiv": step_flops * value / world / 1e12,
         }
-        if args.model != "llama3-8b":
-            out["roofline"]["traffic"] = None
-        if world == 1 and tp == 1:
-            out["prefill"] = prefill_tflops(layers[0], dtype, dev)
+        if world == 1 and not args.no_configs:
+            out["configs"] = extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, ms_per_step, n_launch)
+            if out["configs"] and out["configs"][-1].get("config") == "_prefill_headline":
+                out["prefill"] = out["configs"].pop()
         if world == 1 and not args.no_cpu_baseline:
+            del layers, step, graph
+            torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(cfg, gs)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+class ModulesStep:
+    """The step through the plugin classes' forward() (one launch per fused linear) with the glue as separate torch
+    kernels -- what an HF model with fuse_siblings runs; kept as a comparison leg."""
+
+    def __init__(self, layers, cfg, dtype, x0):
+        self.layers, self.cfg, self.dtype = layers, cfg, dtype
+        self.x_in = x0.clone()
+        self.out = None
+        self.eps = 1e-5
+
+    def _rms(self, v, w):
+        v32 = v.float()
+        return w * (v32 * torch.rsqrt(v32.pow(2).mean(-1, keepdim=True) + self.eps)).to(self.dtype)
+
+    def run(self):
+        q, inter = self.cfg["q"], self.cfg["inter"]
+        h = self.x_in[None]
+        for L in self.layers:
+            qkv = L.qkv(self._rms(h, L.input_norm))
+            h = h + L.o(qkv[:, :q])
+            gu = L.gate_up(self._rms(h, L.post_norm))
+            h = h + L.down(torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:])
+        self.out = h
+        return h
+
+
+def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, ms_headline, n_launch):
+    """One object per BASELINE.json config.  Everything here runs OUTSIDE the timed region of the headline."""
+    res = []
+    gs = 128
+    t_start = time.perf_counter()
+    res.append(decode_entry("C2", f"headline ({mode})", cfg, ms_headline, n_launch, extra={"mode": mode}))
+    for other in ("chain", "chain-serial", "modules"):
+        if other == mode:
+            continue
+        try:
+            st = make_step(other)
+            ms, g = time_graph(st.run, stream, 50, 5)
+            if hasattr(st, "check_status"):
+                st.check_status()
+            res.append(decode_entry("C2", f"same token step, mode={other}", cfg, ms, n_launch, extra={"mode": other}))
+            del g, st
+        except Exception as e:  # noqa: BLE001
+            res.append({"config": "C2", "mode": other, "error": str(e)[:300]})
+    # headline-model prefill (one decoder layer at M=8192, desc_act=False) -- the TFLOPS half of the metric
+    L0 = layers[0]
+    lins = [L0.qkv, L0.o, L0.gate_up, L0.down]
+    pre = prefill_entry("_prefill_headline", "one Llama-3-8B decoder layer's quantised linears (4 launches) at M=8192 tokens",
+                        lins, 8192, dtype, dev, iters=5, kernel="gptqhip::tiled_kernel<BITS=4,...,BM=256,D=2>")
+    # C3: act-order prefill, batch 32 x 2048 ctx = 65536 tokens
+    torch.cuda.empty_cache()
+    try:
+        a44 = make_gptq(4096, 4096, gs, dev, gen, dtype, desc_act=True)
+        res.append(prefill_entry("C3", "GPTQ int4 g128 desc_act=True (act-order g_idx gather), M=65536 (batch 32 x 2048 ctx), "
+                                 "4096x4096 (q/o_proj shape)", [a44], 65536, dtype, dev))
+        del a44
+        agu = make_gptq(4096, 2 * cfg["inter"], gs, dev, gen, dtype, desc_act=True)
+        res.append(prefill_entry("C3", "GPTQ int4 g128 desc_act=True, M=65536, 4096x28672 (fused gate_up)", [agu], 65536, dtype, dev,
+                                 iters=2))
+        del agu
+    except Exception as e:  # noqa: BLE001
+        res.append({"config": "C3", "error": str(e)[:300]})
+    torch.cuda.empty_cache()
+    # C4: AWQ g128 asym -- full-model decode through the same chain + one layer's prefill at M=2048
+    try:
+        awq_layers = build_stack(cfg, lambda k, n: make_awq(k, n, gs, dev, gen, dtype), dev, gen, dtype)
+        from gptqmodel_amd.utils.decode_chain import DecodeStep
+        st = DecodeStep(awq_layers, cfg["hidden"], cfg["q"], dtype, overlap=(mode == "chain"))
+        st.x_in.copy_((torch.randn(cfg["hidden"], device=dev, generator=gen) * 0.5).to(dtype))
+        ms, g = time_graph(st.run, stream, 100, 10)
+        st.check_status()
+        res.append(decode_entry("C4", f"Llama-3-8B AWQ int4 g128 sym=False (AWQ packing, asymmetric qzeros) batch=1 decode, mode={mode}",
+                                cfg, ms, n_launch))
+        del g, st
+        A0 = awq_layers[0]
+        res.append(prefill_entry("C4", "AWQ int4 g128 asym, one decoder layer's linears (4 launches) at M=2048",
+                                 [A0.qkv, A0.o, A0.gate_up, A0.down], 2048, dtype, dev, iters=5))
+        del awq_layers, A0
+    except Exception as e:  # noqa: BLE001
+        res.append({"config": "C4", "error": str(e)[:300]})
+    torch.cuda.empty_cache()
+    # C5 at TP=1: Llama-3-70B shapes, 35.6 GB of packed weights on the one GPU
+    try:
+        if time.perf_counter() - t_start < 150:
+            c70 = LLAMA3_70B
+            base = {}
+
+            def mk70(k, n):
+                # one Philox draw per distinct shape; later layers reuse the words rotated + xored (distinct bytes in HBM)
+                key = (k, n)
+                if key not in base:
+                    base[key] = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=dev, generator=gen)
+                    return make_gptq(k, n, gs, dev, gen, dtype, derive_from=base[key].clone())
+                salt = int(torch.randint(1, 2**31 - 1, (1,), generator=gen, device=dev).item())
+                return make_gptq(k, n, gs, dev, gen, dtype, derive_from=torch.roll(base[key], 1 + salt % 97, 0) ^ salt)
+            l70 = build_stack(c70, mk70, dev, gen, dtype)
+            base.clear()
+            st = DecodeStep(l70, c70["hidden"], c70["q"], dtype, overlap=(mode == "chain"))
+            st.x_in.copy_((torch.randn(c70["hidden"], device=dev, generator=gen) * 0.5).to(dtype))
+            ms, g = time_graph(st.run, stream, 20, 3)
+            st.check_status()
+            res.append(decode_entry("C5", f"Llama-3-70B GPTQ int4 g128 batch=1 decode at TP=1 (560 linears / 320 launches per token), mode={mode}",
+                                    c70, ms, c70["layers"] * 4, extra={"tp": 1}))
+            del g, st, l70
+        else:
+            res.append({"config": "C5", "skipped": "time budget of the default run"})
+    except Exception as e:  # noqa: BLE001
+        res.append({"config": "C5", "error": str(e)[:300]})
+    torch.cuda.empty_cache()
+    res.append(pre)
+    return res
 
 
 if __name__ == "__main__":

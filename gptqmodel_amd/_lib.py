@@ -31,6 +31,8 @@ SIGNATURES = {
     "gptqhip_meta_words": (_sz, [_i, _i, _i]),
     "gptqhip_repack_tiled": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "gptqhip_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "gptqhip_decode_linear": (_i, [_vp, _vp]),
+    "gptqhip_decode_blocks": (_i, [_i, _i, _i]),
     "gptqhip_dequant": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_dequant_tiled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_repack_awq": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -40,6 +42,15 @@ SIGNATURES = {
     "gptqhip_gather_cols": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "gptqhip_set_tuning": (_i, [_i, _i, _i]),
 }
+
+class DecodeOp(ctypes.Structure):
+    """struct gptqhip_decode_op (include/gptqhip.h)."""
+    _fields_ = [("qweight_t", _vp), ("meta", _vp), ("bias", _vp), ("x", _vp), ("norm_weight", _vp), ("residual", _vp),
+                ("out", _vp), ("wait_counters", _vp), ("signal_counters", _vp), ("status", _vp),
+                ("wait_total", _c.c_uint32), ("eps", _c.c_float),
+                ("K", _i), ("N", _i), ("group_size", _i), ("bits", _i), ("act_dtype", _i), ("scale_dtype", _i),
+                ("in_glue", _i)]
+
 
 _lock = threading.Lock()
 _lib = None

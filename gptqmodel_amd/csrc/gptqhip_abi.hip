@@ -293,6 +293,75 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     return GPTQHIP_OK;
 }
 
+static int cu_count_cached() {
+    // CUs of the current device, queried once per device (immutable facts; no other mutable state)
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        __atomic_store_n(&cached[dev], v, __ATOMIC_RELAXED);
+    }
+    return v;
+}
+
+int gptqhip_decode_blocks(int K, int N, int group_size) {
+    if (K <= 0 || N <= 0 || group_size <= 0 || K % group_size != 0) return 0;
+    const Gemv1Plan pl = plan_gemv1(K, N, group_size, cu_count_cached());
+    return pl.ok ? pl.grid : 0;
+}
+
+int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) {
+    if (!op || !op->qweight_t || !op->meta || !op->x || !op->out) {
+        set_error("gptqhip_decode_linear: null tensor pointer");
+        return GPTQHIP_EINVAL;
+    }
+    int rc = validate_common("gptqhip_decode_linear", op->K, op->N, op->group_size, op->bits);
+    if (rc) return rc;
+    if ((op->act_dtype != GPTQHIP_FP16 && op->act_dtype != GPTQHIP_BF16) ||
+        (op->scale_dtype != GPTQHIP_FP16 && op->scale_dtype != GPTQHIP_BF16)) {
+        set_error("gptqhip_decode_linear: dtype tags must be GPTQHIP_FP16/BF16");
+        return GPTQHIP_EINVAL;
+    }
+    if (op->in_glue < GPTQHIP_GLUE_NONE || op->in_glue > GPTQHIP_GLUE_SILU_MUL ||
+        (op->in_glue == GPTQHIP_GLUE_RMSNORM && !op->norm_weight)) {
+        set_error("gptqhip_decode_linear: bad in_glue %d (RMSNORM needs norm_weight)", op->in_glue);
+        return GPTQHIP_EINVAL;
+    }
+    if (op->wait_counters && !op->status) {
+        set_error("gptqhip_decode_linear: wait_counters needs a status word");
+        return GPTQHIP_EINVAL;
+    }
+    const Gemv1Plan pl = plan_gemv1(op->K, op->N, op->group_size, cu_count_cached());
+    if (!pl.ok) {
+        set_error("gptqhip_decode_linear: K=%d group_size=%d not supported by the decode-chain kernel (use gptqhip_gemm)",
+                  op->K, op->group_size);
+        return GPTQHIP_EINVAL;
+    }
+    DecodeArgs a;
+    a.qweight = op->qweight_t;
+    a.meta = op->meta;
+    a.bias = op->bias;
+    a.x = op->x;
+    a.norm_weight = op->norm_weight;
+    a.residual = op->residual;
+    a.out = op->out;
+    a.wait_counters = op->wait_counters;
+    a.signal_counters = op->signal_counters;
+    a.status = op->status;
+    a.wait_total = op->wait_total;
+    a.eps = op->eps;
+    a.K = op->K;
+    a.N = op->N;
+    a.group_size = op->group_size;
+    a.bits = op->bits;
+    a.act_dtype = op->act_dtype;
+    a.scale_dtype = op->scale_dtype;
+    a.in_glue = op->in_glue;
+    return launch_gemv1(a, pl, reinterpret_cast<hipStream_t>(stream));
+}
+
 int gptqhip_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* g_idx,
                     void* out, int K, int N, int group_size, int bits, int scale_dtype, int out_dtype,
                     gptqhip_stream_t stream) {

@@ -274,3 +274,28 @@ def torch_cpu_forward_gptq(x, qweight, qzeros, scales, g_idx, bits: int, bias=No
     if bias is not None:
         out.add_(bias.to(out.dtype))
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Decoder-layer glue between the quantised linears -- NOT part of the reference repo: these restate what the reference's
+# CALLER (HF transformers LlamaDecoderLayer: LlamaRMSNorm.forward, LlamaMLP.forward, the two residual adds) computes between
+# QuantLinear.forward calls, in the activation dtype, so the fused decode ops (gptqhip_decode_linear) have a checker.
+# ----------------------------------------------------------------------------------------------
+def rmsnorm_ref(h_f32: np.ndarray, weight_f32: np.ndarray, eps: float, act_dtype: str) -> np.ndarray:
+    """LlamaRMSNorm: h32 = h.float(); var = mean(h32^2); (h32 * rsqrt(var + eps)).to(dtype) * weight  (rounded)."""
+    h = np.asarray(h_f32, np.float32)
+    var = np.mean(h.astype(np.float64) ** 2, axis=-1, keepdims=True).astype(np.float32)
+    inv = (1.0 / np.sqrt(var.astype(np.float64) + eps)).astype(np.float32)
+    return round_to(np.asarray(weight_f32, np.float32) * round_to(h * inv, act_dtype), act_dtype)
+
+
+def silu_mul_ref(gate_f32: np.ndarray, up_f32: np.ndarray, act_dtype: str) -> np.ndarray:
+    """LlamaMLP: act_fn(gate) * up with act_fn = SiLU evaluated in fp32 and rounded to the activation dtype."""
+    g = np.asarray(gate_f32, np.float32)
+    s = round_to((g.astype(np.float64) / (1.0 + np.exp(-g.astype(np.float64)))).astype(np.float32), act_dtype)
+    return round_to(s * np.asarray(up_f32, np.float32), act_dtype)
+
+
+def residual_add_ref(res_f32: np.ndarray, y_f32: np.ndarray, act_dtype: str) -> np.ndarray:
+    """hidden = residual + hidden in the activation dtype (one rounding)."""
+    return round_to(np.asarray(res_f32, np.float32) + np.asarray(y_f32, np.float32), act_dtype)

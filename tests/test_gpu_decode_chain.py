@@ -1,0 +1,193 @@
+"""GPU tests of the batch-1 decode-chain op (gptqhip_decode_linear, csrc/gptqhip_gemv1.hip): the GEMV against the oracle,
+the fused glue against the HF-semantics restatement in the oracle, and the in-launch dependency flags: a chain enqueued on
+two streams (op i+1 prefetching while op i runs) must be BIT-IDENTICAL to the same ops in plain stream order, replay
+after replay, with the inputs changing under it."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_forward_close, f32_to_torch, rel_err, synth_gptq, torch_to_bits, torch_to_f32
+from oracle import gptq_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TDT = {"fp16": torch.float16, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gptqmodel_amd import ops as _ops
+    return _ops
+
+
+def _tiled(ops, qweight, qzeros, scales, gs, bits, sdt="fp16"):
+    sc = f32_to_torch(scales, sdt, DEV)
+    return ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV), sc, None, gs, bits) + (sc,)
+
+
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096), (8192, 1024), (1024, 8192),
+                                 (28672, 512), (4096, 1000)])
+@pytest.mark.parametrize("act,bits", [("fp16", 4), ("bf16", 4), ("fp16", 8)])
+def test_decode_op_plain_vs_oracle(ops, K, N, act, bits):
+    gs = 128
+    qweight, qzeros, scales, g_idx = synth_gptq(100 + K // 128 + N // 8, bits, K, N, gs)
+    rng = np.random.RandomState(3)
+    x = O.round_to(rng.randn(1, K).astype(np.float32) * 0.5, act)
+    bias = O.round_to(rng.randn(N).astype(np.float32) * 0.1, act)
+    qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, gs, bits)
+    assert ops.decode_blocks(K, N, gs) == min(256, -(-N // 16))
+    out = ops.decode_linear(f32_to_torch(x[0], act, DEV), qw_t, meta, f32_to_torch(bias, act, DEV), K, N, gs, bits, sc.dtype)
+    torch.cuda.synchronize()
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, bits, bias, act, "fp16")
+    assert_forward_close(torch_to_f32(out)[None], ref, act)
+    # and against the general kernel of the product path at M = 1 (same rounding chain, different accumulation order)
+    gen = ops.gemm(f32_to_torch(x, act, DEV), qw_t, meta, f32_to_torch(bias, act, DEV), None, N, gs, bits, sc.dtype)
+    assert_forward_close(torch_to_f32(out)[None], torch_to_f32(gen), act)
+
+
+@pytest.mark.parametrize("act", ["fp16", "bf16"])
+def test_decode_op_fused_glue_vs_hf_semantics(ops, act):
+    """RMSNorm prologue, SiLU*mul prologue and residual epilogue against the numpy restatement of HF's LlamaRMSNorm /
+    LlamaMLP / residual adds composed with the oracle's GEMV."""
+    gs, hidden, inter = 128, 4096, 14336
+    rng = np.random.RandomState(11)
+    # (a) gate_up = rmsnorm(h; w) @ Wgu
+    qweight, qzeros, scales, g_idx = synth_gptq(41, 4, hidden, 2 * inter, gs)
+    h = O.round_to(rng.randn(hidden).astype(np.float32) * 2.0, act)
+    w = O.round_to(1.0 + rng.randn(hidden).astype(np.float32) * 0.1, act)
+    qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, gs, 4)
+    gu = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, None, hidden, 2 * inter, gs, 4, sc.dtype,
+                           in_glue=ops.GLUE_RMSNORM, norm_weight=f32_to_torch(w, act, DEV), eps=1e-5)
+    xn = O.rmsnorm_ref(h, w, 1e-5, act)
+    gu_ref = O.forward_gptq(xn[None], qweight, qzeros, scales, g_idx, 4, None, act, "fp16")
+    assert_forward_close(torch_to_f32(gu)[None], gu_ref, act, tag="rmsnorm")
+    # (b) h2 = h + (silu(gate) * up) @ Wdown   -- fed with the DEVICE's gate|up so only this op is under test
+    qweight2, qzeros2, scales2, g_idx2 = synth_gptq(42, 4, inter, hidden, gs)
+    qw2, meta2, sc2 = _tiled(ops, qweight2, qzeros2, scales2, gs, 4)
+    bias = O.round_to(rng.randn(hidden).astype(np.float32) * 0.1, act)
+    h2 = ops.decode_linear(gu, qw2, meta2, f32_to_torch(bias, act, DEV), inter, hidden, gs, 4, sc2.dtype,
+                           in_glue=ops.GLUE_SILU_MUL, residual=f32_to_torch(h, act, DEV))
+    gu_np = torch_to_f32(gu)
+    a = O.silu_mul_ref(gu_np[:inter], gu_np[inter:], act)
+    y = O.forward_gptq(a[None], qweight2, qzeros2, scales2, g_idx2, 4, bias, act, "fp16")
+    h2_ref = O.residual_add_ref(h[None], y, act)
+    assert_forward_close(torch_to_f32(h2)[None], h2_ref, act, tag="silu_mul+residual")
+
+
+def test_decode_op_rejects_unsupported_shapes(ops):
+    qweight, qzeros, scales, _ = synth_gptq(1, 4, 256, 64, 64)
+    qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, 64, 4)
+    assert ops.decode_blocks(256, 64, 64) == 0
+    with pytest.raises(RuntimeError, match="not supported by the decode-chain kernel"):
+        ops.decode_linear(torch.zeros(256, dtype=torch.float16, device=DEV), qw_t, meta, None, 256, 64, 64, 4, sc.dtype)
+    with pytest.raises(RuntimeError, match="norm_weight"):
+        ops.decode_linear(torch.zeros(256, dtype=torch.float16, device=DEV), qw_t, meta, None, 256, 64, 64, 4, sc.dtype,
+                          in_glue=ops.GLUE_RMSNORM)
+
+
+def _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype, seed=0):
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    from gptqmodel_amd.utils.decode_chain import DecodeLayer
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(seed)
+
+    def lin(k, n):
+        m = HipGptqLinear(bits=4, group_size=128, sym=True, desc_act=False, in_features=k, out_features=n, bias=False,
+                          register_buffers=False)
+        m.qweight = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=DEV, generator=gen)
+        m.qzeros = torch.full((k // 128, n // 8), -2004318072, dtype=torch.int32, device=DEV)
+        m.scales = (torch.rand((k // 128, n), device=DEV, generator=gen) * 0.01 + 0.005).to(dtype)
+        m.g_idx = torch.arange(k, device=DEV, dtype=torch.int32) // 128
+        m.bias = None
+        m.qzero_format(format=2)
+        m.eval()
+        m.post_init()
+        return m
+
+    layers = []
+    for _ in range(n_layers):
+        nw = lambda: (1.0 + 0.1 * torch.randn(hidden, device=DEV, generator=gen)).to(dtype)
+        layers.append(DecodeLayer(lin(hidden, q_dim + 2 * kv_dim), lin(q_dim, hidden), lin(hidden, 2 * inter),
+                                  lin(inter, hidden), nw(), nw()))
+    return layers
+
+
+def _reference_step(layers, x_in, q_dim, inter, eps):
+    """The same step from separate launches: torch glue (HF formulas) + the general product kernel HipGptqLinear.forward."""
+    h = x_in.clone()
+    dt = h.dtype
+
+    def rms(v, w):
+        v32 = v.float()
+        return w * (v32 * torch.rsqrt(v32.pow(2).mean(-1, keepdim=True) + eps)).to(dt)
+
+    for L in layers:
+        qkv = L.qkv(rms(h, L.input_norm)[None])[0]
+        h = h + L.o(qkv[None, :q_dim])[0]
+        gu = L.gate_up(rms(h, L.post_norm)[None])[0]
+        h = h + L.down((torch.nn.functional.silu(gu[:inter]) * gu[inter:])[None])[0]
+    return h
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_chain_overlap_equals_serial_and_tracks_unfused_reference(dtype):
+    from gptqmodel_amd.utils.decode_chain import DecodeStep
+    hidden, inter, q_dim, kv_dim, n_layers = 4096, 14336, 4096, 1024, 3
+    layers = _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype)
+    serial = DecodeStep(layers, hidden, q_dim, dtype, overlap=False)
+    over = DecodeStep(layers, hidden, q_dim, dtype, overlap=True)
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(5)
+    xs = [(torch.randn(hidden, device=DEV, generator=gen) * 0.5).to(dtype) for _ in range(3)]
+    want = []
+    for x in xs:
+        serial.x_in.copy_(x)
+        want.append(serial.run().clone())
+        ref = _reference_step(layers, x, q_dim, inter, 1e-5)
+        # fused vs unfused: same math, different kernels / accumulation orders through 12 dependent linears
+        assert rel_err(torch_to_f32(want[-1]), torch_to_f32(ref)) <= (4e-3 if dtype == torch.float16 else 3e-2)
+    torch.cuda.synchronize()
+    # eager two-stream overlap
+    for i in range(30):
+        over.x_in.copy_(xs[i % 3])
+        got = over.run()
+        assert torch.equal(got, want[i % 3]), f"overlap differs from serial at eager step {i}"
+    over.check_status()
+    # graph replay of the two-stream step
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        over.run()
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            out = over.run()
+        for i in range(200):
+            over.x_in.copy_(xs[i % 3], non_blocking=True)
+            g.replay()
+            if i % 20 == 0 or i > 190:
+                assert torch.equal(out, want[i % 3]), f"overlap graph replay {i} differs from serial"
+        s.synchronize()
+    over.check_status()
+
+
+def test_chain_under_foreign_load():
+    """The dependency flags must hold while other work competes for the CUs and the memory system (uneven load is where
+    stale-read bugs show, MI355X_MICROARCH.md): a big elementwise kernel stream runs beside the replays."""
+    from gptqmodel_amd.utils.decode_chain import DecodeStep
+    hidden, inter, q_dim, kv_dim = 4096, 14336, 4096, 1024
+    layers = _make_stack(2, hidden, inter, q_dim, kv_dim, torch.float16, seed=7)
+    serial = DecodeStep(layers, hidden, q_dim, torch.float16, overlap=False)
+    over = DecodeStep(layers, hidden, q_dim, torch.float16, overlap=True)
+    x = (torch.randn(hidden, device=DEV) * 0.5).half()
+    serial.x_in.copy_(x)
+    want = serial.run().clone()
+    over.x_in.copy_(x)
+    noise_stream = torch.cuda.Stream()
+    big = torch.randn(64 << 20, device=DEV)
+    for i in range(40):
+        with torch.cuda.stream(noise_stream):
+            big.mul_(1.0001)
+        got = over.run()
+        assert torch.equal(got, want), i
+    torch.cuda.synchronize()
+    over.check_status()
