@@ -1,220 +1,18 @@
-"""HipGptqLinear -- BACKEND.GPTQ_HIP: the MI355X (gfx950) fused dequant-matmul QuantLinear for GPTQ checkpoints.
-
-Drop-in for the reference's TorchLinear (gptqmodel/nn_modules/qlinear/torch.py:114) on DEVICE.ROCM: same
-constructor, buffers, post_init()/forward()/dequantize_weight() semantics and rounding, but forward() is ONE
-HIP kernel (libgptqhip.so: gptqhip_gemm) instead of ~10 elementwise torch kernels + a dense GEMM.
-Selection priority 120 beats every kernel upstream lists for ROCm.
-"""
+"""HipGptqLinear / HipQuantEmbeddings -- BACKEND.GPTQ_HIP on this package's mirror of the reference plugin contract.
+The implementation is shared with the upstream-tree overlay: see hip_impl.make_hip_classes."""
 from __future__ import annotations
 
-from typing import Optional
+from types import SimpleNamespace
 
-import torch
-
-from ...utils.adapter import Adapter, Lora
+from ...utils.adapter import Lora
 from ...utils.backend import BACKEND
 from ...utils.const import DEVICE, FORMAT, METHOD, PLATFORM
-from . import GPTQQuantLinear
-from .hip_common import act_order_permutation, flatten_input, hip_validate_once
+from . import AWQuantLinear, GPTQQuantLinear
+from .hip_impl import make_hip_classes
 
-
-class HipGptqLinear(GPTQQuantLinear):
-    SUPPORTS_BACKENDS = [BACKEND.GPTQ_HIP]
-    SUPPORTS_METHODS = [METHOD.GPTQ]
-    SUPPORTS_FORMATS = {FORMAT.GPTQ: 120, FORMAT.GPTQ_V2: 120}
-    SUPPORTS_BITS = [4, 8]
-    SUPPORTS_GROUP_SIZE = [-1, 32, 64, 128, 256, 512, 1024]
-    SUPPORTS_DESC_ACT = [True, False]
-    SUPPORTS_SYM = [True, False]
-    SUPPORTS_SHARDS = True
-    SUPPORTS_TRAINING = False
-    SUPPORTS_AUTO_PADDING = False
-    SUPPORTS_IN_FEATURES_DIVISIBLE_BY = [32]
-    SUPPORTS_OUT_FEATURES_DIVISIBLE_BY = [8]
-    SUPPORTS_DEVICES = [DEVICE.ROCM]
-    SUPPORTS_PLATFORM = [PLATFORM.LINUX]
-    SUPPORTS_PACK_DTYPES = [torch.int32]
-    SUPPORTS_ADAPTERS = [Lora]
-    SUPPORTS_DTYPES = [torch.float16, torch.bfloat16]
-
-    REQUIRES_FORMAT_V2 = True  # the loader converts v1 qzeros (+0x11111111) first: utils/model.py:750-844
-    QUANT_TYPE = "hip_gptq"
-    # opt-in: bf16 batch<=4 decode accumulates exact products instead of rounding every weight to bf16 first
-    # (GPTQHIP_GEMM_EXACT_BF16, include/gptqhip.h): ~20 % faster, up to 2 output ulps from the reference's chain
-    EXACT_BF16_DECODE = False
-
-    def __init__(self, bits: int, group_size: int, sym: bool, desc_act: bool, in_features: int, out_features: int,
-                 bias: bool = False, pack_dtype: torch.dtype = torch.int32, adapter: Adapter = None,
-                 register_buffers: bool = True, format: Optional[FORMAT] = None, **kwargs):
-        super().__init__(bits=bits, group_size=group_size, sym=sym, desc_act=desc_act, in_features=in_features,
-                         out_features=out_features, bias=bias, pack_dtype=pack_dtype,
-                         backend=kwargs.pop("backend", BACKEND.GPTQ_HIP), adapter=adapter,
-                         register_buffers=register_buffers, format=format, **kwargs)
-        # derived device tensors, filled by post_init(): non-persistent BUFFERS so that module.to(device) moves them
-        # with the weights and state_dict() never carries them
-        self.register_buffer("perm", None, persistent=False)  # act-order row permutation (int32 [K])
-        self.register_buffer("meta", None, persistent=False)  # pre-baked per-(group, column) constants
-        self._scale_dtype = torch.float16
-        self._ready = False
-        self._bias_cache = None
-
-    @classmethod
-    def validate_once(cls):
-        return hip_validate_once()
-
-    def post_init(self):
-        """One-time device-side relayout into the MFMA-tile-major kernel layout (+ act-order row sort).  The
-        reference's fast kernels repack here too (marlin.py:246-293, exllamav2.py:114-140); saving a loaded model
-        re-reads the checkpoint from disk (models/writer.py:681-685), so replacing `qweight` in place is safe."""
-        super().post_init()
-        from gptqmodel_amd import ops
-        if not self.qweight.is_cuda:
-            raise RuntimeError("HipGptqLinear.post_init: buffers must be on the ROCm device (no CPU fallback)")
-        if self._ready:
-            return  # already in the kernel layout (post_init is idempotent: HF/optimum and the loader may both call it)
-        if self.scales.dtype not in (torch.float16, torch.bfloat16):
-            self.scales.data = self.scales.data.to(torch.float16)
-        if self.format == FORMAT.GPTQ and self.qzero_format() == 1:
-            # a v1 checkpoint (zero-1 on disk) that reached post_init unconverted: the reference loader converts before
-            # post_init whenever a loaded module has REQUIRES_FORMAT_V2 (models/loader.py:1658-1675); a caller that goes
-            # make_quant -> load_state_dict -> gptqmodel_post_init directly gets the same result here instead of zeros
-            # that are silently off by one
-            from ...utils.model import convert_gptq_v1_to_v2_format_module
-            convert_gptq_v1_to_v2_format_module(self, bits=self.bits, pack_dtype=self.pack_dtype)
-        groups = self.scales.shape[0]
-        perm = None
-        if self.g_idx is not None and self.g_idx.numel() == self.in_features:
-            perm = act_order_permutation(self.g_idx, self.group_size, groups)
-        elif self.g_idx is not None and self.g_idx.numel() not in (0, self.in_features):
-            raise NotImplementedError("stacked g_idx (num_itr > 1, torch.py:327) is not supported by the HIP kernel")
-        qw_t, meta = ops.repack_tiled(self.qweight.data, self.qzeros.data, self.scales.data, perm, self.group_size,
-                                      self.bits)
-        self.qweight.data = qw_t  # tiled words; the checkpoint-layout copy is released
-        self.meta = meta
-        self.perm = perm
-        self._scale_dtype = self.scales.dtype
-        self._ready = True
-
-    def _save_to_state_dict(self, destination, prefix, keep_vars):
-        if self._ready:
-            # after post_init `qweight` holds tile-major words under the checkpoint name: writing them out would produce
-            # a checkpoint no loader can read.  The reference saves a loaded quantised model by re-reading the
-            # checkpoint from disk (models/writer.py:681-685), never from the live modules.
-            raise RuntimeError(f"{self.__class__.__name__} `{self.name}`: state_dict() after post_init() would save the "
-                               "kernel (tile-major) layout; save from the original checkpoint instead")
-        super()._save_to_state_dict(destination, prefix, keep_vars)
-
-    def _bias_for(self, dtype: torch.dtype, device: torch.device):
-        if self.bias is None:
-            return None
-        c = self._bias_cache
-        if c is None or c.dtype != dtype or c.device != device or c.data_ptr() == 0:
-            c = self.bias.to(device=device, dtype=dtype).contiguous()  # torch.py:338-342 casts bias to out dtype
-            self._bias_cache = c
-        return c
-
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if not self._ready:
-            raise RuntimeError("HipGptqLinear.forward called before post_init()")
-        from gptqmodel_amd import ops
-        out_shape = x.shape[:-1] + (self.out_features,)
-        x2, in_dtype = flatten_input(self._apply_rotation_to_input(x), self.in_features)
-        out = ops.gemm(x2, self.qweight, self.meta, self._bias_for(x2.dtype, x2.device), self.perm, self.out_features,
-                       self.group_size, self.bits, self._scale_dtype, exact_bf16=self.EXACT_BF16_DECODE)
-        if self.adapter:
-            out = self.adapter.apply(x=x2, out=out)  # torch.py:344-345
-        if out.dtype != in_dtype:
-            out = out.to(in_dtype)
-        return out.reshape(out_shape)
-
-    def pack_block(self, linear: torch.nn.Module, scales: torch.Tensor, zeros: torch.Tensor, g_idx: torch.Tensor,
-                   block_in: int = 8192, workers: int = 1):
-        """Quantise-and-pack a float Linear into this module's checkpoint-layout buffers ON THE DEVICE; same
-        signature and bit-exact output as PackableQuantLinear.pack_block (qlinear/__init__.py:1036-1323):
-        scales / zeros arrive as [out, G]."""
-        from gptqmodel_amd import ops
-        dev = linear.weight.device if linear.weight.is_cuda else torch.device("cuda", torch.cuda.current_device())
-        w = linear.weight.detach().to(dev)
-        sc = scales.T.contiguous().to(dev)
-        zr = zeros.T.contiguous().to(dev)
-        qweight, qzeros = ops.pack_gptq(w, sc, zr, g_idx.to(dev), self.bits)
-        self.register_buffer("qweight", qweight)
-        self.register_buffer("qzeros", qzeros)
-        self.register_buffer("scales", sc.to(torch.float16))
-        self.register_buffer("g_idx", g_idx.to(device=dev, dtype=torch.int32))
-        if linear.bias is not None:
-            self.register_buffer("bias", linear.bias.detach().to(device=dev, dtype=torch.float16))
-        else:
-            self.bias = None
-        self.qzero_format(format=2)
-        self._ready = False
-
-    pack = pack_block
-
-    def forward_partial(self, x: torch.Tensor) -> torch.Tensor:
-        """float32 [.., N] unrounded accumulators without bias: what a row-parallel (K-sharded) tensor-parallel
-        layer all-reduces before the single final rounding (gptqmodel_amd/utils/tp.py)."""
-        if not self._ready:
-            raise RuntimeError("HipGptqLinear.forward_partial called before post_init()")
-        from gptqmodel_amd import ops
-        x2, _ = flatten_input(x, self.in_features)
-        out = ops.gemm(x2, self.qweight, self.meta, None, self.perm, self.out_features, self.group_size, self.bits,
-                       self._scale_dtype, partial_f32=True)
-        return out.reshape(x.shape[:-1] + (self.out_features,))
-
-    def dequantize_weight(self, num_itr: int = 1) -> torch.Tensor:
-        """[K,N] weights in scales.dtype, bit-exact with TorchLinear.dequantize_weight (torch.py:225)."""
-        if num_itr != 1:
-            raise NotImplementedError("num_itr > 1 is not supported")
-        from gptqmodel_amd import ops
-        if not self._ready:  # still in checkpoint layout
-            return ops.dequant(self.qweight, self.qzeros, self.scales, self.g_idx, self.group_size, self.bits)
-        return ops.dequant_tiled(self.qweight, self.meta, self.perm, self.in_features, self.out_features,
-                                 self.group_size, self.bits, self._scale_dtype)
-
-
-class HipQuantEmbeddings(HipGptqLinear):
-    """Quantised embedding table on the HIP backend: the mirror of TorchQuantEmbeddings
-    (gptqmodel/nn_modules/qlinear/torch.py:764-797).  in_features = num_embeddings, out_features = embedding dim; forward
-    takes integer token ids.  Selected by module role, never by backend discovery (SUPPORTS_BACKEND_SELECTION False).
-    Unlike the reference, which dequantises the whole table per call, only the requested rows are decoded."""
-
-    # every SUPPORTS_* must be declared on the class itself (verify_supports_params, like upstream's
-    # TorchQuantEmbeddings which restates them all)
-    SUPPORTS_BACKENDS = [BACKEND.GPTQ_HIP]
-    SUPPORTS_BACKEND_SELECTION = False
-    SUPPORTS_METHODS = [METHOD.GPTQ]
-    SUPPORTS_FORMATS = {FORMAT.GPTQ: 120, FORMAT.GPTQ_V2: 120}
-    SUPPORTS_BITS = [4, 8]
-    SUPPORTS_GROUP_SIZE = [-1, 32, 64, 128, 256, 512, 1024]
-    SUPPORTS_DESC_ACT = [True, False]
-    SUPPORTS_SYM = [True, False]
-    SUPPORTS_SHARDS = True
-    SUPPORTS_TRAINING = False
-    SUPPORTS_AUTO_PADDING = False
-    SUPPORTS_IN_FEATURES_DIVISIBLE_BY = [32]
-    SUPPORTS_OUT_FEATURES_DIVISIBLE_BY = [8]
-    SUPPORTS_DEVICES = [DEVICE.ROCM]
-    SUPPORTS_PLATFORM = [PLATFORM.LINUX]
-    SUPPORTS_PACK_DTYPES = [torch.int32]
-    SUPPORTS_ADAPTERS = []
-    SUPPORTS_DTYPES = [torch.float16, torch.bfloat16]
-    QUANT_TYPE = "hip_gptq_embedding"
-
-    def post_init(self):
-        super().post_init()
-        self._inv_perm = None
-        if self.perm is not None:
-            inv = torch.empty_like(self.perm)
-            inv[self.perm.long()] = torch.arange(self.perm.numel(), dtype=torch.int32, device=self.perm.device)
-            self._inv_perm = inv
-
-    def forward(self, input_ids: torch.Tensor) -> torch.Tensor:
-        if not self._ready:
-            raise RuntimeError("HipQuantEmbeddings.forward called before post_init()")
-        from gptqmodel_amd import ops
-        return ops.embedding(input_ids, self.qweight, self.meta, self._inv_perm, self.in_features, self.out_features,
-                             self.group_size, self.bits, self._scale_dtype)
-
+_NS = SimpleNamespace(GPTQQuantLinear=GPTQQuantLinear, AWQuantLinear=AWQuantLinear, BACKEND=BACKEND, DEVICE=DEVICE,
+                      FORMAT=FORMAT, METHOD=METHOD, PLATFORM=PLATFORM, Lora=Lora)
+HipGptqLinear, HipQuantEmbeddings, _HipAwqLinear = make_hip_classes(_NS, __name__)
+_HipAwqLinear.__module__ = __name__.rsplit(".", 1)[0] + ".hip_awq"
 
 __all__ = ["HipGptqLinear", "HipQuantEmbeddings"]

@@ -375,3 +375,4 @@ def test_fused_module_tensors_are_registered_buffers(kernels_available):
     assert names["qweight"].shape == (32, 96) and names["bias"].shape == (96,)
     assert len(fused.list_buffers()) == 5 and fused.format == FORMAT.GPTQ_V2
     assert "meta" not in fused.state_dict() and "perm" not in fused.state_dict()   # derived tensors are non-persistent
+    assert all(t is not None for t in fused._buffers.values())   # no None-valued buffers (accelerate offload hooks)
