@@ -45,22 +45,67 @@ def shard_gptq_column(t: Dict[str, torch.Tensor], rank: int, world: int, bits: i
     return out
 
 
-def shard_gptq_row(t: Dict[str, torch.Tensor], rank: int, world: int, bits: int, group_size: int) -> Dict[str, torch.Tensor]:
-    """Split along K (in_features) in whole groups; g_idx is rebased.  Act-order checkpoints (g_idx not sequential)
-    reference arbitrary groups from any K-slice and are rejected here (they need a replicated input + global sort)."""
+def _unpack_rows(qweight: torch.Tensor, bits: int) -> torch.Tensor:
+    """[K/pf, N] int32 -> codes uint8 [K, N] (code(pf*r+j, n) = (word >> bits*j) & maxq; qlinear/__init__.py:827-865)."""
+    pf = 32 // bits
+    sh = (torch.arange(pf, dtype=torch.int32, device=qweight.device) * bits).view(1, pf, 1)
+    codes = torch.bitwise_and(torch.bitwise_right_shift(qweight.unsqueeze(1), sh), (1 << bits) - 1)
+    return codes.reshape(qweight.shape[0] * pf, qweight.shape[1]).to(torch.uint8)
+
+
+def _pack_rows(codes: torch.Tensor, bits: int) -> torch.Tensor:
+    pf = 32 // bits
+    k, n = codes.shape
+    c = codes.to(torch.int64).reshape(k // pf, pf, n)
+    sh = (torch.arange(pf, dtype=torch.int64, device=codes.device) * bits).view(1, pf, 1)
+    w = torch.bitwise_left_shift(c, sh).sum(dim=1)                  # disjoint bit fields: sum == or
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+
+
+def shard_gptq_row(t: Dict[str, torch.Tensor], rank: int, world: int, bits: int, group_size: int,
+                   act_order: str = "reject") -> Dict[str, torch.Tensor]:
+    """Split along K (in_features) in whole groups; g_idx is rebased.
+
+    Act-order checkpoints (desc_act=True: g_idx is a permutation of the group ids) reference arbitrary groups from any
+    contiguous K-slice.  act_order="global_sort" follows the rule the reference inherited from vLLM/Marlin for this case
+    (`marlin_is_k_full` / `marlin_repeat_scales_on_all_ranks`, gptqmodel/utils/marlin.py:296-305; row sorting
+    `marlin_sort_g_idx` :368-372): the rows are sorted by group GLOBALLY first (stable argsort of g_idx), then sliced, so
+    every rank again owns whole groups [g0, g1) with its own scales / zeros rows and a sequential local g_idx -- no
+    replicated scales, the kernel sees an ordinary shard.  The price is on the activation side: rank r needs the input
+    features perm[k0:k1], which are scattered over all ranks' column shards, so the returned dict carries
+    `input_index` (int64 [K/world]) and RowParallelQuantLinear all-gathers the sharded activation before selecting them
+    (the alternative -- folding the permutation into the producing column-parallel layer -- only exists for MLPs, not for
+    attention outputs).  act_order="reject" (default) raises instead."""
     pf = 32 // bits
     k = t["qweight"].shape[0] * pf
     k0, k1 = _bounds(k, rank, world, max(group_size, 32), "in_features")
     g0, g1 = k0 // group_size, k1 // group_size
     g_idx = t.get("g_idx")
+    input_index = None
+    qweight = None
     if g_idx is not None:
+        groups = t["scales"].shape[0]
+        g64 = g_idx.to(torch.int64)
+        g64 = torch.where(g64 < 0, g64 + groups, g64)
         seq = torch.arange(k, dtype=torch.int64, device=g_idx.device) // group_size
-        if not torch.equal(g_idx.to(torch.int64), seq):
-            raise NotImplementedError("row-parallel sharding of act-order (desc_act) checkpoints is not supported")
-        g_idx = (g_idx[k0:k1] - g0).contiguous()
-    return {"qweight": t["qweight"][k0 // pf:k1 // pf].contiguous(), "qzeros": t["qzeros"][g0:g1].contiguous(),
-            "scales": t["scales"][g0:g1].contiguous(), "g_idx": g_idx,
-            "bias": None}  # the bias is added ONCE after the all-reduce by RowParallelQuantLinear
+        if not torch.equal(g64, seq):
+            if act_order != "global_sort":
+                raise NotImplementedError("row-parallel sharding of an act-order (desc_act) checkpoint needs "
+                                          "act_order='global_sort' (gathered input)")
+            perm = torch.argsort(g64, stable=True)
+            if not torch.equal(g64[perm], seq):
+                raise NotImplementedError("act-order row sharding requires every group to own exactly group_size rows")
+            input_index = perm[k0:k1].contiguous()
+            qweight = _pack_rows(_unpack_rows(t["qweight"], bits)[input_index], bits)
+        g_idx = (seq[k0:k1] - g0).to(torch.int32).contiguous()
+    if qweight is None:
+        qweight = t["qweight"][k0 // pf:k1 // pf].contiguous()
+    out = {"qweight": qweight, "qzeros": t["qzeros"][g0:g1].contiguous(),
+           "scales": t["scales"][g0:g1].contiguous(), "g_idx": g_idx,
+           "bias": None}  # the bias is added ONCE after the all-reduce by RowParallelQuantLinear
+    if input_index is not None:
+        out["input_index"] = input_index
+    return out
 
 
 def shard_awq_column(t, rank, world):
@@ -103,13 +148,29 @@ class RowParallelQuantLinear(nn.Module):
     its K-slice, ONE all-reduce(sum) over xGMI combines them, then the reference's rounding chain runs once:
     y = round(sum) ; y = round(y + bias)   (torch.py:337-342)."""
 
-    def __init__(self, local: nn.Module, bias: Optional[torch.Tensor] = None, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, local: nn.Module, bias: Optional[torch.Tensor] = None, group: Optional[dist.ProcessGroup] = None,
+                 input_index: Optional[torch.Tensor] = None):
         super().__init__()
         self.local = local
         self.group = group
         self.bias = bias
+        # act-order shards (shard_gptq_row(..., act_order="global_sort")): the input features this rank's rows need, as
+        # indices into the FULL (gathered) activation
+        self.input_index = input_index
+
+    def _gathered_input(self, x_shard: torch.Tensor) -> torch.Tensor:
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world > 1:
+            parts = [torch.empty_like(x_shard) for _ in range(world)]
+            dist.all_gather(parts, x_shard.contiguous(), group=self.group)
+            x_full = torch.cat(parts, dim=-1)
+        else:
+            x_full = x_shard
+        return x_full.index_select(-1, self.input_index.to(x_full.device)).contiguous()
 
     def forward(self, x_shard: torch.Tensor) -> torch.Tensor:
+        if self.input_index is not None:
+            x_shard = self._gathered_input(x_shard)
         partial = self.local.forward_partial(x_shard)  # float32, unrounded
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=self.group)

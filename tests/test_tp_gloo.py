@@ -72,6 +72,16 @@ def _worker(rank, world, port, ret):
         col_g = tp.ColumnParallelQuantLinear(OracleLocal(tp.shard_gptq_column(up, rank, world, bits), bits, gs),
                                              gather_output=True)
         assert torch.equal(col_g(x), h_full)
+        # act-order (desc_act=True) row-parallel layer: rows sorted by group globally, then sliced; the sharded activation is
+        # all-gathered and each rank selects the input features its rows need
+        down_a = dict(down)
+        down_a["g_idx"] = torch.from_numpy((np.random.RandomState(11).permutation(I) // gs).astype(np.int32))
+        sh = tp.shard_gptq_row(down_a, rank, world, bits, gs, act_order="global_sort")
+        row_a = tp.RowParallelQuantLinear(OracleLocal(sh, bits, gs), bias=down_a["bias"], input_index=sh["input_index"])
+        y_a = row_a(h_local)
+        y_a_full = OracleLocal(down_a, bits, gs)(h_full)
+        err_a = (y_a.float() - y_a_full.float()).abs().max().item() / y_a_full.float().abs().max().item()
+        assert err_a <= 1e-3, err_a
         ret[rank] = err
     finally:
         dist.destroy_process_group()
@@ -115,6 +125,19 @@ def test_shard_shapes_and_constraints():
     act["g_idx"] = torch.from_numpy((np.random.RandomState(0).permutation(K) // 128).astype(np.int32))
     with pytest.raises(NotImplementedError):
         tp.shard_gptq_row(act, 0, 2, 4, 128)
+    # act_order="global_sort": the shards tile the GROUP-SORTED matrix; input_index says which input features each owns
+    full_act = O.dequant_gptq(act["qweight"].numpy(), act["qzeros"].numpy(), act["scales"].float().numpy(), act["g_idx"].numpy(), 4)
+    perm = O.act_order_perm(act["g_idx"].numpy())
+    for world in (2, 4):
+        sh = [tp.shard_gptq_row(act, r, world, 4, 128, act_order="global_sort") for r in range(world)]
+        assert np.array_equal(np.concatenate([c["input_index"].numpy() for c in sh]), perm)
+        ws = np.concatenate([O.dequant_gptq(c["qweight"].numpy(), c["qzeros"].numpy(), c["scales"].float().numpy(),
+                                            c["g_idx"].numpy(), 4) for c in sh], axis=0)
+        assert np.array_equal(ws, full_act[perm])
+    # bit-level helpers round-trip
+    assert torch.equal(tp._pack_rows(tp._unpack_rows(t["qweight"], 4), 4), t["qweight"])
+    w8 = torch.from_numpy(np.random.RandomState(1).randint(-2**31, 2**31, size=(16, 8), dtype=np.int64).astype(np.int32))
+    assert torch.equal(tp._pack_rows(tp._unpack_rows(w8, 8), 8), w8)
     # Llama-3-70B shapes satisfy the constraints up to TP=8
     for (k, n) in [(8192, 8192), (8192, 1024), (8192, 28672), (28672, 8192)]:
         for world in (1, 2, 4, 8):
