@@ -160,8 +160,89 @@ __device__ __forceinline__ void stage_input(const Gemv1Params& p, u4_t* xbuf, fl
     }
 }
 
-template <int BITS, int ACT, int SCL, int D>
-__global__ __launch_bounds__(1024, 8) void gemv1_kernel(Gemv1Params p) {
+// Register-staged variant for vectors of at most 2 x 16 bytes per thread (every Llama-3-8B/70B shape except the 70B
+// down_proj): the loads are issued in ONE burst (x / h / gate in `a`, norm weight / up in `b`), so in stream-ordered launches
+// they can be issued BEFORE the weight ring and waited for on their own (vmcnt retires in order), and RMSNorm needs no
+// second pass over memory.
+struct XRegs {
+    u4_t a[2], b[2];
+};
+__device__ __forceinline__ void load_x_regs(const Gemv1Params& p, XRegs& r) {
+    const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
+    const int n16 = p.K >> 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * nthr;
+        const int ci = idx < n16 ? idx : 0;  // clamped (unconditional loads keep the waits countable); masked at use
+        r.a[i] = load16_agent(p.x, ci);
+        if (p.in_glue == kGlueSiluMul) {
+            r.b[i] = load16_agent(p.x, n16 + ci);
+        } else if (p.in_glue == kGlueRmsNorm) {
+            r.b[i] = reinterpret_cast<const u4_t*>(p.norm_w)[ci];
+        }
+    }
+}
+template <int ACT>
+__device__ __forceinline__ void stage_from_regs(const Gemv1Params& p, const XRegs& r, u4_t* xbuf, float* scratch) {
+    const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
+    const int n16 = p.K >> 3, n16p = p.chunks * 16;
+    float inv = 0.f;
+    if (p.in_glue == kGlueRmsNorm) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (tid + i * nthr < n16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = lo16<ACT>(r.a[i][j]), b = hi16<ACT>(r.a[i][j]);
+                    ss = __builtin_fmaf(a, a, ss);
+                    ss = __builtin_fmaf(b, b, ss);
+                }
+            }
+        }
+        ss = wave_sum(ss);
+        if ((tid & 63) == 0) scratch[tid >> 6] = ss;
+        __syncthreads();
+        float tot = 0.f;
+        for (int w = 0; w < (nthr >> 6); ++w) tot += scratch[w];  // fixed order: deterministic
+        inv = rsqrtf(tot / (float)p.K + p.eps);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * nthr;
+        if (idx < n16p) {
+            u4_t o = {0u, 0u, 0u, 0u};
+            if (idx < n16) {
+                if (p.in_glue == kGlueNone) {
+                    o = r.a[i];
+                } else if (p.in_glue == kGlueSiluMul) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float g0 = lo16<ACT>(r.a[i][j]), g1 = hi16<ACT>(r.a[i][j]);
+                        const float s0 = round_through<ACT>(g0 / (1.0f + __expf(-g0)));
+                        const float s1 = round_through<ACT>(g1 / (1.0f + __expf(-g1)));
+                        o[j] = pack16<ACT>(s0 * lo16<ACT>(r.b[i][j]), s1 * hi16<ACT>(r.b[i][j]));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = round_through<ACT>(lo16<ACT>(r.a[i][j]) * inv);
+                        const float b = round_through<ACT>(hi16<ACT>(r.a[i][j]) * inv);
+                        o[j] = pack16<ACT>(lo16<ACT>(r.b[i][j]) * a, hi16<ACT>(r.b[i][j]) * b);
+                    }
+                }
+            }
+            xbuf[idx] = o;
+        }
+    }
+}
+
+// WAIT = 1: the op waits on its producer's arrival counters inside the kernel (two-stream overlap); WAIT = 0: ordinary
+// stream-ordered launch -- the input vector is then requested BEFORE the weight ring.
+// Register budget: WAIT = 1 ops must fit TWO blocks per CU (<= 64 VGPRs at 16 waves each); a stream-ordered op has the CU
+// to itself (128 VGPRs: room for the register-staged input vector next to the ring).
+template <int BITS, int ACT, int SCL, int D, int WAIT>
+__global__ __launch_bounds__(1024, WAIT ? 8 : 4) void gemv1_kernel(Gemv1Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     // [xbuf: chunks*256 B][red: 2 x 16 waves x 16 floats][scratch: 16 floats][ostage: 16 waves x 16 halves]
     u4_t* xbuf = reinterpret_cast<u4_t*>(lds_raw);
@@ -180,7 +261,15 @@ __global__ __launch_bounds__(1024, 8) void gemv1_kernel(Gemv1Params p) {
     constexpr int WPC = BITS == 4 ? 1 : 2;
     constexpr int kBlockBytes = WPC * 1024;
 
-    // ---- 1. weight ring prologue: depends on nothing, issued before anything else ---------------------------------
+    // ---- 0. stream-ordered launch: the input vector (L2-resident) is requested first, so staging it does not wait for HBM
+    // (8-bit ring stages are twice as large: no registers to spare for the staged vector -> looped staging there)
+    const bool xfast = BITS == 4 && (p.K >> 3) <= 2 * (int)blockDim.x && p.chunks * 16 <= 2 * (int)blockDim.x;
+    XRegs xr;
+    if constexpr (WAIT == 0) {
+        if (xfast) load_x_regs(p, xr);
+    }
+
+    // ---- 1. weight ring prologue: depends on nothing ------------------------------------------------------------------
     const char* wbase = reinterpret_cast<const char*>(p.qw) + (uint32_t)lane * 16u;
     const char* mbase = reinterpret_cast<const char*>(p.meta) + (uint32_t)c * 4u;
     int lt = 0, lc = 0;  // load cursor: tile index within the block's list, chunk index within the wave's list
@@ -201,7 +290,7 @@ __global__ __launch_bounds__(1024, 8) void gemv1_kernel(Gemv1Params p) {
     for (int d = 0; d < D; ++d) issue(st[d]);
 
     // ---- 2. dependency: ONE wave polls the producer's arrival counters, then the block reads its output (agent loads) ----
-    if (p.wait_ctr != nullptr) {
+    if constexpr (WAIT == 1) {
         if (wave == 0) {
             unsigned spins = 0;
             for (;;) {
@@ -218,7 +307,12 @@ __global__ __launch_bounds__(1024, 8) void gemv1_kernel(Gemv1Params p) {
     }
 
     // ---- 3. stage the input vector (+ glue) into LDS --------------------------------------------------------------
-    stage_input<ACT>(p, xbuf, scratch);
+    if (xfast) {
+        if constexpr (WAIT == 1) load_x_regs(p, xr);
+        stage_from_regs<ACT>(p, xr, xbuf, scratch);
+    } else {
+        stage_input<ACT>(p, xbuf, scratch);
+    }
     __syncthreads();
 
     // ---- 4. ring: compute unit j, refill its stage with unit j + D ---------------------------------------------------
@@ -313,7 +407,7 @@ __global__ __launch_bounds__(1024, 8) void gemv1_kernel(Gemv1Params p) {
     }
 
     // ---- 5. arrive: every wave that stored outputs (write-through) drains them, then ONE relaxed agent-scope add ---------
-    if (p.signal_ctr != nullptr) {
+    if (p.signal_ctr != nullptr) {  // (also allowed without WAIT: the first op of a chain only signals)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_fetch_add(p.signal_ctr + (b & (kCounterShards - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -350,15 +444,19 @@ Gemv1Plan plan_gemv1(int K, int N, int group_size, int cu_count) {
     return pl;
 }
 
-template <int BITS, int ACT, int SCL>
+template <int BITS, int ACT, int SCL, int WAIT>
 static int launch_gemv1_depth(const Gemv1Params& p, const Gemv1Plan& pl, hipStream_t stream) {
     const dim3 grid(pl.grid), block(64 * pl.waves);
-    if (pl.depth == 4) {
-        hipLaunchKernelGGL((gemv1_kernel<BITS, ACT, SCL, 4>), grid, block, pl.lds_bytes, stream, p);
-    } else if (pl.depth == 2) {
-        hipLaunchKernelGGL((gemv1_kernel<BITS, ACT, SCL, 2>), grid, block, pl.lds_bytes, stream, p);
+    if constexpr (BITS == 4) {  // 8-bit stages are 9 VGPRs each: four of them spill beside the 64-VGPR co-residency budget
+        if (pl.depth == 4) {
+            hipLaunchKernelGGL((gemv1_kernel<BITS, ACT, SCL, 4, WAIT>), grid, block, pl.lds_bytes, stream, p);
+            return check_hip(hipGetLastError(), "gemv1_kernel launch");
+        }
+    }
+    if (pl.depth >= 2) {
+        hipLaunchKernelGGL((gemv1_kernel<BITS, ACT, SCL, 2, WAIT>), grid, block, pl.lds_bytes, stream, p);
     } else {
-        hipLaunchKernelGGL((gemv1_kernel<BITS, ACT, SCL, 1>), grid, block, pl.lds_bytes, stream, p);
+        hipLaunchKernelGGL((gemv1_kernel<BITS, ACT, SCL, 1, WAIT>), grid, block, pl.lds_bytes, stream, p);
     }
     return check_hip(hipGetLastError(), "gemv1_kernel launch");
 }
@@ -387,7 +485,9 @@ int launch_gemv1(const DecodeArgs& a, const Gemv1Plan& pl, hipStream_t stream) {
     while ((kChunkK << sh) < a.group_size) ++sh;
     p.cpg_shift = sh;
     p.in_glue = a.in_glue;
-#define GPTQHIP_DISPATCH(B, A_, S_) return launch_gemv1_depth<B, A_, S_>(p, pl, stream)
+#define GPTQHIP_DISPATCH(B, A_, S_)                                                        \
+    return p.wait_ctr != nullptr ? launch_gemv1_depth<B, A_, S_, 1>(p, pl, stream) \
+                                 : launch_gemv1_depth<B, A_, S_, 0>(p, pl, stream)
     if (a.bits == 4) {
         if (a.act_dtype == kFP16 && a.scale_dtype == kFP16) GPTQHIP_DISPATCH(4, kFP16, kFP16);
         if (a.act_dtype == kBF16 && a.scale_dtype == kFP16) GPTQHIP_DISPATCH(4, kBF16, kFP16);
