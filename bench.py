@@ -19,8 +19,8 @@ Extra objects on the JSON line (tier contract):
                 launch from the committed rocprofv3 --pmc passes (traffic_source says which file; it is NOT measured in
                 this run -- PMC counters cannot be read from inside the process).
   configs       one object per BASELINE.json config with its own workload / value / roofline (outside the timed region):
-                C2 variants (this step without overlap; per-module launches), C3 act-order prefill at M=65536, C4 AWQ
-                decode + M=2048 prefill, C5 Llama-3-70B decode at TP=1.
+                C2 variant (per-module launches + torch glue kernels), C3 act-order prefill at M=65536, C4 AWQ decode +
+                M=2048 prefill, C5 Llama-3-70B decode at TP=1.
   cpu_baseline  the oracle's torch-CPU PORT of BACKEND.TORCH (oracle/gptq_oracle.py:torch_cpu_forward_gptq) on this
                 host's cores, thread count swept, rank 0 at N=1 only: C1 (single 4096x4096 linear, M in {1,32,2048}, fp16 and
                 bf16) and one decoder layer at M=1 extrapolated to tokens/s.
@@ -79,9 +79,14 @@ def make_gptq(k, n, gs, dev, gen, dtype, desc_act=False, derive_from=None):
     lin = HipGptqLinear(bits=4, group_size=gs, sym=True, desc_act=desc_act, in_features=k, out_features=n, bias=False,
                         register_buffers=False)
     if derive_from is None:
-        lin.qweight = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=dev, generator=gen)
+        w = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=dev, generator=gen)
     else:
-        lin.qweight = derive_from
+        w = derive_from
+    # code 0 -> 8: the 16 code values become symmetric around the sym zero-point 8, i.e. ZERO-MEAN weights like a real
+    # checkpoint.  With plain uniform codes E[q - 8] = -0.5, every linear gets a DC gain of -0.005 * K and the fp16 residual
+    # stream of the dependent chain overflows within three layers (found by the chain parity test).
+    lin.qweight = w | (((~(w | (w >> 1) | (w >> 2) | (w >> 3))) & 0x11111111) << 3)
+    del w
     lin.qzeros = torch.full((k // gs, n // 8), -2004318072, dtype=torch.int32, device=dev)  # 0x88888888
     lin.scales = (torch.rand((k // gs, n), device=dev, generator=gen) * 0.01 + 0.005).to(dtype)
     if desc_act:
@@ -224,8 +229,13 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
     c1 = {}
     for dt, tag in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
         for m in (1, 32, 2048):
+            if dt == torch.float16 and m > 1:
+                # aten's CPU fp16 matmul is pathologically slow (measured on the GPU box's host: 2.6 s at M=32, 183 s at
+                # M=2048 per call; upstream flags it too, tests/test_q4_torch.py:52-53): not part of a bounded leg
+                c1[f"{tag}_m{m}"] = None
+                continue
             x = (torch.randn(m, k) * 0.5).to(dt)
-            ms, it = _time_cpu(lambda: torch_cpu_forward_gptq(x, *t[dt], 4), budget_s * 0.06, 4)
+            ms, it = _time_cpu(lambda: torch_cpu_forward_gptq(x, *t[dt], 4), budget_s * 0.05, 4)
             c1[f"{tag}_m{m}"] = round(ms, 3)
     # one decoder layer at M=1 (7 linears, bf16), extrapolated to the model
     mods = []
@@ -243,7 +253,8 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
                   f"extrapolated x{cfg['layers']}; torch CPU port of BACKEND.TORCH (oracle/gptq_oracle.py), not the reference "
                   f"module itself; host os.cpu_count()={ncpu}",
         "ms_per_layer": per_layer, "threads_swept": per_thread, "best_threads": best,
-        "c1_ms": c1, "c1_workload": "single QuantLinear 4096x4096 int4 g128 sym=True, eager dequant + matmul, best_threads",
+        "c1_ms": c1, "c1_workload": "single QuantLinear 4096x4096 int4 g128 sym=True, eager dequant + matmul, best_threads "
+                                      "(null: fp16 CPU matmul at M>1 takes 2.6-183 s per call on this host; not timed)",
         "sweep_s": round(time.perf_counter() - t_sweep0, 1),
     }
 
@@ -272,9 +283,9 @@ def main():
                     help="llama3-8b: the headline config, ranks are independent replicas (weak scaling). "
                          "llama3-70b: BASELINE configs[4], tensor parallel over all ranks (strong scaling): column-parallel "
                          "qkv/gate_up, row-parallel o/down with one fp32 all-reduce each (gptqmodel_amd/utils/tp.py)")
-    ap.add_argument("--mode", default="chain", choices=["chain", "chain-serial", "modules"],
-                    help="chain: decode ops with fused glue, two-stream overlap with device-side dependency flags (default); "
-                         "chain-serial: the same ops in plain stream order; modules: HipGptqLinear.forward per launch + torch glue")
+    ap.add_argument("--mode", default="chain", choices=["chain", "modules"],
+                    help="chain: decode ops with the layer glue fused into the GEMV, 4 launches per layer (default); "
+                         "modules: HipGptqLinear.forward per launch + the glue as separate torch kernels (what an HF model runs)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per token")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs[] array (C3/C4/C5 legs)")
@@ -315,7 +326,7 @@ def main():
     def make_step(mode):
         if mode == "modules":
             return ModulesStep(layers, cfg, dtype, x0)
-        st = DecodeStep(layers, cfg["hidden"], cfg["q"], dtype, overlap=(mode == "chain"))
+        st = DecodeStep(layers, cfg["hidden"], cfg["q"], dtype)
         st.x_in.copy_(x0)
         return st
 
@@ -323,19 +334,11 @@ def main():
     step = make_step(mode)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        step.run()
+        out0 = step.run()
         stream.synchronize()
-    if mode == "chain":
-        # the overlapped chain must reproduce the serial chain bit for bit, else fall back loudly
-        ser = make_step("chain-serial")
-        with torch.cuda.stream(stream):
-            want = ser.run().clone()
-            stream.synchronize()
-        bad = int(step.status.item()) != 0 or not torch.equal(step.out, want)
-        if bad:
-            print("bench.py: overlapped decode chain disagrees with the serial chain or timed out -- using chain-serial",
-                  file=sys.stderr, flush=True)
-            mode, step = "chain-serial", ser
+    if not torch.isfinite(out0).all():
+        raise SystemExit("bench.py: the decode chain produced non-finite activations; refusing to time garbage")
+    del out0
     graph = None
     if not args.no_graph:
         with torch.cuda.stream(stream):
@@ -369,9 +372,6 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
-    if hasattr(step, "check_status"):
-        step.check_status()
-
     tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -384,8 +384,7 @@ def main():
         launch_us = ev_ms * 1e3 / (args.steps * n_launch)   # average launch duration incl. whatever the ops do not overlap
         bytes_per_launch = step_bytes / n_launch
         achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
-        kernel = {"chain": "gptqhip::gemv1_kernel<BITS=4,ACT,SCL,D> (two-stream overlap, device-side dependency flags)",
-                  "chain-serial": "gptqhip::gemv1_kernel<BITS=4,ACT,SCL,D> (stream order)",
+        kernel = {"chain": "gptqhip::skinny_kernel<BITS=4,ACT,SCL,MT=1,GPC=1,AM_ROW1,D=4,GLUE> (decode op, glue fused)",
                   "modules": "gptqhip::skinny_kernel<BITS=4,ACT,SCL,MT=1,GPC=1,AM_ROW1,D=4>"}[mode]
         out = {
             "metric": "llama3_8b_gptq_int4_g128_decode_linear_stack_tokens_per_s",
@@ -402,8 +401,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel, "bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_us,
-                         "note": "event-timed over the timed region; with overlap the launches of consecutive ops run "
-                                 "concurrently, so avg_launch_us is step time / launches, not a single kernel's duration"},
+                         "note": "event-timed over the timed region: avg_launch_us = step time / launches (kernel + "
+                                 "dependent-launch gap)"},
             "gemm_tflops_equiv": step_flops * value / world / 1e12,
         }
         if world == 1 and not args.no_configs:
@@ -451,14 +450,12 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
     gs = 128
     t_start = time.perf_counter()
     res.append(decode_entry("C2", f"headline ({mode})", cfg, ms_headline, n_launch, extra={"mode": mode}))
-    for other in ("chain", "chain-serial", "modules"):
+    for other in ("chain", "modules"):
         if other == mode:
             continue
         try:
             st = make_step(other)
             ms, g = time_graph(st.run, stream, 50, 5)
-            if hasattr(st, "check_status"):
-                st.check_status()
             res.append(decode_entry("C2", f"same token step, mode={other}", cfg, ms, n_launch, extra={"mode": other}))
             del g, st
         except Exception as e:  # noqa: BLE001
@@ -486,11 +483,10 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
     try:
         awq_layers = build_stack(cfg, lambda k, n: make_awq(k, n, gs, dev, gen, dtype), dev, gen, dtype)
         from gptqmodel_amd.utils.decode_chain import DecodeStep
-        st = DecodeStep(awq_layers, cfg["hidden"], cfg["q"], dtype, overlap=(mode == "chain"))
+        st = DecodeStep(awq_layers, cfg["hidden"], cfg["q"], dtype)
         st.x_in.copy_((torch.randn(cfg["hidden"], device=dev, generator=gen) * 0.5).to(dtype))
         ms, g = time_graph(st.run, stream, 100, 10)
-        st.check_status()
-        res.append(decode_entry("C4", f"Llama-3-8B AWQ int4 g128 sym=False (AWQ packing, asymmetric qzeros) batch=1 decode, mode={mode}",
+        res.append(decode_entry("C4", "Llama-3-8B AWQ int4 g128 sym=False (AWQ packing, asymmetric qzeros) batch=1 decode, decode chain",
                                 cfg, ms, n_launch))
         del g, st
         A0 = awq_layers[0]
@@ -516,11 +512,10 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
                 return make_gptq(k, n, gs, dev, gen, dtype, derive_from=torch.roll(base[key], 1 + salt % 97, 0) ^ salt)
             l70 = build_stack(c70, mk70, dev, gen, dtype)
             base.clear()
-            st = DecodeStep(l70, c70["hidden"], c70["q"], dtype, overlap=(mode == "chain"))
+            st = DecodeStep(l70, c70["hidden"], c70["q"], dtype)
             st.x_in.copy_((torch.randn(c70["hidden"], device=dev, generator=gen) * 0.5).to(dtype))
             ms, g = time_graph(st.run, stream, 20, 3)
-            st.check_status()
-            res.append(decode_entry("C5", f"Llama-3-70B GPTQ int4 g128 batch=1 decode at TP=1 (560 linears / 320 launches per token), mode={mode}",
+            res.append(decode_entry("C5", "Llama-3-70B GPTQ int4 g128 batch=1 decode at TP=1 (560 linears / 320 launches per token), decode chain",
                                     c70, ms, c70["layers"] * 4, extra={"tp": 1}))
             del g, st, l70
         else:

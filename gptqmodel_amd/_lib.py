@@ -17,7 +17,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libgptqhip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/gptqhip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -32,7 +32,7 @@ SIGNATURES = {
     "gptqhip_repack_tiled": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "gptqhip_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_decode_linear": (_i, [_vp, _vp]),
-    "gptqhip_decode_blocks": (_i, [_i, _i, _i]),
+    "gptqhip_decode_supported": (_i, [_i, _i, _i]),
     "gptqhip_dequant": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_dequant_tiled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_repack_awq": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -46,8 +46,7 @@ SIGNATURES = {
 class DecodeOp(ctypes.Structure):
     """struct gptqhip_decode_op (include/gptqhip.h)."""
     _fields_ = [("qweight_t", _vp), ("meta", _vp), ("bias", _vp), ("x", _vp), ("norm_weight", _vp), ("residual", _vp),
-                ("out", _vp), ("wait_counters", _vp), ("signal_counters", _vp), ("status", _vp),
-                ("wait_total", _c.c_uint32), ("eps", _c.c_float),
+                ("out", _vp), ("workspace", _vp), ("workspace_bytes", _sz), ("eps", _c.c_float),
                 ("K", _i), ("N", _i), ("group_size", _i), ("bits", _i), ("act_dtype", _i), ("scale_dtype", _i),
                 ("in_glue", _i)]
 

@@ -293,23 +293,12 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     return GPTQHIP_OK;
 }
 
-static int cu_count_cached() {
-    // CUs of the current device, queried once per device (immutable facts; no other mutable state)
-    static int cached[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    int v = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
-    if (v == 0) {
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        __atomic_store_n(&cached[dev], v, __ATOMIC_RELAXED);
-    }
-    return v;
-}
-
-int gptqhip_decode_blocks(int K, int N, int group_size) {
-    if (K <= 0 || N <= 0 || group_size <= 0 || K % group_size != 0) return 0;
-    const Gemv1Plan pl = plan_gemv1(K, N, group_size, cu_count_cached());
-    return pl.ok ? pl.grid : 0;
+int gptqhip_decode_supported(int K, int N, int group_size) {
+    // the decode op rides on the skinny kernel's regular batch-1 pipeline (straight-line counted-wait ring, one group
+    // constant per 128-row chunk): same predicate as the planner's
+    if (K <= 0 || N <= 0 || group_size <= 0 || K % group_size != 0 || K % 32 != 0 || N % 8 != 0) return 0;
+    const SkinnyPlan pl = plan_skinny(1, K, N, group_size, 0, 0);
+    return (pl.regular && pl.gpc == 1 && pl.mt == 1) ? 1 : 0;
 }
 
 int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) {
@@ -329,37 +318,42 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
         set_error("gptqhip_decode_linear: bad in_glue %d (RMSNORM needs norm_weight)", op->in_glue);
         return GPTQHIP_EINVAL;
     }
-    if (op->wait_counters && !op->status) {
-        set_error("gptqhip_decode_linear: wait_counters needs a status word");
+    if ((size_t)ceil_div(op->N, kTileN) * sizeof(int) > kCounterBytes) {
+        set_error("gptqhip_decode_linear: N=%d too large", op->N);
         return GPTQHIP_EINVAL;
     }
-    const Gemv1Plan pl = plan_gemv1(op->K, op->N, op->group_size, cu_count_cached());
-    if (!pl.ok) {
-        set_error("gptqhip_decode_linear: K=%d group_size=%d not supported by the decode-chain kernel (use gptqhip_gemm)",
+    const SkinnyPlan pl = plan_skinny(1, op->K, op->N, op->group_size, 0, 0);
+    if (!(pl.regular && pl.gpc == 1 && pl.mt == 1)) {
+        set_error("gptqhip_decode_linear: K=%d group_size=%d is outside the decode op's regular pipeline (use gptqhip_gemm)",
                   op->K, op->group_size);
         return GPTQHIP_EINVAL;
     }
-    DecodeArgs a;
+    const WorkspaceLayout L = layout_workspace(1, op->K, op->N, op->group_size, op->bits, 0);
+    if (pl.splits > 1 && (!op->workspace || op->workspace_bytes < L.total)) {
+        set_error("gptqhip_decode_linear: workspace %zu bytes < required %zu", op->workspace_bytes, L.total);
+        return GPTQHIP_ENOMEM;
+    }
+    char* ws = reinterpret_cast<char*>(op->workspace);
+    GemmArgs a;
+    a.x = op->x;
     a.qweight = op->qweight_t;
     a.meta = op->meta;
     a.bias = op->bias;
-    a.x = op->x;
-    a.norm_weight = op->norm_weight;
-    a.residual = op->residual;
     a.out = op->out;
-    a.wait_counters = op->wait_counters;
-    a.signal_counters = op->signal_counters;
-    a.status = op->status;
-    a.wait_total = op->wait_total;
-    a.eps = op->eps;
+    a.M = 1;
     a.K = op->K;
     a.N = op->N;
     a.group_size = op->group_size;
     a.bits = op->bits;
     a.act_dtype = op->act_dtype;
     a.scale_dtype = op->scale_dtype;
+    a.out_f32 = 0;
     a.in_glue = op->in_glue;
-    return launch_gemv1(a, pl, reinterpret_cast<hipStream_t>(stream));
+    a.glue_b = op->norm_weight;
+    a.residual = op->residual;
+    a.eps = op->eps;
+    return launch_skinny(a, pl, ws ? reinterpret_cast<float*>(ws + L.slabs_off) : nullptr,
+                         ws ? reinterpret_cast<int*>(ws + L.counters_off) : nullptr, reinterpret_cast<hipStream_t>(stream));
 }
 
 int gptqhip_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* g_idx,

@@ -19,6 +19,11 @@ struct GemmArgs {
     const int32_t* perm = nullptr;  // act-order permutation the kernel applies to x itself (decode, M == 1), else nullptr
     int exact_bf16 = 0;  // GPTQHIP_GEMM_EXACT_BF16 (decode kernel, bf16 activations)
     int ldo = 0;  // output row stride in elements (0: N) -- lets a launch cover a column sub-range of a wider output
+    // batch-1 decode op (gptqhip_decode_linear): fused decoder-layer glue of the skinny kernel's M == 1 variant
+    int in_glue = 0;                 // GPTQHIP_GLUE_*
+    const void* glue_b = nullptr;    // RMSNORM: norm weight [K]
+    const void* residual = nullptr;  // [N]: out = act(residual + y)
+    float eps = 0.f;
 };
 
 struct SkinnyPlan {
@@ -42,33 +47,6 @@ struct TiledPlan {
     int tail_cols = 0;  // trailing block columns (256 wide) handed to a second launch with 128-row tiles; 0: none
 };
 
-// batch-1 decode op with fused glue and dependency flags (gptqhip_gemv1.hip; include/gptqhip.h: gptqhip_decode_op)
-struct DecodeArgs {
-    const uint32_t* qweight;
-    const uint32_t* meta;
-    const void* bias;
-    const void* x;
-    const void* norm_weight;
-    const void* residual;
-    void* out;
-    uint32_t* wait_counters;
-    uint32_t* signal_counters;
-    uint32_t* status;
-    uint32_t wait_total;
-    float eps;
-    int K, N, group_size, bits, act_dtype, scale_dtype, in_glue;
-};
-
-struct Gemv1Plan {
-    int ok;      // 0: shape not supported by this kernel (K % 128, group_size not 128 * 2^n, odd chunk counts)
-    int chunks, tiles;
-    int waves;   // waves per block = largest divisor of chunks <= 16
-    int cpw;     // chunks per wave per tile
-    int grid;    // blocks = min(tiles, CUs): at most one block per CU
-    int depth;   // register-ring depth (4, 2, 1)
-    size_t lds_bytes;
-};
-
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
@@ -77,9 +55,6 @@ int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* co
 
 TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_variant, int force_split);
 int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, hipStream_t stream);
-
-Gemv1Plan plan_gemv1(int K, int N, int group_size, int cu_count);
-int launch_gemv1(const DecodeArgs& a, const Gemv1Plan& pl, hipStream_t stream);
 
 int launch_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* g_idx, void* out,
                    int K, int N, int group_size, int bits, int scale_dtype, int out_dtype, hipStream_t stream);

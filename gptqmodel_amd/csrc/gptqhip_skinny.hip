@@ -21,6 +21,8 @@
 //     the chip does K also split across blocks (grid.y): fp32 slabs published with write-through (sc1) stores + one
 //     relaxed agent-scope ticket, reduced by the last arriver in a fixed order (deterministic, no float atomics)
 //     -- cdna_hip_programming.md §5 "in-launch split-K reduction".
+#include <stdlib.h>
+
 #include "gptqhip_device.h"
 #include "gptqhip_host.h"
 
@@ -43,7 +45,34 @@ struct SkinnyParams {
     int regular;           // every wave owns a multiple of D chunks: straight-line counted-wait pipeline
     int cpg_shift;         // log2(chunks per group) when group_size is 128 * 2^n, else -1 (integer division)
     int exact_bf16;        // GPTQHIP_GEMM_EXACT_BF16: see compute_stage
+    // batch-1 decode op (gptqhip_decode_linear): decoder-layer glue fused into the GEMV (GLUE template parameter)
+    const void* glue_b;    // RMSNORM: norm weight [K]; SILU_MUL: nullptr (up = x + K)
+    const void* residual;  // [N] or nullptr: out = act(residual + y)
+    float eps;
+    int in_glue;
 };
+
+// Input glue of the batch-1 decode op: what a Llama-style decoder layer computes between two quantised linears, applied
+// to the activation pair of each ring stage on its way into the MFMA A fragment (semantics = HF LlamaRMSNorm / LlamaMLP in
+// the activation dtype).
+constexpr int kGlueNone = 0;
+constexpr int kGlueRmsNorm = 1;  // x' = w * act(h32 * rsqrt(mean(h32^2) + eps))
+constexpr int kGlueSiluMul = 2;  // x' = act(silu(gate)) * up, x = gate | up
+
+template <int ACT>
+__device__ __forceinline__ uint32_t glue_pair(uint32_t a, uint32_t b, float inv, int glue) {
+    const float a0 = bits16_to_f32<ACT>((uint16_t)(a & 0xffffu)), a1 = bits16_to_f32<ACT>((uint16_t)(a >> 16));
+    const float b0 = bits16_to_f32<ACT>((uint16_t)(b & 0xffffu)), b1 = bits16_to_f32<ACT>((uint16_t)(b >> 16));
+    float r0, r1;
+    if (glue == kGlueRmsNorm) {
+        r0 = b0 * round_through<ACT>(a0 * inv);
+        r1 = b1 * round_through<ACT>(a1 * inv);
+    } else {
+        r0 = round_through<ACT>(a0 / (1.0f + __expf(-a0))) * b0;
+        r1 = round_through<ACT>(a1 / (1.0f + __expf(-a1))) * b1;
+    }
+    return (uint32_t)f32_to_16<ACT>(r0) | ((uint32_t)f32_to_16<ACT>(r1) << 16);
+}
 
 // AM: how a wave gets its activations.
 //   AM_ROW1  (M == 1):  ONE 4-byte load per lane per chunk (the chunk's 256 B of the single row), prefetched with the
@@ -85,7 +114,7 @@ struct AStage {
 };
 template <int MT>
 struct AStage<AM_ROW1, MT> {
-    uint32_t a[1];
+    uint32_t a[2];  // [1]: second glue operand (norm weight pair / up pair) of the decode op, unused otherwise
 };
 template <int MT>
 struct AStage<AM_ROW1P, MT> {
@@ -177,7 +206,7 @@ struct LaneOffs {
     uint32_t x[is_rows<AM>() ? 4 * MT : 1];  // byte offsets of this lane's activation loads
 };
 
-template <int BITS, int GPC, int MT, int AM>
+template <int BITS, int GPC, int MT, int AM, int GLUE = 0>
 __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, const SkinnyParams& p, const TileBases& tb,
                                                 const LaneOffs<MT, AM>& lo, Cursor& cu, int stride_chunks) {
     constexpr int WPC = BITS == 4 ? 1 : 2;
@@ -188,6 +217,11 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
     st.meta[0] = *reinterpret_cast<const uint32_t*>(mrow + tb.c4);
     if constexpr (AM == AM_ROW1) {
         st.x.a[0] = *reinterpret_cast<const uint32_t*>(cu.x + lo.x[0]);
+        if constexpr (GLUE == kGlueRmsNorm) {
+            st.x.a[1] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.glue_b) + (cu.x - tb.x) + lo.x[0]);
+        } else if constexpr (GLUE == kGlueSiluMul) {
+            st.x.a[1] = *reinterpret_cast<const uint32_t*>(cu.x + (size_t)p.K * 2 + lo.x[0]);
+        }
     } else if constexpr (AM == AM_ROW1P) {
         const u2_t pr = *reinterpret_cast<const u2_t*>(reinterpret_cast<const char*>(p.perm) + (size_t)cu.chunk * 512 + lo.x[0]);
         st.x.a[0] = pr.x;
@@ -208,15 +242,19 @@ __host__ __device__ constexpr bool kExactBf16() {
     return BITS == 4 && ACT == kBF16 && GPC == 1 && (AM == AM_ROW1 || AM == AM_ROW1P || AM == AM_ROW4);
 }
 
-template <int BITS, int ACT, int SCL, int MT, int GPC, int AM>
+template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int GLUE = 0>
 __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st, const SkinnyParams& p, int chunk,
                                               int lane, u4_t* aslot, const DequantConsts& dk, f4_t (&acc)[MT],
-                                              const uint16_t* xbuf = nullptr) {
+                                              const uint16_t* xbuf = nullptr, float inv = 0.f) {
     const int c = lane & 15;
     const int rq = lane >> 4;
     int abase = 0;  // u4 index of this lane's fragment row inside the wave's LDS slot
     if constexpr (AM == AM_ROW1) {
-        reinterpret_cast<uint32_t*>(aslot)[lane] = st.x.a[0];
+        if constexpr (GLUE == kGlueNone) {
+            reinterpret_cast<uint32_t*>(aslot)[lane] = st.x.a[0];
+        } else {
+            reinterpret_cast<uint32_t*>(aslot)[lane] = glue_pair<ACT>(st.x.a[0], st.x.a[1], inv, GLUE);
+        }
     } else if constexpr (AM == AM_ROW1P) {
         reinterpret_cast<uint32_t*>(aslot)[lane] = (uint32_t)xbuf[st.x.a[0]] | ((uint32_t)xbuf[st.x.a[1]] << 16);
     } else if constexpr (AM == AM_ROW4) {
@@ -287,7 +325,10 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
     }
 }
 
-template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int D>
+// PIPE = 1 (experiment, GPTQHIP_SKINNY_PIPE=1): sched_barrier after every stage's loads in the steady loop, so hipcc cannot
+// sink the four dwordx4 weight loads of a ring round to the end of the round (it does, ISA-checked: the wave then waits a
+// full memory latency once per round instead of keeping D-1 stages in flight under its own compute).
+template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int D, int GLUE = 0, int PIPE = 0>
 __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     // ONE dynamic LDS array (16-B aligned base, no statics in front of it): per-wave activation slots during the K
     // loop, then the split-K reduction buffer red[W][MT*4][64]; the last 16 bytes hold the "last arriver" flag.
@@ -320,6 +361,16 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     tb.c4 = (uint32_t)c * 4u;
     u4_t* aslot = reinterpret_cast<u4_t*>(reinterpret_cast<char*>(lds) + wave * slot_bytes<AM, MT>());
     const DequantConsts dk = make_dequant_consts<BITS>();
+
+    // decode op: the residual of this tile's row-0 outputs (reducer lanes = wave 0, lanes 0..15) is requested up front as
+    // the aligned 32-bit pair holding the column (no zero-extension ALU op behind the load -> no early wait), used in the
+    // epilogue; glue_inv = RMSNorm's rsqrt(mean(h^2) + eps)
+    float glue_inv = 0.f;
+    uint32_t res_raw = 0u;
+    if (p.residual != nullptr && wave == 0 && lane < 16) {
+        const int coln = tile * kTileN + lane;
+        res_raw = reinterpret_cast<const uint32_t*>(p.residual)[(coln < p.N ? coln : 0) >> 1];
+    }
 
     // D-deep register ring: every load of a chunk (weights, constants, activations) is issued D chunks ahead,
     // so a wave keeps D KiB of HBM reads in flight and waits only for the oldest stage.
@@ -373,21 +424,58 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
                 for (int idx = (int)threadIdx.x + 2 * (int)blockDim.x; idx < n16; idx += (int)blockDim.x)
                     reinterpret_cast<u4_t*>(xbuf)[idx] = xs[idx];  // (rows longer than 32 B x threads: rare, plain copy)
                 __syncthreads();
+            } else if constexpr (GLUE == kGlueRmsNorm) {
+                // RMSNorm statistics of the whole input row, once per block: the row (L2-resident) is requested BEFORE the
+                // weight ring so that waiting for it does not wait for HBM (vmcnt retires in issue order); the reduction
+                // runs while the ring's first loads are in flight.  Fixed summation order: deterministic.
+                const u4_t* hs = reinterpret_cast<const u4_t*>(p.x);
+                const int n16 = p.K / 8;
+                u4_t hr[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int idx = (int)threadIdx.x + i * (int)blockDim.x;
+                    hr[i] = hs[idx < n16 ? idx : 0];
+                }
+#pragma unroll
+                for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
+                float ss = 0.f;
+                auto sq = [&](const u4_t& h) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = bits16_to_f32<ACT>((uint16_t)(h[j] & 0xffffu)), b = bits16_to_f32<ACT>((uint16_t)(h[j] >> 16));
+                        ss = __builtin_fmaf(a, a, ss);
+                        ss = __builtin_fmaf(b, b, ss);
+                    }
+                };
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if ((int)threadIdx.x + i * (int)blockDim.x < n16) sq(hr[i]);
+                }
+                for (int idx = (int)threadIdx.x + 2 * (int)blockDim.x; idx < n16; idx += (int)blockDim.x) sq(hs[idx]);
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+                float* scratch = reinterpret_cast<float*>(xbuf);  // (no act-order staging buffer in this variant)
+                if (lane == 0) scratch[wave] = ss;
+                __syncthreads();
+                float tot = 0.f;
+                for (int w = 0; w < W; ++w) tot += scratch[w];
+                glue_inv = rsqrtf(tot / (float)p.K + p.eps);
             } else {
 #pragma unroll
-                for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM>(st[d], p, tb, lo, cu, W);
+                for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
             }
             for (int it = D; it < n_mine; it += D) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc, xbuf);
-                    load_stage_fast<BITS, GPC, MT, AM>(st[d], p, tb, lo, cu, W);
+                    compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE>(st[d], p, cur, lane, aslot, dk, acc, xbuf, glue_inv);
+                    load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
+                    if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
                     cur += W;
                 }
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[d], p, cur, lane, aslot, dk, acc, xbuf);
+                compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE>(st[d], p, cur, lane, aslot, dk, acc, xbuf, glue_inv);
                 cur += W;
             }
         }
@@ -470,6 +558,9 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     } else if (live) {
         float y = round_through<ACT>(v);
         if (p.bias != nullptr) y = y + load16_as_f32<ACT>(p.bias, (size_t)n);
+        if (p.residual != nullptr) {  // decode op (M == 1): hidden = residual + linear(x), each step rounded like torch
+            y = bits16_to_f32<ACT>((uint16_t)(res_raw >> ((lane & 1) * 16))) + round_through<ACT>(y);
+        }
         reinterpret_cast<uint16_t*>(p.out)[(size_t)m * p.N + n] = f32_to_16<ACT>(y);
     }
 }
@@ -482,7 +573,24 @@ static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStr
     const dim3 grid(ceil_div(p.N, kTileN), p.splits);
     const dim3 block(64 * pl.waves);
     constexpr int kSlot = slot_bytes<AM, MT>() > MT * 1024 ? slot_bytes<AM, MT>() : MT * 1024;
-    const size_t lds_bytes = (size_t)pl.waves * kSlot + 16 + (AM == AM_ROW1P ? (size_t)p.K * 2 : 0);
+    const size_t lds_bytes = (size_t)pl.waves * kSlot + 16 + (AM == AM_ROW1P ? (size_t)p.K * 2 : 64);
+    if constexpr (AM == AM_ROW1 && MT == 1 && D == 4) {
+        static const bool pipe = [] { const char* v = getenv("GPTQHIP_SKINNY_PIPE"); return v && *v && *v != '0'; }();
+        if (p.in_glue != kGlueNone) {  // decode op with input glue: regular single-group-per-chunk plans only (ABI checks)
+            if (p.in_glue == kGlueRmsNorm) {
+                if (pipe) hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueRmsNorm, 1>), grid, block, lds_bytes, stream, p);
+                else hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueRmsNorm>), grid, block, lds_bytes, stream, p);
+            } else {
+                if (pipe) hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueSiluMul, 1>), grid, block, lds_bytes, stream, p);
+                else hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueSiluMul>), grid, block, lds_bytes, stream, p);
+            }
+            return check_hip(hipGetLastError(), "skinny_kernel (decode glue) launch");
+        }
+        if (pipe && pl.gpc == 1) {
+            hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, 0, 1>), grid, block, lds_bytes, stream, p);
+            return check_hip(hipGetLastError(), "skinny_kernel launch");
+        }
+    }
     if (pl.gpc == 1) {
         hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D>), grid, block, lds_bytes, stream, p);
     } else {
@@ -577,6 +685,10 @@ int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* co
         }
     }
     p.exact_bf16 = a.exact_bf16;
+    p.glue_b = a.glue_b;
+    p.residual = a.residual;
+    p.eps = a.eps;
+    p.in_glue = a.in_glue;
 #define GPTQHIP_DISPATCH(B, A_, S_) return launch_skinny_mt<B, A_, S_>(p, pl, stream)
     if (a.bits == 4) {
         if (a.act_dtype == kFP16 && a.scale_dtype == kFP16) GPTQHIP_DISPATCH(4, kFP16, kFP16);

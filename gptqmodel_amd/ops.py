@@ -143,23 +143,21 @@ def gemm(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Opt
 
 
 GLUE_NONE, GLUE_RMSNORM, GLUE_SILU_MUL = 0, 1, 2
-COUNTER_SHARDS = 64  # uint32 arrival counters per decode op (one 256-byte line)
 
 
-def decode_blocks(K: int, N: int, group_size: int) -> int:
-    """Blocks gptqhip_decode_linear launches for a [K,N] layer (= the wait_total its consumer passes); 0 = the
-    decode-chain kernel does not support the shape."""
-    return int(_lib.load().gptqhip_decode_blocks(K, N, group_size))
+def decode_supported(K: int, N: int, group_size: int) -> bool:
+    """True when gptqhip_decode_linear handles a [K,N] layer (regular batch-1 pipeline), else use gemm()."""
+    return bool(_lib.load().gptqhip_decode_supported(K, N, group_size))
 
 
 def make_decode_op(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,
                    K: int, N: int, group_size: int, bits: int, scale_dtype: torch.dtype, in_glue: int = GLUE_NONE,
                    norm_weight: Optional[torch.Tensor] = None, eps: float = 1e-5, residual: Optional[torch.Tensor] = None,
-                   wait: Optional[torch.Tensor] = None, wait_total: int = 0, signal: Optional[torch.Tensor] = None,
-                   status: Optional[torch.Tensor] = None) -> "_lib.DecodeOp":
+                   workspace: Optional[torch.Tensor] = None) -> "_lib.DecodeOp":
     """Fill a struct gptqhip_decode_op (include/gptqhip.h) from tensors.  The struct only holds raw pointers: the caller
-    keeps the tensors alive (DecodeStep below does) -- binding once and re-launching costs no per-call Python work."""
-    _require_cuda(x, qweight_t, meta, bias, out, norm_weight, residual, wait, signal, status)
+    keeps the tensors alive (DecodeStep does) -- binding once and re-launching costs no per-call Python work.
+    `workspace`: the stream's scratch (workspace_for); taken from the CURRENT stream when omitted."""
+    _require_cuda(x, qweight_t, meta, bias, out, norm_weight, residual, workspace)
     if x.dtype not in _DT or out.dtype != x.dtype or scale_dtype not in _DT:
         raise RuntimeError(f"decode op: unsupported dtypes x={x.dtype} out={out.dtype} scales={scale_dtype}")
     need = 2 * K if in_glue == GLUE_SILU_MUL else K
@@ -168,17 +166,14 @@ def make_decode_op(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor,
     for t, n, what in ((bias, N, "bias"), (residual, N, "residual"), (norm_weight, K, "norm_weight")):
         if t is not None and (t.dtype != x.dtype or t.numel() < n or not t.is_contiguous()):
             raise RuntimeError(f"decode op: {what} must be a contiguous {x.dtype} tensor with >= {n} elements")
-    for t, what in ((wait, "wait"), (signal, "signal")):
-        if t is not None and (t.dtype != torch.int32 or t.numel() < COUNTER_SHARDS or not t.is_contiguous()):
-            raise RuntimeError(f"decode op: {what} counters must be a contiguous int32 tensor of {COUNTER_SHARDS}")
     if in_glue == GLUE_RMSNORM and norm_weight is None:
         raise RuntimeError("decode op: GLUE_RMSNORM needs norm_weight")
-    if wait is not None and status is None:
-        raise RuntimeError("decode op: waiting ops need a status word")
+    if workspace is None:
+        with torch.cuda.device(x.device):
+            workspace = workspace_for(x.device, workspace_bytes(1, K, N, group_size, bits, False))
     p = lambda t: 0 if t is None else t.data_ptr()
-    return _lib.DecodeOp(p(qweight_t), p(meta), p(bias), p(x), p(norm_weight), p(residual), p(out), p(wait), p(signal),
-                         p(status), int(wait_total), float(eps), K, N, group_size, bits, _DT[x.dtype], _DT[scale_dtype],
-                         int(in_glue))
+    return _lib.DecodeOp(p(qweight_t), p(meta), p(bias), p(x), p(norm_weight), p(residual), p(out), p(workspace),
+                         workspace.numel(), float(eps), K, N, group_size, bits, _DT[x.dtype], _DT[scale_dtype], int(in_glue))
 
 
 def launch_decode_op(op: "_lib.DecodeOp", device: torch.device) -> None:
@@ -193,8 +188,8 @@ def decode_linear(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, 
     out = kw.pop("out", None)
     if out is None:
         out = torch.empty(N, dtype=x.dtype, device=x.device)
-    op = make_decode_op(x, qweight_t, meta, bias, out, K, N, group_size, bits, scale_dtype, **kw)
     with torch.cuda.device(x.device):
+        op = make_decode_op(x, qweight_t, meta, bias, out, K, N, group_size, bits, scale_dtype, **kw)
         launch_decode_op(op, x.device)
     return out
 

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 2
+#define GPTQHIP_ABI_VERSION 3
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -116,30 +116,25 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight_t, const uint32_t* meta,
                  int M, int K, int N, int group_size, int bits,
                  int act_dtype, int scale_dtype, int flags, gptqhip_stream_t stream);
 
-/* BATCH-1 DECODE OP with fused decoder-layer glue and in-launch dependency flags (gptqmodel_amd/csrc/gptqhip_gemv1.hip).
+/* BATCH-1 DECODE OP with fused decoder-layer glue (the skinny kernel's M = 1 pipeline, gptqmodel_amd/csrc/gptqhip_skinny.hip).
  *
  * One call = one quantised linear of a decode step, out[N] = glue_out( glue_in(x)[K] @ dequant(qweight_t, meta) + bias ):
  * the same contraction and rounding chain as gptqhip_gemm at M = 1 (TorchLinear.forward, torch.py:302-347), plus the
- * elementwise ops a Llama-style decoder layer runs between its linears, so that no separate glue launches sit on the
- * token's critical path:
+ * elementwise ops a Llama-style decoder layer runs between its linears, so that no separate glue launches (each one a
+ * dependent-kernel boundary of ~2-3 us at batch 1) sit on the token's critical path:
  *   in_glue  GPTQHIP_GLUE_NONE      x [K]
  *            GPTQHIP_GLUE_RMSNORM   x [K] = the residual stream h; the kernel feeds norm_weight * act(h32 * rsqrt(mean(h32^2)
  *                                   + eps)) (HF LlamaRMSNorm: fp32 statistics, rounded to the activation dtype, then * weight)
  *            GPTQHIP_GLUE_SILU_MUL  x [2K] = gate | up; the kernel feeds act(silu(gate)) * up (HF LlamaMLP)
- *   residual [N] or NULL: out = act(residual + y)   (hidden = residual + hidden, one rounding)
- * Dependency flags (optional): ops of one decode step form a chain.  Consecutive ops may be enqueued on TWO streams
- * (even ops / odd ops) so that op i+1 already streams its packed weights while op i finishes: op i+1 then waits in the
- * kernel -- after issuing its first weight loads -- until the 64 arrival counters at wait_counters sum to wait_total
- * (= the producer's block count, gptqhip_decode_blocks()), and op i arrives on signal_counters once its outputs are
- * stored (agent-scope write-through stores, read by agent-scope loads: no fences on the edge).  Every op has a fixed
- * footprint of at most one block of <= 16 waves per CU, <= 64 VGPRs, < 80 KiB LDS, so two ops are always co-resident and
- * a spinning consumer can never starve its producer; spins are bounded and report through *status (|= 1) instead of
- * hanging.  Counters must be zero before the first op of a step (hipMemsetAsync / memset graph node: 256 B per op).
- * Without flags (both NULL) the op is an ordinary stream-ordered launch.
- * Supported: K % 128 == 0, group_size = 128 * 2^n, K/128 with a divisor in [4,16] (all Llama shapes), bits 4 | 8;
- * anything else returns GPTQHIP_EINVAL -- use gptqhip_gemm (+ separate glue) there.  No new reference interface is
- * replaced by the glue: it mirrors what the reference's caller (HF LlamaDecoderLayer) does between QuantLinear.forward
- * calls. */
+ *   residual [N] or NULL: out = act(residual + y)   (hidden = residual + hidden, one more rounding)
+ * The glue is applied to each ring stage's activation pair on its way into the MFMA A fragment (RMSNorm statistics are
+ * reduced once per block while the first weight loads are in flight).  Stream-ordered like every other entry point.
+ * Supported: shapes on the decode kernel's regular pipeline (K % 128 == 0, group_size = 128 * 2^n, a wave count dividing
+ * K / 128 evenly -- every Llama-3 8B / 70B shape, also tensor-parallel shards), bits 4 | 8, no act-order permutation;
+ * gptqhip_decode_supported() tells, anything else returns GPTQHIP_EINVAL -- use gptqhip_gemm (+ separate glue) there.
+ * workspace: as gptqhip_gemm (gptqhip_workspace_bytes(1, K, N, ...)); only narrow layers (cross-block split-K) touch it.
+ * The glue replaces no reference interface: it mirrors what the reference's caller (HF LlamaDecoderLayer) does between
+ * QuantLinear.forward calls. */
 #define GPTQHIP_GLUE_NONE 0
 #define GPTQHIP_GLUE_RMSNORM 1
 #define GPTQHIP_GLUE_SILU_MUL 2
@@ -151,16 +146,14 @@ typedef struct gptqhip_decode_op {
     const void* norm_weight;     /* [K] act dtype (GPTQHIP_GLUE_RMSNORM) else NULL             */
     const void* residual;        /* [N] act dtype or NULL                                      */
     void* out;                   /* [N] act dtype                                              */
-    uint32_t* wait_counters;     /* [64] or NULL                                               */
-    uint32_t* signal_counters;   /* [64] or NULL                                               */
-    uint32_t* status;            /* device word (required with wait_counters)                  */
-    uint32_t wait_total;
+    void* workspace;             /* zero-initialised scratch as for gptqhip_gemm, or NULL      */
+    size_t workspace_bytes;
     float eps;
     int K, N, group_size, bits, act_dtype, scale_dtype, in_glue;
 } gptqhip_decode_op;
 int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream);
-/* Blocks the op above launches for a [K,N] layer (= what its consumer passes as wait_total); 0 if unsupported. */
-int gptqhip_decode_blocks(int K, int N, int group_size);
+/* 1 if gptqhip_decode_linear supports a [K,N] layer with this group size, else 0. */
+int gptqhip_decode_supported(int K, int N, int group_size);
 
 /* Materialise W[K,N] from the CHECKPOINT layout in `out_dtype` (= scales dtype in the reference).  Replaces
  * TorchLinear.dequantize_weight (torch.py:225) / PackableQuantLinear.dequantize_weight

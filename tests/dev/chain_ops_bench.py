@@ -38,7 +38,7 @@ for name, K, N, glue, res in SHAPES:
             ops.gemm(x2, l.qweight, l.meta, None, None, N, 128, 4, l._scale_dtype)
     by = B.algorithmic_bytes(1, K, N)
     res_line = [f"{name:8s} K={K:5d} N={N:5d} {by/1e6:6.2f} MB"]
-    for tag, fn in (("gemv1+glue", run_gemv1), ("gemv1", run_gemv1_plain), ("skinny", run_skinny)):
+    for tag, fn in (("decode+glue", run_gemv1), ("decode", run_gemv1_plain), ("gemm(M=1)", run_skinny)):
         ms, g = B.time_graph(fn, stream, 30, 5)
         us = ms * 1e3 / NL
         res_line.append(f"{tag} {us:6.2f} us {by/us/1e6:5.2f} TB/s")

@@ -1,7 +1,6 @@
-"""GPU tests of the batch-1 decode-chain op (gptqhip_decode_linear, csrc/gptqhip_gemv1.hip): the GEMV against the oracle,
-the fused glue against the HF-semantics restatement in the oracle, and the in-launch dependency flags: a chain enqueued on
-two streams (op i+1 prefetching while op i runs) must be BIT-IDENTICAL to the same ops in plain stream order, replay
-after replay, with the inputs changing under it."""
+"""GPU tests of the batch-1 decode op (gptqhip_decode_linear: the skinny kernel's M = 1 pipeline with fused decoder-layer
+glue): the GEMV against the oracle, the fused glue against the HF-semantics restatement in the oracle, and a chain of
+dependent ops (DecodeStep) against the same step run as separate launches (plugin forward() + torch glue)."""
 import numpy as np
 import pytest
 import torch
@@ -25,8 +24,8 @@ def _tiled(ops, qweight, qzeros, scales, gs, bits, sdt="fp16"):
     return ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV), sc, None, gs, bits) + (sc,)
 
 
-@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096), (8192, 1024), (1024, 8192),
-                                 (28672, 512), (4096, 1000)])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096), (8192, 1024), (8192, 10240),
+                                 (28672, 512), (4096, 1000), (4096, 512)])
 @pytest.mark.parametrize("act,bits", [("fp16", 4), ("bf16", 4), ("fp16", 8)])
 def test_decode_op_plain_vs_oracle(ops, K, N, act, bits):
     gs = 128
@@ -35,7 +34,7 @@ def test_decode_op_plain_vs_oracle(ops, K, N, act, bits):
     x = O.round_to(rng.randn(1, K).astype(np.float32) * 0.5, act)
     bias = O.round_to(rng.randn(N).astype(np.float32) * 0.1, act)
     qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, gs, bits)
-    assert ops.decode_blocks(K, N, gs) == min(256, -(-N // 16))
+    assert ops.decode_supported(K, N, gs)
     out = ops.decode_linear(f32_to_torch(x[0], act, DEV), qw_t, meta, f32_to_torch(bias, act, DEV), K, N, gs, bits, sc.dtype)
     torch.cuda.synchronize()
     ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, bits, bias, act, "fp16")
@@ -77,8 +76,8 @@ def test_decode_op_fused_glue_vs_hf_semantics(ops, act):
 def test_decode_op_rejects_unsupported_shapes(ops):
     qweight, qzeros, scales, _ = synth_gptq(1, 4, 256, 64, 64)
     qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, 64, 4)
-    assert ops.decode_blocks(256, 64, 64) == 0
-    with pytest.raises(RuntimeError, match="not supported by the decode-chain kernel"):
+    assert not ops.decode_supported(256, 64, 64)
+    with pytest.raises(RuntimeError, match="outside the decode op's regular pipeline"):
         ops.decode_linear(torch.zeros(256, dtype=torch.float16, device=DEV), qw_t, meta, None, 256, 64, 64, 4, sc.dtype)
     with pytest.raises(RuntimeError, match="norm_weight"):
         ops.decode_linear(torch.zeros(256, dtype=torch.float16, device=DEV), qw_t, meta, None, 256, 64, 64, 4, sc.dtype,
@@ -94,7 +93,10 @@ def _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype, seed=0):
     def lin(k, n):
         m = HipGptqLinear(bits=4, group_size=128, sym=True, desc_act=False, in_features=k, out_features=n, bias=False,
                           register_buffers=False)
-        m.qweight = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=DEV, generator=gen)
+        w = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=DEV, generator=gen)
+        # code 0 -> 8: codes symmetric around the sym zero-point 8, i.e. zero-mean weights like a real checkpoint (with
+        # plain uniform codes every linear has a DC gain of -0.005*K and the fp16 residual stream overflows in 3 layers)
+        m.qweight = w | (((~(w | (w >> 1) | (w >> 2) | (w >> 3))) & 0x11111111) << 3)
         m.qzeros = torch.full((k // 128, n // 8), -2004318072, dtype=torch.int32, device=DEV)
         m.scales = (torch.rand((k // 128, n), device=DEV, generator=gen) * 0.01 + 0.005).to(dtype)
         m.g_idx = torch.arange(k, device=DEV, dtype=torch.int32) // 128
@@ -130,64 +132,32 @@ def _reference_step(layers, x_in, q_dim, inter, eps):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_chain_overlap_equals_serial_and_tracks_unfused_reference(dtype):
+def test_chain_tracks_unfused_reference_and_replays_identically(dtype):
     from gptqmodel_amd.utils.decode_chain import DecodeStep
     hidden, inter, q_dim, kv_dim, n_layers = 4096, 14336, 4096, 1024, 3
     layers = _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype)
-    serial = DecodeStep(layers, hidden, q_dim, dtype, overlap=False)
-    over = DecodeStep(layers, hidden, q_dim, dtype, overlap=True)
+    step = DecodeStep(layers, hidden, q_dim, dtype)
     gen = torch.Generator(device=DEV)
     gen.manual_seed(5)
     xs = [(torch.randn(hidden, device=DEV, generator=gen) * 0.5).to(dtype) for _ in range(3)]
     want = []
     for x in xs:
-        serial.x_in.copy_(x)
-        want.append(serial.run().clone())
+        step.x_in.copy_(x)
+        want.append(step.run().clone())
         ref = _reference_step(layers, x, q_dim, inter, 1e-5)
-        # fused vs unfused: same math, different kernels / accumulation orders through 12 dependent linears
+        assert torch.isfinite(want[-1]).all() and torch.isfinite(ref).all()
+        # fused vs unfused: same math, different launches / glue kernels through 12 dependent linears
         assert rel_err(torch_to_f32(want[-1]), torch_to_f32(ref)) <= (4e-3 if dtype == torch.float16 else 3e-2)
-    torch.cuda.synchronize()
-    # eager two-stream overlap
-    for i in range(30):
-        over.x_in.copy_(xs[i % 3])
-        got = over.run()
-        assert torch.equal(got, want[i % 3]), f"overlap differs from serial at eager step {i}"
-    over.check_status()
-    # graph replay of the two-stream step
+    # graph replay of the step: deterministic, tracks the changing input
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
-        over.run()
+        step.run()
         s.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
-            out = over.run()
-        for i in range(200):
-            over.x_in.copy_(xs[i % 3], non_blocking=True)
+            out = step.run()
+        for i in range(30):
+            step.x_in.copy_(xs[i % 3], non_blocking=True)
             g.replay()
-            if i % 20 == 0 or i > 190:
-                assert torch.equal(out, want[i % 3]), f"overlap graph replay {i} differs from serial"
+            assert torch.equal(out, want[i % 3]), f"graph replay {i} differs from the eager step"
         s.synchronize()
-    over.check_status()
-
-
-def test_chain_under_foreign_load():
-    """The dependency flags must hold while other work competes for the CUs and the memory system (uneven load is where
-    stale-read bugs show, MI355X_MICROARCH.md): a big elementwise kernel stream runs beside the replays."""
-    from gptqmodel_amd.utils.decode_chain import DecodeStep
-    hidden, inter, q_dim, kv_dim = 4096, 14336, 4096, 1024
-    layers = _make_stack(2, hidden, inter, q_dim, kv_dim, torch.float16, seed=7)
-    serial = DecodeStep(layers, hidden, q_dim, torch.float16, overlap=False)
-    over = DecodeStep(layers, hidden, q_dim, torch.float16, overlap=True)
-    x = (torch.randn(hidden, device=DEV) * 0.5).half()
-    serial.x_in.copy_(x)
-    want = serial.run().clone()
-    over.x_in.copy_(x)
-    noise_stream = torch.cuda.Stream()
-    big = torch.randn(64 << 20, device=DEV)
-    for i in range(40):
-        with torch.cuda.stream(noise_stream):
-            big.mul_(1.0001)
-        got = over.run()
-        assert torch.equal(got, want), i
-    torch.cuda.synchronize()
-    over.check_status()
