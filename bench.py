@@ -119,6 +119,9 @@ def build_stack(cfg, maker, dev, gen, dtype, n_layers=None):
     layers = []
     for _ in range(n_layers or cfg["layers"]):
         qkv, o, gu, down = [maker(k, n) for k, n in launch_shapes(cfg)]
+        # random columns: the fused gate|up module counts as interleaved in blocks of 8 (utils.model.fuse_gate_up_interleaved),
+        # so the decode chain applies SiLU*mul in its epilogue; the "modules" mode de-interleaves its output accordingly
+        gu.gate_up_interleaved = True
         nw = lambda: (1.0 + 0.1 * torch.randn(cfg["hidden"], device=dev, generator=gen)).to(dtype)
         layers.append(DecodeLayer(qkv, o, gu, down, nw(), nw()))
     return layers
@@ -433,13 +436,14 @@ class ModulesStep:
         return w * (v32 * torch.rsqrt(v32.pow(2).mean(-1, keepdim=True) + self.eps)).to(self.dtype)
 
     def run(self):
-        q, inter = self.cfg["q"], self.cfg["inter"]
+        from gptqmodel_amd.utils.model import deinterleave_gate_up
+        q = self.cfg["q"]
         h = self.x_in[None]
         for L in self.layers:
             qkv = L.qkv(self._rms(h, L.input_norm))
             h = h + L.o(qkv[:, :q])
-            gu = L.gate_up(self._rms(h, L.post_norm))
-            h = h + L.down(torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:])
+            g, u = deinterleave_gate_up(L.gate_up(self._rms(h, L.post_norm)))
+            h = h + L.down(torch.nn.functional.silu(g) * u)
         self.out = h
         return h
 

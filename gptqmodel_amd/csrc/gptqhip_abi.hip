@@ -322,6 +322,18 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
         set_error("gptqhip_decode_linear: N=%d too large", op->N);
         return GPTQHIP_EINVAL;
     }
+    if (op->out_glue != GPTQHIP_OUT_NONE && op->out_glue != GPTQHIP_OUT_SILU_MUL_PAIRED) {
+        set_error("gptqhip_decode_linear: bad out_glue %d", op->out_glue);
+        return GPTQHIP_EINVAL;
+    }
+    if (op->out_glue == GPTQHIP_OUT_SILU_MUL_PAIRED && (op->N % 16 != 0 || op->residual || op->stats_out)) {
+        set_error("gptqhip_decode_linear: OUT_SILU_MUL_PAIRED needs N %% 16 == 0 and excludes residual / stats_out");
+        return GPTQHIP_EINVAL;
+    }
+    if (op->stats_in && (op->in_glue != GPTQHIP_GLUE_RMSNORM || op->stats_n <= 0 || op->stats_n > 512)) {
+        set_error("gptqhip_decode_linear: stats_in needs in_glue RMSNORM and 1..512 partial sums (got %d)", op->stats_n);
+        return GPTQHIP_EINVAL;
+    }
     const SkinnyPlan pl = plan_skinny(1, op->K, op->N, op->group_size, 0, 0);
     if (!(pl.regular && pl.gpc == 1 && pl.mt == 1)) {
         set_error("gptqhip_decode_linear: K=%d group_size=%d is outside the decode op's regular pipeline (use gptqhip_gemm)",
@@ -352,6 +364,10 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
     a.glue_b = op->norm_weight;
     a.residual = op->residual;
     a.eps = op->eps;
+    a.stats_in = op->stats_in;
+    a.stats_n = op->stats_n;
+    a.stats_out = op->stats_out;
+    a.out_glue = op->out_glue;
     return launch_skinny(a, pl, ws ? reinterpret_cast<float*>(ws + L.slabs_off) : nullptr,
                          ws ? reinterpret_cast<int*>(ws + L.counters_off) : nullptr, reinterpret_cast<hipStream_t>(stream));
 }

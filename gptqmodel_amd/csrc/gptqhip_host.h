@@ -24,6 +24,10 @@ struct GemmArgs {
     const void* glue_b = nullptr;    // RMSNORM: norm weight [K]
     const void* residual = nullptr;  // [N]: out = act(residual + y)
     float eps = 0.f;
+    const float* stats_in = nullptr; // RMSNORM: producer's per-tile sums of h^2
+    int stats_n = 0;
+    float* stats_out = nullptr;      // per-tile sums of out^2 for the next op's RMSNorm
+    int out_glue = 0;                // GPTQHIP_OUT_*
 };
 
 struct SkinnyPlan {

@@ -48,9 +48,16 @@ struct SkinnyParams {
     // batch-1 decode op (gptqhip_decode_linear): decoder-layer glue fused into the GEMV (GLUE template parameter)
     const void* glue_b;    // RMSNORM: norm weight [K]; SILU_MUL: nullptr (up = x + K)
     const void* residual;  // [N] or nullptr: out = act(residual + y)
+    const float* stats_in; // RMSNORM: per-producer-tile sums of h^2 ([stats_n] floats) written by the op that produced h; nullptr: the
+                           // block reduces the row itself
+    float* stats_out;      // [ceil(N/16)] or nullptr: sum over this tile's 16 outputs of out^2 (the next op's RMSNorm statistic)
     float eps;
     int in_glue;
+    int out_glue;          // kOutSiluMul: column tiles hold 8 gate + 8 up columns; out[N/2] = act(silu(gate)) * up
+    int stats_n;
 };
+constexpr int kOutNone = 0;
+constexpr int kOutSiluMul = 1;
 
 // Input glue of the batch-1 decode op: what a Llama-style decoder layer computes between two quantised linears, applied
 // to the activation pair of each ring stage on its way into the MFMA A fragment (semantics = HF LlamaRMSNorm / LlamaMLP in
@@ -424,7 +431,26 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
                 for (int idx = (int)threadIdx.x + 2 * (int)blockDim.x; idx < n16; idx += (int)blockDim.x)
                     reinterpret_cast<u4_t*>(xbuf)[idx] = xs[idx];  // (rows longer than 32 B x threads: rare, plain copy)
                 __syncthreads();
+            } else if (GLUE == kGlueRmsNorm && p.stats_in != nullptr) {
+                // RMSNorm statistics handed over by the op that produced h (one partial per 16-column tile, its epilogue's
+                // sum of out^2): every wave sums them itself in a fixed order -- one L2 load per lane issued before the
+                // weight ring, a shuffle tree, no LDS, no block barrier, and nothing redundant but 1 KiB per wave
+                float ssum = 0.f;
+                float sv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int idx = lane + 64 * i;
+                    sv[i] = (i * 64 < p.stats_n) ? p.stats_in[idx < p.stats_n ? idx : 0] : 0.f;
+                }
+#pragma unroll
+                for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ssum += (lane + 64 * i < p.stats_n) ? sv[i] : 0.f;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) ssum += __shfl_xor(ssum, m, 64);
+                glue_inv = rsqrtf(ssum / (float)p.K + p.eps);
             } else if constexpr (GLUE == kGlueRmsNorm) {
+                // (no producer statistics: e.g. the first op of a step, whose input comes from outside the chain)
                 // RMSNorm statistics of the whole input row, once per block: the row (L2-resident) is requested BEFORE the
                 // weight ring so that waiting for it does not wait for HBM (vmcnt retires in issue order); the reduction
                 // runs while the ring's first loads are in flight.  Fixed summation order: deterministic.
@@ -555,6 +581,29 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     // ---- epilogue: round like the reference (matmul result, then += bias in the activation dtype) ----
     if (live && p.out_f32) {
         reinterpret_cast<float*>(p.out)[(size_t)m * p.N + n] = v;
+    } else if (p.out_glue == kOutSiluMul || p.stats_out != nullptr) {
+        // decode op (M == 1) epilogues that combine the tile's 16 outputs: wave 0 (accumulator row 0 = lanes 0..15) runs them
+        // wave-uniformly so the lane shuffles are legal
+        if (wave == 0) {
+            float y = round_through<ACT>(v);
+            if (p.bias != nullptr && live) y = round_through<ACT>(y + load16_as_f32<ACT>(p.bias, (size_t)n));
+            if (p.out_glue == kOutSiluMul) {
+                // interleaved gate|up tile (fuse_gate_up_interleaved): lanes 0..7 hold gate columns j, lanes 8..15 the matching
+                // up columns; HF LlamaMLP: act(silu(gate)) * up, each rounded in the activation dtype
+                const float up = __shfl_down(y, 8, 64);
+                const float a = round_through<ACT>(y / (1.0f + __expf(-y))) * up;
+                const int j = tile * 8 + lane;
+                if (live && lane < 8 && j < p.N / 2) reinterpret_cast<uint16_t*>(p.out)[j] = f32_to_16<ACT>(a);
+            } else {
+                if (p.residual != nullptr) y = bits16_to_f32<ACT>((uint16_t)(res_raw >> ((lane & 1) * 16))) + y;
+                const float h = round_through<ACT>(y);
+                if (live) reinterpret_cast<uint16_t*>(p.out)[n] = f32_to_16<ACT>(h);
+                float sq = live ? h * h : 0.f;  // RMSNorm statistic of the NEXT op: fixed shuffle tree over the 16 columns
+#pragma unroll
+                for (int mk = 8; mk >= 1; mk >>= 1) sq += __shfl_xor(sq, mk, 64);
+                if (lane == 0) p.stats_out[tile] = sq;
+            }
+        }
     } else if (live) {
         float y = round_through<ACT>(v);
         if (p.bias != nullptr) y = y + load16_as_f32<ACT>(p.bias, (size_t)n);
@@ -689,6 +738,10 @@ int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* co
     p.residual = a.residual;
     p.eps = a.eps;
     p.in_glue = a.in_glue;
+    p.stats_in = a.stats_in;
+    p.stats_out = a.stats_out;
+    p.out_glue = a.out_glue;
+    p.stats_n = a.stats_n;
 #define GPTQHIP_DISPATCH(B, A_, S_) return launch_skinny_mt<B, A_, S_>(p, pl, stream)
     if (a.bits == 4) {
         if (a.act_dtype == kFP16 && a.scale_dtype == kFP16) GPTQHIP_DISPATCH(4, kFP16, kFP16);

@@ -143,6 +143,7 @@ def gemm(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Opt
 
 
 GLUE_NONE, GLUE_RMSNORM, GLUE_SILU_MUL = 0, 1, 2
+OUT_NONE, OUT_SILU_MUL_PAIRED = 0, 1
 
 
 def decode_supported(K: int, N: int, group_size: int) -> bool:
@@ -153,16 +154,22 @@ def decode_supported(K: int, N: int, group_size: int) -> bool:
 def make_decode_op(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,
                    K: int, N: int, group_size: int, bits: int, scale_dtype: torch.dtype, in_glue: int = GLUE_NONE,
                    norm_weight: Optional[torch.Tensor] = None, eps: float = 1e-5, residual: Optional[torch.Tensor] = None,
-                   workspace: Optional[torch.Tensor] = None) -> "_lib.DecodeOp":
+                   workspace: Optional[torch.Tensor] = None, out_glue: int = OUT_NONE,
+                   stats_in: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None) -> "_lib.DecodeOp":
     """Fill a struct gptqhip_decode_op (include/gptqhip.h) from tensors.  The struct only holds raw pointers: the caller
     keeps the tensors alive (DecodeStep does) -- binding once and re-launching costs no per-call Python work.
     `workspace`: the stream's scratch (workspace_for); taken from the CURRENT stream when omitted."""
-    _require_cuda(x, qweight_t, meta, bias, out, norm_weight, residual, workspace)
+    _require_cuda(x, qweight_t, meta, bias, out, norm_weight, residual, workspace, stats_in, stats_out)
     if x.dtype not in _DT or out.dtype != x.dtype or scale_dtype not in _DT:
         raise RuntimeError(f"decode op: unsupported dtypes x={x.dtype} out={out.dtype} scales={scale_dtype}")
     need = 2 * K if in_glue == GLUE_SILU_MUL else K
-    if x.numel() < need or not x.is_contiguous() or out.numel() < N or not out.is_contiguous():
-        raise RuntimeError(f"decode op: x needs >= {need} contiguous elements (has {x.numel()}), out >= {N}")
+    n_out = N // 2 if out_glue == OUT_SILU_MUL_PAIRED else N
+    if x.numel() < need or not x.is_contiguous() or out.numel() < n_out or not out.is_contiguous():
+        raise RuntimeError(f"decode op: x needs >= {need} contiguous elements (has {x.numel()}), out >= {n_out}")
+    tiles_in, tiles_out = -(-K // 16), -(-N // 16)
+    for t, n, what in ((stats_in, tiles_in, "stats_in"), (stats_out, tiles_out, "stats_out")):
+        if t is not None and (t.dtype != torch.float32 or t.numel() < n or not t.is_contiguous()):
+            raise RuntimeError(f"decode op: {what} must be a contiguous float32 tensor with >= {n} elements")
     for t, n, what in ((bias, N, "bias"), (residual, N, "residual"), (norm_weight, K, "norm_weight")):
         if t is not None and (t.dtype != x.dtype or t.numel() < n or not t.is_contiguous()):
             raise RuntimeError(f"decode op: {what} must be a contiguous {x.dtype} tensor with >= {n} elements")
@@ -173,7 +180,8 @@ def make_decode_op(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor,
             workspace = workspace_for(x.device, workspace_bytes(1, K, N, group_size, bits, False))
     p = lambda t: 0 if t is None else t.data_ptr()
     return _lib.DecodeOp(p(qweight_t), p(meta), p(bias), p(x), p(norm_weight), p(residual), p(out), p(workspace),
-                         workspace.numel(), float(eps), K, N, group_size, bits, _DT[x.dtype], _DT[scale_dtype], int(in_glue))
+                         workspace.numel(), p(stats_in), p(stats_out), float(eps), K, N, group_size, bits, _DT[x.dtype],
+                         _DT[scale_dtype], int(in_glue), int(out_glue), tiles_in if stats_in is not None else 0)
 
 
 def launch_decode_op(op: "_lib.DecodeOp", device: torch.device) -> None:

@@ -11,8 +11,12 @@ Per layer (h = residual stream [hidden], activation dtype):
     qkv = rmsnorm(h; w_in) @ Wqkv                       in_glue RMSNORM
     a   = attention(qkv)                                 NOT a quantised linear: the stand-in "a = q" here
     h1  = h + a @ Wo                                     residual epilogue
-    gu  = rmsnorm(h1; w_post) @ Wgate_up                 in_glue RMSNORM
-    h2  = h1 + (silu(gate) * up) @ Wdown                 in_glue SILU_MUL + residual epilogue
+    a   = silu(g) * u,  g|u = rmsnorm(h1; w_post) @ Wgate_up     in_glue RMSNORM + OUT_SILU_MUL_PAIRED epilogue when the fused
+                                                          gate_up columns are interleaved (utils.model.fuse_gate_up_interleaved)
+    h2  = h1 + a @ Wdown                                 residual epilogue
+  (gate_up fused by plain concatenation instead: gu = ... @ Wgate_up, then in_glue SILU_MUL on the down op.)
+RMSNorm statistics travel with the data: the op that writes a residual-stream vector also writes the per-tile sums of its
+squares (stats_out), the normalising consumer sums those 256 partials per wave instead of re-reducing the row per block.
 
 (An in-launch dependency scheme -- consecutive ops on two streams, op i+1 prefetching its packed weights while spinning on
 op i's arrival counters -- was built and measured in round 2: bit-identical results but 2x SLOWER than plain stream order
@@ -63,7 +67,9 @@ class DecodeStep:
         # residual stream: h1 / h2 of every layer get their own buffers (no reuse, no WAR reasoning)
         self.h = torch.zeros((len(self.layers), 2, hidden), dtype=dtype, device=dev)
         self.qkv_out = torch.zeros(qkv_n, dtype=dtype, device=dev)
-        self.gu_out = torch.zeros(inter2, dtype=dtype, device=dev)
+        self.gu_out = torch.zeros(inter2, dtype=dtype, device=dev)   # gate|up, or silu(gate)*up in its first half (interleaved)
+        # per-tile sums of squares of every residual-stream vector written by the chain
+        self.stats = torch.zeros((len(self.layers), 2, -(-hidden // 16)), dtype=torch.float32, device=dev)
         self._keep = []   # tensors the raw-pointer structs refer to
         self.ops: List = []
         # one scratch for the whole chain (only narrow layers use it), sized for the largest request
@@ -72,16 +78,20 @@ class DecodeStep:
             for lin in (L.qkv, L.o, L.gate_up, L.down):
                 need = max(need, ops.workspace_bytes(1, lin.in_features, lin.out_features, lin.group_size, lin.bits, False))
         self.workspace = torch.zeros(max(need, 1 << 20), dtype=torch.uint8, device=dev)
-        h_in = self.x_in
+        h_in, st_in = self.x_in, None     # the step's input comes from outside the chain: no producer statistics
         for li, L in enumerate(self.layers):
             h1, h2 = self.h[li, 0], self.h[li, 1]
+            st1, st2 = self.stats[li, 0], self.stats[li, 1]
+            paired = bool(getattr(L.gate_up, "gate_up_interleaved", False))
             plan = [
-                (L.qkv, h_in, self.qkv_out, ops.GLUE_RMSNORM, L.input_norm, None),
-                (L.o, self.qkv_out, h1, ops.GLUE_NONE, None, h_in),           # stand-in attention: a = q = qkv[:q_dim]
-                (L.gate_up, h1, self.gu_out, ops.GLUE_RMSNORM, L.post_norm, None),
-                (L.down, self.gu_out, h2, ops.GLUE_SILU_MUL, None, h1),
+                # (module, x, out, in_glue, norm weight, residual, out_glue, stats_in, stats_out)
+                (L.qkv, h_in, self.qkv_out, ops.GLUE_RMSNORM, L.input_norm, None, ops.OUT_NONE, st_in, None),
+                (L.o, self.qkv_out, h1, ops.GLUE_NONE, None, h_in, ops.OUT_NONE, None, st1),   # stand-in attention: a = q
+                (L.gate_up, h1, self.gu_out, ops.GLUE_RMSNORM, L.post_norm, None,
+                 ops.OUT_SILU_MUL_PAIRED if paired else ops.OUT_NONE, st1, None),
+                (L.down, self.gu_out, h2, ops.GLUE_NONE if paired else ops.GLUE_SILU_MUL, None, h1, ops.OUT_NONE, None, st2),
             ]
-            for j, (lin, x, out, glue, nw, res) in enumerate(plan):
+            for j, (lin, x, out, glue, nw, res, oglue, s_in, s_out) in enumerate(plan):
                 qw, meta, bias, sdt = _lin_tensors(lin, dtype)
                 K, N = lin.in_features, lin.out_features
                 if j == 1 and K != q_dim:
@@ -90,8 +100,9 @@ class DecodeStep:
                     raise NotImplementedError(f"decode chain: layer shape K={K} N={N} group_size={lin.group_size} unsupported")
                 self._keep.extend([qw, meta, bias, nw])
                 self.ops.append(ops.make_decode_op(x, qw, meta, bias, out, K, N, lin.group_size, lin.bits, sdt, in_glue=glue,
-                                                   norm_weight=nw, eps=eps, residual=res, workspace=self.workspace))
-            h_in = h2
+                                                   norm_weight=nw, eps=eps, residual=res, workspace=self.workspace,
+                                                   out_glue=oglue, stats_in=s_in, stats_out=s_out))
+            h_in, st_in = h2, st2
         self.out = h_in
 
     def run(self) -> torch.Tensor:

@@ -238,6 +238,63 @@ def fuse_quant_linears(mods: List[BaseQuantLinear]) -> BaseQuantLinear:
     return fused
 
 
+def _interleave_cols(a: torch.Tensor, b: torch.Tensor, block: int) -> torch.Tensor:
+    """[R, C] x 2 -> [R, 2C]: blocks of `block` columns of a and b alternate (a0..a7 b0..b7 a8..a15 ...)."""
+    r, c = a.shape
+    return torch.stack([a.reshape(r, c // block, block), b.reshape(r, c // block, block)], dim=2).reshape(r, 2 * c).contiguous()
+
+
+def fuse_gate_up_interleaved(gate: BaseQuantLinear, up: BaseQuantLinear) -> BaseQuantLinear:
+    """gate_proj + up_proj -> ONE module whose output columns alternate in blocks of 8: [g0..g7, u0..u7, g8..g15, u8..u15, ...].
+    Every 16-column MFMA tile of the kernel then holds both halves of 8 MLP neurons, so the batch-1 decode op can apply
+    SiLU(gate) * up in its epilogue (GPTQHIP_OUT_SILU_MUL_PAIRED) -- once per element, by the block that produced it.
+    Blocks of 8 keep the packed words whole (qzeros / AWQ qweight pack 8 four-bit columns per int32).  Must run BEFORE
+    post_init().  forward() of the result returns the interleaved [.., 2*inter] tensor; `deinterleave_gate_up` undoes it."""
+    for m in (gate, up):
+        if getattr(m, "_ready", False):
+            raise RuntimeError("fuse_gate_up_interleaved must be called before post_init()")
+    same = (type(gate) is type(up) and gate.bits == up.bits and gate.group_size == up.group_size and gate.sym == up.sym
+            and gate.in_features == up.in_features and gate.out_features == up.out_features and gate.desc_act == up.desc_act
+            and gate.scales.dtype == up.scales.dtype and (gate.bias is None) == (up.bias is None))
+    g0, g1 = getattr(gate, "g_idx", None), getattr(up, "g_idx", None)
+    if not same or (g0 is None) != (g1 is None) or (g0 is not None and not torch.equal(g0, g1)):
+        raise NotImplementedError("gate/up differ in quantisation parameters (or act-order permutation); not fusing")
+    n = gate.out_features
+    if n % 8 != 0:
+        raise NotImplementedError("out_features must be a multiple of 8")
+    fused = type(gate)(bits=gate.bits, group_size=gate.requested_group_size, sym=gate.sym, desc_act=gate.desc_act,
+                       in_features=gate.in_features, out_features=2 * n, bias=gate.bias is not None,
+                       register_buffers=False, name=f"{gate.name}|{up.name}", adapter=None)
+    cpw = 32 // gate.bits                       # columns per packed word along N
+    n_packed = gate.qzeros.shape[1]             # words per row of an N-packed tensor
+    if gate.qweight.shape[1] == n:              # GPTQ: qweight is K-packed, one column per element
+        fused.register_buffer("qweight", _interleave_cols(gate.qweight, up.qweight, 8))
+    else:                                       # AWQ: qweight is N-packed like qzeros
+        fused.register_buffer("qweight", _interleave_cols(gate.qweight, up.qweight, 8 // cpw))
+    fused.register_buffer("qzeros", _interleave_cols(gate.qzeros, up.qzeros, 8 // cpw))
+    assert fused.qzeros.shape[1] == 2 * n_packed
+    fused.register_buffer("scales", _interleave_cols(gate.scales, up.scales, 8))
+    if g0 is not None:
+        fused.register_buffer("g_idx", g0)
+    if gate.bias is not None:
+        fused.register_buffer("bias", _interleave_cols(gate.bias[None], up.bias[None], 8)[0])
+    else:
+        fused.bias = None
+    if hasattr(gate, "qzero_format"):
+        fused.qzero_format(format=gate.qzero_format())
+    if getattr(gate, "format", None) is not None and hasattr(fused, "format"):
+        fused.format = gate.format
+    fused.gate_up_interleaved = True
+    fused.train(gate.training)
+    return fused
+
+
+def deinterleave_gate_up(y: torch.Tensor):
+    """[.., 2*inter] output of a fuse_gate_up_interleaved module -> (gate [.., inter], up [.., inter])."""
+    v = y.reshape(y.shape[:-1] + (y.shape[-1] // 16, 2, 8))
+    return v[..., 0, :].reshape(y.shape[:-1] + (-1,)), v[..., 1, :].reshape(y.shape[:-1] + (-1,))
+
+
 def fuse_siblings(parent: nn.Module, names: List[str]) -> Optional[_FusedGroup]:
     """Fuse parent.<names> (quant modules sharing their input) and replace them by views.  Returns the group, or None
     when fusion is not possible (the original modules are left untouched)."""

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 3
+#define GPTQHIP_ABI_VERSION 4
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -127,6 +127,14 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight_t, const uint32_t* meta,
  *                                   + eps)) (HF LlamaRMSNorm: fp32 statistics, rounded to the activation dtype, then * weight)
  *            GPTQHIP_GLUE_SILU_MUL  x [2K] = gate | up; the kernel feeds act(silu(gate)) * up (HF LlamaMLP)
  *   residual [N] or NULL: out = act(residual + y)   (hidden = residual + hidden, one more rounding)
+ *   out_glue GPTQHIP_OUT_SILU_MUL_PAIRED: the layer is a fused gate|up projection whose columns were interleaved in blocks of
+ *            8 (8 gate columns, the 8 matching up columns, ...: utils.model.fuse_gate_up_interleaved), so every 16-column
+ *            tile holds both halves of 8 MLP neurons and the epilogue writes out[N/2] = act(silu(gate)) * up directly -- the
+ *            activation is computed ONCE per element by the producer instead of by every consumer block
+ *   stats_out [ceil(N/16)] floats or NULL: per-tile sum of out^2 -- the RMSNorm statistic of the op consuming `out`
+ *   stats_in / stats_n: with GPTQHIP_GLUE_RMSNORM, the producer's stats_out for this op's x (stats_n = ceil(K/16) <= 512):
+ *            each wave sums the partials in a fixed order (one load per lane, no block barrier); NULL: every block reduces the
+ *            row itself (first op of a step, whose input comes from outside the chain)
  * The glue is applied to each ring stage's activation pair on its way into the MFMA A fragment (RMSNorm statistics are
  * reduced once per block while the first weight loads are in flight).  Stream-ordered like every other entry point.
  * Supported: shapes on the decode kernel's regular pipeline (K % 128 == 0, group_size = 128 * 2^n, a wave count dividing
@@ -138,6 +146,8 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight_t, const uint32_t* meta,
 #define GPTQHIP_GLUE_NONE 0
 #define GPTQHIP_GLUE_RMSNORM 1
 #define GPTQHIP_GLUE_SILU_MUL 2
+#define GPTQHIP_OUT_NONE 0
+#define GPTQHIP_OUT_SILU_MUL_PAIRED 1
 typedef struct gptqhip_decode_op {
     const uint32_t* qweight_t;   /* tiled words (gptqhip_repack_tiled)                         */
     const uint32_t* meta;        /* [tiles][G][16] constants                                   */
@@ -145,11 +155,13 @@ typedef struct gptqhip_decode_op {
     const void* x;               /* [K] or [2K] act dtype, see in_glue                         */
     const void* norm_weight;     /* [K] act dtype (GPTQHIP_GLUE_RMSNORM) else NULL             */
     const void* residual;        /* [N] act dtype or NULL                                      */
-    void* out;                   /* [N] act dtype                                              */
+    void* out;                   /* [N] act dtype ([N/2] with OUT_SILU_MUL_PAIRED)             */
     void* workspace;             /* zero-initialised scratch as for gptqhip_gemm, or NULL      */
     size_t workspace_bytes;
+    const float* stats_in;       /* see above                                                  */
+    float* stats_out;
     float eps;
-    int K, N, group_size, bits, act_dtype, scale_dtype, in_glue;
+    int K, N, group_size, bits, act_dtype, scale_dtype, in_glue, out_glue, stats_n;
 } gptqhip_decode_op;
 int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream);
 /* 1 if gptqhip_decode_linear supports a [K,N] layer with this group size, else 0. */

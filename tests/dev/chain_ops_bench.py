@@ -11,7 +11,7 @@ gen = torch.Generator(device=dev); gen.manual_seed(1)
 dtype = torch.float16 if (len(sys.argv) < 2 or sys.argv[1] != "bf16") else torch.bfloat16
 NL = 24
 SHAPES = [("qkv", 4096, 6144, ops.GLUE_RMSNORM, False), ("o", 4096, 4096, ops.GLUE_NONE, True),
-          ("gate_up", 4096, 28672, ops.GLUE_RMSNORM, False), ("down", 14336, 4096, ops.GLUE_SILU_MUL, True)]
+          ("gate_up", 4096, 28672, ops.GLUE_RMSNORM, False), ("down", 14336, 4096, ops.GLUE_NONE, True)]
 stream = torch.cuda.Stream()
 for name, K, N, glue, res in SHAPES:
     lins = [B.make_gptq(K, N, 128, dev, gen, dtype) for _ in range(NL)]
@@ -19,8 +19,12 @@ for name, K, N, glue, res in SHAPES:
     nw = torch.ones(K, dtype=dtype, device=dev)
     resid = torch.zeros(N, dtype=dtype, device=dev)
     outs = [torch.empty(N, dtype=dtype, device=dev) for _ in range(NL)]
+    st_in = torch.ones(K // 16, dtype=torch.float32, device=dev)
+    st_out = torch.zeros(N // 16, dtype=torch.float32, device=dev)
     dops = [ops.make_decode_op(xin, l.qweight, l.meta, None, o, K, N, 128, 4, l._scale_dtype, in_glue=glue,
-                               norm_weight=nw if glue == ops.GLUE_RMSNORM else None, residual=resid if res else None)
+                               norm_weight=nw if glue == ops.GLUE_RMSNORM else None, residual=resid if res else None,
+                               stats_in=st_in if glue == ops.GLUE_RMSNORM else None, stats_out=st_out if res else None,
+                               out_glue=ops.OUT_SILU_MUL_PAIRED if name == "gate_up" else ops.OUT_NONE)
             for l, o in zip(lins, outs)]
     plain = [ops.make_decode_op(xin, l.qweight, l.meta, None, o, K, N, 128, 4, l._scale_dtype) for l, o in zip(lins, outs)]
     x2 = xin[:K].reshape(1, K).contiguous()

@@ -25,7 +25,7 @@ def _tiled(ops, qweight, qzeros, scales, gs, bits, sdt="fp16"):
 
 
 @pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096), (8192, 1024), (8192, 10240),
-                                 (28672, 512), (4096, 1000), (4096, 512)])
+                                 (28672, 512), (4096, 1000), (4096, 1024)])
 @pytest.mark.parametrize("act,bits", [("fp16", 4), ("bf16", 4), ("fp16", 8)])
 def test_decode_op_plain_vs_oracle(ops, K, N, act, bits):
     gs = 128
@@ -71,6 +71,33 @@ def test_decode_op_fused_glue_vs_hf_semantics(ops, act):
     y = O.forward_gptq(a[None], qweight2, qzeros2, scales2, g_idx2, 4, bias, act, "fp16")
     h2_ref = O.residual_add_ref(h[None], y, act)
     assert_forward_close(torch_to_f32(h2)[None], h2_ref, act, tag="silu_mul+residual")
+    # (c) the same two ops the way the decode chain runs them: the producer of h hands over the per-tile sums of h^2
+    #     (stats_out -> stats_in), gate|up columns interleaved in blocks of 8 with the SiLU*mul in the producer's epilogue
+    qw_o, qz_o, sc_o, gi_o = synth_gptq(43, 4, hidden, hidden, gs)
+    qwo_t, meta_o, sco = _tiled(ops, qw_o, qz_o, sc_o, gs, 4)
+    a_in = O.round_to(rng.randn(hidden).astype(np.float32) * 0.5, act)
+    stats = torch.zeros(hidden // 16, dtype=torch.float32, device=DEV)
+    h1 = ops.decode_linear(f32_to_torch(a_in, act, DEV), qwo_t, meta_o, None, hidden, hidden, gs, 4, sco.dtype,
+                           residual=f32_to_torch(h, act, DEV), stats_out=stats)
+    h1_np = torch_to_f32(h1)
+    y_o = O.forward_gptq(a_in[None], qw_o, qz_o, sc_o, gi_o, 4, None, act, "fp16")
+    assert_forward_close(h1_np[None], O.residual_add_ref(h[None], y_o, act), act, tag="residual+stats")
+    want_stats = (h1_np.astype(np.float64) ** 2).reshape(-1, 16).sum(axis=1)
+    assert np.allclose(stats.cpu().numpy(), want_stats, rtol=1e-5), "stats_out must be the per-tile sums of out^2"
+    gate_cols, up_cols = np.arange(inter), inter + np.arange(inter)
+    order = np.stack([gate_cols.reshape(-1, 8), up_cols.reshape(-1, 8)], axis=1).reshape(-1)       # g0..7 u0..7 g8..15 ...
+    qw_i = np.ascontiguousarray(qweight[:, order])
+    sc_i = np.ascontiguousarray(scales[:, order])
+    zz = O.unpack_cols(qzeros, 4)[:, order]
+    qz_i = O.pack_cols(zz, 4)
+    qwi_t, meta_i, sci = _tiled(ops, qw_i, qz_i, sc_i, gs, 4)
+    a_dev = torch.zeros(2 * inter, dtype=TDT[act], device=DEV)
+    ops.decode_linear(h1, qwi_t, meta_i, None, hidden, 2 * inter, gs, 4, sci.dtype, out=a_dev, in_glue=ops.GLUE_RMSNORM,
+                      norm_weight=f32_to_torch(w, act, DEV), eps=1e-5, out_glue=ops.OUT_SILU_MUL_PAIRED, stats_in=stats)
+    xn1 = O.rmsnorm_ref(h1_np, w, 1e-5, act)
+    gu1 = O.forward_gptq(xn1[None], qweight, qzeros, scales, g_idx, 4, None, act, "fp16")[0]
+    a_ref = O.silu_mul_ref(gu1[:inter], gu1[inter:], act)
+    assert_forward_close(torch_to_f32(a_dev)[None, :inter], a_ref[None], act, tag="stats_in rmsnorm + paired silu*mul")
 
 
 def test_decode_op_rejects_unsupported_shapes(ops):
@@ -84,7 +111,7 @@ def test_decode_op_rejects_unsupported_shapes(ops):
                           in_glue=ops.GLUE_RMSNORM)
 
 
-def _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype, seed=0):
+def _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype, seed=0, interleave=True):
     from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
     from gptqmodel_amd.utils.decode_chain import DecodeLayer
     gen = torch.Generator(device=DEV)
@@ -106,11 +133,35 @@ def _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype, seed=0):
         m.post_init()
         return m
 
+    def raw(k, n):
+        m = HipGptqLinear(bits=4, group_size=128, sym=True, desc_act=False, in_features=k, out_features=n, bias=False,
+                          register_buffers=False)
+        w = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=DEV, generator=gen)
+        m.qweight = w | (((~(w | (w >> 1) | (w >> 2) | (w >> 3))) & 0x11111111) << 3)
+        m.qzeros = torch.full((k // 128, n // 8), -2004318072, dtype=torch.int32, device=DEV)
+        m.scales = (torch.rand((k // 128, n), device=DEV, generator=gen) * 0.01 + 0.005).to(dtype)
+        m.g_idx = torch.arange(k, device=DEV, dtype=torch.int32) // 128
+        m.bias = None
+        m.qzero_format(format=2)
+        m.eval()
+        return m
+
+    from gptqmodel_amd.utils.model import fuse_gate_up_interleaved
     layers = []
-    for _ in range(n_layers):
+    for li in range(n_layers):
         nw = lambda: (1.0 + 0.1 * torch.randn(hidden, device=DEV, generator=gen)).to(dtype)
-        layers.append(DecodeLayer(lin(hidden, q_dim + 2 * kv_dim), lin(q_dim, hidden), lin(hidden, 2 * inter),
-                                  lin(inter, hidden), nw(), nw()))
+        gate, up = raw(hidden, inter), raw(hidden, inter)
+        if interleave and li % 2 == 0:    # both fusion layouts in one stack
+            gu = fuse_gate_up_interleaved(gate, up)
+        else:
+            gu = raw(hidden, 2 * inter)
+            gu.qweight = torch.cat([gate.qweight, up.qweight], dim=1).contiguous()
+            gu.scales = torch.cat([gate.scales, up.scales], dim=1).contiguous()
+        for m in (gate, up, gu):
+            m.post_init()
+        L = DecodeLayer(lin(hidden, q_dim + 2 * kv_dim), lin(q_dim, hidden), gu, lin(inter, hidden), nw(), nw())
+        L.gate, L.up = gate, up           # separate projections: what the unfused reference step runs
+        layers.append(L)
     return layers
 
 
@@ -126,8 +177,8 @@ def _reference_step(layers, x_in, q_dim, inter, eps):
     for L in layers:
         qkv = L.qkv(rms(h, L.input_norm)[None])[0]
         h = h + L.o(qkv[None, :q_dim])[0]
-        gu = L.gate_up(rms(h, L.post_norm)[None])[0]
-        h = h + L.down((torch.nn.functional.silu(gu[:inter]) * gu[inter:])[None])[0]
+        xn = rms(h, L.post_norm)[None]
+        h = h + L.down(torch.nn.functional.silu(L.gate(xn)) * L.up(xn))[0]
     return h
 
 

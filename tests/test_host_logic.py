@@ -376,3 +376,33 @@ def test_fused_module_tensors_are_registered_buffers(kernels_available):
     assert len(fused.list_buffers()) == 5 and fused.format == FORMAT.GPTQ_V2
     assert "meta" not in fused.state_dict() and "perm" not in fused.state_dict()   # derived tensors are non-persistent
     assert all(t is not None for t in fused._buffers.values())   # no None-valued buffers (accelerate offload hooks)
+
+
+def test_gate_up_interleaved_fusion_layout(kernels_available):
+    """fuse_gate_up_interleaved: output columns alternate in blocks of 8 (g0..7 u0..7 g8..15 ...) on the CHECKPOINT tensors
+    (whole packed words move); the dequantised fused matrix is the column-interleave of the two, deinterleave undoes it."""
+    import numpy as np
+    from helpers import synth_gptq
+    from oracle import gptq_oracle as O
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    from gptqmodel_amd.utils.model import deinterleave_gate_up, fuse_gate_up_interleaved
+    for bits in (4, 8):
+        K, N, gs = 256, 48, 64
+        mods, dense = [], []
+        for seed in (1, 2):
+            qweight, qzeros, scales, g_idx = synth_gptq(seed, bits, K, N, gs)
+            m = HipGptqLinear(bits=bits, group_size=gs, sym=False, desc_act=False, in_features=K, out_features=N, bias=True,
+                              register_buffers=True)
+            m.load_state_dict({"qweight": torch.from_numpy(qweight), "qzeros": torch.from_numpy(qzeros),
+                               "scales": torch.from_numpy(scales).half(), "g_idx": torch.from_numpy(g_idx),
+                               "bias": torch.arange(N).half() + 100 * seed})
+            mods.append(m)
+            dense.append(O.dequant_gptq(qweight, qzeros, scales, g_idx, bits))
+        f = fuse_gate_up_interleaved(*mods)
+        assert f.out_features == 2 * N and f.gate_up_interleaved and set(dict(f.named_buffers())) >= {"qweight", "qzeros", "scales", "bias"}
+        w = O.dequant_gptq(f.qweight.numpy(), f.qzeros.numpy(), f.scales.float().numpy(), f.g_idx.numpy(), bits)
+        g, u = deinterleave_gate_up(torch.from_numpy(w))
+        assert np.array_equal(g.numpy(), dense[0]) and np.array_equal(u.numpy(), dense[1])
+        assert np.array_equal(w[:, :8], dense[0][:, :8]) and np.array_equal(w[:, 8:16], dense[1][:, :8])
+        bg, bu = deinterleave_gate_up(f.bias[None])
+        assert torch.equal(bg[0], mods[0].bias) and torch.equal(bu[0], mods[1].bias)
