@@ -68,6 +68,17 @@ constexpr int kGlueSiluMul = 2;  // x' = act(silu(gate)) * up, x = gate | up
 
 template <int ACT>
 __device__ __forceinline__ uint32_t glue_pair(uint32_t a, uint32_t b, float inv, int glue) {
+    if constexpr (ACT == kFP16) {
+        if (glue == kGlueRmsNorm) {
+            // fp16: three VALU ops per pair instead of ~14.  v_fma_mix{lo,hi}_f16 read the f16 half of h and the f32 inv,
+            // multiply in f32 and round ONCE to f16 (== (h.float() * inv).to(fp16)); v_pk_mul_f16 by the weight pair is the
+            // rounded fp16 product HF's `weight * hidden` computes.
+            uint32_t t = 0u;
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "+v"(t) : "v"(a), "v"(inv));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(t) : "v"(a), "v"(inv));
+            return as_u32(as_h2(b) * as_h2(t));
+        }
+    }
     const float a0 = bits16_to_f32<ACT>((uint16_t)(a & 0xffffu)), a1 = bits16_to_f32<ACT>((uint16_t)(a >> 16));
     const float b0 = bits16_to_f32<ACT>((uint16_t)(b & 0xffffu)), b1 = bits16_to_f32<ACT>((uint16_t)(b >> 16));
     float r0, r1;
@@ -332,10 +343,9 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
     }
 }
 
-// PIPE = 1 (experiment, GPTQHIP_SKINNY_PIPE=1): sched_barrier after every stage's loads in the steady loop, so hipcc cannot
-// sink the four dwordx4 weight loads of a ring round to the end of the round (it does, ISA-checked: the wave then waits a
-// full memory latency once per round instead of keeping D-1 stages in flight under its own compute).
-template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int D, int GLUE = 0, int PIPE = 0>
+// (Measured and dropped in round 2: a sched_barrier after every stage's loads, which keeps hipcc from sinking the four dwordx4
+// weight loads of a ring round to the end of the round -- per-shape times moved by < 1.5 % either way, other waves cover.)
+template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int D, int GLUE = 0>
 __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     // ONE dynamic LDS array (16-B aligned base, no statics in front of it): per-wave activation slots during the K
     // loop, then the split-K reduction buffer red[W][MT*4][64]; the last 16 bytes hold the "last arriver" flag.
@@ -495,7 +505,6 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
                 for (int d = 0; d < D; ++d) {
                     compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE>(st[d], p, cur, lane, aslot, dk, acc, xbuf, glue_inv);
                     load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
-                    if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
                     cur += W;
                 }
             }
@@ -624,20 +633,13 @@ static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStr
     constexpr int kSlot = slot_bytes<AM, MT>() > MT * 1024 ? slot_bytes<AM, MT>() : MT * 1024;
     const size_t lds_bytes = (size_t)pl.waves * kSlot + 16 + (AM == AM_ROW1P ? (size_t)p.K * 2 : 64);
     if constexpr (AM == AM_ROW1 && MT == 1 && D == 4) {
-        static const bool pipe = [] { const char* v = getenv("GPTQHIP_SKINNY_PIPE"); return v && *v && *v != '0'; }();
         if (p.in_glue != kGlueNone) {  // decode op with input glue: regular single-group-per-chunk plans only (ABI checks)
             if (p.in_glue == kGlueRmsNorm) {
-                if (pipe) hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueRmsNorm, 1>), grid, block, lds_bytes, stream, p);
-                else hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueRmsNorm>), grid, block, lds_bytes, stream, p);
+                hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueRmsNorm>), grid, block, lds_bytes, stream, p);
             } else {
-                if (pipe) hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueSiluMul, 1>), grid, block, lds_bytes, stream, p);
-                else hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueSiluMul>), grid, block, lds_bytes, stream, p);
+                hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueSiluMul>), grid, block, lds_bytes, stream, p);
             }
             return check_hip(hipGetLastError(), "skinny_kernel (decode glue) launch");
-        }
-        if (pipe && pl.gpc == 1) {
-            hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, 0, 1>), grid, block, lds_bytes, stream, p);
-            return check_hip(hipGetLastError(), "skinny_kernel launch");
         }
     }
     if (pl.gpc == 1) {

@@ -32,6 +32,12 @@ def _stream(device: torch.device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+try:  # raw current-stream handle without building a torch.cuda.Stream object (~1.5 us saved per eager launch)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # pragma: no cover - older / newer torch
+    _raw_stream = None
+
+
 def _require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -49,9 +55,19 @@ def device_info(device: int = 0):
     return {"cu_count": cu.value, "hbm_bytes": hbm.value, "arch": arch.value.decode()}
 
 
-def workspace_for(device: torch.device, nbytes: int) -> torch.Tensor:
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
+def _dev_index(device: torch.device) -> int:
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
+def _stream_handle(dev_index: int) -> int:
+    if _raw_stream is not None:
+        return _raw_stream(dev_index)
+    return torch.cuda.current_stream(dev_index).cuda_stream
+
+
+def workspace_for(device: torch.device, nbytes: int, stream_handle: Optional[int] = None) -> torch.Tensor:
+    idx = _dev_index(device)
+    key = (idx, _stream_handle(idx) if stream_handle is None else stream_handle)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         if ws is not None:
@@ -118,11 +134,17 @@ def gemm(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Opt
     partial_f32=True returns the unrounded float32 accumulators (tensor-parallel partial sums, no bias).
     exact_bf16=True opts in to GPTQHIP_GEMM_EXACT_BF16 (bf16 decode without the per-weight bf16 rounding; see
     include/gptqhip.h)."""
+    # Hot eager path (HF generate calls this once per quantised linear per token): every line here is host time in front
+    # of a 5-15 us kernel (tests/dev/eager_overhead.py), so no generic loops, no Stream / c_void_p objects, no device context
+    # switch unless the tensor lives on another device than the current one.
     lib = _lib.load()
-    _require_cuda(x, qweight_t, meta, bias, perm)
+    if not (x.is_cuda and qweight_t.is_cuda and meta.is_cuda):
+        raise RuntimeError("gptqmodel_amd HIP ops need tensors on a ROCm device (got a CPU tensor); "
+                           "there is no CPU fallback")
     if x.dim() != 2 or not x.is_contiguous():
         raise RuntimeError("gemm: x must be a contiguous [M,K] tensor")
-    if x.dtype not in _DT or scale_dtype not in _DT:
+    adt, sdt = _DT.get(x.dtype), _DT.get(scale_dtype)
+    if adt is None or sdt is None:
         raise RuntimeError(f"gemm: unsupported dtypes x={x.dtype} scales={scale_dtype}")
     if bias is not None and bias.dtype != x.dtype:
         raise RuntimeError("gemm: bias dtype must equal activation dtype")
@@ -133,12 +155,22 @@ def gemm(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Opt
         out = torch.empty((M, N), dtype=torch.float32 if partial_f32 else x.dtype, device=x.device)
     if M == 0:
         return out
-    with torch.cuda.device(x.device):
-        ws = workspace_for(x.device, workspace_bytes(M, K, N, group_size, bits, perm is not None))
-        rc = lib.gptqhip_gemm(_ptr(x), _ptr(qweight_t), _ptr(meta), _ptr(perm), _ptr(bias), _ptr(out), _ptr(ws),
-                              ws.numel(), M, K, N, group_size, bits, _DT[x.dtype], _DT[scale_dtype],
-                              (1 if partial_f32 else 0) | (2 if exact_bf16 else 0), _stream(x.device))
-    _lib.check(rc, "gptqhip_gemm")
+    idx = x.device.index
+    switch = idx != torch.cuda.current_device()
+    if switch:
+        prev = torch.cuda.current_device()
+        torch.cuda.set_device(idx)
+    try:
+        sh = _stream_handle(idx)
+        ws = workspace_for(x.device, workspace_bytes(M, K, N, group_size, bits, perm is not None), sh)
+        rc = lib.gptqhip_gemm(x.data_ptr(), qweight_t.data_ptr(), meta.data_ptr(), 0 if perm is None else perm.data_ptr(),
+                              0 if bias is None else bias.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), M, K, N,
+                              group_size, bits, adt, sdt, (1 if partial_f32 else 0) | (2 if exact_bf16 else 0), sh)
+    finally:
+        if switch:
+            torch.cuda.set_device(prev)
+    if rc != 0:
+        _lib.check(rc, "gptqhip_gemm")
     return out
 
 
