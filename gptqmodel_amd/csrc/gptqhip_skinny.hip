@@ -447,11 +447,15 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
                 // weight ring, a shuffle tree, no LDS, no block barrier, and nothing redundant but 1 KiB per wave
                 float ssum = 0.f;
                 float sv[8];
+                // eight UNCONDITIONAL clamped loads (a select or branch on the count between them made hipcc wait for the first
+                // one on the spot -- an L2 round trip in front of the whole weight prologue, +2.7 us on the 1792-block gate_up)
+                const int last = p.stats_n - 1;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int idx = lane + 64 * i;
-                    sv[i] = (i * 64 < p.stats_n) ? p.stats_in[idx < p.stats_n ? idx : 0] : 0.f;
+                    sv[i] = p.stats_in[idx < last ? idx : last];
                 }
+                __builtin_amdgcn_sched_barrier(0);  // keep all eight in FRONT of the weight ring (hipcc sank one behind it -> vmcnt(0))
 #pragma unroll
                 for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
 #pragma unroll
