@@ -442,27 +442,33 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
                     reinterpret_cast<u4_t*>(xbuf)[idx] = xs[idx];  // (rows longer than 32 B x threads: rare, plain copy)
                 __syncthreads();
             } else if (GLUE == kGlueRmsNorm && p.stats_in != nullptr) {
-                // RMSNorm statistics handed over by the op that produced h (one partial per 16-column tile, its epilogue's
-                // sum of out^2): every wave sums them itself in a fixed order -- one L2 load per lane issued before the
-                // weight ring, a shuffle tree, no LDS, no block barrier, and nothing redundant but 1 KiB per wave
-                float ssum = 0.f;
+                // RMSNorm statistics handed over by the op that produced h (one partial per 16-column tile: its epilogue's
+                // sum of out^2).  ONE wave per block sums them in a fixed order -- eight clamped loads per lane issued in
+                // front of the weight ring, a shuffle tree -- and shares 1/rms through LDS.  (Every wave loading them itself
+                // doubled the memory instructions of the 70B gate_up: 16 waves x 3584 blocks x 8 loads of the same 2 KiB.)
                 float sv[8];
-                // eight UNCONDITIONAL clamped loads (a select or branch on the count between them made hipcc wait for the first
-                // one on the spot -- an L2 round trip in front of the whole weight prologue, +2.7 us on the 1792-block gate_up)
-                const int last = p.stats_n - 1;
+                if (wave == 0) {
+                    const int last = p.stats_n - 1;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int idx = lane + 64 * i;
-                    sv[i] = p.stats_in[idx < last ? idx : last];
+                    for (int i = 0; i < 8; ++i) {
+                        const int idx = lane + 64 * i;
+                        sv[i] = p.stats_in[idx < last ? idx : last];
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);  // keep all eight in FRONT of the weight ring (hipcc sank one behind it -> vmcnt(0))
+                __builtin_amdgcn_sched_barrier(0);  // keep them in FRONT of the ring (hipcc sank one behind it -> vmcnt(0))
 #pragma unroll
                 for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
+                float* scratch = reinterpret_cast<float*>(xbuf);
+                if (wave == 0) {
+                    float ssum = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) ssum += (lane + 64 * i < p.stats_n) ? sv[i] : 0.f;
+                    for (int i = 0; i < 8; ++i) ssum += (lane + 64 * i < p.stats_n) ? sv[i] : 0.f;
 #pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) ssum += __shfl_xor(ssum, m, 64);
-                glue_inv = rsqrtf(ssum / (float)p.K + p.eps);
+                    for (int m = 32; m >= 1; m >>= 1) ssum += __shfl_xor(ssum, m, 64);
+                    if (lane == 0) scratch[0] = rsqrtf(ssum / (float)p.K + p.eps);
+                }
+                __syncthreads();
+                glue_inv = scratch[0];
             } else if constexpr (GLUE == kGlueRmsNorm) {
                 // (no producer statistics: e.g. the first op of a step, whose input comes from outside the chain)
                 // RMSNorm statistics of the whole input row, once per block: the row (L2-resident) is requested BEFORE the
