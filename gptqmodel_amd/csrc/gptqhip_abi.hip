@@ -334,7 +334,7 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
         set_error("gptqhip_decode_linear: stats_in needs in_glue RMSNORM and 1..512 partial sums (got %d)", op->stats_n);
         return GPTQHIP_EINVAL;
     }
-    const SkinnyPlan pl = plan_skinny(1, op->K, op->N, op->group_size, 0, 0);
+    const SkinnyPlan pl = plan_skinny(1, op->K, op->N, op->group_size, g_force_split, g_force_waves);
     if (!(pl.regular && pl.gpc == 1 && pl.mt == 1)) {
         set_error("gptqhip_decode_linear: K=%d group_size=%d is outside the decode op's regular pipeline (use gptqhip_gemm)",
                   op->K, op->group_size);

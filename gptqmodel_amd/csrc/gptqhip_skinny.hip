@@ -686,7 +686,25 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     // prefer a wave count that gives every wave a multiple of the ring depth (regular pipeline, counted waits):
     // e.g. K=14336 -> 112 chunks -> 14 waves x 8 chunks
     pl.depth = (pl.mt == 1 && M <= 4) ? 4 : 2;
-    {
+    bool chosen = false;
+    if (pl.mt == 1 && M <= 4) {
+        // batch <= 4 (measured in round 2, profiles/r02_waves_sweep.txt): what matters is the number of waves on the chip, not
+        // per block -- about 16 per CU (4096 in flight), each with a long K run (>= 2 ring rounds): fewer, longer-lived blocks
+        // amortise the ramp, the statistics / reduce prologue and the tail.  Llama-3-70B gate_up (3584 tiles, K=8192): 16 waves
+        // per block 61 us, 4 waves 47 us; qkv 15.5 -> 12.8 (8 waves); down (K=28672) 29.5 -> 27.0 (8 waves).
+        int target = 4096 / (tiles > 0 ? tiles : 1);
+        target = target < 4 ? 4 : (target > 16 ? 16 : target);
+        int best = 0;
+        for (int w = 4; w <= 16; ++w) {
+            if (pl.chunks % (w * pl.depth) != 0) continue;
+            if (best == 0 || abs(w - target) < abs(best - target) || (abs(w - target) == abs(best - target) && w > best)) best = w;
+        }
+        if (best > 0) {
+            waves = best;
+            chosen = true;
+        }
+    }
+    if (!chosen) {
         int best = 0;
         for (int w = 16; w >= 4; --w) {
             if (pl.chunks % (w * pl.depth) == 0 && w >= waves / 2) { best = w; break; }

@@ -23,6 +23,10 @@ for name, K, N in SH:
     outs = [torch.empty(N, dtype=dtype, device=dev) for _ in range(NL)]
     st_in = torch.ones(K // 16, dtype=torch.float32, device=dev)
     st_out = torch.zeros(N // 16, dtype=torch.float32, device=dev)
+    if os.environ.get("ONLY"):
+        keep = os.environ["ONLY"].split(",")
+    else:
+        keep = None
     variants = {
         "plain": dict(),
         "rms(stats)": dict(in_glue=ops.GLUE_RMSNORM, norm_weight=nw, stats_in=st_in),
@@ -35,6 +39,8 @@ for name, K, N in SH:
     }
     line = [f"{name:8s}"]
     for tag, kw in variants.items():
+      if keep and tag not in keep:
+          continue
       try:
         dops = [ops.make_decode_op(xin, l.qweight, l.meta, None, o, K, N, 128, 4, l._scale_dtype, **kw) for l, o in zip(lins, outs)]
         def run():
