@@ -21,6 +21,8 @@ Extra objects on the JSON line (tier contract):
   configs       one object per BASELINE.json config with its own workload / value / roofline (outside the timed region):
                 C2 variant (per-module launches + torch glue kernels), C3 act-order prefill at M=65536, C4 AWQ decode +
                 M=2048 prefill, C5 Llama-3-70B decode at TP=1.
+  e2e           tokens/s of a whole HF LlamaForCausalLM with Llama-3-8B shapes (random init, real attention / KV cache / norms /
+                lm_head) decoding through the plugin classes: eager generate() and one HIP graph per decode step.
   cpu_baseline  the oracle's torch-CPU PORT of BACKEND.TORCH (oracle/gptq_oracle.py:torch_cpu_forward_gptq) on this
                 host's cores, thread count swept, rank 0 at N=1 only: C1 (single 4096x4096 linear, M in {1,32,2048}, fp16 and
                 bf16) and one decoder layer at M=1 extrapolated to tokens/s.
@@ -292,6 +294,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per token")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs[] array (C3/C4/C5 legs)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end HF Llama-3-8B-shaped decode leg (`e2e` key)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     args = ap.parse_args()
 
@@ -412,9 +415,21 @@ def main():
             out["configs"] = extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, ms_per_step, n_launch)
             if out["configs"] and out["configs"][-1].get("config") == "_prefill_headline":
                 out["prefill"] = out["configs"].pop()
-        if world == 1 and not args.no_cpu_baseline:
-            del layers, step, graph
+        del layers, step, graph
+        torch.cuda.empty_cache()
+        if world == 1 and not args.no_e2e and not args.no_configs:
+            # the whole model, not just the quantised linears: HF LlamaForCausalLM with Llama-3-8B shapes (random init), real
+            # attention / KV cache / norms / lm_head, decode through make_quant -> fuse_siblings -> post_init -- eager
+            # generate() and one captured graph per decode step (the reference's speed metric is generate() wall time,
+            # tests/inference_speed.py:95-113).  Outside the timed region.
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "examples"))
+                from hf_llama_dropin import run as e2e_run
+                out["e2e"] = e2e_run("8b", args.dtype, 64)
+            except Exception as e:  # noqa: BLE001
+                out["e2e"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
             torch.cuda.empty_cache()
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, gs)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -48,6 +48,17 @@ def main():
     ap.add_argument("--no-fuse", action="store_true")
     ap.add_argument("--quant-lm-head", action="store_true", help="also quantise lm_head (qcfg.lm_head upstream, loader.py:1376)")
     args = ap.parse_args()
+    run(args.size, args.dtype, args.new_tokens, not args.no_fuse, args.quant_lm_head, verbose=True)
+
+
+def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=False, verbose=False):
+    """Returns {"eager_tokens_per_s", "graph_tokens_per_s" | None, "build_s", ...}; bench.py reports it as `e2e`."""
+    import types
+    args = types.SimpleNamespace(size=size, dtype=dtype_name, new_tokens=new_tokens, no_fuse=not fuse, quant_lm_head=quant_lm_head)
+    out = {"model": f"random-init HF LlamaForCausalLM, Llama-3-{size} shapes, every decoder nn.Linear RTN-quantised to int4 g128 "
+                    "and swapped through make_quant -> fuse_siblings -> gptqmodel_post_init; real attention / norms / rotary / lm_head",
+           "new_tokens": new_tokens}
+    say = print if verbose else (lambda *a, **k: None)
     from transformers import LlamaConfig, LlamaForCausalLM
     from gptqmodel_amd.utils.backend import BACKEND
     from gptqmodel_amd.utils.const import FORMAT
@@ -79,8 +90,10 @@ def main():
     gptqmodel_post_init(model)
     torch.cuda.synchronize()
     nq = sum(1 for m in model.modules() if type(m).__name__ == "HipGptqLinear")
-    print(f"built + quantised + packed + repacked {len(names)} linears ({nq} launches/token) in {time.time() - t0:.1f} s; "
-          f"GPU memory {torch.cuda.memory_allocated() / 2**30:.2f} GiB")
+    out["build_s"] = time.time() - t0
+    out["quant_launches_per_token"] = nq
+    say(f"built + quantised + packed + repacked {len(names)} linears ({nq} launches/token) in {time.time() - t0:.1f} s; "
+        f"GPU memory {torch.cuda.memory_allocated() / 2**30:.2f} GiB")
 
     ids = torch.randint(0, cfg.vocab_size, (1, 16), device=dev)
     with torch.no_grad():
@@ -90,7 +103,8 @@ def main():
         out = model.generate(input_ids=ids, max_new_tokens=args.new_tokens, do_sample=False, pad_token_id=0)
         torch.cuda.synchronize()
         dt = time.time() - t0
-    print(f"HF generate (eager, Python-bound): {args.new_tokens / dt:.1f} tokens/s")
+    out["eager_tokens_per_s"] = args.new_tokens / dt
+    say(f"HF generate (eager, Python-bound): {args.new_tokens / dt:.1f} tokens/s")
 
     # one HIP graph per decode step over a static KV cache
     try:
@@ -119,9 +133,15 @@ def main():
                     s_pos.add_(1)
                 stream.synchronize()
                 dt = time.time() - t0
-        print(f"graph-replayed decode step (static KV cache): {args.new_tokens / dt:.1f} tokens/s")
+        out["graph_tokens_per_s"] = args.new_tokens / dt
+        say(f"graph-replayed decode step (static KV cache): {args.new_tokens / dt:.1f} tokens/s")
     except Exception as e:  # transformers API drift must not hide the eager result above
-        print(f"graph-replayed decode skipped: {type(e).__name__}: {e}")
+        out["graph_tokens_per_s"] = None
+        out["graph_error"] = f"{type(e).__name__}: {str(e)[:200]}"
+        say(f"graph-replayed decode skipped: {type(e).__name__}: {e}")
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":
