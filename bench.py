@@ -213,36 +213,14 @@ def _time_cpu(fn, budget_s, max_iters):
 
 def cpu_baseline(cfg, gs=128, budget_s=24.0):
     """Reference path on the host cores: upstream's CPU test runs bf16 (tests/test_q4_torch.py:27,50) and
-    flags fp16 CPU matmul as slow (:52-53); both are timed.  The torch.compile'd dequant upstream enables in post_init
+    flags fp16 CPU matmul as slow (:52-53); both are timed.  The thread count is swept on the actual sample (one decoder
+    layer's 7 linears at M=1) and the best is used.  The torch.compile'd dequant upstream enables in post_init
     (torch.py:215-216,259) is NOT timed: inductor needs a C++ toolchain run per shape that does not fit this bounded leg."""
     from oracle.gptq_oracle import torch_cpu_forward_gptq
     torch.manual_seed(1234)
     ncpu = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
-    k = n = 4096
-    t = {dt: _cpu_tensors(k, n, gs, dt) for dt in (torch.bfloat16, torch.float16)}
-    x1 = {dt: (torch.randn(1, k) * 0.5).to(dt) for dt in t}
-    sweep = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu})
-    per_thread = {}
-    t_sweep0 = time.perf_counter()
-    for th in sweep:   # M=1 bf16 on the C1 layer: the op mix the decode token is made of
-        torch.set_num_threads(th)
-        ms, _ = _time_cpu(lambda: torch_cpu_forward_gptq(x1[torch.bfloat16], *t[torch.bfloat16], 4), budget_s * 0.04, 6)
-        per_thread[str(th)] = round(ms, 3)
-    best = int(min(per_thread, key=lambda s: per_thread[s]))
-    torch.set_num_threads(best)
-    c1 = {}
-    for dt, tag in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
-        for m in (1, 32, 2048):
-            if dt == torch.float16 and m > 1:
-                # aten's CPU fp16 matmul is pathologically slow (measured on the GPU box's host: 2.6 s at M=32, 183 s at
-                # M=2048 per call; upstream flags it too, tests/test_q4_torch.py:52-53): not part of a bounded leg
-                c1[f"{tag}_m{m}"] = None
-                continue
-            x = (torch.randn(m, k) * 0.5).to(dt)
-            ms, it = _time_cpu(lambda: torch_cpu_forward_gptq(x, *t[dt], 4), budget_s * 0.05, 4)
-            c1[f"{tag}_m{m}"] = round(ms, 3)
-    # one decoder layer at M=1 (7 linears, bf16), extrapolated to the model
+    t_start = time.perf_counter()
     mods = []
     for _, kk, nn in layer_shapes(cfg):
         mods.append(((torch.randn(1, kk) * 0.5).to(torch.bfloat16),) + _cpu_tensors(kk, nn, gs, torch.bfloat16))
@@ -250,17 +228,41 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
     def one_pass():
         for x, qw, qz, sc, gi in mods:
             torch_cpu_forward_gptq(x, qw, qz, sc, gi, 4)
-    per_layer, iters = _time_cpu(one_pass, budget_s * 0.35, 20)
+    sweep = sorted({c for c in (8, 16, 32, 64, 128) if c <= ncpu})
+    per_thread = {}
+    for th in sweep:   # one decoder layer per thread count (after a warm-up pass), the workload the tokens/s is extrapolated from
+        torch.set_num_threads(th)
+        ms, _ = _time_cpu(one_pass, budget_s * 0.05, 2)
+        per_thread[str(th)] = round(ms, 2)
+    best = int(min(per_thread, key=lambda s: per_thread[s]))
+    torch.set_num_threads(best)
+    per_layer, iters = _time_cpu(one_pass, budget_s * 0.3, 20)
+    del mods
+    # C1: single QuantLinear 4096x4096 g128 sym=True
+    k = n = 4096
+    c1 = {}
+    for dt, tag in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
+        t = _cpu_tensors(k, n, gs, dt)
+        for m in (1, 32, 2048):
+            if dt == torch.float16 and m > 1:
+                # aten's CPU fp16 matmul is pathologically slow (measured on a GPU box's host: 2.6 s at M=32, 183 s at
+                # M=2048 per call; upstream flags it too, tests/test_q4_torch.py:52-53): not part of a bounded leg
+                c1[f"{tag}_m{m}"] = None
+                continue
+            x = (torch.randn(m, k) * 0.5).to(dt)
+            ms, _ = _time_cpu(lambda: torch_cpu_forward_gptq(x, *t, 4), budget_s * 0.05, 4)
+            c1[f"{tag}_m{m}"] = round(ms, 3)
     torch.set_num_threads(default_threads)
     return {
         "value": 1e3 / (per_layer * cfg["layers"]), "unit": "tokens/s", "cores": best, "kind": "port",
         "sample": f"1 of {cfg['layers']} decoder layers (7 linears, M=1, bf16 like upstream's CPU test), {iters} passes, "
                   f"extrapolated x{cfg['layers']}; torch CPU port of BACKEND.TORCH (oracle/gptq_oracle.py), not the reference "
                   f"module itself; host os.cpu_count()={ncpu}",
-        "ms_per_layer": per_layer, "threads_swept": per_thread, "best_threads": best,
+        "ms_per_layer": per_layer, "threads_swept": per_thread, "threads_swept_unit": "ms per decoder layer (7 linears, M=1, bf16)",
+        "best_threads": best,
         "c1_ms": c1, "c1_workload": "single QuantLinear 4096x4096 int4 g128 sym=True, eager dequant + matmul, best_threads "
-                                      "(null: fp16 CPU matmul at M>1 takes 2.6-183 s per call on this host; not timed)",
-        "sweep_s": round(time.perf_counter() - t_sweep0, 1),
+                                      "(null: fp16 CPU matmul at M>1 takes 2.6-183 s per call on such a host; not timed)",
+        "leg_s": round(time.perf_counter() - t_start, 1),
     }
 
 

@@ -55,7 +55,7 @@ def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=Fa
     """Returns {"eager_tokens_per_s", "graph_tokens_per_s" | None, "build_s", ...}; bench.py reports it as `e2e`."""
     import types
     args = types.SimpleNamespace(size=size, dtype=dtype_name, new_tokens=new_tokens, no_fuse=not fuse, quant_lm_head=quant_lm_head)
-    out = {"model": f"random-init HF LlamaForCausalLM, Llama-3-{size} shapes, every decoder nn.Linear RTN-quantised to int4 g128 "
+    res = {"model": f"random-init HF LlamaForCausalLM, Llama-3-{size} shapes, every decoder nn.Linear RTN-quantised to int4 g128 "
                     "and swapped through make_quant -> fuse_siblings -> gptqmodel_post_init; real attention / norms / rotary / lm_head",
            "new_tokens": new_tokens}
     say = print if verbose else (lambda *a, **k: None)
@@ -90,8 +90,8 @@ def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=Fa
     gptqmodel_post_init(model)
     torch.cuda.synchronize()
     nq = sum(1 for m in model.modules() if type(m).__name__ == "HipGptqLinear")
-    out["build_s"] = time.time() - t0
-    out["quant_launches_per_token"] = nq
+    res["build_s"] = time.time() - t0
+    res["quant_launches_per_token"] = nq
     say(f"built + quantised + packed + repacked {len(names)} linears ({nq} launches/token) in {time.time() - t0:.1f} s; "
         f"GPU memory {torch.cuda.memory_allocated() / 2**30:.2f} GiB")
 
@@ -103,7 +103,7 @@ def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=Fa
         out = model.generate(input_ids=ids, max_new_tokens=args.new_tokens, do_sample=False, pad_token_id=0)
         torch.cuda.synchronize()
         dt = time.time() - t0
-    out["eager_tokens_per_s"] = args.new_tokens / dt
+    res["eager_tokens_per_s"] = args.new_tokens / dt
     say(f"HF generate (eager, Python-bound): {args.new_tokens / dt:.1f} tokens/s")
 
     # one HIP graph per decode step over a static KV cache
@@ -133,15 +133,15 @@ def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=Fa
                     s_pos.add_(1)
                 stream.synchronize()
                 dt = time.time() - t0
-        out["graph_tokens_per_s"] = args.new_tokens / dt
+        res["graph_tokens_per_s"] = args.new_tokens / dt
         say(f"graph-replayed decode step (static KV cache): {args.new_tokens / dt:.1f} tokens/s")
     except Exception as e:  # transformers API drift must not hide the eager result above
-        out["graph_tokens_per_s"] = None
-        out["graph_error"] = f"{type(e).__name__}: {str(e)[:200]}"
+        res["graph_tokens_per_s"] = None
+        res["graph_error"] = f"{type(e).__name__}: {str(e)[:200]}"
         say(f"graph-replayed decode skipped: {type(e).__name__}: {e}")
     del model
     torch.cuda.empty_cache()
-    return out
+    return res
 
 
 if __name__ == "__main__":
