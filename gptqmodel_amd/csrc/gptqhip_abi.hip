@@ -220,7 +220,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     if (perm && M == 1 && g_force_kernel != 2) {
         const SkinnyPlan pl1 = plan_skinny(1, K, N, group_size, g_force_split, g_force_waves);
         // (the kernel keeps the x row in LDS next to 16 KiB of per-wave slots: stay inside the default 64 KiB of dynamic LDS)
-        fused_perm = pl1.regular && pl1.gpc == 1 && (size_t)K * 2 <= 44 * 1024;
+        fused_perm = pl1.regular && pl1.gpc == 1 && pl1.depth == 4 && (size_t)K * 2 <= 44 * 1024;
     }
     if (perm && !fused_perm) {
         void* gbuf = ws + L.gather_off;

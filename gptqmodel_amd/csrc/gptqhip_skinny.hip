@@ -642,7 +642,7 @@ static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStr
     const dim3 block(64 * pl.waves);
     constexpr int kSlot = slot_bytes<AM, MT>() > MT * 1024 ? slot_bytes<AM, MT>() : MT * 1024;
     const size_t lds_bytes = (size_t)pl.waves * kSlot + 16 + (AM == AM_ROW1P ? (size_t)p.K * 2 : 64);
-    if constexpr (AM == AM_ROW1 && MT == 1 && D == 4) {
+    if constexpr (AM == AM_ROW1 && MT == 1 && (D == 4 || D == 2)) {
         if (p.in_glue != kGlueNone) {  // decode op with input glue: regular single-group-per-chunk plans only (ABI checks)
             if (p.in_glue == kGlueRmsNorm) {
                 hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueRmsNorm>), grid, block, lds_bytes, stream, p);
@@ -663,6 +663,7 @@ static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStr
 template <int BITS, int ACT, int SCL>
 static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
     if (pl.mt == 1 && p.M == 1 && p.perm != nullptr) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1P, 4>(p, pl, stream);
+    if (pl.mt == 1 && p.M == 1 && pl.depth == 2) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1, 2>(p, pl, stream);
     if (pl.mt == 1 && p.M == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1, 4>(p, pl, stream);
     if (pl.mt == 1 && p.M <= 4) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW4, 4>(p, pl, stream);
     if (pl.mt == 1 && p.M <= 8) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROWSH, 2>(p, pl, stream);
@@ -673,6 +674,7 @@ static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStre
 }
 
 SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves) {
+    static const bool allow_depth2 = [] { const char* v = getenv("GPTQHIP_NO_DEPTH2"); return !(v && *v && *v != '0'); }();
     SkinnyPlan pl;
     const int mtiles = ceil_div(M, 16);
     pl.mt = mtiles <= 1 ? 1 : 2;  // gptqhip_gemm feeds at most 32 rows per launch
@@ -694,13 +696,29 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
         // per block 61 us, 4 waves 47 us; qkv 15.5 -> 12.8 (8 waves); down (K=28672) 29.5 -> 27.0 (8 waves).
         int target = 4096 / (tiles > 0 ? tiles : 1);
         target = target < 4 ? 4 : (target > 16 ? 16 : target);
-        int best = 0;
-        for (int w = 4; w <= 16; ++w) {
-            if (pl.chunks % (w * pl.depth) != 0) continue;
-            if (best == 0 || abs(w - target) < abs(best - target) || (abs(w - target) == abs(best - target) && w > best)) best = w;
+        int best = 0, best_depth = pl.depth;
+        // batch 1 may also run a 2-deep ring (16 waves x 2 chunks on K = 4096: twice the waves dequantise the same bytes
+        // once they have landed -- narrow layers like o_proj are latency-, not stream-bound)
+        const int force_s = force_split > 0 ? (force_split < pl.chunks ? force_split : pl.chunks) : 0;
+        for (int depth = 4; depth >= (M == 1 && allow_depth2 ? 2 : 4); depth -= 2) {
+            for (int w = 4; w <= 16; ++w) {
+                // the candidate must stay on the regular pipeline AFTER the cross-block split-K decision below (narrow layers)
+                int sp = 1;
+                if (tiles < 48 && pl.chunks >= 4 * w) sp = ceil_div(48, tiles);
+                const int max_sp = pl.chunks / w < 1 ? 1 : pl.chunks / w;
+                if (sp > max_sp) sp = max_sp;
+                if (force_s > 0) sp = force_s;
+                const int cps = ceil_div(pl.chunks, sp);
+                if (pl.chunks % cps != 0 || cps % (w * depth) != 0) continue;
+                if (best == 0 || abs(w - target) < abs(best - target) || (abs(w - target) == abs(best - target) && depth == best_depth && w > best)) {
+                    best = w;
+                    best_depth = depth;
+                }
+            }
         }
         if (best > 0) {
             waves = best;
+            pl.depth = best_depth;
             chosen = true;
         }
     }
