@@ -212,3 +212,29 @@ def test_chain_tracks_unfused_reference_and_replays_identically(dtype):
             g.replay()
             assert torch.equal(out, want[i % 3]), f"graph replay {i} differs from the eager step"
         s.synchronize()
+
+
+@pytest.mark.parametrize("act,bits,sdt", [("fp16", 8, "fp16"), ("bf16", 4, "bf16"), ("bf16", 8, "fp16")])
+def test_decode_op_glue_variants_ragged_n_bias(ops, act, bits, sdt):
+    """Glue on the less-travelled instantiations: 8-bit codes, bf16 scales, bias + residual + stats_out together, N that is not a
+    multiple of 16 (half-filled last tile), in-block RMSNorm statistics (no producer)."""
+    gs, K, N = 128, 4096, 1000
+    qweight, qzeros, scales, g_idx = synth_gptq(77 + bits, bits, K, N, gs, scale_dtype=sdt)
+    rng = np.random.RandomState(5)
+    h = O.round_to(rng.randn(K).astype(np.float32) * 3.0, act)
+    w = O.round_to(1.0 + rng.randn(K).astype(np.float32) * 0.1, act)
+    res = O.round_to(rng.randn(N).astype(np.float32), act)
+    bias = O.round_to(rng.randn(N).astype(np.float32) * 0.1, act)
+    qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, gs, bits, sdt)
+    stats = torch.zeros(-(-N // 16), dtype=torch.float32, device=DEV)
+    out = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, f32_to_torch(bias, act, DEV), K, N, gs, bits, sc.dtype,
+                            in_glue=ops.GLUE_RMSNORM, norm_weight=f32_to_torch(w, act, DEV), eps=1e-6,
+                            residual=f32_to_torch(res, act, DEV), stats_out=stats)
+    xn = O.rmsnorm_ref(h, w, 1e-6, act)
+    y = O.forward_gptq(xn[None], qweight, qzeros, scales, g_idx, bits, bias, act, sdt)
+    ref = O.residual_add_ref(res[None], y, act)
+    got = torch_to_f32(out)
+    assert_forward_close(got[None], ref, act)
+    pad = np.zeros(len(stats) * 16, dtype=np.float64)
+    pad[:N] = got.astype(np.float64) ** 2
+    assert np.allclose(stats.cpu().numpy(), pad.reshape(-1, 16).sum(axis=1), rtol=1e-5)
