@@ -40,24 +40,43 @@ def run_70b(args, rank, local_rank, world, dev, dist):
     if dist is not None:
         dist.broadcast(x0, 0)
     qs, inter_s = q // tp, inter // tp
+    # decode messages (hidden * 4 B = 32 KB) go through the one-shot peer-to-peer all-reduce (one kernel, rounding + residual
+    # fused, capture-safe: csrc/gptqhip_comm.hip); RCCL all-reduce is the fallback
+    comm = None
+    if tp > 1 and not os.environ.get("GPTQHIP_BENCH_RCCL"):
+        try:
+            from gptqmodel_amd.utils.xgmi_allreduce import OneShotAllReduce
+            comm = OneShotAllReduce(h, dev)
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(f"bench_tp: one-shot all-reduce unavailable ({str(e)[:160]}); using RCCL all_reduce", flush=True)
+            comm = None
+        flag = torch.tensor([1 if comm is not None else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # all ranks or none
+        if int(flag.item()) == 0:
+            comm = None
 
     def rms(v, w):
         v32 = v.float()
         return w * (v32 * torch.rsqrt(v32.pow(2).mean(-1, keepdim=True) + eps)).to(dtype)
+
+    def reduce_add(part, hcur):
+        """hidden = residual + act(sum over ranks of the fp32 partials): the reference's single rounding, then the residual add."""
+        if comm is not None:
+            return comm(part, out_dtype=dtype, residual=hcur.contiguous())
+        if tp > 1:
+            dist.all_reduce(part)                                  # RCCL over xGMI
+        return hcur + part.to(dtype)
 
     def token_step():
         hcur = x0[None]
         for (qkv, o, gu, down), (w_in, w_post) in layers:
             a = qkv(rms(hcur, w_in))[:, :qs]                       # this rank's query heads stand in for its attention output
             part = o.forward_partial(a.contiguous())               # fp32 partial sums over this rank's K-shard
-            if tp > 1:
-                dist.all_reduce(part)                              # RCCL over xGMI
-            hcur = hcur + part.to(dtype)                           # the reference's single rounding, then the residual add
+            hcur = reduce_add(part, hcur)
             g = gu(rms(hcur, w_post))
             part = down.forward_partial((torch.nn.functional.silu(g[:, :inter_s]) * g[:, inter_s:]).contiguous())
-            if tp > 1:
-                dist.all_reduce(part)
-            hcur = hcur + part.to(dtype)
+            hcur = reduce_add(part, hcur)
         return hcur
 
     stream = torch.cuda.Stream(device=dev)
@@ -113,7 +132,9 @@ def run_70b(args, rank, local_rank, world, dev, dist):
                                    f"tensor parallel TP={tp} (column qkv/gate_up, row o/down + fp32 all-reduce), true data "
                                    "dependencies through the layer glue, random packed weights",
                        "parallelism": f"tp{tp}", "launches_per_step": n_launch, "graph": graph is not None,
-                       "weight_bytes_per_token": step_bytes, "allreduce_per_token": 2 * cfg["layers"] if tp > 1 else 0},
+                       "weight_bytes_per_token": step_bytes, "allreduce_per_token": 2 * cfg["layers"] if tp > 1 else 0,
+                       "allreduce": ("one-shot peer-to-peer kernel (gptqhip_allreduce_oneshot)" if comm is not None else
+                                     ("RCCL all_reduce" if tp > 1 else "none"))},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": B.HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / B.HBM_PEAK_GBS,
                          "traffic": None, "traffic_source": "none", "kernel": "gptqhip::skinny_kernel (per rank)",
                          "bytes_per_launch": step_bytes / tp / n_launch, "avg_launch_us": ms * 1e3 / n_launch},

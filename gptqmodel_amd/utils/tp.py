@@ -149,11 +149,14 @@ class RowParallelQuantLinear(nn.Module):
     y = round(sum) ; y = round(y + bias)   (torch.py:337-342)."""
 
     def __init__(self, local: nn.Module, bias: Optional[torch.Tensor] = None, group: Optional[dist.ProcessGroup] = None,
-                 input_index: Optional[torch.Tensor] = None):
+                 input_index: Optional[torch.Tensor] = None, comm=None):
         super().__init__()
         self.local = local
         self.group = group
         self.bias = bias
+        # utils.xgmi_allreduce.OneShotAllReduce: small (decode) messages go through ONE peer-to-peer kernel that also applies
+        # the rounding + bias; larger ones keep the RCCL all-reduce
+        self.comm = comm
         # act-order shards (shard_gptq_row(..., act_order="global_sort")): the input features this rank's rows need, as
         # indices into the FULL (gathered) activation
         self.input_index = input_index
@@ -172,6 +175,12 @@ class RowParallelQuantLinear(nn.Module):
         if self.input_index is not None:
             x_shard = self._gathered_input(x_shard)
         partial = self.local.forward_partial(x_shard)  # float32, unrounded
+        odt = x_shard.dtype if x_shard.dtype in (torch.float16, torch.bfloat16) else torch.float16
+        if self.comm is not None and partial.numel() <= self.comm.n_max and partial.numel() % 4 == 0:
+            bias = None if self.bias is None else self.bias.to(device=partial.device, dtype=odt)
+            if bias is not None and partial.dim() > 1 and partial.numel() != bias.numel():
+                bias = bias.expand(partial.shape).contiguous()
+            return self.comm(partial.contiguous(), out_dtype=odt, bias=bias)
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=self.group)
         out = partial.to(x_shard.dtype if x_shard.dtype in (torch.float16, torch.bfloat16) else torch.float16)

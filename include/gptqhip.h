@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 4
+#define GPTQHIP_ABI_VERSION 5
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -212,6 +212,32 @@ int gptqhip_pack_gptq_host(const float* weight, const float* scales, const int32
 /* out[m, k'] = x[m, perm[k']]  (16-bit elements).  Used by gptqhip_gemm internally and exported for tests
  * (ExllamaV2 gathers A through q_perm: gptqmodel_ext/exllamav2/cuda/q_gemm_kernel_gptq.cuh:79-90). */
 int gptqhip_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, gptqhip_stream_t stream);
+
+/* ONE-SHOT ALL-REDUCE for the tensor-parallel decode step (gptqmodel_amd/csrc/gptqhip_comm.hip).  The reference has no
+ * tensor parallelism and no collectives -- nothing upstream is replaced; this is the MI355X design for the 70B
+ * config's 160 latency-bound all-reduces per token (32 KB each at batch 1): every rank pushes its fp32 partial vector straight
+ * into every rank's peer-mapped buffer over xGMI (point-to-point, no intermediate hop), waits for the `world` arrival flags in
+ * its OWN buffer, sums the slots in rank order (bit-identical on all ranks) and applies the reference's rounding chain
+ * (act(sum); act(+bias); act(residual + .)) in the same kernel.  Epochs live in device memory: capture-safe.
+ *   gptqhip_comm_bytes(world, n_max)   bytes of one rank's communication buffer for vectors of up to n_max floats (0 = bad args;
+ *                                      world <= 8, n_max <= 65536)
+ *   gptqhip_comm_alloc(bytes, &ptr, handle[64])   uncached (fine-grained) device memory, zero-filled, + its IPC handle
+ *   gptqhip_comm_open(handle, &ptr) / gptqhip_comm_close(ptr)   map / unmap a PEER's buffer in this process
+ *   gptqhip_comm_free(ptr)             free the buffer this rank allocated
+ *   gptqhip_comm_status(own_buf, &st)  host read of the "a bounded wait gave up" word (0 = healthy)
+ *   gptqhip_allreduce_oneshot(partial[n] fp32, peer_bufs[world] (HOST array of device pointers, own buffer at [rank]), rank, world,
+ *                             n (% 4 == 0), n_max (as allocated), bias|NULL, residual|NULL, out[n] act dtype, act_dtype, stream)
+ * Every rank must issue the same sequence of calls.  Status: exercised by two processes sharing one GPU through real IPC
+ * mappings (tests/test_gpu_comm.py); not yet run across physical GPUs. */
+#define GPTQHIP_IPC_HANDLE_BYTES 64
+size_t gptqhip_comm_bytes(int world, int n_max);
+int gptqhip_comm_alloc(size_t bytes, void** dev_ptr, unsigned char* handle_out);
+int gptqhip_comm_open(const unsigned char* handle, void** dev_ptr);
+int gptqhip_comm_close(void* dev_ptr);
+int gptqhip_comm_free(void* dev_ptr);
+int gptqhip_comm_status(void* own_buf, uint32_t* status_out);
+int gptqhip_allreduce_oneshot(const float* partial, void* const* peer_bufs, int rank, int world, int n, int n_max,
+                              const void* bias, const void* residual, void* out, int act_dtype, gptqhip_stream_t stream);
 
 /* Tuning hook (benchmarks / tests): force the cross-block split-K factor and the waves per block of the skinny
  * kernel (0 = heuristic), or the kernel family (0 auto, 1 skinny, 2 tiled-prefill).  The overrides are THREAD-LOCAL

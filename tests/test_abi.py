@@ -78,6 +78,19 @@ def test_argument_validation_reports_errors_without_a_gpu(lib):
     assert lib.gptqhip_device_info(0, None, None, None, 0) in (0, -19)  # ENODEV on a CPU-only box
 
 
+def test_comm_buffer_sizing_and_argument_checks(lib):
+    """One-shot all-reduce entry points: sizes and validation without a GPU."""
+    one = ctypes.c_void_p(16)
+    assert lib.gptqhip_comm_bytes(8, 8192) >= 2 * 8 * 8192 * 4
+    assert lib.gptqhip_comm_bytes(9, 8192) == 0 and lib.gptqhip_comm_bytes(2, 0) == 0 and lib.gptqhip_comm_bytes(2, 1 << 20) == 0
+    peers = (ctypes.c_void_p * 2)(16, 16)
+    assert lib.gptqhip_allreduce_oneshot(one, peers, 0, 2, 1001, 8192, None, None, one, 0, None) == -22   # n % 4
+    assert lib.gptqhip_allreduce_oneshot(one, peers, 2, 2, 1024, 8192, None, None, one, 0, None) == -22   # rank >= world
+    assert lib.gptqhip_allreduce_oneshot(one, peers, 0, 2, 16384, 8192, None, None, one, 0, None) == -22  # n > n_max
+    assert lib.gptqhip_allreduce_oneshot(one, peers, 0, 2, 1024, 8192, None, None, one, 7, None) == -22   # dtype tag
+    assert lib.gptqhip_comm_open(None, None) == -22
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from gptqmodel_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -1,0 +1,128 @@
+"""One-shot all-reduce (gptqhip_allreduce_oneshot / utils.xgmi_allreduce.OneShotAllReduce): the protocol -- IPC handle exchange,
+peer-mapped pushes, arrival flags, rank-ordered reduction, fused rounding / bias / residual, device-side epochs under graph replay
+-- driven by TWO PROCESSES that share GPU 0 through real IPC mappings (the test boxes have one GPU; across physical GPUs the same
+code path runs over xGMI, which this test cannot cover)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected(parts, bias, residual, dtype):
+    s = parts[0].clone()
+    for p in parts[1:]:
+        s = s + p                       # rank order, fp32
+    y = s.to(dtype)
+    if bias is not None:
+        y = (y.float() + bias.float()).to(dtype)
+    if residual is not None:
+        y = (residual.float() + y.float()).to(dtype)
+    return y
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gptqmodel_amd.utils.xgmi_allreduce import OneShotAllReduce
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        n_max = 8192
+        comm = OneShotAllReduce(n_max, dev)
+        ok = True
+        for it, (n, dtype, use_b, use_r) in enumerate([(8192, torch.float16, False, False), (8192, torch.float16, True, True),
+                                                         (4096, torch.bfloat16, True, False), (1000, torch.float16, False, True),
+                                                         (8192, torch.float16, False, True)] * 3):
+            g = torch.Generator().manual_seed(1000 * it + rank)
+            part = torch.randn(n, generator=g) * 3.0
+            gb = torch.Generator().manual_seed(77 + it)
+            bias = (torch.randn(n, generator=gb) * 0.1).to(dtype) if use_b else None
+            res = torch.randn(n, generator=gb).to(dtype) if use_r else None
+            allp = [torch.empty(n) for _ in range(world)]
+            dist.all_gather(allp, part)
+            want = _expected(allp, bias, res, dtype)
+            got = comm(part.to(dev), out_dtype=dtype, bias=None if bias is None else bias.to(dev),
+                       residual=None if res is None else res.to(dev))
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(got.cpu(), want)
+        # graph replay: epochs live in device memory, so a captured launch keeps working; inputs change under it
+        n, dtype = 8192, torch.float16
+        part_dev = torch.zeros(n, device=dev)
+        res_dev = torch.zeros(n, device=dev, dtype=dtype)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            comm(part_dev, out_dtype=dtype, residual=res_dev)
+            s.synchronize()
+            dist.barrier()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                out = comm(part_dev, out_dtype=dtype, residual=res_dev)
+            for it in range(25):
+                g = torch.Generator().manual_seed(5000 + 10 * it + rank)
+                part = torch.randn(n, generator=g)
+                res = torch.randn(n, generator=torch.Generator().manual_seed(9000 + it)).to(dtype)
+                allp = [torch.empty(n) for _ in range(world)]
+                dist.all_gather(allp, part)
+                part_dev.copy_(part)
+                res_dev.copy_(res)
+                gr.replay()
+                s.synchronize()
+                ok = ok and torch.equal(out.cpu(), _expected(allp, None, res, dtype))
+        comm.check_status()
+        # through the tensor-parallel module: RowParallelQuantLinear(comm=...) == all-reduce path, bit for bit
+        from gptqmodel_amd.utils import tp
+
+        class Local(torch.nn.Module):
+            def __init__(self, w):
+                super().__init__()
+                self.w = w
+
+            def forward_partial(self, x):
+                return x.float() @ self.w
+
+        gw = torch.Generator().manual_seed(31 + rank)
+        w = (torch.randn(256, 4096, generator=gw) * 0.05).to(dev)
+        x = (torch.randn(1, 256, generator=torch.Generator().manual_seed(3 + rank)) * 0.5).half().to(dev)
+        bias = (torch.randn(4096, generator=torch.Generator().manual_seed(8)) * 0.1).half().to(dev)
+        y_comm = tp.RowParallelQuantLinear(Local(w), bias=bias, comm=comm)(x)
+        parts = [torch.empty(1, 4096) for _ in range(world)]
+        dist.all_gather(parts, (x.float() @ w).cpu())
+        want = _expected([p[0] for p in parts], bias.cpu(), None, torch.float16)
+        ok = ok and torch.equal(y_comm.cpu()[0], want)
+        comm.check_status()
+        comm.close()
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_oneshot_allreduce_two_processes_one_gpu():
+    world = 2
+    port = 29700 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_oneshot_allreduce_world1_is_the_rounding_chain():
+    from gptqmodel_amd.utils.xgmi_allreduce import OneShotAllReduce
+    dev = torch.device("cuda", 0)
+    comm = OneShotAllReduce(4096, dev)
+    part = torch.randn(4096, device=dev) * 2.0
+    res = torch.randn(4096, device=dev).half()
+    bias = (torch.randn(4096, device=dev) * 0.1).half()
+    got = comm(part, out_dtype=torch.float16, bias=bias, residual=res)
+    assert torch.equal(got, _expected([part], bias, res, torch.float16))
+    with pytest.raises(RuntimeError, match="elements"):
+        comm(torch.zeros(8192, device=dev))
+    comm.check_status()
+    comm.close()
