@@ -16,11 +16,45 @@ import time
 import torch
 
 
+def _run_tp1_chain(args, dev):
+    """One GPU holds the whole 70B model (35.6 GB packed): the decode chain with fused glue, like the 8B headline."""
+    import bench as B
+    from gptqmodel_amd.utils.decode_chain import DecodeStep
+    cfg = B.LLAMA3_70B
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321)
+    layers = B.build_stack(cfg, lambda k, n: B.make_gptq(k, n, 128, dev, gen, dtype), dev, gen, dtype)
+    step = DecodeStep(layers, cfg["hidden"], cfg["q"], dtype)
+    step.x_in.copy_((torch.randn(cfg["hidden"], device=dev, generator=gen) * 0.5).to(dtype))
+    stream = torch.cuda.Stream(device=dev)
+    t0 = time.perf_counter()
+    ms, g = B.time_graph(step.run, stream, args.steps, args.warmup)
+    if not torch.isfinite(step.out).all():
+        raise SystemExit("bench_tp: non-finite activations")
+    n_launch = cfg["layers"] * 4
+    step_bytes, step_flops = B.model_bytes_flops(cfg)
+    gbs = step_bytes / (ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "llama3_70b_gptq_int4_g128_decode_linear_stack_tokens_per_s", "value": 1e3 / ms, "unit": "tokens/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f16" if dtype == torch.float16 else "bf16", "data": "synthetic",
+        "config": {"workload": "Llama-3-70B GPTQ int4 g128 batch=1 decode: 560 quantised linears per token (x 80 layers) as a dependent "
+                               "chain with the layer glue fused into the GEMVs, M=1, TP=1 (35.6 GB of packed weights on one GPU)",
+                   "parallelism": "tp1", "launches_per_step": n_launch, "graph": True, "weight_bytes_per_token": step_bytes},
+        "roofline": {"bound": "hbm", "achieved": gbs, "peak": B.HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / B.HBM_PEAK_GBS,
+                     "traffic": None, "traffic_source": "none", "kernel": "gptqhip::skinny_kernel<...,GLUE> (decode op)",
+                     "bytes_per_launch": step_bytes / n_launch, "avg_launch_us": ms * 1e3 / n_launch},
+        "gemm_tflops_equiv": step_flops / (ms * 1e-3) / 1e12}), flush=True)
+
+
 def run_70b(args, rank, local_rank, world, dev, dist):
     import bench as B
     from gptqmodel_amd.utils.tp import _bounds
     cfg = B.LLAMA3_70B
     tp = world
+    if tp == 1:
+        return _run_tp1_chain(args, dev)
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     gs = 128
     gen = torch.Generator(device=dev)

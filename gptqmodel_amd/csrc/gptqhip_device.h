@@ -110,6 +110,9 @@ struct ColConst {
     uint32_t zlo;  // half2(-(1024+z), -(1024+z))
     uint32_t zhi;  // half2(-(64+z),   -(64+z))      (4-bit high nibbles only)
     float nzs;     // SCL bf16 only: -zero * scale (exact in fp32: 8 x 8 significant bits)
+    float s16;     // SCL bf16, 4-bit: scale / 16
+    float clo;     //                  -(1024 + zero) * scale        (exact: 11 x 8 significant bits)
+    float chi;     //                  -(64 + zero) * scale  ==  -(1024 + 16 zero) * (scale / 16)
 };
 
 template <int BITS, int SCL>
@@ -122,6 +125,15 @@ __device__ __forceinline__ ColConst expand_meta(uint32_t meta) {
         c.s = sb << 16;
     }
     c.nzs = SCL == kBF16 ? -(float)((meta >> 16) & 0x3FFu) * __builtin_bit_cast(float, sb << 16) : 0.f;
+    if constexpr (SCL == kBF16 && BITS == 4) {
+        const float sf = __builtin_bit_cast(float, sb << 16);
+        const float zf = (float)((meta >> 16) & 0xFu);
+        c.s16 = sf * 0.0625f;
+        c.clo = -(1024.f + zf) * sf;
+        c.chi = -(64.f + zf) * sf;
+    } else {
+        c.s16 = c.clo = c.chi = 0.f;
+    }
     const uint32_t zc = meta >> 16;  // 0xE400 | zero
     c.zlo = zc | (zc << 16);
     if constexpr (BITS == 4) {
@@ -185,31 +197,30 @@ __device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask_sgpr, uint3
 template <int ACT, int SCL>
 __device__ __forceinline__ u4_t dequant_word4(uint32_t w, const ColConst& c, const DequantConsts& k) {
     if constexpr (ACT == kBF16 && SCL == kBF16) {
-        // bf16 scales and activations: W = bf16(s * (q - z)), ONE rounding of the exact product (torch bf16 mul).  No
-        // packed bf16 VALU on gfx950, so go through fp32 with the byte converts: two masks put the 8 codes into the 8
-        // bytes of two dwords, v_cvt_f32_ubyteN + one fma(q, s, -z*s) each (exact: 12 significant bits), cvt_pk.
-        // 23 VALU per word instead of 28 for the half2 route + converts.
+        // bf16 scales and activations: W = bf16(s * (q - z)), ONE rounding of the exact product (torch bf16 mul).  gfx950 has no
+        // packed bf16 VALU, but v_fma_mix_f32 reads an f16 HALF as an fma operand: OR the nibbles into the mantissa of 1024.0h
+        // like the fp16 route (exact 1024 + q, or 1024 + 16 q for the nibbles sitting 4 bits up), then ONE mixed fma per
+        // weight, (1024 + q) * s - (1024 + z) * s, lands on the exact product s * (q - z) in fp32 (19-bit intermediate, 13-bit
+        // result), and v_cvt_pk_bf16_f32 rounds it once.  16 VALU per word (4 and_or + 8 fma_mix + 4 cvt_pk) instead of the 23
+        // of the byte-convert route (2 and + shift, 8 cvt_f32_ubyte, 8 fma, 4 cvt_pk).
         const float s = __builtin_bit_cast(float, c.s);
-        const uint32_t a = w & 0x0F0F0F0Fu;         // bytes: e0, e4, e1, e5   (code e sits at bit 4*(e>>1) + 16*(e&1))
-        const uint32_t b = (w >> 4) & 0x0F0F0F0Fu;  // bytes: e2, e6, e3, e7
-        // (inline asm: hipcc only selects v_cvt_f32_ubyte0 and isolates the other bytes with extra shifts / bfe)
-#define GPTQHIP_UBYTE(N, dst, src) asm("v_cvt_f32_ubyte" #N " %0, %1" : "=v"(dst) : "v"(src))
-        float q0, q1, q2, q3, q4, q5, q6, q7;
-        GPTQHIP_UBYTE(0, q0, a);
-        GPTQHIP_UBYTE(2, q1, a);
-        GPTQHIP_UBYTE(0, q2, b);
-        GPTQHIP_UBYTE(2, q3, b);
-        GPTQHIP_UBYTE(1, q4, a);
-        GPTQHIP_UBYTE(3, q5, a);
-        GPTQHIP_UBYTE(1, q6, b);
-        GPTQHIP_UBYTE(3, q7, b);
-#undef GPTQHIP_UBYTE
-        auto f = [&](float q) { return __builtin_fmaf(q, s, c.nzs); };
+        const uint32_t w8 = w >> 8;
+        const uint32_t t0 = and_or(w, k.lo, k.magic), t1 = and_or(w, k.hi, k.magic);
+        const uint32_t t2 = and_or(w8, k.lo, k.magic), t3 = and_or(w8, k.hi, k.magic);
+        auto mix = [](uint32_t pair, float scale, float addend, float& lo, float& hi) {
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(pair), "v"(scale), "v"(addend));
+            asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(pair), "v"(scale), "v"(addend));
+        };
+        float f0, f1, f2, f3, f4, f5, f6, f7;
+        mix(t0, s, c.clo, f0, f1);      // k0, k1
+        mix(t1, c.s16, c.chi, f2, f3);  // k2, k3
+        mix(t2, s, c.clo, f4, f5);      // k4, k5
+        mix(t3, c.s16, c.chi, f6, f7);  // k6, k7
         u4_t r;
-        r.x = pack_bf16(f(q0), f(q1));
-        r.y = pack_bf16(f(q2), f(q3));
-        r.z = pack_bf16(f(q4), f(q5));
-        r.w = pack_bf16(f(q6), f(q7));
+        r.x = pack_bf16(f0, f1);
+        r.y = pack_bf16(f2, f3);
+        r.z = pack_bf16(f4, f5);
+        r.w = pack_bf16(f6, f7);
         return r;
     }
     const uint32_t LO = k.lo, HI = k.hi;
