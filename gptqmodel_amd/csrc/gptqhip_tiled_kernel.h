@@ -486,7 +486,11 @@ inline int launch_tiled_out(const TiledParams& p, int bm, hipStream_t stream) {
     // loads in flight across the epilogue.  Split-K launches have few tiles by construction: one tile per block.
     const int ntiles = ceil_div(p.N, kTiledBN) * ceil_div(p.M, bm);
     const dim3 grid(p.splits == 1 && ntiles > 256 ? 256 : ntiles, 1, p.splits);
-    if constexpr (BITS == 4 && GPC == 1) {
+    {
+        // 256-row tiles for every variant.  The 8-bit and per-K-step-group-constant stages spill 11-14 VGPRs beside the 128
+        // accumulator registers (profiles/r02_tiled_bm256_isa.txt) and are STILL 19-36 % faster than on 128-row tiles
+        // (profiles/r02_tiled_variants.txt: 8-bit 979 -> 1213 TF, group 64 828 -> 1128 TF at M=8192 4096^2): twice the MFMA work
+        // per dequantised word outweighs a few scratch accesses per chunk.
         if (bm == 256) {
             hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 256, 8, 2, OUTF>), grid, dim3(512), 0, stream, p);
             return check_hip(hipGetLastError(), "tiled_kernel launch");
