@@ -85,7 +85,13 @@ TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_va
     if (force_variant == 2) pl.bm = 128;
     // (round 1 confined 8-bit weights and group sizes 32/64 to 128-row tiles because their register stages spill beside 128
     // accumulators; measured in round 2 they are 19-36 % faster on 256-row tiles anyway -- gptqhip_tiled_kernel.h)
-    if (M <= 64 && force_variant == 0) pl.bm = 64;  // one block row either way: 64-row tiles halve the per-chunk work
+    // few rows: 64-row tiles (half the per-chunk work of a 128-row tile, twice the blocks ahead of the split-K decision).
+    // Round-2 sweep (profiles/r02_tiled_plan_sweep.txt): M=128 4096^2 23.7 -> 17.0 us, M=256 29.4 -> 21.0 us; beyond 128 rows only
+    // while the column count keeps the grid small (M=256, N=28672: 59 us on 128-row tiles vs 77 us)
+    if ((M <= 128 || (M <= 256 && N <= 4608)) && force_variant == 0) {
+        pl.bm = 64;
+        pl.tail_cols = 0;
+    }
     if (force_variant == 3) pl.bm = 64;
     // split K across blocks when the (M, N) grid alone leaves most CUs idle (mid-size M, or K-heavy layers):
     // fp32 partial slabs + a tiny reduce kernel (a kernel boundary is cheaper than re-reading 100s of KB of slabs

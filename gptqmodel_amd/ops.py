@@ -361,4 +361,5 @@ def gather_cols(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
 
 
 def set_tuning(force_split_k: int = 0, force_kernel: int = 0, force_waves: int = 0) -> None:
+    _need_cache.clear()  # forced plans change the workspace layout
     _lib.check(_lib.load().gptqhip_set_tuning(force_split_k, force_kernel, force_waves), "gptqhip_set_tuning")
