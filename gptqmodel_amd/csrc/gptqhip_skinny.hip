@@ -689,8 +689,8 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     // e.g. K=14336 -> 112 chunks -> 14 waves x 8 chunks
     pl.depth = (pl.mt == 1 && M <= 4) ? 4 : 2;
     bool chosen = false;
-    if (pl.mt == 1 && M <= 4) {
-        // batch <= 4 (measured in round 2, profiles/r02_waves_sweep.txt): what matters is the number of waves on the chip, not
+    if (pl.mt == 1) {
+        // (measured in round 2, profiles/r02_waves_sweep.txt, r02_batch_decode_sweep.txt): what matters is the number of waves on the chip, not
         // per block -- about 16 per CU (4096 in flight), each with a long K run (>= 2 ring rounds): fewer, longer-lived blocks
         // amortise the ramp, the statistics / reduce prologue and the tail.  Llama-3-70B gate_up (3584 tiles, K=8192): 16 waves
         // per block 61 us, 4 waves 47 us; qkv 15.5 -> 12.8 (8 waves); down (K=28672) 29.5 -> 27.0 (8 waves).
@@ -700,7 +700,9 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
         // batch 1 may also run a 2-deep ring (16 waves x 2 chunks on K = 4096: twice the waves dequantise the same bytes
         // once they have landed -- narrow layers like o_proj are latency-, not stream-bound)
         const int force_s = force_split > 0 ? (force_split < pl.chunks ? force_split : pl.chunks) : 0;
-        for (int depth = 4; depth >= (M == 1 && allow_depth2 ? 2 : 4); depth -= 2) {
+        const int depth_hi = pl.depth;                                        // the kernel variants: D = 4 up to 4 rows, else 2
+        const int depth_lo = (M == 1 && allow_depth2) ? 2 : pl.depth;
+        for (int depth = depth_hi; depth >= depth_lo; depth -= 2) {
             for (int w = 4; w <= 16; ++w) {
                 // the candidate must stay on the regular pipeline AFTER the cross-block split-K decision below (narrow layers)
                 int sp = 1;
@@ -729,7 +731,13 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
         }
         if (best > 0 && (best >= waves || pl.chunks / (waves * pl.depth) * (waves * pl.depth) != pl.chunks)) waves = best;
     }
-    if (pl.mt == 2 && waves > 8) waves = 8;  // 8.5 KiB of LDS per wave for the padded activation tile
+    if (pl.mt == 2) {
+        // 17..32 rows: 16 waves per block beat the 8 round 1 capped it at (8.5 KiB of LDS per wave for the padded activation
+        // tile: 136 KiB, one block per CU) on every shape: 4096^2 M=32 10.4 -> 7.8 us, gate_up 49.2 -> 43.6 us
+        // (also where 16 does not divide the chunks into whole ring rounds: K=14336 runs the generic path at 19.9 us vs
+        // 21.0 on 8 regular waves and 23.5 on 14)
+        waves = 16;
+    }
     if (waves < 4 * pl.mt) waves = 4 * pl.mt;
     if (force_waves > 0) waves = force_waves < 4 * pl.mt ? 4 * pl.mt : force_waves;
     pl.waves = waves;
