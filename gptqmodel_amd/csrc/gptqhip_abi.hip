@@ -82,7 +82,7 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
     // the SAME plans gptqhip_gemm will make for this (shape, group_size, bits): both sides call these planners with
     // identical arguments, so the layout cannot drift from the launch
     size_t floats = plan_skinny(mchunk, K, N, group_size, g_force_split, g_force_waves).slab_floats;
-    if (M > 8 || g_force_kernel == 2) {
+    if (M > 16 || g_force_kernel == 2) {
         const TiledPlan tp = plan_tiled(M, K, N, group_size, bits, g_force_waves, g_force_split);
         if (tp.slab_floats > floats) floats = tp.slab_floats;
     }
@@ -243,10 +243,11 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     a.perm = fused_perm ? perm : nullptr;
     a.exact_bf16 = (flags & GPTQHIP_GEMM_EXACT_BF16) ? 1 : 0;
 
-    // measured crossover (profiles/r01_m_sweep.txt): the MFMA-tiled kernel (64-row tiles, split-K) wins above 32 rows,
-    // and already above 8 rows on wide layers (N >= 8192, e.g. fused gate_up: 23.7 vs 26.0 us at M=9) where every 16-column
-    // block of the skinny kernel would re-stage the whole activation tile
-    const bool wide = N >= 8192 && M > 8;
+    // measured crossover (profiles/r02_mid_m_sweep.txt, after the round-2 planners): the MFMA-tiled kernel (64-row tiles,
+    // split-K) wins above 32 rows, and above 16 rows on wide layers (N >= 8192, e.g. fused gate_up: 25.4 vs 38.3 us at M=24;
+    // at M=16 the decode kernel still leads 23.5 vs 25.0) where every 16-column block of the skinny kernel re-stages the whole
+    // activation tile
+    const bool wide = N >= 8192 && M > 16;
     const bool use_tiled = (g_force_kernel == 2) || (g_force_kernel == 0 && (M > kSkinnyMaxM || wide));
     if (use_tiled) {
         a.x = xin;

@@ -1,7 +1,7 @@
 """Dev tool: small/mid-M regime -- skinny (force_kernel=1) vs tiled (force_kernel=2).  Graph of many launches over
 rotating weight copies (a single-kernel graph replay has a ~10 us floor that would swamp the kernels)."""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from gptqmodel_amd import ops
 dev = "cuda"; gs = 128
 def gtime(fn, n_launch, reps=5):
@@ -17,7 +17,7 @@ def gtime(fn, n_launch, reps=5):
         e1.record(s); s.synchronize()
     return e0.elapsed_time(e1) * 1e3 / (reps * n_launch)
 Ms = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024]
-for (K, N) in [(4096, 4096), (4096, 28672), (14336, 4096)]:
+for (K, N) in [(4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096)]:
     copies = max(4, min(32, (600 << 20) // (K * N // 2)))
     sets = []
     for _ in range(copies):
