@@ -90,6 +90,18 @@ def run_70b(args, rank, local_rank, world, dev, dist):
         if int(flag.item()) == 0:
             comm = None
 
+    chain = None
+    if comm is not None and not os.environ.get("GPTQHIP_BENCH_TP_MODULES"):
+        # the product path for TP decode: 4 decode ops (glue fused, fp32 partials from the row shards) + 2 one-shot all-reduce
+        # kernels (residual + RMSNorm statistics fused) per layer, one graph per token (utils/decode_chain.TPDecodeStep)
+        from gptqmodel_amd.utils.decode_chain import DecodeLayer, TPDecodeStep
+        dl = []
+        for (qkv, o, gu, down), (w_in, w_post) in layers:
+            gu.gate_up_interleaved = True   # random columns: this rank's gate|up shard counts as interleaved in blocks of 8
+            dl.append(DecodeLayer(qkv, o, gu, down, w_in, w_post))
+        chain = TPDecodeStep(dl, h, q // tp, dtype, comm, eps=eps)
+        chain.x_in.copy_(x0)
+
     def rms(v, w):
         v32 = v.float()
         return w * (v32 * torch.rsqrt(v32.pow(2).mean(-1, keepdim=True) + eps)).to(dtype)
@@ -103,6 +115,8 @@ def run_70b(args, rank, local_rank, world, dev, dist):
         return hcur + part.to(dtype)
 
     def token_step():
+        if chain is not None:
+            return chain.run()
         hcur = x0[None]
         for (qkv, o, gu, down), (w_in, w_post) in layers:
             a = qkv(rms(hcur, w_in))[:, :qs]                       # this rank's query heads stand in for its attention output
@@ -157,6 +171,8 @@ def run_70b(args, rank, local_rank, world, dev, dist):
         ms = wall * 1e3 / args.steps
         step_bytes, step_flops = B.model_bytes_flops(cfg)
         n_launch = cfg["layers"] * 4
+        if not torch.isfinite(token_step()).all():
+            raise SystemExit("bench_tp: non-finite activations")
         gbs = step_bytes / tp / (ms * 1e-3) / 1e9
         out = {
             "metric": "llama3_70b_gptq_int4_g128_decode_linear_stack_tokens_per_s", "value": args.steps / wall, "unit": "tokens/s",
@@ -166,6 +182,7 @@ def run_70b(args, rank, local_rank, world, dev, dist):
                                    f"tensor parallel TP={tp} (column qkv/gate_up, row o/down + fp32 all-reduce), true data "
                                    "dependencies through the layer glue, random packed weights",
                        "parallelism": f"tp{tp}", "launches_per_step": n_launch, "graph": graph is not None,
+                       "path": "TPDecodeStep (decode ops + fused all-reduce)" if chain is not None else "modules + torch glue",
                        "weight_bytes_per_token": step_bytes, "allreduce_per_token": 2 * cfg["layers"] if tp > 1 else 0,
                        "allreduce": ("one-shot peer-to-peer kernel (gptqhip_allreduce_oneshot)" if comm is not None else
                                      ("RCCL all_reduce" if tp > 1 else "none"))},

@@ -17,7 +17,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libgptqhip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/gptqhip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -39,7 +39,7 @@ SIGNATURES = {
     "gptqhip_comm_close": (_i, [_vp]),
     "gptqhip_comm_free": (_i, [_vp]),
     "gptqhip_comm_status": (_i, [_vp, _c.POINTER(_c.c_uint32)]),
-    "gptqhip_allreduce_oneshot": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "gptqhip_allreduce_oneshot": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "gptqhip_dequant": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_dequant_tiled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_repack_awq": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

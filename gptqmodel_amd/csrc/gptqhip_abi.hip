@@ -323,7 +323,11 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
         set_error("gptqhip_decode_linear: N=%d too large", op->N);
         return GPTQHIP_EINVAL;
     }
-    if (op->out_glue != GPTQHIP_OUT_NONE && op->out_glue != GPTQHIP_OUT_SILU_MUL_PAIRED) {
+    if (op->out_glue == GPTQHIP_OUT_PARTIAL_F32 && (op->bias || op->residual || op->stats_out)) {
+        set_error("gptqhip_decode_linear: OUT_PARTIAL_F32 excludes bias / residual / stats_out");
+        return GPTQHIP_EINVAL;
+    }
+    if (op->out_glue != GPTQHIP_OUT_NONE && op->out_glue != GPTQHIP_OUT_SILU_MUL_PAIRED && op->out_glue != GPTQHIP_OUT_PARTIAL_F32) {
         set_error("gptqhip_decode_linear: bad out_glue %d", op->out_glue);
         return GPTQHIP_EINVAL;
     }
@@ -360,7 +364,7 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
     a.bits = op->bits;
     a.act_dtype = op->act_dtype;
     a.scale_dtype = op->scale_dtype;
-    a.out_f32 = 0;
+    a.out_f32 = op->out_glue == GPTQHIP_OUT_PARTIAL_F32 ? 1 : 0;
     a.in_glue = op->in_glue;
     a.glue_b = op->norm_weight;
     a.residual = op->residual;
@@ -368,7 +372,7 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
     a.stats_in = op->stats_in;
     a.stats_n = op->stats_n;
     a.stats_out = op->stats_out;
-    a.out_glue = op->out_glue;
+    a.out_glue = op->out_glue == GPTQHIP_OUT_PARTIAL_F32 ? GPTQHIP_OUT_NONE : op->out_glue;
     return launch_skinny(a, pl, ws ? reinterpret_cast<float*>(ws + L.slabs_off) : nullptr,
                          ws ? reinterpret_cast<int*>(ws + L.counters_off) : nullptr, reinterpret_cast<hipStream_t>(stream));
 }

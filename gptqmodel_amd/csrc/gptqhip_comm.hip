@@ -64,7 +64,8 @@ __device__ __forceinline__ f4_t load16_system(const float* src) {
 template <int ACT>
 __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const float* __restrict__ partial, PeerTable peers, int rank, int world,
                                                                 int n, size_t slot_floats, const void* __restrict__ bias,
-                                                                const void* __restrict__ residual, void* __restrict__ out) {
+                                                                const void* __restrict__ residual, void* __restrict__ out,
+                                                                float* __restrict__ stats_out) {
     __shared__ uint32_t s_epoch;
     const int b = blockIdx.x, tid = threadIdx.x;
     CommHeader* mine = reinterpret_cast<CommHeader*>(peers.base[rank]);
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const float* __r
     __syncthreads();
 
     // ---- reduce in rank order + the reference's rounding chain ----------------------------------------------------------
+    float sq = 0.f;
     if (live) {
         const float* slots = reinterpret_cast<const float*>(peers.base[rank] + comm_data_offset()) + (size_t)par * kCommMaxWorld * slot_floats + i;
         f4_t s = load16_system(slots);
@@ -115,11 +117,19 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const float* __r
             if (bias != nullptr) y = round_through<ACT>(y + load16_as_f32<ACT>(bias, (size_t)i + j));
             if (residual != nullptr) y = load16_as_f32<ACT>(residual, (size_t)i + j) + y;
             r[j] = f32_to_16<ACT>(y);
+            const float h = bits16_to_f32<ACT>(r[j]);
+            sq = __builtin_fmaf(h, h, sq);
         }
         u2_t ov;
         ov.x = (uint32_t)r[0] | ((uint32_t)r[1] << 16);
         ov.y = (uint32_t)r[2] | ((uint32_t)r[3] << 16);
         *reinterpret_cast<u2_t*>(reinterpret_cast<uint16_t*>(out) + i) = ov;
+    }
+    if (stats_out != nullptr) {
+        // RMSNorm statistic of the op that consumes `out` (gptqhip_decode_linear stats_in): sum of out^2 per 16 outputs = 4 lanes
+        sq += __shfl_xor(sq, 1, 64);
+        sq += __shfl_xor(sq, 2, 64);
+        if (live && (tid & 3) == 0) stats_out[i >> 4] = sq;
     }
     if (tid == 0) __hip_atomic_store(&mine->epoch[b], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -193,9 +203,9 @@ int gptqhip_comm_status(void* own_buf, uint32_t* status_out) {
 }
 
 int gptqhip_allreduce_oneshot(const float* partial, void* const* peer_bufs, int rank, int world, int n, int n_max, const void* bias,
-                              const void* residual, void* out, int act_dtype, gptqhip_stream_t stream) {
+                              const void* residual, void* out, float* stats_out, int act_dtype, gptqhip_stream_t stream) {
     if (!partial || !peer_bufs || !out || world < 1 || world > kCommMaxWorld || rank < 0 || rank >= world || n <= 0 || n % 4 != 0 ||
-        n > n_max || gptqhip_comm_bytes(world, n_max) == 0) {
+        n > n_max || gptqhip_comm_bytes(world, n_max) == 0 || (stats_out != nullptr && n % 16 != 0)) {
         set_error("gptqhip_allreduce_oneshot: bad arguments (world <= %d, n %% 4 == 0, n <= n_max <= %d)", kCommMaxWorld,
                   kCommMaxBlocks * kCommBlockFloats);
         return GPTQHIP_EINVAL;
@@ -215,9 +225,9 @@ int gptqhip_allreduce_oneshot(const float* partial, void* const* peer_bufs, int 
     const dim3 grid(ceil_div(n, kCommBlockFloats)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (act_dtype == GPTQHIP_FP16) {
-        hipLaunchKernelGGL((allreduce_oneshot_kernel<kFP16>), grid, block, 0, s, partial, t, rank, world, n, comm_slot_floats(n_max), bias, residual, out);
+        hipLaunchKernelGGL((allreduce_oneshot_kernel<kFP16>), grid, block, 0, s, partial, t, rank, world, n, comm_slot_floats(n_max), bias, residual, out, stats_out);
     } else {
-        hipLaunchKernelGGL((allreduce_oneshot_kernel<kBF16>), grid, block, 0, s, partial, t, rank, world, n, comm_slot_floats(n_max), bias, residual, out);
+        hipLaunchKernelGGL((allreduce_oneshot_kernel<kBF16>), grid, block, 0, s, partial, t, rank, world, n, comm_slot_floats(n_max), bias, residual, out, stats_out);
     }
     return check_hip(hipGetLastError(), "allreduce_oneshot_kernel launch");
 }

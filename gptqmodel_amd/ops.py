@@ -175,7 +175,7 @@ def gemm(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Opt
 
 
 GLUE_NONE, GLUE_RMSNORM, GLUE_SILU_MUL = 0, 1, 2
-OUT_NONE, OUT_SILU_MUL_PAIRED = 0, 1
+OUT_NONE, OUT_SILU_MUL_PAIRED, OUT_PARTIAL_F32 = 0, 1, 2
 
 
 def decode_supported(K: int, N: int, group_size: int) -> bool:
@@ -192,7 +192,8 @@ def make_decode_op(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor,
     keeps the tensors alive (DecodeStep does) -- binding once and re-launching costs no per-call Python work.
     `workspace`: the stream's scratch (workspace_for); taken from the CURRENT stream when omitted."""
     _require_cuda(x, qweight_t, meta, bias, out, norm_weight, residual, workspace, stats_in, stats_out)
-    if x.dtype not in _DT or out.dtype != x.dtype or scale_dtype not in _DT:
+    want_out = torch.float32 if out_glue == OUT_PARTIAL_F32 else x.dtype
+    if x.dtype not in _DT or out.dtype != want_out or scale_dtype not in _DT:
         raise RuntimeError(f"decode op: unsupported dtypes x={x.dtype} out={out.dtype} scales={scale_dtype}")
     need = 2 * K if in_glue == GLUE_SILU_MUL else K
     n_out = N // 2 if out_glue == OUT_SILU_MUL_PAIRED else N

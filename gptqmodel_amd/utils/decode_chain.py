@@ -34,9 +34,12 @@ from .. import ops
 class DecodeLayer:
     """The four (fused) quantised linears of one decoder layer + its two RMSNorm weights."""
 
-    def __init__(self, qkv, o, gate_up, down, input_norm: torch.Tensor, post_norm: torch.Tensor):
+    def __init__(self, qkv, o, gate_up, down, input_norm: torch.Tensor, post_norm: torch.Tensor,
+                 o_bias: Optional[torch.Tensor] = None, down_bias: Optional[torch.Tensor] = None):
         self.qkv, self.o, self.gate_up, self.down = qkv, o, gate_up, down
         self.input_norm, self.post_norm = input_norm, post_norm
+        # tensor parallel only: the FULL-layer bias of the row-parallel o / down projections (added once, after the reduction)
+        self.o_bias, self.down_bias = o_bias, down_bias
 
 
 def _lin_tensors(lin, dtype):
@@ -114,4 +117,80 @@ class DecodeStep:
         return self.out
 
 
-__all__ = ["DecodeLayer", "DecodeStep"]
+class TPDecodeStep:
+    """The same chain for one rank of a tensor-parallel group (Megatron split, utils/tp.py): qkv and gate_up are this rank's
+    COLUMN shards (gate_up interleaved per shard), o and down its ROW shards.  Per layer 4 decode ops + 2 one-shot xGMI
+    all-reduces (utils/xgmi_allreduce.py), every launch capture-safe, no host involvement between them:
+
+        qkv_r = rmsnorm(h; w_in) @ Wqkv[:, shard r]            in_glue RMSNORM (stats from the previous all-reduce)
+        p     = a_r @ Wo[shard r, :]                           OUT_PARTIAL_F32: unrounded fp32 partial sums
+        h1    = h + act(sum_r p) (+ bias)                      all-reduce kernel: rank-ordered sum, rounding chain, residual,
+                                                               per-tile sums of h1^2 for the next RMSNorm
+        a_r   = silu(g_r) * u_r                                gate_up shard with the paired epilogue
+        p     = a_r @ Wdown[shard r, :];  h2 = h1 + act(sum_r p)
+
+    The rounding points are those of the reference's single-GPU module chain (round the full linear output once, then add the
+    residual), so tp=N differs from tp=1 only by the fp32 association of the K-shards' partial sums.  Every rank holds the
+    same h1 / h2 bit for bit (the reduction order is the rank order on every rank)."""
+
+    def __init__(self, layers: Sequence[DecodeLayer], hidden: int, q_dim_local: int, dtype: torch.dtype, comm, eps: float = 1e-5,
+                 device: Optional[torch.device] = None):
+        if not layers:
+            raise ValueError("no layers")
+        if hidden % 16 != 0 or hidden > comm.n_max:
+            raise ValueError("hidden must be a multiple of 16 and fit the communicator")
+        self.layers, self.comm, self.dtype = list(layers), comm, dtype
+        self.device = dev = device or layers[0].qkv.qweight.device
+        self.x_in = torch.zeros(hidden, dtype=dtype, device=dev)
+        self.h = torch.zeros((len(self.layers), 2, hidden), dtype=dtype, device=dev)
+        self.stats = torch.zeros((len(self.layers), 2, hidden // 16), dtype=torch.float32, device=dev)
+        self.qkv_out = torch.zeros(layers[0].qkv.out_features, dtype=dtype, device=dev)
+        self.gu_out = torch.zeros(layers[0].gate_up.out_features, dtype=dtype, device=dev)
+        self.partial = torch.zeros(hidden, dtype=torch.float32, device=dev)
+        need = 0
+        for L in self.layers:
+            for lin in (L.qkv, L.o, L.gate_up, L.down):
+                need = max(need, ops.workspace_bytes(1, lin.in_features, lin.out_features, lin.group_size, lin.bits, False))
+        self.workspace = torch.zeros(max(need, 1 << 20), dtype=torch.uint8, device=dev)
+        self._keep, self.steps = [], []   # steps: ("op", struct) | ("ar", residual, bias, out, stats_out)
+
+        def bind(lin, x, out, glue, nw, oglue, s_in):
+            qw, meta, bias, sdt = _lin_tensors(lin, dtype)
+            K, N = lin.in_features, lin.out_features
+            if oglue == ops.OUT_PARTIAL_F32 and bias is not None:
+                raise ValueError("row-parallel shards must not carry a bias: pass the layer bias as DecodeLayer.o_bias / down_bias")
+            if not ops.decode_supported(K, N, lin.group_size):
+                raise NotImplementedError(f"decode chain: shard shape K={K} N={N} group_size={lin.group_size} unsupported")
+            self._keep.extend([qw, meta, bias, nw])
+            self.steps.append(("op", ops.make_decode_op(x, qw, meta, bias, out, K, N, lin.group_size, lin.bits, sdt, in_glue=glue,
+                                                        norm_weight=nw, eps=eps, workspace=self.workspace, out_glue=oglue,
+                                                        stats_in=s_in)))
+
+        h_in, st_in = self.x_in, None
+        for li, L in enumerate(self.layers):
+            if not getattr(L.gate_up, "gate_up_interleaved", False):
+                raise ValueError("TPDecodeStep needs gate_up shards fused with fuse_gate_up_interleaved")
+            if L.o.in_features != q_dim_local or L.o.out_features != hidden or L.down.out_features != hidden:
+                raise ValueError("row-parallel shard shapes do not match hidden / q_dim_local")
+            h1, h2, st1, st2 = self.h[li, 0], self.h[li, 1], self.stats[li, 0], self.stats[li, 1]
+            bind(L.qkv, h_in, self.qkv_out, ops.GLUE_RMSNORM, L.input_norm, ops.OUT_NONE, st_in)
+            bind(L.o, self.qkv_out, self.partial, ops.GLUE_NONE, None, ops.OUT_PARTIAL_F32, None)   # stand-in attention: a = q_r
+            self.steps.append(("ar", h_in, L.o_bias, h1, st1))
+            bind(L.gate_up, h1, self.gu_out, ops.GLUE_RMSNORM, L.post_norm, ops.OUT_SILU_MUL_PAIRED, st1)
+            bind(L.down, self.gu_out, self.partial, ops.GLUE_NONE, None, ops.OUT_PARTIAL_F32, None)
+            self.steps.append(("ar", h1, L.down_bias, h2, st2))
+            h_in, st_in = h2, st2
+        self.out = h_in
+
+    def run(self) -> torch.Tensor:
+        with torch.cuda.device(self.device):
+            for st in self.steps:
+                if st[0] == "op":
+                    ops.launch_decode_op(st[1], self.device)
+                else:
+                    _, res, bias, out, stats = st
+                    self.comm(self.partial, self.dtype, bias=bias, residual=res, out=out, stats_out=stats)
+        return self.out
+
+
+__all__ = ["DecodeLayer", "DecodeStep", "TPDecodeStep"]

@@ -54,7 +54,8 @@ class OneShotAllReduce:
             dist.barrier(group=group)   # nobody pushes before everybody has mapped everybody
 
     def __call__(self, partial: torch.Tensor, out_dtype: torch.dtype = torch.float16, bias: Optional[torch.Tensor] = None,
-                 residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                 stats_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if partial.dtype != torch.float32 or not partial.is_cuda or not partial.is_contiguous():
             raise RuntimeError("OneShotAllReduce: partial must be a contiguous float32 device tensor")
         n = partial.numel()
@@ -65,10 +66,13 @@ class OneShotAllReduce:
         for t, what in ((bias, "bias"), (residual, "residual")):
             if t is not None and (t.dtype != out.dtype or t.numel() < n or not t.is_contiguous()):
                 raise RuntimeError(f"OneShotAllReduce: {what} must be a contiguous {out.dtype} tensor with >= {n} elements")
+        if stats_out is not None and (stats_out.dtype != torch.float32 or stats_out.numel() < -(-n // 16) or n % 16 != 0):
+            raise RuntimeError("OneShotAllReduce: stats_out must be float32 with >= n/16 elements (n a multiple of 16)")
         p = lambda t: 0 if t is None else t.data_ptr()
         with torch.cuda.device(partial.device):
             rc = _lib.load().gptqhip_allreduce_oneshot(partial.data_ptr(), self._peers, self.rank, self.world, n, self.n_max, p(bias),
-                                                       p(residual), out.data_ptr(), ops._DT[out.dtype], ops._stream(partial.device))
+                                                       p(residual), out.data_ptr(), p(stats_out), ops._DT[out.dtype],
+                                                       ops._stream(partial.device))
         _lib.check(rc, "gptqhip_allreduce_oneshot")
         return out
 

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 5
+#define GPTQHIP_ABI_VERSION 6
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -131,6 +131,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight_t, const uint32_t* meta,
  *            8 (8 gate columns, the 8 matching up columns, ...: utils.model.fuse_gate_up_interleaved), so every 16-column
  *            tile holds both halves of 8 MLP neurons and the epilogue writes out[N/2] = act(silu(gate)) * up directly -- the
  *            activation is computed ONCE per element by the producer instead of by every consumer block
+ *            GPTQHIP_OUT_PARTIAL_F32: out is float32 [N], the unrounded accumulators of a K-shard (tensor parallel row-parallel layer)
  *   stats_out [ceil(N/16)] floats or NULL: per-tile sum of out^2 -- the RMSNorm statistic of the op consuming `out`
  *   stats_in / stats_n: with GPTQHIP_GLUE_RMSNORM, the producer's stats_out for this op's x (stats_n = ceil(K/16) <= 512):
  *            each wave sums the partials in a fixed order (one load per lane, no block barrier); NULL: every block reduces the
@@ -148,6 +149,8 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight_t, const uint32_t* meta,
 #define GPTQHIP_GLUE_SILU_MUL 2
 #define GPTQHIP_OUT_NONE 0
 #define GPTQHIP_OUT_SILU_MUL_PAIRED 1
+#define GPTQHIP_OUT_PARTIAL_F32 2   /* out is float32 [N]: the UNROUNDED accumulators (row-parallel tensor-parallel shard; no bias /
+                                       residual / stats_out -- gptqhip_allreduce_oneshot applies them after the reduction) */
 typedef struct gptqhip_decode_op {
     const uint32_t* qweight_t;   /* tiled words (gptqhip_repack_tiled)                         */
     const uint32_t* meta;        /* [tiles][G][16] constants                                   */
@@ -226,7 +229,8 @@ int gptqhip_gather_cols(const void* x, const int32_t* perm, void* out, int M, in
  *   gptqhip_comm_free(ptr)             free the buffer this rank allocated
  *   gptqhip_comm_status(own_buf, &st)  host read of the "a bounded wait gave up" word (0 = healthy)
  *   gptqhip_allreduce_oneshot(partial[n] fp32, peer_bufs[world] (HOST array of device pointers, own buffer at [rank]), rank, world,
- *                             n (% 4 == 0), n_max (as allocated), bias|NULL, residual|NULL, out[n] act dtype, act_dtype, stream)
+ *                             n (% 4 == 0), n_max (as allocated), bias|NULL, residual|NULL, out[n] act dtype,
+ *                             stats_out[ceil(n/16)]|NULL (per-16 sums of out^2: the next decode op's RMSNorm statistic), act_dtype, stream)
  * Every rank must issue the same sequence of calls.  Status: exercised by two processes sharing one GPU through real IPC
  * mappings (tests/test_gpu_comm.py); not yet run across physical GPUs. */
 #define GPTQHIP_IPC_HANDLE_BYTES 64
@@ -237,7 +241,8 @@ int gptqhip_comm_close(void* dev_ptr);
 int gptqhip_comm_free(void* dev_ptr);
 int gptqhip_comm_status(void* own_buf, uint32_t* status_out);
 int gptqhip_allreduce_oneshot(const float* partial, void* const* peer_bufs, int rank, int world, int n, int n_max,
-                              const void* bias, const void* residual, void* out, int act_dtype, gptqhip_stream_t stream);
+                              const void* bias, const void* residual, void* out, float* stats_out, int act_dtype,
+                              gptqhip_stream_t stream);
 
 /* Tuning hook (benchmarks / tests): force the cross-block split-K factor and the waves per block of the skinny
  * kernel (0 = heuristic), or the kernel family (0 auto, 1 skinny, 2 tiled-prefill).  The overrides are THREAD-LOCAL

@@ -84,10 +84,10 @@ def test_comm_buffer_sizing_and_argument_checks(lib):
     assert lib.gptqhip_comm_bytes(8, 8192) >= 2 * 8 * 8192 * 4
     assert lib.gptqhip_comm_bytes(9, 8192) == 0 and lib.gptqhip_comm_bytes(2, 0) == 0 and lib.gptqhip_comm_bytes(2, 1 << 20) == 0
     peers = (ctypes.c_void_p * 2)(16, 16)
-    assert lib.gptqhip_allreduce_oneshot(one, peers, 0, 2, 1001, 8192, None, None, one, 0, None) == -22   # n % 4
-    assert lib.gptqhip_allreduce_oneshot(one, peers, 2, 2, 1024, 8192, None, None, one, 0, None) == -22   # rank >= world
-    assert lib.gptqhip_allreduce_oneshot(one, peers, 0, 2, 16384, 8192, None, None, one, 0, None) == -22  # n > n_max
-    assert lib.gptqhip_allreduce_oneshot(one, peers, 0, 2, 1024, 8192, None, None, one, 7, None) == -22   # dtype tag
+    assert lib.gptqhip_allreduce_oneshot(one, peers, 0, 2, 1001, 8192, None, None, one, None, 0, None) == -22   # n % 4
+    assert lib.gptqhip_allreduce_oneshot(one, peers, 2, 2, 1024, 8192, None, None, one, None, 0, None) == -22   # rank >= world
+    assert lib.gptqhip_allreduce_oneshot(one, peers, 0, 2, 16384, 8192, None, None, one, None, 0, None) == -22  # n > n_max
+    assert lib.gptqhip_allreduce_oneshot(one, peers, 0, 2, 1024, 8192, None, None, one, None, 7, None) == -22   # dtype tag
     assert lib.gptqhip_comm_open(None, None) == -22
 
 

@@ -113,6 +113,88 @@ def test_oneshot_allreduce_two_processes_one_gpu():
     assert dict(ret) == {0: True, 1: True}
 
 
+def _tp_chain_worker(rank, world, port, ret):
+    """TPDecodeStep on 2 ranks (column shards -> partial-f32 row shards -> one-shot all-reduce with residual + RMSNorm statistics)
+    against the same sharded computation from separate launches: plugin forward() / forward_partial() + torch glue."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_gpu_decode_chain import _make_stack
+        from helpers import rel_err, torch_to_f32
+        from gptqmodel_amd.utils.decode_chain import TPDecodeStep
+        from gptqmodel_amd.utils.xgmi_allreduce import OneShotAllReduce
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dtype, eps = torch.float16, 1e-5
+        hidden, inter, q_dim, kv_dim, n_layers = 4096, 14336, 4096, 1024, 2
+        # every process builds BOTH ranks' shards (seeded), runs its own through the chain and all of them through the reference
+        shards = [_make_stack(n_layers, hidden, inter // world, q_dim // world, kv_dim // world, dtype, seed=50 + r, interleave="all")
+                  for r in range(world)]
+        for r in range(1, world):
+            for li in range(n_layers):   # RMSNorm weights are replicated, not sharded
+                shards[r][li].input_norm, shards[r][li].post_norm = shards[0][li].input_norm, shards[0][li].post_norm
+        comm = OneShotAllReduce(hidden, dev)
+        step = TPDecodeStep(shards[rank], hidden, q_dim // world, dtype, comm, eps=eps)
+
+        def rms(v, w):
+            v32 = v.float()
+            return w * (v32 * torch.rsqrt(v32.pow(2).mean(-1, keepdim=True) + eps)).to(dtype)
+
+        def reference(x):
+            h = x.clone()
+            for li in range(n_layers):
+                xn = rms(h, shards[0][li].input_norm)[None]
+                part = sum(S[li].o.forward_partial(S[li].qkv(xn)[:, :q_dim // world]) for S in shards)
+                h = h + part[0].to(dtype)
+                xn = rms(h, shards[0][li].post_norm)[None]
+                part = sum(S[li].down.forward_partial(torch.nn.functional.silu(S[li].gate(xn)) * S[li].up(xn)) for S in shards)
+                h = h + part[0].to(dtype)
+            return h
+
+        ok = True
+        xs = [(torch.randn(hidden, generator=torch.Generator().manual_seed(40 + i)) * 0.5).to(dtype).to(dev) for i in range(3)]
+        want = []
+        for x in xs:
+            step.x_in.copy_(x)
+            got = step.run().clone()
+            torch.cuda.synchronize()
+            ref = reference(x)
+            ok = ok and bool(torch.isfinite(got).all()) and rel_err(torch_to_f32(got), torch_to_f32(ref)) <= 4e-3
+            both = [torch.empty(hidden, dtype=dtype) for _ in range(world)]
+            dist.all_gather(both, got.cpu())
+            ok = ok and all(torch.equal(both[0], b) for b in both)   # rank-ordered reduction: every rank holds the same bits
+            want.append(got)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            step.run()
+            s.synchronize()
+            dist.barrier()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                out = step.run()
+            for i in range(12):
+                step.x_in.copy_(xs[i % 3], non_blocking=True)
+                gr.replay()
+                s.synchronize()
+                ok = ok and torch.equal(out, want[i % 3])
+        comm.check_status()
+        comm.close()
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tp_decode_chain_two_processes_one_gpu():
+    world = 2
+    port = 31700 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    mp.spawn(_tp_chain_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
 def test_oneshot_allreduce_world1_is_the_rounding_chain():
     from gptqmodel_amd.utils.xgmi_allreduce import OneShotAllReduce
     dev = torch.device("cuda", 0)

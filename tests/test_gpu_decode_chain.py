@@ -151,7 +151,7 @@ def _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype, seed=0, interleav
     for li in range(n_layers):
         nw = lambda: (1.0 + 0.1 * torch.randn(hidden, device=DEV, generator=gen)).to(dtype)
         gate, up = raw(hidden, inter), raw(hidden, inter)
-        if interleave and li % 2 == 0:    # both fusion layouts in one stack
+        if interleave == "all" or (interleave and li % 2 == 0):    # default: both fusion layouts in one stack
             gu = fuse_gate_up_interleaved(gate, up)
         else:
             gu = raw(hidden, 2 * inter)
