@@ -167,11 +167,15 @@ def run_70b(args, rank, local_rank, world, dev, dist):
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
+    with torch.cuda.stream(stream):
+        finite = bool(torch.isfinite(token_step()).all())    # every rank takes part (the step contains all-reduces)
+    if comm is not None:
+        comm.check_status()
     if rank == 0:
         ms = wall * 1e3 / args.steps
         step_bytes, step_flops = B.model_bytes_flops(cfg)
         n_launch = cfg["layers"] * 4
-        if not torch.isfinite(token_step()).all():
+        if not finite:
             raise SystemExit("bench_tp: non-finite activations")
         gbs = step_bytes / tp / (ms * 1e-3) / 1e9
         out = {
