@@ -29,23 +29,6 @@
 #ifndef GPTQHIP_ABLATE   // dev-only timing ablations (tests/dev/ablate.sh); the product build never defines it
 #define GPTQHIP_ABLATE 0
 #endif
-#if GPTQHIP_ABLATE & 16
-__device__ unsigned long long* g_dev_trace = nullptr;   // [blocks][4]: t0, t1, hw_id, xcc_id (100 MHz wall clock)
-extern "C" int gptqhip_dev_set_trace(void* ptr) {
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dev_trace), &ptr, sizeof(ptr));
-}
-#define GPTQHIP_TRACE_BEGIN() const unsigned long long tr_t0 = wall_clock64()
-#define GPTQHIP_TRACE_END()                                                                                   \
-    if (threadIdx.x == 0 && g_dev_trace != nullptr) {                                                         \
-        unsigned long long* t = g_dev_trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;              \
-        t[0] = tr_t0; t[1] = wall_clock64();                                                                  \
-        t[2] = __builtin_amdgcn_s_getreg(63492); t[3] = __builtin_amdgcn_s_getreg(63508);                     \
-    }
-#else
-#define GPTQHIP_TRACE_BEGIN()
-#define GPTQHIP_TRACE_END()
-#endif
-
 namespace gptqhip {
 
 struct SkinnyParams {
@@ -682,218 +665,6 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
 
 
 // ------------------------------------------------------------------------------------------------
-// decode1_kernel: ONE row (M = 1) on the regular pipeline (K % 128 == 0, one group constant per chunk, every wave owns whole
-// ring rounds) -- the batch-1 decode op and the plugin's forward() at batch 1.
-//
-// Round-2 ablation of skinny_kernel<AM_ROW1> at M = 1 (profiles/r02_decode_ablation.txt; Llama-3-8B gate_up, 15.1 us): removing
-// the per-chunk group-constant load saves 1.4 us, the per-chunk activation load 0.6 us, both 2.6 us; the LDS reduce + epilogue
-// 1.1 us; with nothing but the weight ring left the launch takes 10.0 us = the load-only probe.  Each ring stage carried three
-// more memory instructions (64 B of constants, 256 B of x, 256 B of the glue operand) than the 1 KiB of weights it exists for.
-// Here the block stages what every wave needs ONCE, coalesced, through LDS:
-//   xs     the block's K range of the input row with the input glue already applied (RMSNorm / SiLU*mul once per element, by
-//          the thread that staged it) -- the MFMA A fragments are read straight from it (16 lanes broadcast one 16-byte segment);
-//   metas  the block's rows of the tile's group constants.
-// Their loads are issued BEFORE the weight ring (vmcnt retires in order: waiting for them never waits for the HBM stream),
-// the ring stage is ONE 16-byte nontemporal load per lane, and the reduction moves the 16 live floats per wave (all 16 MFMA
-// rows are the same row at M = 1) instead of the whole accumulator tile.
-template <int BITS, int ACT, int SCL, int D, int GLUE>
-__global__ __launch_bounds__(1024) void decode1_kernel(SkinnyParams p) {
-    constexpr int WPC = BITS == 4 ? 1 : 2;   // 1 KiB loads per chunk
-    constexpr int XL = 2;                    // staged 16-byte x segments per thread held in registers across the ring prologue
-    GPTQHIP_TRACE_BEGIN();
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, T = blockDim.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int W = T >> 6;
-    const int c = lane & 15, rq = lane >> 4;
-    const int tile = blockIdx.x, split = blockIdx.y;
-    const int cps = p.chunks_per_split;                 // regular: every block owns exactly cps chunks
-    const int c_begin = split * cps;
-    const int sh = p.cpg_shift;
-    const int g0 = c_begin >> sh;
-    const int ng = ((c_begin + cps - 1) >> sh) - g0 + 1;
-
-    u4_t* xs = reinterpret_cast<u4_t*>(lds);                                                   // [cps * 16] u4
-    uint32_t* metas = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds) + (size_t)cps * 256);   // [ng * 16] (<= cps * 16)
-    float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + (size_t)cps * 320);     // [W * 16]
-    int* s_last = reinterpret_cast<int*>(red + W * 16);
-    float* scratch = reinterpret_cast<float*>(s_last + 4);
-
-    const DequantConsts dk = make_dequant_consts<BITS>();
-    uint32_t res_raw = 0u;
-    if (p.residual != nullptr && wave == 0 && lane < 16) {
-        const int coln = tile * kTileN + lane;
-        res_raw = reinterpret_cast<const uint32_t*>(p.residual)[(coln < p.N ? coln : 0) >> 1];
-    }
-
-    // ---- RMSNorm statistics: 1/rms of the WHOLE input row ------------------------------------------------------------
-    float sv[8];
-    if constexpr (GLUE == kGlueRmsNorm) {
-        if (p.stats_in != nullptr) {
-            if (wave == 0) {   // the producer's per-tile sums of squares: eight clamped loads, in front of everything else
-                const int last = p.stats_n - 1;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int idx = lane + 64 * i;
-                    sv[i] = p.stats_in[idx < last ? idx : last];
-                }
-            }
-        } else {
-            // no producer (the first op of a step): reduce the row here, before the ring (one op per token pays this)
-            const u4_t* hs = reinterpret_cast<const u4_t*>(p.x);
-            float ss = 0.f;
-            for (int idx = tid; idx < p.K / 8; idx += T) {
-                const u4_t h = hs[idx];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a = bits16_to_f32<ACT>((uint16_t)(h[j] & 0xffffu)), b = bits16_to_f32<ACT>((uint16_t)(h[j] >> 16));
-                    ss = __builtin_fmaf(a, a, ss);
-                    ss = __builtin_fmaf(b, b, ss);
-                }
-            }
-#pragma unroll
-            for (int mk = 32; mk >= 1; mk >>= 1) ss += __shfl_xor(ss, mk, 64);
-            if (lane == 0) scratch[1 + wave] = ss;   // (scratch has room for 1 + 16 floats, see the launch)
-            __syncthreads();
-            if (tid == 0) {
-                float tot = 0.f;
-                for (int w = 0; w < W; ++w) tot += scratch[1 + w];
-                scratch[0] = rsqrtf(tot / (float)p.K + p.eps);
-            }
-        }
-    }
-
-    // ---- staging loads (L2-resident x / norm weight, this tile's constants), then the weight ring's prologue ---------------
-    const int n16 = cps * 16;
-    const u4_t* xsrc = reinterpret_cast<const u4_t*>(p.x) + (size_t)c_begin * 16;
-    const u4_t* gsrc = GLUE == kGlueRmsNorm ? reinterpret_cast<const u4_t*>(p.glue_b) + (size_t)c_begin * 16
-                                             : reinterpret_cast<const u4_t*>(p.x) + (size_t)p.K / 8 + (size_t)c_begin * 16;
-    u4_t xr[XL], gr[XL];
-#pragma unroll
-    for (int i = 0; i < XL; ++i) {
-        const int idx = tid + i * T;
-        xr[i] = xsrc[idx < n16 ? idx : 0];
-        if constexpr (GLUE != kGlueNone) gr[i] = gsrc[idx < n16 ? idx : 0];
-    }
-    const int nm4 = ng * 4;   // 16-byte pieces of the constants
-    const u4_t* msrc = reinterpret_cast<const u4_t*>(p.meta + ((size_t)tile * p.G + g0) * 16);
-    const u4_t mr = msrc[tid < nm4 ? tid : 0];
-    __builtin_amdgcn_sched_barrier(0);   // keep everything above in FRONT of the ring
-
-    u4_t ring[D][WPC];
-    const char* wp = reinterpret_cast<const char*>(p.qw) + ((size_t)tile * p.chunks + c_begin + wave) * (WPC * 1024) + lane * 16;
-    const size_t wstride = (size_t)W * (WPC * 1024);
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-#pragma unroll
-        for (int h = 0; h < WPC; ++h) ring[d][h] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wp + h * 1024));
-        wp += wstride;
-    }
-
-    float inv = 0.f;
-    if constexpr (GLUE == kGlueRmsNorm) {
-        if (p.stats_in != nullptr && wave == 0) {
-            float ssum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ssum += (lane + 64 * i < p.stats_n) ? sv[i] : 0.f;
-#pragma unroll
-            for (int mk = 32; mk >= 1; mk >>= 1) ssum += __shfl_xor(ssum, mk, 64);
-            if (lane == 0) scratch[0] = rsqrtf(ssum / (float)p.K + p.eps);
-        }
-        __syncthreads();
-        inv = scratch[0];
-    }
-    auto glued = [&](const u4_t& xv, const u4_t& gv) {
-        if constexpr (GLUE == kGlueNone) {
-            return xv;
-        } else {
-            u4_t r;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = glue_pair<ACT>(xv[j], gv[j], inv, GLUE);
-            return r;
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < XL; ++i) {
-        const int idx = tid + i * T;
-        if (idx < n16) xs[idx] = glued(xr[i], gr[i]);
-    }
-    for (int idx = tid + XL * T; idx < n16; idx += T) {   // K ranges longer than 32 B x threads: rare, plain copy
-        u4_t gv = {0u, 0u, 0u, 0u};
-        if constexpr (GLUE != kGlueNone) gv = gsrc[idx];
-        xs[idx] = glued(xsrc[idx], gv);
-    }
-    if (tid < nm4) reinterpret_cast<u4_t*>(metas)[tid] = mr;
-    for (int idx = tid + T; idx < nm4; idx += T) reinterpret_cast<u4_t*>(metas)[idx] = msrc[idx];
-    __syncthreads();
-
-    // ---- the ring -------------------------------------------------------------------------------------------------------
-    f4_t acc = {0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](const u4_t (&w)[WPC], int lc) {   // lc: chunk index inside the block's K range
-        const ColConst cc = expand_meta<BITS, SCL>(metas[(((c_begin + lc) >> sh) - g0) * 16 + c]);
-        const u4_t* xa = xs + lc * 16 + rq;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            u4_t b;
-            if constexpr (BITS == 4) {
-                b = dequant_word4<ACT, SCL>(w[0][j], cc, dk);
-            } else {
-                b = dequant_word8<ACT, SCL>(w[j >> 1][(j & 1) * 2], w[j >> 1][(j & 1) * 2 + 1], cc, dk);
-            }
-            acc = mfma16<ACT>(xa[4 * j], b, acc);
-        }
-    };
-    const int n_mine = cps / W;   // regular: a multiple of D
-    int lc = wave;
-    for (int it = D; it < n_mine; it += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            compute(ring[d], lc);
-#pragma unroll
-            for (int h = 0; h < WPC; ++h) ring[d][h] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wp + h * 1024));
-            wp += wstride;
-            lc += W;
-        }
-    }
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        compute(ring[d], lc);
-        lc += W;
-    }
-
-    // ---- in-block reduction: accumulator row 0 (lanes 0..15, register 0) of every wave ------------------------------------
-    if (lane < 16) red[wave * 16 + lane] = acc[0];
-    __syncthreads();
-    const int n = tile * kTileN + c;
-    const bool live = wave == 0 && lane < 16 && n < p.N;
-    float v = 0.f;
-    if (wave == 0 && lane < 16) {
-        for (int w = 0; w < W; ++w) v += red[w * 16 + lane];
-    }
-    finish_outputs<ACT>(p, v, live, 0, n, tile, split, wave, lane, res_raw, s_last);
-    GPTQHIP_TRACE_END();
-}
-
-constexpr size_t kDecode1MaxLds = 64 * 1024;
-__host__ inline size_t decode1_lds_bytes(int cps, int waves) { return (size_t)cps * 320 + (size_t)waves * 64 + 16 + 4 * 20; }
-
-template <int BITS, int ACT, int SCL, int D>
-static int launch_decode1(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
-    const dim3 grid(ceil_div(p.N, kTileN), p.splits);
-    const dim3 block(64 * pl.waves);
-    const size_t lds_bytes = decode1_lds_bytes(pl.chunks_per_split, pl.waves);
-    if (p.in_glue == kGlueRmsNorm) {
-        hipLaunchKernelGGL((decode1_kernel<BITS, ACT, SCL, D, kGlueRmsNorm>), grid, block, lds_bytes, stream, p);
-    } else if (p.in_glue == kGlueSiluMul) {
-        hipLaunchKernelGGL((decode1_kernel<BITS, ACT, SCL, D, kGlueSiluMul>), grid, block, lds_bytes, stream, p);
-    } else {
-        hipLaunchKernelGGL((decode1_kernel<BITS, ACT, SCL, D, kGlueNone>), grid, block, lds_bytes, stream, p);
-    }
-    return check_hip(hipGetLastError(), "decode1_kernel launch");
-}
-
-// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 template <int BITS, int ACT, int SCL, int MT, int AM, int D>
@@ -922,13 +693,6 @@ static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStr
 
 template <int BITS, int ACT, int SCL>
 static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
-    static const bool no_decode1 = [] { const char* v = getenv("GPTQHIP_NO_DECODE1"); return v && *v && *v != '0'; }();
-    if (pl.mt == 1 && p.M == 1 && p.perm == nullptr && pl.regular && pl.gpc == 1 && !p.exact_bf16 && !no_decode1 &&
-        decode1_lds_bytes(pl.chunks_per_split, pl.waves) <= kDecode1MaxLds) {
-        static const int deep = [] { const char* v = getenv("GPTQHIP_DECODE1_DEEP"); return v && *v ? atoi(v) : 0; }();
-        if (BITS == 4 && deep == 8 && pl.depth == 4 && pl.chunks_per_split % (pl.waves * 8) == 0) return launch_decode1<BITS, ACT, SCL, 8>(p, pl, stream);
-        return pl.depth == 2 ? launch_decode1<BITS, ACT, SCL, 2>(p, pl, stream) : launch_decode1<BITS, ACT, SCL, 4>(p, pl, stream);
-    }
     if (pl.mt == 1 && p.M == 1 && p.perm != nullptr) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1P, 4>(p, pl, stream);
     if (pl.mt == 1 && p.M == 1 && pl.depth == 2) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1, 2>(p, pl, stream);
     if (pl.mt == 1 && p.M == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1, 4>(p, pl, stream);
@@ -1006,7 +770,7 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
         waves = 16;
     }
     if (waves < 4 * pl.mt) waves = 4 * pl.mt;
-    if (force_waves > 0) waves = (force_waves < 4 * pl.mt && !(M == 1 && getenv("GPTQHIP_DEV_THIN"))) ? 4 * pl.mt : force_waves;
+    if (force_waves > 0) waves = force_waves < 4 * pl.mt ? 4 * pl.mt : force_waves;
     pl.waves = waves;
     // cross-block split-K costs a publish + ticket + re-read round trip (~1.5-2 us measured): only worth it
     // when the tiles alone leave most of the chip idle AND there is a long K range to share
