@@ -43,6 +43,8 @@ static const EnvTuning& env_tuning() {
 #define g_force_kernel (t_force_kernel ? t_force_kernel : env_tuning().kernel)
 #define g_force_waves (t_force_waves ? t_force_waves : env_tuning().waves)
 
+constexpr size_t kInKernelPermMaxRowBytes = 44 * 1024;   // AM_ROW1P keeps the x row in LDS next to 16 KiB of per-wave slots
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -218,9 +220,9 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     // the regular straight-line pipeline; everything else gathers x once into the workspace first
     bool fused_perm = false;
     if (perm && M == 1 && g_force_kernel != 2) {
-        const SkinnyPlan pl1 = plan_skinny(1, K, N, group_size, g_force_split, g_force_waves);
+        const SkinnyPlan pl1 = plan_skinny(1, K, N, group_size, g_force_split, g_force_waves, true);
         // (the kernel keeps the x row in LDS next to 16 KiB of per-wave slots: stay inside the default 64 KiB of dynamic LDS)
-        fused_perm = pl1.regular && pl1.gpc == 1 && pl1.depth == 4 && (size_t)K * 2 <= 44 * 1024;
+        fused_perm = pl1.regular && pl1.gpc == 1 && pl1.depth == 4 && (size_t)K * 2 <= kInKernelPermMaxRowBytes;
     }
     if (perm && !fused_perm) {
         void* gbuf = ws + L.gather_off;
@@ -287,7 +289,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         a.x = reinterpret_cast<const char*>(xin) + (size_t)m0 * K * 2;
         a.out = reinterpret_cast<char*>(out) + (size_t)m0 * N * (partial_f32 ? 4 : 2);
         a.M = mc;
-        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves);
+        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves, fused_perm);
         rc = launch_skinny(a, pl, slabs, counters, stream);
         if (rc) return rc;
     }
@@ -339,7 +341,11 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
         set_error("gptqhip_decode_linear: stats_in needs in_glue RMSNORM and 1..512 partial sums (got %d)", op->stats_n);
         return GPTQHIP_EINVAL;
     }
-    const SkinnyPlan pl = plan_skinny(1, op->K, op->N, op->group_size, g_force_split, g_force_waves);
+    const SkinnyPlan pl = plan_skinny(1, op->K, op->N, op->group_size, g_force_split, g_force_waves, op->perm != nullptr);
+    if (op->perm && !(pl.depth == 4 && (size_t)op->K * 2 <= kInKernelPermMaxRowBytes)) {
+        set_error("gptqhip_decode_linear: K=%d is outside the in-kernel act-order variant (gather x and pass perm = NULL)", op->K);
+        return GPTQHIP_EINVAL;
+    }
     if (!(pl.regular && pl.gpc == 1 && pl.mt == 1)) {
         set_error("gptqhip_decode_linear: K=%d group_size=%d is outside the decode op's regular pipeline (use gptqhip_gemm)",
                   op->K, op->group_size);
@@ -353,6 +359,7 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
     char* ws = reinterpret_cast<char*>(op->workspace);
     GemmArgs a;
     a.x = op->x;
+    a.perm = op->perm;
     a.qweight = op->qweight_t;
     a.meta = op->meta;
     a.bias = op->bias;

@@ -54,7 +54,8 @@ struct TiledPlan {
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
-SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves);
+// in_kernel_perm: the plan is for the batch-1 act-order variant (AM_ROW1P), which only exists with the 4-deep ring
+SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm = false);
 int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* counters, hipStream_t stream);
 
 TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_variant, int force_split);

@@ -507,24 +507,93 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
             cu.chunk = cur;
             if constexpr (AM == AM_ROW1P) {
                 // the x row goes to LDS once per block: its (L2-hit) loads are issued BEFORE the weight ring so that
-                // waiting for them does not wait for the HBM stream behind them (vmcnt retires in issue order)
+                // waiting for them does not wait for the HBM stream behind them (vmcnt retires in issue order).  Decode op:
+                // the input glue (RMSNorm / SiLU*mul) is applied HERE, once per element, on the way into LDS -- the ring's
+                // gather then reads finished activations.
                 const u4_t* xs = reinterpret_cast<const u4_t*>(p.x);
+                const u4_t* gs = GLUE == kGlueRmsNorm ? reinterpret_cast<const u4_t*>(p.glue_b) : xs + p.K / 8;  // norm weight | up half
                 const int n16 = p.K / 8;
-                u4_t xr[2];
+                float* scratch = reinterpret_cast<float*>(xbuf + p.K);   // 1 + 16 floats behind the row (see the launch)
+                float sv[8];
+                if constexpr (GLUE == kGlueRmsNorm) {
+                    if (p.stats_in != nullptr && wave == 0) {   // the producer's per-tile sums of squares, in front of everything
+                        const int last = p.stats_n - 1;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int idx = lane + 64 * i;
+                            sv[i] = p.stats_in[idx < last ? idx : last];
+                        }
+                    }
+                }
+                u4_t xr[2], gr[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int idx = (int)threadIdx.x + i * (int)blockDim.x;
                     xr[i] = xs[idx < n16 ? idx : 0];
+                    if constexpr (GLUE != kGlueNone) gr[i] = gs[idx < n16 ? idx : 0];
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM>(st[d], p, tb, lo, cu, W);
+                if constexpr (GLUE == kGlueRmsNorm) {
+                    if (p.stats_in != nullptr) {
+                        if (wave == 0) {
+                            float ssum = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) ssum += (lane + 64 * i < p.stats_n) ? sv[i] : 0.f;
+#pragma unroll
+                            for (int mk = 32; mk >= 1; mk >>= 1) ssum += __shfl_xor(ssum, mk, 64);
+                            if (lane == 0) scratch[0] = rsqrtf(ssum / (float)p.K + p.eps);
+                        }
+                    } else {   // no producer statistics: reduce the row in the block (fixed order)
+                        float ss = 0.f;
+                        auto sq = [&](const u4_t& h) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float a = bits16_to_f32<ACT>((uint16_t)(h[j] & 0xffffu)), b = bits16_to_f32<ACT>((uint16_t)(h[j] >> 16));
+                                ss = __builtin_fmaf(a, a, ss);
+                                ss = __builtin_fmaf(b, b, ss);
+                            }
+                        };
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            if ((int)threadIdx.x + i * (int)blockDim.x < n16) sq(xr[i]);
+                        }
+                        for (int idx = (int)threadIdx.x + 2 * (int)blockDim.x; idx < n16; idx += (int)blockDim.x) sq(xs[idx]);
+#pragma unroll
+                        for (int mk = 32; mk >= 1; mk >>= 1) ss += __shfl_xor(ss, mk, 64);
+                        if (lane == 0) scratch[1 + wave] = ss;
+                        __syncthreads();
+                        if (threadIdx.x == 0) {
+                            float tot = 0.f;
+                            for (int w = 0; w < W; ++w) tot += scratch[1 + w];
+                            scratch[0] = rsqrtf(tot / (float)p.K + p.eps);
+                        }
+                    }
+                    __syncthreads();
+                    glue_inv = scratch[0];
+                }
+                auto glued = [&](const u4_t& xv, const u4_t& gv) {
+                    if constexpr (GLUE == kGlueNone) {
+                        return xv;
+                    } else {
+                        u4_t r;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) r[j] = glue_pair<ACT>(xv[j], gv[j], glue_inv, GLUE);
+                        return r;
+                    }
+                };
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int idx = (int)threadIdx.x + i * (int)blockDim.x;
-                    if (idx < n16) reinterpret_cast<u4_t*>(xbuf)[idx] = xr[i];
+                    if (idx < n16) reinterpret_cast<u4_t*>(xbuf)[idx] = glued(xr[i], gr[i]);
                 }
-                for (int idx = (int)threadIdx.x + 2 * (int)blockDim.x; idx < n16; idx += (int)blockDim.x)
-                    reinterpret_cast<u4_t*>(xbuf)[idx] = xs[idx];  // (rows longer than 32 B x threads: rare, plain copy)
+                for (int idx = (int)threadIdx.x + 2 * (int)blockDim.x; idx < n16; idx += (int)blockDim.x) {
+                    // (rows longer than 32 B x threads: rare, plain copy)
+                    u4_t gv = {0u, 0u, 0u, 0u};
+                    if constexpr (GLUE != kGlueNone) gv = gs[idx];
+                    reinterpret_cast<u4_t*>(xbuf)[idx] = glued(xs[idx], gv);
+                }
                 __syncthreads();
             } else if (GLUE == kGlueRmsNorm && p.stats_in != nullptr) {
                 // RMSNorm statistics handed over by the op that produced h (one partial per 16-column tile: its epilogue's
@@ -672,8 +741,8 @@ static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStr
     const dim3 grid(ceil_div(p.N, kTileN), p.splits);
     const dim3 block(64 * pl.waves);
     constexpr int kSlot = slot_bytes<AM, MT>() > MT * 1024 ? slot_bytes<AM, MT>() : MT * 1024;
-    const size_t lds_bytes = (size_t)pl.waves * kSlot + 16 + (AM == AM_ROW1P ? (size_t)p.K * 2 : 64);
-    if constexpr (AM == AM_ROW1 && MT == 1 && (D == 4 || D == 2)) {
+    const size_t lds_bytes = (size_t)pl.waves * kSlot + 16 + (AM == AM_ROW1P ? (size_t)p.K * 2 + 80 : 64);
+    if constexpr ((AM == AM_ROW1 && MT == 1 && (D == 4 || D == 2)) || (AM == AM_ROW1P && MT == 1 && D == 4)) {
         if (p.in_glue != kGlueNone) {  // decode op with input glue: regular single-group-per-chunk plans only (ABI checks)
             if (p.in_glue == kGlueRmsNorm) {
                 hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueRmsNorm>), grid, block, lds_bytes, stream, p);
@@ -704,7 +773,7 @@ static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStre
     return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWS, 2>(p, pl, stream);  // (callers chunk M to <= 32 rows)
 }
 
-SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves) {
+SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm) {
     static const bool allow_depth2 = [] { const char* v = getenv("GPTQHIP_NO_DEPTH2"); return !(v && *v && *v != '0'); }();
     SkinnyPlan pl;
     const int mtiles = ceil_div(M, 16);
@@ -732,7 +801,7 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
         // once they have landed -- narrow layers like o_proj are latency-, not stream-bound)
         const int force_s = force_split > 0 ? (force_split < pl.chunks ? force_split : pl.chunks) : 0;
         const int depth_hi = pl.depth;                                        // the kernel variants: D = 4 up to 4 rows, else 2
-        const int depth_lo = (M == 1 && allow_depth2) ? 2 : pl.depth;
+        const int depth_lo = (M == 1 && allow_depth2 && !in_kernel_perm) ? 2 : pl.depth;
         for (int depth = depth_hi; depth >= depth_lo; depth -= 2) {
             for (int w = 4; w <= 16; ++w) {
                 // the candidate must stay on the regular pipeline AFTER the cross-block split-K decision below (narrow layers)

@@ -187,11 +187,15 @@ def make_decode_op(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor,
                    K: int, N: int, group_size: int, bits: int, scale_dtype: torch.dtype, in_glue: int = GLUE_NONE,
                    norm_weight: Optional[torch.Tensor] = None, eps: float = 1e-5, residual: Optional[torch.Tensor] = None,
                    workspace: Optional[torch.Tensor] = None, out_glue: int = OUT_NONE,
-                   stats_in: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None) -> "_lib.DecodeOp":
+                   stats_in: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None,
+                   perm: Optional[torch.Tensor] = None) -> "_lib.DecodeOp":
     """Fill a struct gptqhip_decode_op (include/gptqhip.h) from tensors.  The struct only holds raw pointers: the caller
     keeps the tensors alive (DecodeStep does) -- binding once and re-launching costs no per-call Python work.
-    `workspace`: the stream's scratch (workspace_for); taken from the CURRENT stream when omitted."""
-    _require_cuda(x, qweight_t, meta, bias, out, norm_weight, residual, workspace, stats_in, stats_out)
+    `workspace`: the stream's scratch (workspace_for); taken from the CURRENT stream when omitted.
+    `perm`: the module's act-order permutation (int32 [K]); applied to the glued input inside the kernel."""
+    _require_cuda(x, qweight_t, meta, bias, out, norm_weight, residual, workspace, stats_in, stats_out, perm)
+    if perm is not None and (perm.dtype != torch.int32 or perm.numel() != K or not perm.is_contiguous()):
+        raise RuntimeError("decode op: perm must be a contiguous int32 [K] tensor")
     want_out = torch.float32 if out_glue == OUT_PARTIAL_F32 else x.dtype
     if x.dtype not in _DT or out.dtype != want_out or scale_dtype not in _DT:
         raise RuntimeError(f"decode op: unsupported dtypes x={x.dtype} out={out.dtype} scales={scale_dtype}")
@@ -213,7 +217,7 @@ def make_decode_op(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor,
             workspace = workspace_for(x.device, workspace_bytes(1, K, N, group_size, bits, False))
     p = lambda t: 0 if t is None else t.data_ptr()
     return _lib.DecodeOp(p(qweight_t), p(meta), p(bias), p(x), p(norm_weight), p(residual), p(out), p(workspace),
-                         workspace.numel(), p(stats_in), p(stats_out), float(eps), K, N, group_size, bits, _DT[x.dtype],
+                         workspace.numel(), p(stats_in), p(stats_out), p(perm), float(eps), K, N, group_size, bits, _DT[x.dtype],
                          _DT[scale_dtype], int(in_glue), int(out_glue), tiles_in if stats_in is not None else 0)
 
 

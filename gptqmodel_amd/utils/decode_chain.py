@@ -43,16 +43,15 @@ class DecodeLayer:
 
 
 def _lin_tensors(lin, dtype):
-    """(qweight_t, meta, bias, scale_dtype) of a post_init()ed HIP QuantLinear for activations of `dtype`."""
+    """(qweight_t, meta, bias, scale_dtype, perm) of a post_init()ed HIP QuantLinear for activations of `dtype`.
+    perm: the act-order (desc_act) permutation of the module's input features or None; the decode op applies it in the kernel."""
     if not getattr(lin, "_ready", False):
         raise RuntimeError("DecodeStep needs post_init()ed HIP QuantLinear modules")
-    if getattr(lin, "perm", None) is not None:
-        raise NotImplementedError("act-order (desc_act) modules are not supported by the decode chain; use forward()")
     if hasattr(lin, "_runtime"):  # HipAwqLinear: constants depend on the compute dtype
         meta, bias = lin._runtime(dtype)
-        return lin.qweight, meta, bias, dtype
+        return lin.qweight, meta, bias, dtype, None
     bias = lin._bias_for(dtype, lin.qweight.device)
-    return lin.qweight, lin.meta, bias, lin._scale_dtype
+    return lin.qweight, lin.meta, bias, lin._scale_dtype, getattr(lin, "perm", None)
 
 
 class DecodeStep:
@@ -95,16 +94,16 @@ class DecodeStep:
                 (L.down, self.gu_out, h2, ops.GLUE_NONE if paired else ops.GLUE_SILU_MUL, None, h1, ops.OUT_NONE, None, st2),
             ]
             for j, (lin, x, out, glue, nw, res, oglue, s_in, s_out) in enumerate(plan):
-                qw, meta, bias, sdt = _lin_tensors(lin, dtype)
+                qw, meta, bias, sdt, perm = _lin_tensors(lin, dtype)
                 K, N = lin.in_features, lin.out_features
                 if j == 1 and K != q_dim:
                     raise ValueError("o_proj in_features must equal q_dim")
                 if not ops.decode_supported(K, N, lin.group_size):
                     raise NotImplementedError(f"decode chain: layer shape K={K} N={N} group_size={lin.group_size} unsupported")
-                self._keep.extend([qw, meta, bias, nw])
+                self._keep.extend([qw, meta, bias, nw, perm])
                 self.ops.append(ops.make_decode_op(x, qw, meta, bias, out, K, N, lin.group_size, lin.bits, sdt, in_glue=glue,
                                                    norm_weight=nw, eps=eps, residual=res, workspace=self.workspace,
-                                                   out_glue=oglue, stats_in=s_in, stats_out=s_out))
+                                                   out_glue=oglue, stats_in=s_in, stats_out=s_out, perm=perm))
             h_in, st_in = h2, st2
         self.out = h_in
 
@@ -155,7 +154,10 @@ class TPDecodeStep:
         self._keep, self.steps = [], []   # steps: ("op", struct) | ("ar", residual, bias, out, stats_out)
 
         def bind(lin, x, out, glue, nw, oglue, s_in):
-            qw, meta, bias, sdt = _lin_tensors(lin, dtype)
+            qw, meta, bias, sdt, perm = _lin_tensors(lin, dtype)
+            if perm is not None:
+                raise NotImplementedError("TPDecodeStep: act-order shards need the row-parallel input exchange of "
+                                          "utils.tp.RowParallelQuantLinear; use the module path")
             K, N = lin.in_features, lin.out_features
             if oglue == ops.OUT_PARTIAL_F32 and bias is not None:
                 raise ValueError("row-parallel shards must not carry a bias: pass the layer bias as DecodeLayer.o_bias / down_bias")

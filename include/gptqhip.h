@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 6
+#define GPTQHIP_ABI_VERSION 7
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -163,6 +163,8 @@ typedef struct gptqhip_decode_op {
     size_t workspace_bytes;
     const float* stats_in;       /* see above                                                  */
     float* stats_out;
+    const int32_t* perm;         /* act-order (desc_act) permutation [K] as for gptqhip_gemm, applied to the GLUED input inside the
+                                    kernel, or NULL.  Needs K * 2 bytes <= 44 KiB (else gather first).                */
     float eps;
     int K, N, group_size, bits, act_dtype, scale_dtype, in_glue, out_glue, stats_n;
 } gptqhip_decode_op;

@@ -100,6 +100,47 @@ def test_decode_op_fused_glue_vs_hf_semantics(ops, act):
     assert_forward_close(torch_to_f32(a_dev)[None, :inter], a_ref[None], act, tag="stats_in rmsnorm + paired silu*mul")
 
 
+@pytest.mark.parametrize("act", ["fp16", "bf16"])
+def test_decode_op_act_order_in_kernel_perm_with_glue(ops, act):
+    """desc_act=True checkpoints: the decode op applies the act-order permutation inside the kernel to the GLUED input
+    (RMSNorm from producer statistics and from an in-block reduction; residual + stats_out epilogue) -- against the oracle's
+    forward with the checkpoint's g_idx."""
+    gs, bits = 128, 4
+    rng = np.random.RandomState(21)
+    for K, N, with_stats in ((4096, 6144, True), (4096, 1024, False), (14336, 4096, False), (8192, 10240, True)):
+        qweight, qzeros, scales, g_idx = synth_gptq(300 + K // 128 + N // 16, bits, K, N, gs, desc_act=True)
+        perm = torch.from_numpy(np.argsort(g_idx, kind="stable").astype(np.int32)).to(DEV)
+        sc = f32_to_torch(scales, "fp16", DEV)
+        qw_t, meta = ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV), sc, perm, gs, bits)
+        h = O.round_to(rng.randn(K).astype(np.float32) * 1.5, act)
+        w = O.round_to(1.0 + rng.randn(K).astype(np.float32) * 0.1, act)
+        res = O.round_to(rng.randn(N).astype(np.float32), act)
+        st_in = None
+        if with_stats:
+            st_in = torch.from_numpy((h.astype(np.float64) ** 2).reshape(-1, 16).sum(axis=1).astype(np.float32)).to(DEV)
+        st_out = torch.zeros(-(-N // 16), dtype=torch.float32, device=DEV)
+        out = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, in_glue=ops.GLUE_RMSNORM,
+                                norm_weight=f32_to_torch(w, act, DEV), eps=1e-5, residual=f32_to_torch(res, act, DEV),
+                                stats_in=st_in, stats_out=st_out, perm=perm)
+        xn = O.rmsnorm_ref(h, w, 1e-5, act)
+        y = O.forward_gptq(xn[None], qweight, qzeros, scales, g_idx, bits, None, act, "fp16")
+        ref = O.residual_add_ref(res[None], y, act)
+        got = torch_to_f32(out)
+        assert_forward_close(got[None], ref, act, tag=(K, N, with_stats))
+        assert np.allclose(st_out.cpu().numpy(), (got.astype(np.float64) ** 2).reshape(-1, 16).sum(axis=1), rtol=1e-5)
+        # plain (no glue) with the permutation == the plugin path's batch-1 kernel
+        plain = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, perm=perm)
+        gen = ops.gemm(f32_to_torch(h[None], act, DEV), qw_t, meta, None, perm, N, gs, bits, sc.dtype)
+        assert torch.equal(plain, gen[0])
+    with pytest.raises(RuntimeError, match="in-kernel act-order"):   # row too long for the LDS-resident variant
+        K, N = 28672, 512
+        qweight, qzeros, scales, g_idx = synth_gptq(9, bits, K, N, gs, desc_act=True)
+        perm = torch.from_numpy(np.argsort(g_idx, kind="stable").astype(np.int32)).to(DEV)
+        sc = f32_to_torch(scales, "fp16", DEV)
+        qw_t, meta = ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV), sc, perm, gs, bits)
+        ops.decode_linear(torch.zeros(K, dtype=TDT[act], device=DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, perm=perm)
+
+
 def test_decode_op_rejects_unsupported_shapes(ops):
     qweight, qzeros, scales, _ = synth_gptq(1, 4, 256, 64, 64)
     qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, 64, 4)
@@ -111,14 +152,24 @@ def test_decode_op_rejects_unsupported_shapes(ops):
                           in_glue=ops.GLUE_RMSNORM)
 
 
-def _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype, seed=0, interleave=True):
+def _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype, seed=0, interleave=True, desc_act=False):
     from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
     from gptqmodel_amd.utils.decode_chain import DecodeLayer
     gen = torch.Generator(device=DEV)
     gen.manual_seed(seed)
+    gidx = {}
+
+    def g_idx_for(k):
+        # one act-order permutation per input width (siblings that share an input share it, as in real checkpoints)
+        if k not in gidx:
+            if desc_act:
+                gidx[k] = (torch.randperm(k, device=DEV, generator=gen) // 128).to(torch.int32)
+            else:
+                gidx[k] = torch.arange(k, device=DEV, dtype=torch.int32) // 128
+        return gidx[k]
 
     def lin(k, n):
-        m = HipGptqLinear(bits=4, group_size=128, sym=True, desc_act=False, in_features=k, out_features=n, bias=False,
+        m = HipGptqLinear(bits=4, group_size=128, sym=True, desc_act=desc_act, in_features=k, out_features=n, bias=False,
                           register_buffers=False)
         w = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=DEV, generator=gen)
         # code 0 -> 8: codes symmetric around the sym zero-point 8, i.e. zero-mean weights like a real checkpoint (with
@@ -126,7 +177,7 @@ def _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype, seed=0, interleav
         m.qweight = w | (((~(w | (w >> 1) | (w >> 2) | (w >> 3))) & 0x11111111) << 3)
         m.qzeros = torch.full((k // 128, n // 8), -2004318072, dtype=torch.int32, device=DEV)
         m.scales = (torch.rand((k // 128, n), device=DEV, generator=gen) * 0.01 + 0.005).to(dtype)
-        m.g_idx = torch.arange(k, device=DEV, dtype=torch.int32) // 128
+        m.g_idx = g_idx_for(k)
         m.bias = None
         m.qzero_format(format=2)
         m.eval()
@@ -134,13 +185,13 @@ def _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype, seed=0, interleav
         return m
 
     def raw(k, n):
-        m = HipGptqLinear(bits=4, group_size=128, sym=True, desc_act=False, in_features=k, out_features=n, bias=False,
+        m = HipGptqLinear(bits=4, group_size=128, sym=True, desc_act=desc_act, in_features=k, out_features=n, bias=False,
                           register_buffers=False)
         w = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=DEV, generator=gen)
         m.qweight = w | (((~(w | (w >> 1) | (w >> 2) | (w >> 3))) & 0x11111111) << 3)
         m.qzeros = torch.full((k // 128, n // 8), -2004318072, dtype=torch.int32, device=DEV)
         m.scales = (torch.rand((k // 128, n), device=DEV, generator=gen) * 0.01 + 0.005).to(dtype)
-        m.g_idx = torch.arange(k, device=DEV, dtype=torch.int32) // 128
+        m.g_idx = g_idx_for(k)
         m.bias = None
         m.qzero_format(format=2)
         m.eval()
@@ -154,7 +205,7 @@ def _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype, seed=0, interleav
         if interleave == "all" or (interleave and li % 2 == 0):    # default: both fusion layouts in one stack
             gu = fuse_gate_up_interleaved(gate, up)
         else:
-            gu = raw(hidden, 2 * inter)
+            gu = raw(hidden, 2 * inter)     # (a fresh per-width g_idx lookup: same tensor as gate / up)
             gu.qweight = torch.cat([gate.qweight, up.qweight], dim=1).contiguous()
             gu.scales = torch.cat([gate.scales, up.scales], dim=1).contiguous()
         for m in (gate, up, gu):
@@ -182,11 +233,13 @@ def _reference_step(layers, x_in, q_dim, inter, eps):
     return h
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_chain_tracks_unfused_reference_and_replays_identically(dtype):
+@pytest.mark.parametrize("dtype,desc_act", [(torch.float16, False), (torch.bfloat16, False), (torch.float16, True)])
+def test_chain_tracks_unfused_reference_and_replays_identically(dtype, desc_act):
     from gptqmodel_amd.utils.decode_chain import DecodeStep
     hidden, inter, q_dim, kv_dim, n_layers = 4096, 14336, 4096, 1024, 3
-    layers = _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype)
+    layers = _make_stack(n_layers, hidden, inter, q_dim, kv_dim, dtype, desc_act=desc_act)
+    if desc_act:
+        assert all(L.qkv.perm is not None and L.down.perm is not None for L in layers)
     step = DecodeStep(layers, hidden, q_dim, dtype)
     gen = torch.Generator(device=DEV)
     gen.manual_seed(5)
