@@ -497,6 +497,15 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
         res.append(prefill_entry("C3", "GPTQ int4 g128 desc_act=True, M=65536, 4096x28672 (fused gate_up)", [agu], 65536, dtype, dev,
                                  iters=2))
         del agu
+        # the same checkpoint kind at batch-1 decode: the act-order permutation is applied inside the decode op
+        from gptqmodel_amd.utils.decode_chain import DecodeStep as _DS
+        act_layers = build_stack(cfg, lambda k, n: make_gptq(k, n, gs, dev, gen, dtype, desc_act=True), dev, gen, dtype)
+        st = _DS(act_layers, cfg["hidden"], cfg["q"], dtype)
+        st.x_in.copy_((torch.randn(cfg["hidden"], device=dev, generator=gen) * 0.5).to(dtype))
+        ms, g = time_graph(st.run, stream, 100, 10)
+        res.append(decode_entry("C3", "Llama-3-8B GPTQ int4 g128 desc_act=True batch=1 decode, decode chain (permutation applied in the "
+                                "kernel on the glued input row)", cfg, ms, n_launch))
+        del g, st, act_layers
     except Exception as e:  # noqa: BLE001
         res.append({"config": "C3", "error": str(e)[:300]})
     torch.cuda.empty_cache()
