@@ -305,14 +305,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GPTQHIP_BENCH_SHARE_GPU=1 (smoke-testing the N > 1 code path on a one-GPU box, tests/dev): every rank uses cuda:0 and
+    # the process group runs on gloo (RCCL refuses two ranks on one device); the numbers of such a run mean nothing.
+    share = bool(os.environ.get("GPTQHIP_BENCH_SHARE_GPU")) and world > 1
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.model == "llama3-70b":
         from bench_tp import run_70b   # tensor-parallel 70B leg lives in its own file
