@@ -11,6 +11,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r02_stats
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/r02_pmc_fetch -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-graph > $O/r02_pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/r02_pmc_write -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-graph > $O/r02_pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $O/r02_pmc_sq -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-graph > $O/r02_pmc_sq.log 2>&1
+for d in r02_pmc_fetch r02_pmc_write r02_pmc_sq; do python $R/tests/dev/pmc_agg.py $O/$d > /dev/null 2>&1; done
 find $O/r02_stats $O/r02_pmc_fetch $O/r02_pmc_write $O/r02_pmc_sq -type f -size +12M -delete 2>/dev/null
 cd $R
 # (3) plain runs

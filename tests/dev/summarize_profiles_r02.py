@@ -27,6 +27,10 @@ allv = [d for v in agg.values() for d in v]
 def pmc(d, name):
     p = f"{src}{tag}_{d}/bench_counter_collection.csv"
     if not os.path.exists(p):
+        ps = f"{src}{tag}_{d}/pmc_summary.json"      # aggregated on the GPU box (tests/dev/pmc_agg.py) when the CSV was too big
+        if os.path.exists(ps):
+            v = json.load(open(ps)).get("skinny_kernel", {}).get(name)
+            return None if v is None else v["avg_per_dispatch_row"]
         return None
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(p)) if "skinny_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name]
     return sum(vals) / len(vals) if vals else None
@@ -43,7 +47,15 @@ summ = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- pyth
         "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide (16 B/lane) coalesced streaming read -> doubled; WRITE_SIZE uncalibrated (negligible here)",
         "algorithmic_bytes_per_launch": bench_prof["roofline"]["bytes_per_launch"],
         "traffic_over_algorithmic": None if fetch is None else 2 * 1024 * fetch / bench_prof["roofline"]["bytes_per_launch"],
-        "sq_per_launch": {n: pmc("pmc_sq", n) for n in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU")}}
+        "sq_per_launch": {n: pmc("pmc_sq", n) for n in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU")}
+                         | {n: pmc("pmc_sq2", n) for n in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VMEM", "SQ_INSTS_LDS", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES")}}
+sq = summ["sq_per_launch"]
+if sq.get("SQ_INSTS_VALU") and summ["avg_kernel_us_rocprof"]:
+    # 1024 SIMDs, 4 cycles per wave64 VALU instruction, 2.4 GHz: share of the average launch the VALU pipes are issuing
+    summ["derived"] = {"valu_instr_per_simd": sq["SQ_INSTS_VALU"] / 1024,
+                       "valu_issue_us_per_simd_at_2p4GHz": sq["SQ_INSTS_VALU"] / 1024 * 4 / 2400,
+                       "valu_share_of_avg_launch": sq["SQ_INSTS_VALU"] / 1024 * 4 / 2400 / summ["avg_kernel_us_rocprof"],
+                       "note": "averaged over the four launch shapes of a layer; on gate_up alone the loop issues 66 VALU per 1 KiB chunk = 6.3 us of its 14.7"}
 json.dump(summ, open(f"{dst}{tag}_pmc_summary.json", "w"), indent=1)
 for f in ("bench.json", "bench_bf16.json", "bench_modules.json", "decode_ops.txt", "eager_overhead.txt", "e2e_llama8b.txt", "configs.txt", "torch_gpu_baseline.txt"):
     if os.path.exists(f"{src}{tag}_{f}"): shutil.copy(f"{src}{tag}_{f}", f"{dst}{tag}_{f}")
