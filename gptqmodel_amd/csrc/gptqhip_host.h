@@ -36,7 +36,8 @@ struct SkinnyPlan {
     int chunks;            // ceil(K / 128)
     int waves;             // waves per block (in-block split-K)
     int depth;             // register-ring depth of the kernel variant the launcher will pick
-    int regular;           // every wave owns a multiple of `depth` chunks
+    int regular;           // straight-line pipeline: every wave runs `rounds` whole ring rounds (the last may hold padding chunks)
+    int rounds;            // ring rounds per wave on the regular pipeline: rounds * depth * waves >= chunks_per_split
     int chunks_per_split;  // chunks handled by one block
     int splits;            // grid.y (cross-block split-K)
     size_t slab_floats;    // fp32 partial slabs, 0 when splits == 1

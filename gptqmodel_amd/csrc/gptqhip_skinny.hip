@@ -45,6 +45,7 @@ struct SkinnyParams {
     int chunks_per_split;  // chunks handled by one block
     int splits;
     int out_f32;           // epilogue writes raw fp32 accumulators (TP partial sums)
+    int n_mine;            // regular pipeline: chunks per wave incl. padding = rounds * D
     int regular;           // every wave owns a multiple of D chunks: straight-line counted-wait pipeline
     int cpg_shift;         // log2(chunks per group) when group_size is 128 * 2^n, else -1 (integer division)
     int exact_bf16;        // GPTQHIP_GEMM_EXACT_BF16: see compute_stage
@@ -220,6 +221,9 @@ struct Cursor {
     const char* w;  // next (tile, chunk) block this wave loads
     const char* x;  // activations, advanced to that chunk (row 0)
     int chunk;
+    int end;        // first chunk past this block's REAL K range: chunks >= end are padding of the last ring round (the planner
+                    // rounds every wave up to whole rounds); their loads are clamped to the last real chunk (wave-uniform scalar
+                    // selects, no branch: the waits stay counted) and their stage is skipped at compute time
 };
 
 template <int MT, int AM>
@@ -231,10 +235,15 @@ template <int BITS, int GPC, int MT, int AM, int GLUE = 0>
 __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, const SkinnyParams& p, const TileBases& tb,
                                                 const LaneOffs<MT, AM>& lo, Cursor& cu, int stride_chunks) {
     constexpr int WPC = BITS == 4 ? 1 : 2;
+    const int over = cu.chunk - (cu.end - 1);
+    const size_t back = over > 0 ? (size_t)over : 0;                 // 0 for every real chunk
+    const char* wsrc = cu.w - back * (WPC * 1024);
+    const char* xsrc = cu.x - back * 256;
+    const int ch = cu.chunk - (int)back;
 #pragma unroll
     for (int h = 0; h < WPC; ++h)
-        st.w[h] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(cu.w + h * 1024 + tb.lane16));
-    const char* mrow = reinterpret_cast<const char*>(tb.meta) + ((size_t)(cu.chunk >> p.cpg_shift) << 6);
+        st.w[h] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wsrc + h * 1024 + tb.lane16));
+    const char* mrow = reinterpret_cast<const char*>(tb.meta) + ((size_t)(ch >> p.cpg_shift) << 6);
 #if GPTQHIP_ABLATE & 1
     st.meta[0] = 0x00082000u;
 #else
@@ -244,22 +253,22 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
 #if GPTQHIP_ABLATE & 2
         st.x.a[0] = 0x3c003c00u;
 #else
-        st.x.a[0] = *reinterpret_cast<const uint32_t*>(cu.x + lo.x[0]);
+        st.x.a[0] = *reinterpret_cast<const uint32_t*>(xsrc + lo.x[0]);
 #endif
         if constexpr (GLUE == kGlueRmsNorm) {
-            st.x.a[1] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.glue_b) + (cu.x - tb.x) + lo.x[0]);
+            st.x.a[1] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.glue_b) + (xsrc - tb.x) + lo.x[0]);
         } else if constexpr (GLUE == kGlueSiluMul) {
-            st.x.a[1] = *reinterpret_cast<const uint32_t*>(cu.x + (size_t)p.K * 2 + lo.x[0]);
+            st.x.a[1] = *reinterpret_cast<const uint32_t*>(xsrc + (size_t)p.K * 2 + lo.x[0]);
         }
     } else if constexpr (AM == AM_ROW1P) {
-        const u2_t pr = *reinterpret_cast<const u2_t*>(reinterpret_cast<const char*>(p.perm) + (size_t)cu.chunk * 512 + lo.x[0]);
+        const u2_t pr = *reinterpret_cast<const u2_t*>(reinterpret_cast<const char*>(p.perm) + (size_t)ch * 512 + lo.x[0]);
         st.x.a[0] = pr.x;
         st.x.a[1] = pr.y;
     } else if constexpr (AM == AM_ROW4) {
-        st.x.a[0] = *reinterpret_cast<const u4_t*>(cu.x + lo.x[0]);
+        st.x.a[0] = *reinterpret_cast<const u4_t*>(xsrc + lo.x[0]);
     } else if constexpr (is_rows<AM>()) {
 #pragma unroll
-        for (int i = 0; i < row_quads<AM, MT>(); ++i) st.x.a[i] = *reinterpret_cast<const u4_t*>(cu.x + lo.x[i]);
+        for (int i = 0; i < row_quads<AM, MT>(); ++i) st.x.a[i] = *reinterpret_cast<const u4_t*>(xsrc + lo.x[i]);
     }
     cu.w += (size_t)stride_chunks * (WPC * 1024);
     cu.x += (size_t)stride_chunks * 256;
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     // D-deep register ring: every load of a chunk (weights, constants, activations) is issued D chunks ahead,
     // so a wave keeps D KiB of HBM reads in flight and waits only for the oldest stage.
     Stage<BITS, GPC, MT, AM> st[D];
-    const int n_mine = c_begin + wave < c_end ? (c_end - c_begin - wave + W - 1) / W : 0;  // chunks of this wave
+    const int n_mine = p.regular ? p.n_mine : (c_begin + wave < c_end ? (c_end - c_begin - wave + W - 1) / W : 0);  // chunks of this wave
     if (p.regular) {
         // REGULAR: every wave owns a multiple of D chunks (the planner picks W for that), K % 128 == 0 and one
         // group constant per chunk.  Straight-line prologue / steady loop / drain with unconditional loads, so the
@@ -505,6 +514,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
             cu.w = tb.w + (size_t)cur * (BITS == 4 ? 1024 : 2048);
             cu.x = tb.x + (size_t)cur * 256;
             cu.chunk = cur;
+            cu.end = c_end;
             if constexpr (AM == AM_ROW1P) {
                 // the x row goes to LDS once per block: its (L2-hit) loads are issued BEFORE the weight ring so that
                 // waiting for them does not wait for the HBM stream behind them (vmcnt retires in issue order).  Decode op:
@@ -674,7 +684,8 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE>(st[d], p, cur, lane, aslot, dk, acc, xbuf, glue_inv);
+                // (only the last ring round can hold padding chunks: wave-uniform skip)
+                if (cur < c_end) compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE>(st[d], p, cur, lane, aslot, dk, acc, xbuf, glue_inv);
                 cur += W;
             }
         }
@@ -775,6 +786,7 @@ static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStre
 
 SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm) {
     static const bool allow_depth2 = [] { const char* v = getenv("GPTQHIP_NO_DEPTH2"); return !(v && *v && *v != '0'); }();
+    static const bool allow_pad = [] { const char* v = getenv("GPTQHIP_NO_PAD"); return !(v && *v && *v != '0'); }();   // A/B switch
     SkinnyPlan pl;
     const int mtiles = ceil_div(M, 16);
     pl.mt = mtiles <= 1 ? 1 : 2;  // gptqhip_gemm feeds at most 32 rows per launch
@@ -802,19 +814,39 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
         const int force_s = force_split > 0 ? (force_split < pl.chunks ? force_split : pl.chunks) : 0;
         const int depth_hi = pl.depth;                                        // the kernel variants: D = 4 up to 4 rows, else 2
         const int depth_lo = (M == 1 && allow_depth2 && !in_kernel_perm) ? 2 : pl.depth;
-        for (int depth = depth_hi; depth >= depth_lo; depth -= 2) {
-            for (int w = 4; w <= 16; ++w) {
-                // the candidate must stay on the regular pipeline AFTER the cross-block split-K decision below (narrow layers)
-                int sp = 1;
-                if (tiles < 48 && pl.chunks >= 4 * w) sp = ceil_div(48, tiles);
-                const int max_sp = pl.chunks / w < 1 ? 1 : pl.chunks / w;
-                if (sp > max_sp) sp = max_sp;
-                if (force_s > 0) sp = force_s;
-                const int cps = ceil_div(pl.chunks, sp);
-                if (pl.chunks % cps != 0 || cps % (w * depth) != 0) continue;
-                if (best == 0 || abs(w - target) < abs(best - target) || (abs(w - target) == abs(best - target) && depth == best_depth && w > best)) {
-                    best = w;
-                    best_depth = depth;
+        // pass 0: exact plans (every wave's chunks are whole ring rounds); pass 1: plans whose LAST round carries padding chunks
+        // (clamped loads, skipped compute -- see Cursor) for chunk counts with awkward factors (Llama-2 down_proj: 86 = 2 * 43,
+        // Qwen2-7B: 148 = 4 * 37), accepted up to 1/8 of wasted loads, least waste first
+        float best_score = 0.f;
+        for (int pass = 0; pass < (allow_pad ? 2 : 1) && best == 0; ++pass) {
+            for (int depth = depth_hi; depth >= depth_lo; depth -= 2) {
+                for (int w = 4; w <= 16; ++w) {
+                    // the candidate must stay on the regular pipeline AFTER the cross-block split-K decision below (narrow layers)
+                    int sp = 1;
+                    if (tiles < 48 && pl.chunks >= 4 * w) sp = ceil_div(48, tiles);
+                    const int max_sp = pl.chunks / w < 1 ? 1 : pl.chunks / w;
+                    if (sp > max_sp) sp = max_sp;
+                    if (force_s > 0) sp = force_s;
+                    const int cps = ceil_div(pl.chunks, sp);
+                    const int nsp = ceil_div(pl.chunks, cps);
+                    const int virt = ceil_div(cps, w * depth) * w * depth * nsp;
+                    const int waste = virt - pl.chunks;
+                    if (pass == 0 ? waste != 0 : waste * 8 > pl.chunks) continue;
+                    // pass 1 trades wasted loads against the distance from the wave target: one wave off ~ 1 % of extra loads
+                    const float score = (float)waste / (float)pl.chunks + 0.01f * (float)abs(w - target);
+                    bool better;
+                    if (best == 0) {
+                        better = true;
+                    } else if (pass == 1) {
+                        better = score < best_score;
+                    } else {
+                        better = abs(w - target) < abs(best - target) || (abs(w - target) == abs(best - target) && depth == best_depth && w > best);
+                    }
+                    if (better) {
+                        best = w;
+                        best_depth = depth;
+                        best_score = score;
+                    }
                 }
             }
         }
@@ -853,8 +885,10 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     pl.chunks_per_split = ceil_div(pl.chunks, s);
     pl.splits = ceil_div(pl.chunks, pl.chunks_per_split);
     pl.slab_floats = pl.splits > 1 ? (size_t)pl.splits * M * N : 0;
-    pl.regular = (pl.chunks % pl.chunks_per_split == 0) && (pl.chunks_per_split % (pl.waves * pl.depth) == 0) &&
-                         pl.gpc == 1 && K % kChunkK == 0 && ((group_size / kChunkK) & (group_size / kChunkK - 1)) == 0
+    pl.rounds = ceil_div(pl.chunks_per_split, pl.waves * pl.depth);
+    const int virt_chunks = pl.rounds * pl.waves * pl.depth * pl.splits;   // incl. the padding of every block's last ring round
+    pl.regular = (allow_pad ? (virt_chunks - pl.chunks) * 8 <= pl.chunks : virt_chunks == pl.chunks) && pl.gpc == 1 && K % kChunkK == 0 &&
+                         ((group_size / kChunkK) & (group_size / kChunkK - 1)) == 0
                      ? 1
                      : 0;
     return pl;
@@ -880,6 +914,7 @@ int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* co
     p.splits = pl.splits;
     p.out_f32 = a.out_f32;
     p.regular = pl.regular;
+    p.n_mine = pl.rounds * pl.depth;
     p.cpg_shift = -1;
     if (a.group_size % kChunkK == 0) {
         const int cpg = a.group_size / kChunkK;

@@ -394,6 +394,33 @@ def test_persistent_tile_loop_short_k(ops, K, variant, partial):
         assert_forward_close(torch_to_f32(out), ref, "fp16")
 
 
+@pytest.mark.parametrize("K,N", [(11008, 1024), (18944, 256), (11008, 192), (5504, 512), (2816, 4096)])
+@pytest.mark.parametrize("M,desc_act", [(1, False), (1, True), (3, False), (8, False), (13, True), (20, False)])
+def test_padded_ring_rounds_awkward_chunk_counts(ops, K, N, M, desc_act):
+    """K / 128 with no usable factorisation into waves x ring depth (Llama-2-7B down_proj 86 = 2 * 43, Qwen2-7B 148 = 4 * 37,
+    43, 22): the planner rounds every wave up to whole ring rounds, the padding chunks' loads are clamped and their stages
+    skipped.  Narrow N adds the cross-block split-K with a shorter last split.  The decode op accepts these shapes."""
+    gs, act = 128, "fp16"
+    qweight, qzeros, scales, g_idx = synth_gptq(500 + K // 128 + M, 4, K, N, gs, desc_act=desc_act)
+    rng = np.random.RandomState(13)
+    x = O.round_to(rng.randn(M, K).astype(np.float32) * 0.5, act)
+    bias = O.round_to(rng.randn(N).astype(np.float32) * 0.1, act)
+    got = torch_to_f32(run_gptq(ops, x, qweight, qzeros, scales, g_idx, 4, gs, bias, act, "fp16"))
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, bias, act, "fp16")
+    assert_forward_close(got, ref, act, tag=(K, N, M, desc_act))
+    assert ops.decode_supported(K, N, gs)
+    if M == 1 and not desc_act:
+        sc = f32_to_torch(scales, "fp16", DEV)
+        qw_t, meta = ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV), sc, None, gs, 4)
+        w = O.round_to(1.0 + rng.randn(K).astype(np.float32) * 0.1, act)
+        res = O.round_to(rng.randn(N).astype(np.float32), act)
+        out = ops.decode_linear(f32_to_torch(x[0], act, DEV), qw_t, meta, None, K, N, gs, 4, sc.dtype, in_glue=ops.GLUE_RMSNORM,
+                                norm_weight=f32_to_torch(w, act, DEV), eps=1e-5, residual=f32_to_torch(res, act, DEV))
+        xn = O.rmsnorm_ref(x[0], w, 1e-5, act)
+        y = O.forward_gptq(xn[None], qweight, qzeros, scales, g_idx, 4, None, act, "fp16")
+        assert_forward_close(torch_to_f32(out)[None], O.residual_add_ref(res[None], y, act), act, tag="decode op")
+
+
 @pytest.mark.parametrize("K,N,act", [(4096, 4096, "fp16"), (4096, 512, "bf16"), (14336, 1024, "fp16")])
 def test_decode_act_order_fused_gather(ops, K, N, act):
     """Batch-1 decode of an act-order checkpoint: regular plans apply the permutation inside the kernel (no gather
