@@ -243,12 +243,21 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
 #pragma unroll
     for (int h = 0; h < WPC; ++h)
         st.w[h] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wsrc + h * 1024 + tb.lane16));
-    const char* mrow = reinterpret_cast<const char*>(tb.meta) + ((size_t)(ch >> p.cpg_shift) << 6);
+    if constexpr (GPC == 1) {
+        const char* mrow = reinterpret_cast<const char*>(tb.meta) + ((size_t)(ch >> p.cpg_shift) << 6);
 #if GPTQHIP_ABLATE & 1
-    st.meta[0] = 0x00082000u;
+        st.meta[0] = 0x00082000u;
 #else
-    st.meta[0] = *reinterpret_cast<const uint32_t*>(mrow + tb.c4);
+        st.meta[0] = *reinterpret_cast<const uint32_t*>(mrow + tb.c4);
 #endif
+    } else {
+        // group_size 32 / 64: one constant row per 32-row K-step; cpg_shift holds log2(group_size / 32) here
+#pragma unroll
+        for (int j = 0; j < GPC; ++j) {
+            const char* mrow = reinterpret_cast<const char*>(tb.meta) + ((size_t)((ch * 4 + j) >> p.cpg_shift) << 6);
+            st.meta[j] = *reinterpret_cast<const uint32_t*>(mrow + tb.c4);
+        }
+    }
     if constexpr (AM == AM_ROW1) {
 #if GPTQHIP_ABLATE & 2
         st.x.a[0] = 0x3c003c00u;
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
         // group constant per chunk.  Straight-line prologue / steady loop / drain with unconditional loads, so the
         // compiler's s_waitcnt insertion can COUNT (vmcnt(3*(D-1)) style) instead of draining the queue -- with
         // conditional loads it falls back to vmcnt(0) before every stage, which serialises the ring.
-        if constexpr (GPC == 1) {
+        {
             LaneOffs<MT, AM> lo;
             if constexpr (AM == AM_ROW1) {
                 lo.x[0] = (uint32_t)lane * 4u;
@@ -887,8 +896,9 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     pl.slab_floats = pl.splits > 1 ? (size_t)pl.splits * M * N : 0;
     pl.rounds = ceil_div(pl.chunks_per_split, pl.waves * pl.depth);
     const int virt_chunks = pl.rounds * pl.waves * pl.depth * pl.splits;   // incl. the padding of every block's last ring round
-    pl.regular = (allow_pad ? (virt_chunks - pl.chunks) * 8 <= pl.chunks : virt_chunks == pl.chunks) && pl.gpc == 1 && K % kChunkK == 0 &&
-                         ((group_size / kChunkK) & (group_size / kChunkK - 1)) == 0
+    pl.regular = (allow_pad ? (virt_chunks - pl.chunks) * 8 <= pl.chunks : virt_chunks == pl.chunks) && K % kChunkK == 0 &&
+                         (pl.gpc == 1 ? (group_size >= K || ((group_size / kChunkK) & (group_size / kChunkK - 1)) == 0)
+                                      : (group_size == 32 || group_size == 64))
                      ? 1
                      : 0;
     return pl;
@@ -916,13 +926,17 @@ int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* co
     p.regular = pl.regular;
     p.n_mine = pl.rounds * pl.depth;
     p.cpg_shift = -1;
-    if (a.group_size % kChunkK == 0) {
+    if (a.group_size >= a.K) {
+        p.cpg_shift = 20;   // one group for the whole K (group_size = -1 checkpoints): every chunk index >> 20 is group 0
+    } else if (a.group_size % kChunkK == 0) {
         const int cpg = a.group_size / kChunkK;
         if ((cpg & (cpg - 1)) == 0) {
             int sh = 0;
             while ((1 << sh) < cpg) ++sh;
             p.cpg_shift = sh;
         }
+    } else if (pl.regular) {
+        p.cpg_shift = a.group_size == 64 ? 1 : 0;   // GPC == 4 on the regular pipeline: K-steps (32 rows) per group, log2
     }
     p.exact_bf16 = a.exact_bf16;
     p.glue_b = a.glue_b;

@@ -69,6 +69,7 @@ def test_decode_op_shape_predicate_is_host_logic(lib):
     assert lib.gptqhip_decode_supported(4096, 4096, 64) == 0      # four constants per 128-row chunk: general kernel
     assert lib.gptqhip_decode_supported(4000, 4096, 32) == 0      # K % 128 != 0
     assert lib.gptqhip_decode_supported(4096, 4096, 4096) == 1    # one group for the whole K (group_size = -1 checkpoints)
+    assert lib.gptqhip_decode_supported(14336, 4096, 14336) == 1
     assert lib.gptqhip_decode_supported(0, 4096, 128) == 0
 
 

@@ -124,6 +124,12 @@ SHAPES = [
     (1024, 1000, 64, 3),     # N not a multiple of 64 (ragged strip)
     (2048, 2048, 32, 5),
     (2048, 512, 2048, 2),    # group_size == K
+    (4096, 4096, 64, 1),     # sub-128 groups on the counted-wait pipeline (four constants per chunk)
+    (4096, 512, 32, 1),      # ... with cross-block split-K
+    (11008, 256, 64, 8),     # ... with a padded last ring round
+    (4096, 1024, 32, 20),    # ... two row tiles
+    (14336, 256, 14336, 1),  # group_size == K with K / 128 not a power of two (per-channel checkpoints, group_size = -1)
+    (11008, 256, 11008, 5),
     (64, 32, 32, 4),         # the reference's own unit-test shape (K < one 128-row chunk, N = 2 tiles)
     (96, 8, 32, 1),          # ragged everywhere: K % 128 != 0, N < one tile
 ]
