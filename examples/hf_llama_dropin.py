@@ -46,12 +46,13 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--new-tokens", type=int, default=64)
     ap.add_argument("--no-fuse", action="store_true")
+    ap.add_argument("--siblings-only", action="store_true", help="fuse q/k/v and gate/up only (no decode-op layer fast path)")
     ap.add_argument("--quant-lm-head", action="store_true", help="also quantise lm_head (qcfg.lm_head upstream, loader.py:1376)")
     args = ap.parse_args()
-    run(args.size, args.dtype, args.new_tokens, not args.no_fuse, args.quant_lm_head, verbose=True)
+    run(args.size, args.dtype, args.new_tokens, not args.no_fuse, args.quant_lm_head, verbose=True, decode_ops=not args.siblings_only)
 
 
-def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=False, verbose=False):
+def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=False, verbose=False, decode_ops=True):
     """Returns {"eager_tokens_per_s", "graph_tokens_per_s" | None, "build_s", ...}; bench.py reports it as `e2e`."""
     import types
     args = types.SimpleNamespace(size=size, dtype=dtype_name, new_tokens=new_tokens, no_fuse=not fuse, quant_lm_head=quant_lm_head)
@@ -83,15 +84,27 @@ def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=Fa
         scales, zeros = rtn(lin.weight.data, 128, 4)
         qm.pack(lin, scales, zeros, (torch.arange(lin.in_features) // 128).to(torch.int32))
     del floats
-    if not args.no_fuse:
+    res["layer_path"] = "per-module launches"
+    if not args.no_fuse and decode_ops:
+        # decoder layers on the decode ops: 4 launches per layer with the norms / SiLU*mul / residual adds fused (batch-1 decode)
+        from gptqmodel_amd.utils.hf_llama import fuse_llama_decoder_layers
+        fused_layers, skipped = fuse_llama_decoder_layers(model)
+        res["layer_path"] = f"decode ops in {len(fused_layers)} layers ({len(skipped)} skipped)"
+    elif not args.no_fuse:
         for layer in model.model.layers:
             fuse_siblings(layer.self_attn, ["q_proj", "k_proj", "v_proj"])
             fuse_siblings(layer.mlp, ["gate_proj", "up_proj"])
+        res["layer_path"] = "fused siblings (q|k|v, gate|up), torch glue"
     gptqmodel_post_init(model)
     torch.cuda.synchronize()
+    del mods, qm, lin   # (the pre-fusion modules are no longer part of the model: release their checkpoint-layout tensors)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     nq = sum(1 for m in model.modules() if type(m).__name__ == "HipGptqLinear")
     res["build_s"] = time.time() - t0
     res["quant_launches_per_token"] = nq
+    say(f"layer path: {res['layer_path']}")
     say(f"built + quantised + packed + repacked {len(names)} linears ({nq} launches/token) in {time.time() - t0:.1f} s; "
         f"GPU memory {torch.cuda.memory_allocated() / 2**30:.2f} GiB")
 

@@ -296,11 +296,12 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     return GPTQHIP_OK;
 }
 
-int gptqhip_decode_supported(int K, int N, int group_size) {
+int gptqhip_decode_supported(int K, int N, int group_size, int has_perm) {
     // the decode op rides on the skinny kernel's regular batch-1 pipeline (straight-line counted-wait ring, one group
     // constant per 128-row chunk): same predicate as the planner's
     if (K <= 0 || N <= 0 || group_size <= 0 || K % group_size != 0 || K % 32 != 0 || N % 8 != 0) return 0;
-    const SkinnyPlan pl = plan_skinny(1, K, N, group_size, 0, 0);
+    const SkinnyPlan pl = plan_skinny(1, K, N, group_size, 0, 0, has_perm != 0);
+    if (has_perm && !(pl.depth == 4 && (size_t)K * 2 <= kInKernelPermMaxRowBytes)) return 0;
     return (pl.regular && pl.gpc == 1 && pl.mt == 1) ? 1 : 0;
 }
 

@@ -178,9 +178,10 @@ GLUE_NONE, GLUE_RMSNORM, GLUE_SILU_MUL = 0, 1, 2
 OUT_NONE, OUT_SILU_MUL_PAIRED, OUT_PARTIAL_F32 = 0, 1, 2
 
 
-def decode_supported(K: int, N: int, group_size: int) -> bool:
-    """True when gptqhip_decode_linear handles a [K,N] layer (regular batch-1 pipeline), else use gemm()."""
-    return bool(_lib.load().gptqhip_decode_supported(K, N, group_size))
+def decode_supported(K: int, N: int, group_size: int, has_perm: bool = False) -> bool:
+    """True when gptqhip_decode_linear handles a [K,N] layer (regular batch-1 pipeline; has_perm: with an act-order
+    permutation applied in the kernel), else use gemm()."""
+    return bool(_lib.load().gptqhip_decode_supported(K, N, group_size, 1 if has_perm else 0))
 
 
 def make_decode_op(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,

@@ -98,7 +98,7 @@ class DecodeStep:
                 K, N = lin.in_features, lin.out_features
                 if j == 1 and K != q_dim:
                     raise ValueError("o_proj in_features must equal q_dim")
-                if not ops.decode_supported(K, N, lin.group_size):
+                if not ops.decode_supported(K, N, lin.group_size, perm is not None):
                     raise NotImplementedError(f"decode chain: layer shape K={K} N={N} group_size={lin.group_size} unsupported")
                 self._keep.extend([qw, meta, bias, nw, perm])
                 self.ops.append(ops.make_decode_op(x, qw, meta, bias, out, K, N, lin.group_size, lin.bits, sdt, in_glue=glue,

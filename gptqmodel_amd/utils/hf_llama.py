@@ -1,0 +1,230 @@
+"""Llama-family decoder layers on the decode ops (the callers of the quantised linears are HF's
+`LlamaAttention` / `LlamaMLP`; this is the optional module-graph rewrite around `gptqmodel_post_init`).
+
+`fuse_siblings` (utils/model.py) already cuts a layer from 7 to 4 quantised launches.  At batch 1 the rest of the layer's
+non-attention work is glue between those launches -- two RMSNorms (6 small kernels each in eager HF), SiLU, the gate*up
+product and two residual adds: ~16 dependent launches per layer.  `fuse_llama_decoder_layers` keeps HF's module tree but
+
+  * fuses q/k/v into one module (views stand in for the three projections, as with fuse_siblings) and gate/up into ONE
+    module with the columns interleaved in blocks of 8 (utils.model.fuse_gate_up_interleaved);
+  * gives every decoder layer a decode fast path: when the layer is called with exactly ONE token (batch 1, q_len 1, eval),
+    the layer runs as 4 decode ops (gptqhip_decode_linear: RMSNorm on the input of qkv / gate_up with the statistics handed
+    over by the op that produced the residual stream, SiLU*mul in the gate_up epilogue, residual add + next statistics in
+    the o / down epilogue) around HF's own rotary / KV-cache update / attention call.  Everything else (prefill, batches,
+    training-mode calls) takes HF's original path through the same fused modules.
+
+The fast path binds raw pointers once per layer (buffers owned by the layer), so a decode step is capture-safe and costs 4
+ctypes calls per layer on the host.  It follows transformers' `LlamaAttention.forward` of the installed version
+(>= 4.48 attention-interface API); `fuse_llama_decoder_layers` verifies the attributes it relies on and leaves a layer
+untouched (returns it in `skipped`) when something does not match.
+
+Reference behaviour preserved: each op's arithmetic is the reference's TorchLinear.forward chain (torch.py:326-347) composed
+with HF's LlamaRMSNorm / LlamaMLP / residual formulas -- tests/test_gpu_e2e_llama.py compares logits with the unfused model.
+"""
+from __future__ import annotations
+
+import types
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..nn_modules.qlinear import BaseQuantLinear
+from .model import (FusedSiblingView, _FusedGroup, deinterleave_gate_up, fuse_gate_up_interleaved, fuse_quant_linears)
+
+
+def _is_quant(m) -> bool:
+    return isinstance(m, BaseQuantLinear) and getattr(m, "adapter", None) is None
+
+
+class _LayerDecodeState:
+    """Buffers + bound decode ops of one decoder layer (built lazily on the first single-token call)."""
+
+    def __init__(self, layer, prev: Optional["_LayerDecodeState"], dtype: torch.dtype, workspace: torch.Tensor):
+        attn, mlp = layer.self_attn, layer.mlp
+        qkv, o = attn.fused_q_proj_k_proj_v_proj.fused, attn.o_proj
+        gu, down = mlp.fused_gate_up.fused, mlp.down_proj
+        dev = qkv.qweight.device
+        hidden = qkv.in_features
+        self.hidden, self.dtype, self.device = hidden, dtype, dev
+        self.q_dim, self.kv_dim = attn.fused_q_proj_k_proj_v_proj.sizes[0], attn.fused_q_proj_k_proj_v_proj.sizes[1]
+        self.x_in = torch.zeros(hidden, dtype=dtype, device=dev)               # used when the input is not the previous layer's h2
+        self.qkv_out = torch.zeros(qkv.out_features, dtype=dtype, device=dev)
+        self.attn_in = torch.zeros(o.in_features, dtype=dtype, device=dev)     # attention output, copied in (HF returns a fresh tensor)
+        self.h1 = torch.zeros(hidden, dtype=dtype, device=dev)
+        self.h2 = torch.zeros(hidden, dtype=dtype, device=dev)
+        self.act = torch.zeros(gu.out_features // 2, dtype=dtype, device=dev)
+        self.st1 = torch.zeros(-(-hidden // 16), dtype=torch.float32, device=dev)
+        self.st2 = torch.zeros(-(-hidden // 16), dtype=torch.float32, device=dev)
+        self.prev = prev
+        eps_in = float(getattr(layer.input_layernorm, "variance_epsilon", 1e-6))
+        eps_post = float(getattr(layer.post_attention_layernorm, "variance_epsilon", 1e-6))
+        w_in = layer.input_layernorm.weight.detach().to(dtype).contiguous()
+        w_post = layer.post_attention_layernorm.weight.detach().to(dtype).contiguous()
+        self._keep = [w_in, w_post, workspace]
+
+        def bind(lin, x, out, **kw):
+            from .decode_chain import _lin_tensors
+            qw, meta, bias, sdt, perm = _lin_tensors(lin, dtype)
+            self._keep.extend([qw, meta, bias, perm])
+            return ops.make_decode_op(x, qw, meta, bias, out, lin.in_features, lin.out_features, lin.group_size, lin.bits, sdt,
+                                      workspace=workspace, perm=perm, **kw)
+
+        # qkv comes in two flavours: chained to the previous layer's h2 (+ its statistics), or fed from x_in (first layer, or
+        # whenever the caller hands over some other tensor)
+        self.op_qkv_chain = None
+        if prev is not None:
+            self.op_qkv_chain = bind(qkv, prev.h2, self.qkv_out, in_glue=ops.GLUE_RMSNORM, norm_weight=w_in, eps=eps_in,
+                                     stats_in=prev.st2)
+        self.op_qkv_first = bind(qkv, self.x_in, self.qkv_out, in_glue=ops.GLUE_RMSNORM, norm_weight=w_in, eps=eps_in)
+        self.op_o_chain = None if prev is None else bind(o, self.attn_in, self.h1, residual=prev.h2, stats_out=self.st1)
+        self.op_o_first = bind(o, self.attn_in, self.h1, residual=self.x_in, stats_out=self.st1)
+        self.op_gu = bind(gu, self.h1, self.act, in_glue=ops.GLUE_RMSNORM, norm_weight=w_post, eps=eps_post, stats_in=self.st1,
+                          out_glue=ops.OUT_SILU_MUL_PAIRED)
+        self.op_down = bind(down, self.act, self.h2, residual=self.h1, stats_out=self.st2)
+
+
+def _decode_supported(layer) -> bool:
+    attn, mlp = layer.self_attn, layer.mlp
+    lins = [attn.fused_q_proj_k_proj_v_proj.fused, attn.o_proj, mlp.fused_gate_up.fused, mlp.down_proj]
+    for lin in lins:
+        if not getattr(lin, "_ready", False):
+            return False
+        if not ops.decode_supported(lin.in_features, lin.out_features, lin.group_size, getattr(lin, "perm", None) is not None):
+            return False
+    return lins[0].in_features % 16 == 0 and lins[0].in_features // 16 <= 512
+
+
+def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
+                   position_embeddings=None, **kwargs):
+    """LlamaDecoderLayer.forward with the single-token fast path in front of HF's original."""
+    fd = self._gptqhip_fused
+    if (hidden_states.numel() != fd["hidden"] or self.training or not hidden_states.is_cuda or position_embeddings is None
+            or torch.is_grad_enabled() and hidden_states.requires_grad or fd["disabled"]):
+        return fd["orig_forward"](hidden_states, attention_mask=attention_mask, position_ids=position_ids,
+                                  past_key_values=past_key_values, use_cache=use_cache,
+                                  position_embeddings=position_embeddings, **kwargs)
+    st: Optional[_LayerDecodeState] = fd["state"]
+    if st is None or st.dtype != hidden_states.dtype:
+        if not _decode_supported(self):
+            fd["disabled"] = True
+            return fd["orig_forward"](hidden_states, attention_mask=attention_mask, position_ids=position_ids,
+                                      past_key_values=past_key_values, use_cache=use_cache,
+                                      position_embeddings=position_embeddings, **kwargs)
+        prev_layer = fd["prev"]
+        prev_state = None
+        if prev_layer is not None:
+            prev_state = prev_layer._gptqhip_fused["state"]
+            if prev_state is not None and prev_state.dtype != hidden_states.dtype:
+                prev_state = None
+        st = fd["state"] = _LayerDecodeState(self, prev_state, hidden_states.dtype, fd["workspace"]())
+    dev = hidden_states.device
+    attn = self.self_attn
+    chained = st.prev is not None and hidden_states.data_ptr() == st.prev.h2.data_ptr()
+    with torch.cuda.device(dev):
+        if chained:
+            ops.launch_decode_op(st.op_qkv_chain, dev)
+        else:
+            st.x_in.copy_(hidden_states.reshape(-1))
+            ops.launch_decode_op(st.op_qkv_first, dev)
+        # ---- HF's attention between the projections (LlamaAttention.forward, projections removed) ----------------------------
+        q_dim, kv_dim, hd = st.q_dim, st.kv_dim, attn.head_dim
+        q = st.qkv_out[:q_dim].view(1, 1, -1, hd).transpose(1, 2)
+        k = st.qkv_out[q_dim:q_dim + kv_dim].view(1, 1, -1, hd).transpose(1, 2)
+        v = st.qkv_out[q_dim + kv_dim:].view(1, 1, -1, hd).transpose(1, 2)
+        cos, sin = position_embeddings
+        q, k = fd["rotary"](q, k, cos, sin)
+        if past_key_values is not None:
+            k, v = past_key_values.update(k, v, attn.layer_idx)
+        interface = fd["interfaces"].get_interface(attn.config._attn_implementation, fd["eager_attention"])
+        attn_out, _ = interface(attn, q, k, v, attention_mask, dropout=0.0, scaling=attn.scaling, **kwargs)
+        st.attn_in.copy_(attn_out.reshape(-1))
+        # ---- o_proj + residual, MLP ---------------------------------------------------------------------------------------------
+        ops.launch_decode_op(st.op_o_chain if chained else st.op_o_first, dev)
+        ops.launch_decode_op(st.op_gu, dev)
+        ops.launch_decode_op(st.op_down, dev)
+    return st.h2.view(hidden_states.shape)
+
+
+def _mlp_forward(self, x):
+    """LlamaMLP.forward through the interleaved gate|up module (prefill / batched path)."""
+    g, u = deinterleave_gate_up(self.fused_gate_up.fused(x))
+    return self.down_proj(self.act_fn(g) * u)
+
+
+def fuse_llama_decoder_layers(model: nn.Module) -> Tuple[List[nn.Module], List[Tuple[nn.Module, str]]]:
+    """Call BEFORE gptqmodel_post_init (the modules must still be in the checkpoint layout).  Returns (fused layers, skipped
+    [(layer, reason)]).  Works on any HF model whose decoder layers look like Llama's (self_attn.{q,k,v,o}_proj,
+    mlp.{gate,up,down}_proj with SiLU, input_layernorm / post_attention_layernorm RMSNorms): Llama, Mistral, Qwen2 (their
+    q/k/v biases are carried by the fused module) ..."""
+    try:
+        from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+        import transformers.models.llama.modeling_llama as hf_llama
+        rotary, eager_attention = hf_llama.apply_rotary_pos_emb, hf_llama.eager_attention_forward
+    except Exception as e:  # noqa: BLE001
+        raise RuntimeError(f"fuse_llama_decoder_layers needs transformers' attention-interface API: {e}") from e
+    layers = [m for m in model.modules() if all(hasattr(m, a) for a in ("self_attn", "mlp", "input_layernorm", "post_attention_layernorm"))]
+    ws_holder = {}
+
+    def workspace():
+        # one scratch for every layer's ops (cross-block split-K slabs + arrival counters, zero-initialised; ops are serialised)
+        if "t" not in ws_holder:
+            need = 1 << 20
+            for L in fused:
+                for lin in (L.self_attn.fused_q_proj_k_proj_v_proj.fused, L.self_attn.o_proj, L.mlp.fused_gate_up.fused, L.mlp.down_proj):
+                    need = max(need, ops.workspace_bytes(1, lin.in_features, lin.out_features, lin.group_size, lin.bits, False))
+            ws_holder["t"] = torch.zeros(need, dtype=torch.uint8, device=fused[0].self_attn.o_proj.qweight.device)
+        return ws_holder["t"]
+
+    fused: List[nn.Module] = []
+    skipped: List[Tuple[nn.Module, str]] = []
+    prev = None
+    for layer in layers:
+        attn, mlp = layer.self_attn, layer.mlp
+        names_a, names_m = ("q_proj", "k_proj", "v_proj", "o_proj"), ("gate_proj", "up_proj", "down_proj")
+        if not all(_is_quant(getattr(attn, n, None)) for n in names_a) or not all(_is_quant(getattr(mlp, n, None)) for n in names_m):
+            skipped.append((layer, "projections are not (adapter-free) HIP quant modules"))
+            prev = None
+            continue
+        if any(getattr(getattr(p, n), "_ready", False) for p, ns in ((attn, names_a), (mlp, names_m)) for n in ns):
+            skipped.append((layer, "already post_init()ed"))
+            prev = None
+            continue
+        act = getattr(mlp, "act_fn", None)
+        if not (isinstance(act, nn.SiLU) or type(act).__name__ in ("SiLU", "SiLUActivation")):
+            skipped.append((layer, "MLP activation is not SiLU"))
+            prev = None
+            continue
+        if not all(hasattr(attn, a) for a in ("head_dim", "scaling", "layer_idx", "config")):
+            skipped.append((layer, "attention module does not follow the attention-interface layout"))
+            prev = None
+            continue
+        try:
+            qkv = fuse_quant_linears([attn.q_proj, attn.k_proj, attn.v_proj])
+            gu = fuse_gate_up_interleaved(mlp.gate_proj, mlp.up_proj)
+        except NotImplementedError as e:
+            skipped.append((layer, f"siblings cannot share a launch: {e}"))
+            prev = None
+            continue
+        sizes = [attn.q_proj.out_features, attn.k_proj.out_features, attn.v_proj.out_features]
+        in_f = attn.q_proj.in_features
+        group = _FusedGroup(qkv, sizes)
+        attn.fused_q_proj_k_proj_v_proj = group
+        for i, n in enumerate(("q_proj", "k_proj", "v_proj")):
+            setattr(attn, n, FusedSiblingView(group, i, in_f, sizes[i]))
+        # gate/up: the interleaved module serves both; the stand-ins only exist so that module walks still find two names
+        gu_group = _FusedGroup(gu, [gu.out_features])
+        mlp.fused_gate_up = gu_group
+        del mlp.gate_proj, mlp.up_proj
+        mlp.forward = types.MethodType(_mlp_forward, mlp)
+        layer._gptqhip_fused = {"hidden": in_f, "state": None, "prev": prev, "disabled": False, "workspace": workspace,
+                                "orig_forward": layer.forward, "rotary": rotary, "eager_attention": eager_attention,
+                                "interfaces": ALL_ATTENTION_FUNCTIONS}
+        layer.forward = types.MethodType(_layer_forward, layer)
+        fused.append(layer)
+        prev = layer
+    return fused, skipped
+
+
+__all__ = ["fuse_llama_decoder_layers"]

@@ -239,9 +239,15 @@ def fuse_quant_linears(mods: List[BaseQuantLinear]) -> BaseQuantLinear:
 
 
 def _interleave_cols(a: torch.Tensor, b: torch.Tensor, block: int) -> torch.Tensor:
-    """[R, C] x 2 -> [R, 2C]: blocks of `block` columns of a and b alternate (a0..a7 b0..b7 a8..a15 ...)."""
+    """[R, C] x 2 -> [R, 2C]: blocks of `block` columns of a and b alternate (a0..a7 b0..b7 a8..a15 ...).
+    The result owns its storage (written through a strided view of a fresh tensor): a reshape()d torch.stack would be a VIEW
+    whose base stays alive behind `tensor.data = ...` in post_init -- one extra copy of the packed weights per layer."""
     r, c = a.shape
-    return torch.stack([a.reshape(r, c // block, block), b.reshape(r, c // block, block)], dim=2).reshape(r, 2 * c).contiguous()
+    out = torch.empty((r, 2 * c), dtype=a.dtype, device=a.device)
+    v = out.view(r, c // block, 2, block)
+    v[:, :, 0, :] = a.reshape(r, c // block, block)
+    v[:, :, 1, :] = b.reshape(r, c // block, block)
+    return out
 
 
 def fuse_gate_up_interleaved(gate: BaseQuantLinear, up: BaseQuantLinear) -> BaseQuantLinear:

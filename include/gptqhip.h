@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 7
+#define GPTQHIP_ABI_VERSION 8
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -169,8 +169,8 @@ typedef struct gptqhip_decode_op {
     int K, N, group_size, bits, act_dtype, scale_dtype, in_glue, out_glue, stats_n;
 } gptqhip_decode_op;
 int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream);
-/* 1 if gptqhip_decode_linear supports a [K,N] layer with this group size, else 0. */
-int gptqhip_decode_supported(int K, int N, int group_size);
+/* 1 if gptqhip_decode_linear supports a [K,N] layer with this group size (has_perm: with an act-order permutation), else 0. */
+int gptqhip_decode_supported(int K, int N, int group_size, int has_perm);
 
 /* Materialise W[K,N] from the CHECKPOINT layout in `out_dtype` (= scales dtype in the reference).  Replaces
  * TorchLinear.dequantize_weight (torch.py:225) / PackableQuantLinear.dequantize_weight

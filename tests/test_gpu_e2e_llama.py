@@ -35,7 +35,7 @@ def _get(model, name):
     return mod
 
 
-def _build(desc_act: bool, fuse: bool, dtype):
+def _build(desc_act: bool, fuse, dtype):
     from transformers import LlamaConfig, LlamaForCausalLM
     from gptqmodel_amd import ops
     from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
@@ -44,8 +44,12 @@ def _build(desc_act: bool, fuse: bool, dtype):
     from gptqmodel_amd.utils.model import fuse_siblings, gptqmodel_post_init, make_quant
 
     torch.manual_seed(7)
-    cfg = LlamaConfig(hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=8,
-                      num_key_value_heads=2, vocab_size=2048, max_position_embeddings=128, tie_word_embeddings=False)
+    # the decoder-layer fast path needs shapes inside the decode op's pipeline (K = 1024 -> 8 chunks, 2816 -> 22 padded to 24)
+    dims = dict(hidden_size=512, intermediate_size=1408)
+    if fuse == "layers":   # (act-order in the kernel needs whole 4-deep ring rounds: 16 chunks)
+        dims = dict(hidden_size=2048, intermediate_size=4096) if desc_act else dict(hidden_size=1024, intermediate_size=2816)
+    cfg = LlamaConfig(num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2, vocab_size=2048,
+                      max_position_embeddings=128, tie_word_embeddings=False, **dims)
     dense = LlamaForCausalLM(cfg).to(dtype).cuda().eval()
     quant = copy.deepcopy(dense)
     names = [n for n, m in dense.named_modules() if isinstance(m, nn.Linear) and ".layers." in n]
@@ -69,7 +73,11 @@ def _build(desc_act: bool, fuse: bool, dtype):
         qm.pack(lin, scales, zeros, g_idx)
         w = ops.dequant(qm.qweight, qm.qzeros, qm.scales, qm.g_idx, gs, bits, dtype)       # [K, N]
         lin.weight.data.copy_(w.T)
-    if fuse:
+    if fuse == "layers":
+        from gptqmodel_amd.utils.hf_llama import fuse_llama_decoder_layers
+        fused, skipped = fuse_llama_decoder_layers(quant)
+        assert len(fused) == 2 and not skipped
+    elif fuse:
         for layer in quant.model.layers:
             assert fuse_siblings(layer.self_attn, ["q_proj", "k_proj", "v_proj"]) is not None
             assert fuse_siblings(layer.mlp, ["gate_proj", "up_proj"]) is not None
@@ -98,6 +106,39 @@ def test_llama_prefill_and_decode_match_dense_dequantised_model(desc_act, fuse, 
             assert rel_err(s_q.logits.float().cpu().numpy(), s_d.logits.float().cpu().numpy()) < tol
             pk_d, pk_q = s_d.past_key_values, s_q.past_key_values
             tok = s_d.logits[:, -1].argmax(-1, keepdim=True)
+
+
+@pytest.mark.parametrize("desc_act,dtype", [(False, torch.float16), (True, torch.float16), (False, torch.bfloat16)])
+def test_llama_decoder_layers_on_decode_ops_match_dense(desc_act, dtype):
+    """fuse_llama_decoder_layers: prefill (HF path through the fused modules) and single-token KV-cache decode (4 decode ops
+    per layer around HF's attention) against the dense model holding the dequantised weights; the fast path must have run."""
+    dense, quant = _build(desc_act, "layers", dtype)
+    tol = 2e-2 if dtype == torch.float16 else 6e-2
+    torch.manual_seed(13)
+    ids = torch.randint(0, 2048, (1, 20), device="cuda")
+    with torch.no_grad():
+        o_d = dense(input_ids=ids, use_cache=True)
+        o_q = quant(input_ids=ids, use_cache=True)
+        assert rel_err(o_q.logits.float().cpu().numpy(), o_d.logits.float().cpu().numpy()) < tol
+        assert all(L._gptqhip_fused["state"] is None for L in quant.model.layers)     # 20 tokens: HF's path
+        pk_d, pk_q = o_d.past_key_values, o_q.past_key_values
+        tok = o_d.logits[:, -1].argmax(-1, keepdim=True)
+        for _ in range(8):
+            s_d = dense(input_ids=tok, past_key_values=pk_d, use_cache=True)
+            s_q = quant(input_ids=tok, past_key_values=pk_q, use_cache=True)
+            assert torch.isfinite(s_q.logits).all()
+            assert rel_err(s_q.logits.float().cpu().numpy(), s_d.logits.float().cpu().numpy()) < tol
+            pk_d, pk_q = s_d.past_key_values, s_q.past_key_values
+            tok = s_d.logits[:, -1].argmax(-1, keepdim=True)
+    states = [L._gptqhip_fused["state"] for L in quant.model.layers]
+    assert all(st is not None for st in states) and not any(L._gptqhip_fused["disabled"] for L in quant.model.layers)
+    assert states[1].prev is states[0]          # layer 1 consumes layer 0's residual stream + statistics in place
+    # batch 2 at q_len 1 is not the fast path: same modules, HF's layer code
+    with torch.no_grad():
+        ids2 = torch.randint(0, 2048, (2, 1), device="cuda")
+        assert rel_err(quant(input_ids=ids2).logits.float().cpu().numpy(), dense(input_ids=ids2).logits.float().cpu().numpy()) < tol
+        out = quant.generate(input_ids=ids[:, :8], max_new_tokens=6, do_sample=False, pad_token_id=0)
+    assert out.shape == (1, 14)
 
 
 def test_llama_generate_runs_on_quantised_model():

@@ -378,6 +378,15 @@ def test_fused_module_tensors_are_registered_buffers(kernels_available):
     assert all(t is not None for t in fused._buffers.values())   # no None-valued buffers (accelerate offload hooks)
 
 
+def test_interleave_cols_owns_its_storage():
+    """post_init replaces `qweight.data`; a view result would keep its base (a second copy of the packed weights) alive."""
+    from gptqmodel_amd.utils.model import _interleave_cols
+    a, b = torch.arange(32, dtype=torch.int32).reshape(2, 16), 100 + torch.arange(32, dtype=torch.int32).reshape(2, 16)
+    out = _interleave_cols(a, b, 8)
+    assert out._base is None and out.is_contiguous()
+    assert out[0].tolist() == list(range(0, 8)) + list(range(100, 108)) + list(range(8, 16)) + list(range(108, 116))
+
+
 def test_gate_up_interleaved_fusion_layout(kernels_available):
     """fuse_gate_up_interleaved: output columns alternate in blocks of 8 (g0..7 u0..7 g8..15 ...) on the CHECKPOINT tensors
     (whole packed words move); the dequantised fused matrix is the column-interleave of the two, deinterleave undoes it."""
