@@ -138,6 +138,8 @@ def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, 
         if past_key_values is not None:
             k, v = past_key_values.update(k, v, attn.layer_idx)
         interface = fd["interfaces"].get_interface(attn.config._attn_implementation, fd["eager_attention"])
+        if fd["sliding_window"]:   # Mistral / Qwen2 hand their window to the attention interface
+            kwargs = dict(kwargs, sliding_window=attn.sliding_window)
         attn_out, _ = interface(attn, q, k, v, attention_mask, dropout=0.0, scaling=attn.scaling, **kwargs)
         st.attn_in.copy_(attn_out.reshape(-1))
         # ---- o_proj + residual, MLP ---------------------------------------------------------------------------------------------
@@ -153,11 +155,18 @@ def _mlp_forward(self, x):
     return self.down_proj(self.act_fn(g) * u)
 
 
-def fuse_llama_decoder_layers(model: nn.Module) -> Tuple[List[nn.Module], List[Tuple[nn.Module, str]]]:
+# decoder layers whose single-token arithmetic IS the Llama formula the fast path implements (RMSNorm `w * act(x * rsqrt(mean x^2
+# + eps))`, rotary on q / k straight after the projections, SiLU MLP, plain residual adds).  Architectures with per-head q/k norms
+# (Qwen3, OLMo2), (1 + w) norms or GELU (Gemma), parallel residuals etc. are NOT in this list and are left untouched.
+_KNOWN_ATTENTION = ("LlamaAttention", "MistralAttention", "Qwen2Attention")
+_KNOWN_NORMS = ("LlamaRMSNorm", "MistralRMSNorm", "Qwen2RMSNorm")
+
+
+def fuse_llama_decoder_layers(model: nn.Module, allow_unknown: bool = False) -> Tuple[List[nn.Module], List[Tuple[nn.Module, str]]]:
     """Call BEFORE gptqmodel_post_init (the modules must still be in the checkpoint layout).  Returns (fused layers, skipped
-    [(layer, reason)]).  Works on any HF model whose decoder layers look like Llama's (self_attn.{q,k,v,o}_proj,
-    mlp.{gate,up,down}_proj with SiLU, input_layernorm / post_attention_layernorm RMSNorms): Llama, Mistral, Qwen2 (their
-    q/k/v biases are carried by the fused module) ..."""
+    [(layer, reason)]).  Handles HF decoder layers of the Llama / Mistral / Qwen2 families (q/k/v biases are carried by the
+    fused module); `allow_unknown=True` also takes look-alike layers of other classes -- only when you know their
+    single-token arithmetic is Llama's."""
     try:
         from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
         import transformers.models.llama.modeling_llama as hf_llama
@@ -200,6 +209,12 @@ def fuse_llama_decoder_layers(model: nn.Module) -> Tuple[List[nn.Module], List[T
             skipped.append((layer, "attention module does not follow the attention-interface layout"))
             prev = None
             continue
+        known = (type(attn).__name__ in _KNOWN_ATTENTION and type(layer.input_layernorm).__name__ in _KNOWN_NORMS
+                 and type(layer.post_attention_layernorm).__name__ in _KNOWN_NORMS)
+        if any(hasattr(attn, a) for a in ("q_norm", "k_norm")) or (not known and not allow_unknown):
+            skipped.append((layer, f"{type(attn).__name__} / {type(layer.input_layernorm).__name__}: not a known Llama-formula layer"))
+            prev = None
+            continue
         try:
             qkv = fuse_quant_linears([attn.q_proj, attn.k_proj, attn.v_proj])
             gu = fuse_gate_up_interleaved(mlp.gate_proj, mlp.up_proj)
@@ -220,6 +235,7 @@ def fuse_llama_decoder_layers(model: nn.Module) -> Tuple[List[nn.Module], List[T
         mlp.forward = types.MethodType(_mlp_forward, mlp)
         layer._gptqhip_fused = {"hidden": in_f, "state": None, "prev": prev, "disabled": False, "workspace": workspace,
                                 "orig_forward": layer.forward, "rotary": rotary, "eager_attention": eager_attention,
+                                "sliding_window": getattr(attn, "sliding_window", None) is not None,
                                 "interfaces": ALL_ATTENTION_FUNCTIONS}
         layer.forward = types.MethodType(_layer_forward, layer)
         fused.append(layer)
