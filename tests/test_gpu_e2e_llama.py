@@ -35,7 +35,7 @@ def _get(model, name):
     return mod
 
 
-def _build(desc_act: bool, fuse, dtype):
+def _build(desc_act: bool, fuse, dtype, family="llama"):
     from transformers import LlamaConfig, LlamaForCausalLM
     from gptqmodel_amd import ops
     from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
@@ -48,9 +48,19 @@ def _build(desc_act: bool, fuse, dtype):
     dims = dict(hidden_size=512, intermediate_size=1408)
     if fuse == "layers":   # (act-order in the kernel needs whole 4-deep ring rounds: 16 chunks)
         dims = dict(hidden_size=2048, intermediate_size=4096) if desc_act else dict(hidden_size=1024, intermediate_size=2816)
-    cfg = LlamaConfig(num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2, vocab_size=2048,
-                      max_position_embeddings=128, tie_word_embeddings=False, **dims)
-    dense = LlamaForCausalLM(cfg).to(dtype).cuda().eval()
+    common = dict(num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2, vocab_size=2048,
+                  max_position_embeddings=128, tie_word_embeddings=False, **dims)
+    if family == "qwen2":      # q/k/v carry a bias; same layer formula
+        from transformers import Qwen2Config, Qwen2ForCausalLM
+        dense = Qwen2ForCausalLM(Qwen2Config(**common)).to(dtype).cuda().eval()
+        for layer in dense.model.layers:   # (random-init biases are zero: make them matter)
+            for n in ("q_proj", "k_proj", "v_proj"):
+                getattr(layer.self_attn, n).bias.data.normal_(0, 0.05)
+    elif family == "mistral":
+        from transformers import MistralConfig, MistralForCausalLM
+        dense = MistralForCausalLM(MistralConfig(sliding_window=64, **common)).to(dtype).cuda().eval()
+    else:
+        dense = LlamaForCausalLM(LlamaConfig(**common)).to(dtype).cuda().eval()
     quant = copy.deepcopy(dense)
     names = [n for n, m in dense.named_modules() if isinstance(m, nn.Linear) and ".layers." in n]
     assert len(names) == 14
@@ -108,11 +118,13 @@ def test_llama_prefill_and_decode_match_dense_dequantised_model(desc_act, fuse, 
             tok = s_d.logits[:, -1].argmax(-1, keepdim=True)
 
 
-@pytest.mark.parametrize("desc_act,dtype", [(False, torch.float16), (True, torch.float16), (False, torch.bfloat16)])
-def test_llama_decoder_layers_on_decode_ops_match_dense(desc_act, dtype):
+@pytest.mark.parametrize("desc_act,dtype,family", [(False, torch.float16, "llama"), (True, torch.float16, "llama"),
+                                                   (False, torch.bfloat16, "llama"), (False, torch.float16, "qwen2"),
+                                                   (False, torch.float16, "mistral")])
+def test_llama_decoder_layers_on_decode_ops_match_dense(desc_act, dtype, family):
     """fuse_llama_decoder_layers: prefill (HF path through the fused modules) and single-token KV-cache decode (4 decode ops
     per layer around HF's attention) against the dense model holding the dequantised weights; the fast path must have run."""
-    dense, quant = _build(desc_act, "layers", dtype)
+    dense, quant = _build(desc_act, "layers", dtype, family)
     tol = 2e-2 if dtype == torch.float16 else 6e-2
     torch.manual_seed(13)
     ids = torch.randint(0, 2048, (1, 20), device="cuda")
