@@ -488,6 +488,21 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
             del g, st
         except Exception as e:  # noqa: BLE001
             res.append({"config": "C2", "mode": other, "error": str(e)[:300]})
+    # round 1's way of timing the same 128 launches (kept for continuity, NOT a decode step): constant input, no glue, no data
+    # dependencies between the launches -- shows what the dependent chain + fused glue cost on the same kernels
+    try:
+        xs = {k: (torch.randn((1, k), device=dev, generator=gen) * 0.5).to(dtype) for k in (cfg["hidden"], cfg["inter"])}
+        pairs = [(lin, xs[lin.in_features if lin.in_features in xs else cfg["hidden"]]) for L in layers for lin in (L.qkv, L.o, L.gate_up, L.down)]
+
+        def indep():
+            for lin, x in pairs:
+                lin(x)
+        ms, g = time_graph(indep, stream, 50, 5)
+        res.append(decode_entry("C2", "round-1 method: the same 128 launches with a constant input, no glue, no data dependencies (not a "
+                                "decode step)", cfg, ms, n_launch, extra={"mode": "independent launches"}))
+        del g
+    except Exception as e:  # noqa: BLE001
+        res.append({"config": "C2", "mode": "independent launches", "error": str(e)[:300]})
     # headline-model prefill (one decoder layer at M=8192, desc_act=False) -- the TFLOPS half of the metric
     L0 = layers[0]
     lins = [L0.qkv, L0.o, L0.gate_up, L0.down]

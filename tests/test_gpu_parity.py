@@ -259,6 +259,26 @@ def test_random_shape_stress(ops):
         assert_forward_close(torch_to_f32(out), ref, act, tag=(it, bits, gs, K, N, M, act, desc))
 
 
+def test_random_long_k_stress(ops):
+    """Random LONG K (20..160 chunks of 128 rows: every waves x ring-depth factorisation incl. padded last rounds, cross-block
+    split-K with a shorter last split), batch 1..32, all group sizes incl. per-channel, act-order: the decode kernel's planner space."""
+    rng = np.random.RandomState(77)
+    for it in range(36):
+        chunks = int(rng.randint(20, 161))
+        K = 128 * chunks
+        gs = int(rng.choice([32, 64, 128, 128, 128, K]))
+        N = 8 * int(rng.choice([2, 4, 6, 16, 32, 33, 64]))
+        M = int(rng.choice([1, 1, 1, 2, 4, 7, 8, 16, 17, 32]))
+        act = str(rng.choice(["fp16", "bf16"]))
+        desc = bool(rng.randint(0, 3) == 0) and gs != K
+        bits = 8 if rng.randint(0, 6) == 0 else 4
+        qweight, qzeros, scales, g_idx = synth_gptq(3000 + it, bits, K, N, gs, desc_act=desc)
+        x = O.round_to(rng.randn(M, K).astype(np.float32) * 0.5, act)
+        out = run_gptq(ops, x, qweight, qzeros, scales, g_idx, bits, gs, None, act, "fp16")
+        ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, bits, None, act, "fp16")
+        assert_forward_close(torch_to_f32(out), ref, act, tag=(it, bits, gs, K, N, M, act, desc))
+
+
 TILED_CASES = [
     # bits, K, N, gs, M, act, desc_act  (force_kernel=2 routes every M through the MFMA-tiled prefill kernel)
     (4, 4096, 4096, 128, 300, "fp16", False),
