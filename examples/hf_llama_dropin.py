@@ -57,7 +57,7 @@ def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=Fa
     import types
     args = types.SimpleNamespace(size=size, dtype=dtype_name, new_tokens=new_tokens, no_fuse=not fuse, quant_lm_head=quant_lm_head)
     res = {"model": f"random-init HF LlamaForCausalLM, Llama-3-{size} shapes, every decoder nn.Linear RTN-quantised to int4 g128 "
-                    "and swapped through make_quant -> fuse_siblings -> gptqmodel_post_init; real attention / norms / rotary / lm_head",
+                    "and swapped through make_quant -> (layer fusion, see layer_path) -> gptqmodel_post_init; real attention / rotary / KV cache / lm_head",
            "new_tokens": new_tokens}
     say = print if verbose else (lambda *a, **k: None)
     from transformers import LlamaConfig, LlamaForCausalLM
