@@ -17,7 +17,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libgptqhip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # every symbol include/gptqhip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -32,7 +32,7 @@ SIGNATURES = {
     "gptqhip_repack_tiled": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "gptqhip_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_decode_linear": (_i, [_vp, _vp]),
-    "gptqhip_decode_supported": (_i, [_i, _i, _i, _i]),
+    "gptqhip_decode_supported": (_i, [_i, _i, _i, _i, _i]),
     "gptqhip_comm_bytes": (_sz, [_i, _i]),
     "gptqhip_comm_alloc": (_i, [_sz, _c.POINTER(_vp), _c.c_char_p]),
     "gptqhip_comm_open": (_i, [_c.c_char_p, _c.POINTER(_vp)]),
@@ -56,7 +56,7 @@ class DecodeOp(ctypes.Structure):
                 ("out", _vp), ("workspace", _vp), ("workspace_bytes", _sz), ("stats_in", _vp), ("stats_out", _vp),
                 ("perm", _vp), ("eps", _c.c_float),
                 ("K", _i), ("N", _i), ("group_size", _i), ("bits", _i), ("act_dtype", _i), ("scale_dtype", _i),
-                ("in_glue", _i), ("out_glue", _i), ("stats_n", _i)]
+                ("in_glue", _i), ("out_glue", _i), ("stats_n", _i), ("M", _i)]
 
 
 _lock = threading.Lock()

@@ -296,11 +296,12 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     return GPTQHIP_OK;
 }
 
-int gptqhip_decode_supported(int K, int N, int group_size, int has_perm) {
+int gptqhip_decode_supported(int K, int N, int group_size, int has_perm, int M) {
     // the decode op rides on the skinny kernel's regular batch-1 pipeline (straight-line counted-wait ring, one group
     // constant per 128-row chunk): same predicate as the planner's
     if (K <= 0 || N <= 0 || group_size <= 0 || K % group_size != 0 || K % 32 != 0 || N % 8 != 0) return 0;
-    const SkinnyPlan pl = plan_skinny(1, K, N, group_size, 0, 0, has_perm != 0);
+    if (M < 1 || M > 4 || (M > 1 && has_perm)) return 0;
+    const SkinnyPlan pl = plan_skinny(M, K, N, group_size, 0, 0, has_perm != 0);
     if (has_perm && !(pl.depth == 4 && (size_t)K * 2 <= kInKernelPermMaxRowBytes)) return 0;
     return (pl.regular && pl.gpc == 1 && pl.mt == 1) ? 1 : 0;
 }
@@ -342,7 +343,12 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
         set_error("gptqhip_decode_linear: stats_in needs in_glue RMSNORM and 1..512 partial sums (got %d)", op->stats_n);
         return GPTQHIP_EINVAL;
     }
-    const SkinnyPlan pl = plan_skinny(1, op->K, op->N, op->group_size, g_force_split, g_force_waves, op->perm != nullptr);
+    const int M = op->M;
+    if (M < 1 || M > 4 || (M > 1 && (op->perm || op->in_glue == GPTQHIP_GLUE_SILU_MUL))) {
+        set_error("gptqhip_decode_linear: M=%d outside 1..4, or M > 1 with perm / SiLU*mul input glue", M);
+        return GPTQHIP_EINVAL;
+    }
+    const SkinnyPlan pl = plan_skinny(M, op->K, op->N, op->group_size, g_force_split, g_force_waves, op->perm != nullptr);
     if (op->perm && !(pl.depth == 4 && (size_t)op->K * 2 <= kInKernelPermMaxRowBytes)) {
         set_error("gptqhip_decode_linear: K=%d is outside the in-kernel act-order variant (gather x and pass perm = NULL)", op->K);
         return GPTQHIP_EINVAL;
@@ -352,7 +358,7 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
                   op->K, op->group_size);
         return GPTQHIP_EINVAL;
     }
-    const WorkspaceLayout L = layout_workspace(1, op->K, op->N, op->group_size, op->bits, 0);
+    const WorkspaceLayout L = layout_workspace(M, op->K, op->N, op->group_size, op->bits, 0);
     if (pl.splits > 1 && (!op->workspace || op->workspace_bytes < L.total)) {
         set_error("gptqhip_decode_linear: workspace %zu bytes < required %zu", op->workspace_bytes, L.total);
         return GPTQHIP_ENOMEM;
@@ -365,7 +371,7 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
     a.meta = op->meta;
     a.bias = op->bias;
     a.out = op->out;
-    a.M = 1;
+    a.M = M;
     a.K = op->K;
     a.N = op->N;
     a.group_size = op->group_size;

@@ -132,7 +132,7 @@ __host__ __device__ constexpr int row_quads() {  // 4-row groups actually loaded
 
 template <int AM, int MT>
 struct AStage {
-    u4_t a[AM == AM_ROW4 ? 1 : 4 * MT];
+    u4_t a[AM == AM_ROW4 ? 2 : 4 * MT];   // AM_ROW4: [1] = the norm-weight segment of the decode op's RMSNorm glue, unused otherwise
 };
 template <int MT>
 struct AStage<AM_ROW1, MT> {
@@ -275,6 +275,9 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
         st.x.a[1] = pr.y;
     } else if constexpr (AM == AM_ROW4) {
         st.x.a[0] = *reinterpret_cast<const u4_t*>(xsrc + lo.x[0]);
+        if constexpr (GLUE == kGlueRmsNorm) {   // the same 16-byte weight segment for all four rows
+            st.x.a[1] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (xsrc - tb.x) + tb.c4 * 4u);
+        }
     } else if constexpr (is_rows<AM>()) {
 #pragma unroll
         for (int i = 0; i < row_quads<AM, MT>(); ++i) st.x.a[i] = *reinterpret_cast<const u4_t*>(xsrc + lo.x[i]);
@@ -312,7 +315,14 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
     } else if constexpr (AM == AM_ROW1P) {
         reinterpret_cast<uint32_t*>(aslot)[lane] = (uint32_t)xbuf[st.x.a[0]] | ((uint32_t)xbuf[st.x.a[1]] << 16);
     } else if constexpr (AM == AM_ROW4) {
-        aslot[lane] = st.x.a[0];
+        if constexpr (GLUE == kGlueRmsNorm) {   // `inv` = this lane's row's 1/rms (rows >= M carry row 0's: nobody stores them)
+            u4_t g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = glue_pair<ACT>(st.x.a[0][j], st.x.a[1][j], inv, GLUE);
+            aslot[lane] = g;
+        } else {
+            aslot[lane] = st.x.a[0];
+        }
         abase = (c < p.M ? c : 0) << 4;  // lanes of unused rows re-read row 0: a broadcast, no extra bank traffic
     } else if constexpr (is_rows<AM>()) {
         // rows of skipped quads keep whatever the slot held: they only feed output rows >= M, which nobody stores
@@ -414,9 +424,10 @@ __device__ __forceinline__ void finish_outputs(const SkinnyParams& p, float v, b
     if (live && p.out_f32) {
         reinterpret_cast<float*>(p.out)[(size_t)m * p.N + n] = v;
     } else if (p.out_glue == kOutSiluMul || p.stats_out != nullptr) {
-        // decode op (M == 1) epilogues that combine the tile's 16 outputs: wave 0 (accumulator row 0 = lanes 0..15) runs them
-        // wave-uniformly so the lane shuffles are legal
-        if (wave == 0) {
+        // decode op (M <= 4) epilogues that combine a tile's 16 outputs of one row: reducer wave w holds row w in lanes 0..15
+        // (accumulator register w of the lanes with rq == 0) and runs them wave-uniformly so the lane shuffles are legal
+        if (wave < p.M) {
+            const int tiles = (p.N + kTileN - 1) / kTileN;
             float y = round_through<ACT>(v);
             if (p.bias != nullptr && live) y = round_through<ACT>(y + load16_as_f32<ACT>(p.bias, (size_t)n));
             if (p.out_glue == kOutSiluMul) {
@@ -425,15 +436,15 @@ __device__ __forceinline__ void finish_outputs(const SkinnyParams& p, float v, b
                 const float up = __shfl_down(y, 8, 64);
                 const float a = round_through<ACT>(y / (1.0f + __expf(-y))) * up;
                 const int j = tile * 8 + lane;
-                if (live && lane < 8 && j < p.N / 2) reinterpret_cast<uint16_t*>(p.out)[j] = f32_to_16<ACT>(a);
+                if (live && lane < 8 && j < p.N / 2) reinterpret_cast<uint16_t*>(p.out)[(size_t)m * (p.N / 2) + j] = f32_to_16<ACT>(a);
             } else {
                 if (p.residual != nullptr) y = bits16_to_f32<ACT>((uint16_t)(res_raw >> ((lane & 1) * 16))) + y;
                 const float h = round_through<ACT>(y);
-                if (live) reinterpret_cast<uint16_t*>(p.out)[n] = f32_to_16<ACT>(h);
+                if (live) reinterpret_cast<uint16_t*>(p.out)[(size_t)m * p.N + n] = f32_to_16<ACT>(h);
                 float sq = live ? h * h : 0.f;  // RMSNorm statistic of the NEXT op: fixed shuffle tree over the 16 columns
 #pragma unroll
                 for (int mk = 8; mk >= 1; mk >>= 1) sq += __shfl_xor(sq, mk, 64);
-                if (lane == 0) p.stats_out[tile] = sq;
+                if (lane == 0) p.stats_out[(size_t)wave * tiles + tile] = sq;
             }
         }
     } else if (live) {
@@ -487,9 +498,9 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     // epilogue; glue_inv = RMSNorm's rsqrt(mean(h^2) + eps)
     float glue_inv = 0.f;
     uint32_t res_raw = 0u;
-    if (p.residual != nullptr && wave == 0 && lane < 16) {
+    if (p.residual != nullptr && wave < p.M && lane < 16) {   // (decode op: M <= 4, reducer wave w holds output row w)
         const int coln = tile * kTileN + lane;
-        res_raw = reinterpret_cast<const uint32_t*>(p.residual)[(coln < p.N ? coln : 0) >> 1];
+        res_raw = reinterpret_cast<const uint32_t*>(p.residual)[((size_t)wave * p.N + (coln < p.N ? coln : 0)) >> 1];
     }
 
     // D-deep register ring: every load of a chunk (weights, constants, activations) is issued D chunks ahead,
@@ -614,6 +625,56 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
                     reinterpret_cast<u4_t*>(xbuf)[idx] = glued(xs[idx], gv);
                 }
                 __syncthreads();
+            } else if constexpr (AM == AM_ROW4 && GLUE == kGlueRmsNorm) {
+                // decode op on up to four rows: wave w (< M) owns row w's RMSNorm statistic -- the producer's per-tile sums of
+                // squares (eight clamped loads per lane, in front of the weight ring), or a wave-local reduction of the row when
+                // there is no producer (first op of a step) -- and shares 1/rms through LDS
+                float* scratch = reinterpret_cast<float*>(xbuf);
+                const bool mine = wave < p.M;
+                float sv[8];
+                if (p.stats_in != nullptr) {
+                    if (mine) {
+                        const float* srow = p.stats_in + (size_t)wave * p.stats_n;
+                        const int last = p.stats_n - 1;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int idx = lane + 64 * i;
+                            sv[i] = srow[idx < last ? idx : last];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
+                    if (mine) {
+                        float ssum = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) ssum += (lane + 64 * i < p.stats_n) ? sv[i] : 0.f;
+#pragma unroll
+                        for (int mk = 32; mk >= 1; mk >>= 1) ssum += __shfl_xor(ssum, mk, 64);
+                        if (lane == 0) scratch[wave] = rsqrtf(ssum / (float)p.K + p.eps);
+                    }
+                } else {
+                    if (mine) {
+                        const u4_t* hs = reinterpret_cast<const u4_t*>(p.x) + (size_t)wave * (p.K / 8);
+                        float ss = 0.f;
+                        for (int idx = lane; idx < p.K / 8; idx += 64) {
+                            const u4_t h = hs[idx];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float a = bits16_to_f32<ACT>((uint16_t)(h[j] & 0xffffu)), b = bits16_to_f32<ACT>((uint16_t)(h[j] >> 16));
+                                ss = __builtin_fmaf(a, a, ss);
+                                ss = __builtin_fmaf(b, b, ss);
+                            }
+                        }
+#pragma unroll
+                        for (int mk = 32; mk >= 1; mk >>= 1) ss += __shfl_xor(ss, mk, 64);
+                        if (lane == 0) scratch[wave] = rsqrtf(ss / (float)p.K + p.eps);
+                    }
+#pragma unroll
+                    for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
+                }
+                __syncthreads();
+                glue_inv = scratch[rq < p.M ? rq : 0];
             } else if (GLUE == kGlueRmsNorm && p.stats_in != nullptr) {
                 // RMSNorm statistics handed over by the op that produced h (one partial per 16-column tile: its epilogue's
                 // sum of out^2).  ONE wave per block sums them in a fixed order -- eight clamped loads per lane issued in
@@ -762,12 +823,15 @@ static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStr
     const dim3 block(64 * pl.waves);
     constexpr int kSlot = slot_bytes<AM, MT>() > MT * 1024 ? slot_bytes<AM, MT>() : MT * 1024;
     const size_t lds_bytes = (size_t)pl.waves * kSlot + 16 + (AM == AM_ROW1P ? (size_t)p.K * 2 + 80 : 64);
-    if constexpr ((AM == AM_ROW1 && MT == 1 && (D == 4 || D == 2)) || (AM == AM_ROW1P && MT == 1 && D == 4)) {
+    if constexpr ((AM == AM_ROW1 && MT == 1 && (D == 4 || D == 2)) || (AM == AM_ROW1P && MT == 1 && D == 4) || (AM == AM_ROW4 && MT == 1 && D == 4)) {
         if (p.in_glue != kGlueNone) {  // decode op with input glue: regular single-group-per-chunk plans only (ABI checks)
             if (p.in_glue == kGlueRmsNorm) {
                 hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueRmsNorm>), grid, block, lds_bytes, stream, p);
-            } else {
+            } else if constexpr (AM != AM_ROW4) {
                 hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueSiluMul>), grid, block, lds_bytes, stream, p);
+            } else {
+                set_error("decode op: SiLU*mul INPUT glue exists for one row only (use the paired gate_up epilogue)");
+                return -22;   // GPTQHIP_EINVAL (the ABI layer rejects this combination before it gets here)
             }
             return check_hip(hipGetLastError(), "skinny_kernel (decode glue) launch");
         }

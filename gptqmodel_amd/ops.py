@@ -178,10 +178,10 @@ GLUE_NONE, GLUE_RMSNORM, GLUE_SILU_MUL = 0, 1, 2
 OUT_NONE, OUT_SILU_MUL_PAIRED, OUT_PARTIAL_F32 = 0, 1, 2
 
 
-def decode_supported(K: int, N: int, group_size: int, has_perm: bool = False) -> bool:
-    """True when gptqhip_decode_linear handles a [K,N] layer (regular batch-1 pipeline; has_perm: with an act-order
-    permutation applied in the kernel), else use gemm()."""
-    return bool(_lib.load().gptqhip_decode_supported(K, N, group_size, 1 if has_perm else 0))
+def decode_supported(K: int, N: int, group_size: int, has_perm: bool = False, M: int = 1) -> bool:
+    """True when gptqhip_decode_linear handles a [K,N] layer (regular pipeline; has_perm: with an act-order permutation
+    applied in the kernel; M: rows 1..4), else use gemm()."""
+    return bool(_lib.load().gptqhip_decode_supported(K, N, group_size, 1 if has_perm else 0, M))
 
 
 def make_decode_op(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor,
@@ -189,37 +189,40 @@ def make_decode_op(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor,
                    norm_weight: Optional[torch.Tensor] = None, eps: float = 1e-5, residual: Optional[torch.Tensor] = None,
                    workspace: Optional[torch.Tensor] = None, out_glue: int = OUT_NONE,
                    stats_in: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None,
-                   perm: Optional[torch.Tensor] = None) -> "_lib.DecodeOp":
+                   perm: Optional[torch.Tensor] = None, M: int = 1) -> "_lib.DecodeOp":
     """Fill a struct gptqhip_decode_op (include/gptqhip.h) from tensors.  The struct only holds raw pointers: the caller
     keeps the tensors alive (DecodeStep does) -- binding once and re-launching costs no per-call Python work.
     `workspace`: the stream's scratch (workspace_for); taken from the CURRENT stream when omitted.
-    `perm`: the module's act-order permutation (int32 [K]); applied to the glued input inside the kernel."""
+    `perm`: the module's act-order permutation (int32 [K]); applied to the glued input inside the kernel.
+    `M`: rows (1..4): x [M,K], out / residual [M,N], stats_in [M, K/16], stats_out [M, ceil(N/16)], all contiguous."""
     _require_cuda(x, qweight_t, meta, bias, out, norm_weight, residual, workspace, stats_in, stats_out, perm)
+    if not 1 <= M <= 4:
+        raise RuntimeError("decode op: M must be 1..4")
     if perm is not None and (perm.dtype != torch.int32 or perm.numel() != K or not perm.is_contiguous()):
         raise RuntimeError("decode op: perm must be a contiguous int32 [K] tensor")
     want_out = torch.float32 if out_glue == OUT_PARTIAL_F32 else x.dtype
     if x.dtype not in _DT or out.dtype != want_out or scale_dtype not in _DT:
         raise RuntimeError(f"decode op: unsupported dtypes x={x.dtype} out={out.dtype} scales={scale_dtype}")
-    need = 2 * K if in_glue == GLUE_SILU_MUL else K
-    n_out = N // 2 if out_glue == OUT_SILU_MUL_PAIRED else N
+    need = (2 * K if in_glue == GLUE_SILU_MUL else K) * M
+    n_out = (N // 2 if out_glue == OUT_SILU_MUL_PAIRED else N) * M
     if x.numel() < need or not x.is_contiguous() or out.numel() < n_out or not out.is_contiguous():
         raise RuntimeError(f"decode op: x needs >= {need} contiguous elements (has {x.numel()}), out >= {n_out}")
     tiles_in, tiles_out = -(-K // 16), -(-N // 16)
-    for t, n, what in ((stats_in, tiles_in, "stats_in"), (stats_out, tiles_out, "stats_out")):
+    for t, n, what in ((stats_in, M * tiles_in, "stats_in"), (stats_out, M * tiles_out, "stats_out")):
         if t is not None and (t.dtype != torch.float32 or t.numel() < n or not t.is_contiguous()):
             raise RuntimeError(f"decode op: {what} must be a contiguous float32 tensor with >= {n} elements")
-    for t, n, what in ((bias, N, "bias"), (residual, N, "residual"), (norm_weight, K, "norm_weight")):
+    for t, n, what in ((bias, N, "bias"), (residual, M * N, "residual"), (norm_weight, K, "norm_weight")):
         if t is not None and (t.dtype != x.dtype or t.numel() < n or not t.is_contiguous()):
             raise RuntimeError(f"decode op: {what} must be a contiguous {x.dtype} tensor with >= {n} elements")
     if in_glue == GLUE_RMSNORM and norm_weight is None:
         raise RuntimeError("decode op: GLUE_RMSNORM needs norm_weight")
     if workspace is None:
         with torch.cuda.device(x.device):
-            workspace = workspace_for(x.device, workspace_bytes(1, K, N, group_size, bits, False))
+            workspace = workspace_for(x.device, workspace_bytes(M, K, N, group_size, bits, False))
     p = lambda t: 0 if t is None else t.data_ptr()
     return _lib.DecodeOp(p(qweight_t), p(meta), p(bias), p(x), p(norm_weight), p(residual), p(out), p(workspace),
                          workspace.numel(), p(stats_in), p(stats_out), p(perm), float(eps), K, N, group_size, bits, _DT[x.dtype],
-                         _DT[scale_dtype], int(in_glue), int(out_glue), tiles_in if stats_in is not None else 0)
+                         _DT[scale_dtype], int(in_glue), int(out_glue), tiles_in if stats_in is not None else 0, int(M))
 
 
 def launch_decode_op(op: "_lib.DecodeOp", device: torch.device) -> None:
@@ -233,7 +236,10 @@ def decode_linear(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, 
     """One-shot convenience wrapper (tests): out[N] of a batch-1 decode op with optional fused glue."""
     out = kw.pop("out", None)
     if out is None:
-        out = torch.empty(N, dtype=x.dtype, device=x.device)
+        M = int(kw.get("M", 1))
+        n_out = N // 2 if kw.get("out_glue", OUT_NONE) == OUT_SILU_MUL_PAIRED else N
+        out = torch.empty(n_out if M == 1 else (M, n_out), dtype=torch.float32 if kw.get("out_glue") == OUT_PARTIAL_F32 else x.dtype,
+                          device=x.device)
     with torch.cuda.device(x.device):
         op = make_decode_op(x, qweight_t, meta, bias, out, K, N, group_size, bits, scale_dtype, **kw)
         launch_decode_op(op, x.device)

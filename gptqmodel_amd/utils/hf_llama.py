@@ -7,8 +7,8 @@ product and two residual adds: ~16 dependent launches per layer.  `fuse_llama_de
 
   * fuses q/k/v into one module (views stand in for the three projections, as with fuse_siblings) and gate/up into ONE
     module with the columns interleaved in blocks of 8 (utils.model.fuse_gate_up_interleaved);
-  * gives every decoder layer a decode fast path: when the layer is called with exactly ONE token (batch 1, q_len 1, eval),
-    the layer runs as 4 decode ops (gptqhip_decode_linear: RMSNorm on the input of qkv / gate_up with the statistics handed
+  * gives every decoder layer a decode fast path: when the layer is called with at most FOUR tokens (batch x q_len <= 4, eval:
+    single-sequence decode, a few sequences, or speculative tokens of one), the layer runs as 4 decode ops (gptqhip_decode_linear: RMSNorm on the input of qkv / gate_up with the statistics handed
     over by the op that produced the residual stream, SiLU*mul in the gate_up epilogue, residual add + next statistics in
     the o / down epilogue) around HF's own rotary / KV-cache update / attention call.  Everything else (prefill, batches,
     training-mode calls) takes HF's original path through the same fused modules.
@@ -38,80 +38,98 @@ def _is_quant(m) -> bool:
     return isinstance(m, BaseQuantLinear) and getattr(m, "adapter", None) is None
 
 
+MAX_ROWS = 4   # tokens per call on the fast path (gptqhip_decode_op.M): a few sequences at q_len 1, or speculative tokens of one
+
+
 class _LayerDecodeState:
-    """Buffers + bound decode ops of one decoder layer (built lazily on the first single-token call)."""
+    """Buffers + bound decode ops of one decoder layer (built lazily on the first fast-path call; ops per row count M)."""
 
     def __init__(self, layer, prev: Optional["_LayerDecodeState"], dtype: torch.dtype, workspace: torch.Tensor):
         attn, mlp = layer.self_attn, layer.mlp
-        qkv, o = attn.fused_q_proj_k_proj_v_proj.fused, attn.o_proj
-        gu, down = mlp.fused_gate_up.fused, mlp.down_proj
+        self.lins = (attn.fused_q_proj_k_proj_v_proj.fused, attn.o_proj, mlp.fused_gate_up.fused, mlp.down_proj)
+        qkv, o, gu, down = self.lins
         dev = qkv.qweight.device
         hidden = qkv.in_features
-        self.hidden, self.dtype, self.device = hidden, dtype, dev
+        self.hidden, self.dtype, self.device, self.workspace = hidden, dtype, dev, workspace
         self.q_dim, self.kv_dim = attn.fused_q_proj_k_proj_v_proj.sizes[0], attn.fused_q_proj_k_proj_v_proj.sizes[1]
-        self.x_in = torch.zeros(hidden, dtype=dtype, device=dev)               # used when the input is not the previous layer's h2
-        self.qkv_out = torch.zeros(qkv.out_features, dtype=dtype, device=dev)
-        self.attn_in = torch.zeros(o.in_features, dtype=dtype, device=dev)     # attention output, copied in (HF returns a fresh tensor)
-        self.h1 = torch.zeros(hidden, dtype=dtype, device=dev)
-        self.h2 = torch.zeros(hidden, dtype=dtype, device=dev)
-        self.act = torch.zeros(gu.out_features // 2, dtype=dtype, device=dev)
-        self.st1 = torch.zeros(-(-hidden // 16), dtype=torch.float32, device=dev)
-        self.st2 = torch.zeros(-(-hidden // 16), dtype=torch.float32, device=dev)
+        R = MAX_ROWS
+        self.x_in = torch.zeros((R, hidden), dtype=dtype, device=dev)          # used when the input is not the previous layer's h2
+        self.qkv_out = torch.zeros((R, qkv.out_features), dtype=dtype, device=dev)
+        self.attn_in = torch.zeros((R, o.in_features), dtype=dtype, device=dev)  # attention output, copied in (HF returns a fresh tensor)
+        self.h1 = torch.zeros((R, hidden), dtype=dtype, device=dev)
+        self.h2 = torch.zeros((R, hidden), dtype=dtype, device=dev)
+        self.act = torch.zeros((R, gu.out_features // 2), dtype=dtype, device=dev)
+        self.st1 = torch.zeros((R, -(-hidden // 16)), dtype=torch.float32, device=dev)
+        self.st2 = torch.zeros((R, -(-hidden // 16)), dtype=torch.float32, device=dev)
         self.prev = prev
-        eps_in = float(getattr(layer.input_layernorm, "variance_epsilon", 1e-6))
-        eps_post = float(getattr(layer.post_attention_layernorm, "variance_epsilon", 1e-6))
-        w_in = layer.input_layernorm.weight.detach().to(dtype).contiguous()
-        w_post = layer.post_attention_layernorm.weight.detach().to(dtype).contiguous()
-        self._keep = [w_in, w_post, workspace]
+        self.eps_in = float(getattr(layer.input_layernorm, "variance_epsilon", 1e-6))
+        self.eps_post = float(getattr(layer.post_attention_layernorm, "variance_epsilon", 1e-6))
+        self.w_in = layer.input_layernorm.weight.detach().to(dtype).contiguous()
+        self.w_post = layer.post_attention_layernorm.weight.detach().to(dtype).contiguous()
+        self._keep = []
+        self.ops = {}      # M -> (qkv_chain | None, qkv_first, o_chain | None, o_first, gate_up, down)
+
+    def supported(self, M: int) -> bool:
+        for lin in self.lins:
+            if not ops.decode_supported(lin.in_features, lin.out_features, lin.group_size, getattr(lin, "perm", None) is not None, M):
+                return False
+        return True
+
+    def ops_for(self, M: int):
+        """The six bound ops for M rows (rows are packed at the front of the [MAX_ROWS, ..] buffers: row stride = feature
+        count, so the M-row views are contiguous)."""
+        if M in self.ops:
+            return self.ops[M]
+        qkv, o, gu, down = self.lins
+        prev, dtype, ws = self.prev, self.dtype, self.workspace
 
         def bind(lin, x, out, **kw):
             from .decode_chain import _lin_tensors
             qw, meta, bias, sdt, perm = _lin_tensors(lin, dtype)
             self._keep.extend([qw, meta, bias, perm])
             return ops.make_decode_op(x, qw, meta, bias, out, lin.in_features, lin.out_features, lin.group_size, lin.bits, sdt,
-                                      workspace=workspace, perm=perm, **kw)
+                                      workspace=ws, perm=perm, M=M, **kw)
 
-        # qkv comes in two flavours: chained to the previous layer's h2 (+ its statistics), or fed from x_in (first layer, or
+        # qkv / o come in two flavours: chained to the previous layer's h2 (+ its statistics), or fed from x_in (first layer, or
         # whenever the caller hands over some other tensor)
-        self.op_qkv_chain = None
-        if prev is not None:
-            self.op_qkv_chain = bind(qkv, prev.h2, self.qkv_out, in_glue=ops.GLUE_RMSNORM, norm_weight=w_in, eps=eps_in,
-                                     stats_in=prev.st2)
-        self.op_qkv_first = bind(qkv, self.x_in, self.qkv_out, in_glue=ops.GLUE_RMSNORM, norm_weight=w_in, eps=eps_in)
-        self.op_o_chain = None if prev is None else bind(o, self.attn_in, self.h1, residual=prev.h2, stats_out=self.st1)
-        self.op_o_first = bind(o, self.attn_in, self.h1, residual=self.x_in, stats_out=self.st1)
-        self.op_gu = bind(gu, self.h1, self.act, in_glue=ops.GLUE_RMSNORM, norm_weight=w_post, eps=eps_post, stats_in=self.st1,
-                          out_glue=ops.OUT_SILU_MUL_PAIRED)
-        self.op_down = bind(down, self.act, self.h2, residual=self.h1, stats_out=self.st2)
-
-
-def _decode_supported(layer) -> bool:
-    attn, mlp = layer.self_attn, layer.mlp
-    lins = [attn.fused_q_proj_k_proj_v_proj.fused, attn.o_proj, mlp.fused_gate_up.fused, mlp.down_proj]
-    for lin in lins:
-        if not getattr(lin, "_ready", False):
-            return False
-        if not ops.decode_supported(lin.in_features, lin.out_features, lin.group_size, getattr(lin, "perm", None) is not None):
-            return False
-    return lins[0].in_features % 16 == 0 and lins[0].in_features // 16 <= 512
+        rms_in = dict(in_glue=ops.GLUE_RMSNORM, norm_weight=self.w_in, eps=self.eps_in)
+        chain_ok = prev is not None
+        bound = (
+            bind(qkv, prev.h2, self.qkv_out, stats_in=prev.st2, **rms_in) if chain_ok else None,
+            bind(qkv, self.x_in, self.qkv_out, **rms_in),
+            bind(o, self.attn_in, self.h1, residual=prev.h2, stats_out=self.st1) if chain_ok else None,
+            bind(o, self.attn_in, self.h1, residual=self.x_in, stats_out=self.st1),
+            bind(gu, self.h1, self.act, in_glue=ops.GLUE_RMSNORM, norm_weight=self.w_post, eps=self.eps_post, stats_in=self.st1,
+                 out_glue=ops.OUT_SILU_MUL_PAIRED),
+            bind(down, self.act, self.h2, residual=self.h1, stats_out=self.st2),
+        )
+        self.ops[M] = bound
+        return bound
 
 
 def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
                    position_embeddings=None, **kwargs):
-    """LlamaDecoderLayer.forward with the single-token fast path in front of HF's original."""
+    """LlamaDecoderLayer.forward with the few-token fast path in front of HF's original."""
     fd = self._gptqhip_fused
-    if (hidden_states.numel() != fd["hidden"] or self.training or not hidden_states.is_cuda or position_embeddings is None
-            or torch.is_grad_enabled() and hidden_states.requires_grad or fd["disabled"]):
+
+    def original():
         return fd["orig_forward"](hidden_states, attention_mask=attention_mask, position_ids=position_ids,
                                   past_key_values=past_key_values, use_cache=use_cache,
                                   position_embeddings=position_embeddings, **kwargs)
+
+    hidden = fd["hidden"]
+    M = hidden_states.numel() // hidden
+    if (M < 1 or M > MAX_ROWS or hidden_states.dim() != 3 or hidden_states.shape[-1] != hidden or self.training
+            or not hidden_states.is_cuda or position_embeddings is None or fd["disabled"]
+            or (torch.is_grad_enabled() and hidden_states.requires_grad)):
+        return original()
     st: Optional[_LayerDecodeState] = fd["state"]
     if st is None or st.dtype != hidden_states.dtype:
-        if not _decode_supported(self):
+        if not all(getattr(lin, "_ready", False) for lin in (self.self_attn.fused_q_proj_k_proj_v_proj.fused, self.self_attn.o_proj,
+                                                             self.mlp.fused_gate_up.fused, self.mlp.down_proj)) \
+                or hidden % 16 != 0 or hidden // 16 > 512:
             fd["disabled"] = True
-            return fd["orig_forward"](hidden_states, attention_mask=attention_mask, position_ids=position_ids,
-                                      past_key_values=past_key_values, use_cache=use_cache,
-                                      position_embeddings=position_embeddings, **kwargs)
+            return original()
         prev_layer = fd["prev"]
         prev_state = None
         if prev_layer is not None:
@@ -119,20 +137,27 @@ def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, 
             if prev_state is not None and prev_state.dtype != hidden_states.dtype:
                 prev_state = None
         st = fd["state"] = _LayerDecodeState(self, prev_state, hidden_states.dtype, fd["workspace"]())
+    if M not in st.ops and not st.supported(M):
+        if M == 1:
+            fd["disabled"] = True
+        return original()
+    op_qkv_chain, op_qkv_first, op_o_chain, op_o_first, op_gu, op_down = st.ops_for(M)
     dev = hidden_states.device
     attn = self.self_attn
-    chained = st.prev is not None and hidden_states.data_ptr() == st.prev.h2.data_ptr()
+    bsz, q_len = hidden_states.shape[0], hidden_states.shape[1]
+    chained = op_qkv_chain is not None and hidden_states.data_ptr() == st.prev.h2.data_ptr()
     with torch.cuda.device(dev):
         if chained:
-            ops.launch_decode_op(st.op_qkv_chain, dev)
+            ops.launch_decode_op(op_qkv_chain, dev)
         else:
-            st.x_in.copy_(hidden_states.reshape(-1))
-            ops.launch_decode_op(st.op_qkv_first, dev)
+            st.x_in[:M].copy_(hidden_states.reshape(M, hidden))
+            ops.launch_decode_op(op_qkv_first, dev)
         # ---- HF's attention between the projections (LlamaAttention.forward, projections removed) ----------------------------
         q_dim, kv_dim, hd = st.q_dim, st.kv_dim, attn.head_dim
-        q = st.qkv_out[:q_dim].view(1, 1, -1, hd).transpose(1, 2)
-        k = st.qkv_out[q_dim:q_dim + kv_dim].view(1, 1, -1, hd).transpose(1, 2)
-        v = st.qkv_out[q_dim + kv_dim:].view(1, 1, -1, hd).transpose(1, 2)
+        qkv = st.qkv_out[:M]
+        q = qkv[:, :q_dim].reshape(bsz, q_len, -1, hd).transpose(1, 2)
+        k = qkv[:, q_dim:q_dim + kv_dim].reshape(bsz, q_len, -1, hd).transpose(1, 2)
+        v = qkv[:, q_dim + kv_dim:].reshape(bsz, q_len, -1, hd).transpose(1, 2)
         cos, sin = position_embeddings
         q, k = fd["rotary"](q, k, cos, sin)
         if past_key_values is not None:
@@ -141,12 +166,12 @@ def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, 
         if fd["sliding_window"]:   # Mistral / Qwen2 hand their window to the attention interface
             kwargs = dict(kwargs, sliding_window=attn.sliding_window)
         attn_out, _ = interface(attn, q, k, v, attention_mask, dropout=0.0, scaling=attn.scaling, **kwargs)
-        st.attn_in.copy_(attn_out.reshape(-1))
+        st.attn_in[:M].copy_(attn_out.reshape(M, -1))
         # ---- o_proj + residual, MLP ---------------------------------------------------------------------------------------------
-        ops.launch_decode_op(st.op_o_chain if chained else st.op_o_first, dev)
-        ops.launch_decode_op(st.op_gu, dev)
-        ops.launch_decode_op(st.op_down, dev)
-    return st.h2.view(hidden_states.shape)
+        ops.launch_decode_op(op_o_chain if chained else op_o_first, dev)
+        ops.launch_decode_op(op_gu, dev)
+        ops.launch_decode_op(op_down, dev)
+    return st.h2[:M].view(hidden_states.shape)
 
 
 def _mlp_forward(self, x):

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 8
+#define GPTQHIP_ABI_VERSION 9
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -167,10 +167,13 @@ typedef struct gptqhip_decode_op {
                                     kernel, or NULL.  Needs K * 2 bytes <= 44 KiB (else gather first).                */
     float eps;
     int K, N, group_size, bits, act_dtype, scale_dtype, in_glue, out_glue, stats_n;
+    int M;                       /* rows (1..4): x [M,K], residual / out [M,N], stats_in [M][stats_n], stats_out [M][ceil(N/16)].
+                                    M > 1 (a few sequences, or speculative tokens of one): in_glue NONE | RMSNORM, perm NULL.   */
 } gptqhip_decode_op;
 int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream);
-/* 1 if gptqhip_decode_linear supports a [K,N] layer with this group size (has_perm: with an act-order permutation), else 0. */
-int gptqhip_decode_supported(int K, int N, int group_size, int has_perm);
+/* 1 if gptqhip_decode_linear supports a [K,N] layer with this group size (has_perm: with an act-order
+ * permutation; M: rows, 1..4), else 0. */
+int gptqhip_decode_supported(int K, int N, int group_size, int has_perm, int M);
 
 /* Materialise W[K,N] from the CHECKPOINT layout in `out_dtype` (= scales dtype in the reference).  Replaces
  * TorchLinear.dequantize_weight (torch.py:225) / PackableQuantLinear.dequantize_weight

@@ -65,15 +65,18 @@ def test_decode_op_shape_predicate_is_host_logic(lib):
     yes = [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096), (8192, 10240), (8192, 8192), (8192, 57344), (28672, 8192),
            (11008, 4096), (4096, 22016), (18944, 3584), (3584, 37888), (5120, 27648), (13824, 5120), (1536, 8960), (8960, 1536)]
     for K, N in yes:
-        assert lib.gptqhip_decode_supported(K, N, 128, 0) == 1, (K, N)
-    assert lib.gptqhip_decode_supported(4096, 4096, 64, 0) == 0      # four constants per 128-row chunk: general kernel
-    assert lib.gptqhip_decode_supported(4000, 4096, 32, 0) == 0      # K % 128 != 0
-    assert lib.gptqhip_decode_supported(4096, 4096, 4096, 0) == 1    # one group for the whole K (group_size = -1 checkpoints)
-    assert lib.gptqhip_decode_supported(14336, 4096, 14336, 0) == 1
-    assert lib.gptqhip_decode_supported(0, 4096, 128, 0) == 0
+        assert lib.gptqhip_decode_supported(K, N, 128, 0, 1) == 1, (K, N)
+    assert lib.gptqhip_decode_supported(4096, 4096, 64, 0, 1) == 0      # four constants per 128-row chunk: general kernel
+    assert lib.gptqhip_decode_supported(4000, 4096, 32, 0, 1) == 0      # K % 128 != 0
+    assert lib.gptqhip_decode_supported(4096, 4096, 4096, 0, 1) == 1    # one group for the whole K (group_size = -1 checkpoints)
+    assert lib.gptqhip_decode_supported(14336, 4096, 14336, 0, 1) == 1
+    assert lib.gptqhip_decode_supported(0, 4096, 128, 0, 1) == 0
     # act-order in the kernel: 4-deep ring only, and the x row must fit in LDS next to the wave slots
-    assert lib.gptqhip_decode_supported(4096, 4096, 128, 1) == 1 and lib.gptqhip_decode_supported(14336, 4096, 128, 1) == 1
-    assert lib.gptqhip_decode_supported(1024, 1024, 128, 1) == 0 and lib.gptqhip_decode_supported(28672, 8192, 128, 1) == 0
+    assert lib.gptqhip_decode_supported(4096, 4096, 128, 1, 1) == 1 and lib.gptqhip_decode_supported(14336, 4096, 128, 1, 1) == 1
+    assert lib.gptqhip_decode_supported(1024, 1024, 128, 1, 1) == 0 and lib.gptqhip_decode_supported(28672, 8192, 128, 1, 1) == 0
+    # up to four rows (no permutation there); five are gptqhip_gemm's business
+    assert lib.gptqhip_decode_supported(4096, 28672, 128, 0, 4) == 1 and lib.gptqhip_decode_supported(14336, 4096, 128, 0, 3) == 1
+    assert lib.gptqhip_decode_supported(4096, 4096, 128, 0, 5) == 0 and lib.gptqhip_decode_supported(4096, 4096, 128, 1, 2) == 0
 
 
 def test_argument_validation_reports_errors_without_a_gpu(lib):

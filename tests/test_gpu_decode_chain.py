@@ -141,6 +141,61 @@ def test_decode_op_act_order_in_kernel_perm_with_glue(ops, act):
         ops.decode_linear(torch.zeros(K, dtype=TDT[act], device=DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, perm=perm)
 
 
+@pytest.mark.parametrize("M", [2, 3, 4])
+@pytest.mark.parametrize("act", ["fp16", "bf16"])
+def test_decode_op_rows_2_to_4(ops, M, act):
+    """The decode op on up to four rows (a few sequences, or speculative tokens of one): per-row RMSNorm statistics (from the
+    producer and reduced in the kernel), per-row residual + stats_out, the paired SiLU*mul epilogue, bias, cross-block split-K
+    and a padded plan -- each against the oracle composed with HF's glue formulas, row by row."""
+    gs, bits = 128, 4
+    rng = np.random.RandomState(31 + M)
+    for K, N, with_stats, paired in ((4096, 6144, True, False), (4096, 4096, False, False), (4096, 512, True, False),
+                                     (11008, 1024, False, False), (4096, 2048, True, True)):
+        qweight, qzeros, scales, g_idx = synth_gptq(700 + K // 128 + N // 16, bits, K, N, gs)
+        if paired:   # interleave gate|up columns in blocks of 8 (what fuse_gate_up_interleaved stores)
+            inter = N // 2
+            order = np.stack([np.arange(inter).reshape(-1, 8), inter + np.arange(inter).reshape(-1, 8)], axis=1).reshape(-1)
+        sc = f32_to_torch(scales, "fp16", DEV)
+        if paired:
+            qw_i = np.ascontiguousarray(qweight[:, order])
+            qz_i = O.pack_cols(O.unpack_cols(qzeros, 4)[:, order], 4)
+            sc_i = f32_to_torch(np.ascontiguousarray(scales[:, order]), "fp16", DEV)
+            qw_t, meta = ops.repack_tiled(torch.from_numpy(qw_i).to(DEV), torch.from_numpy(qz_i).to(DEV), sc_i, None, gs, bits)
+        else:
+            qw_t, meta = ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV), sc, None, gs, bits)
+        h = O.round_to(rng.randn(M, K).astype(np.float32) * (1.0 + np.arange(M)[:, None]), act)    # rows of different scale
+        w = O.round_to(1.0 + rng.randn(K).astype(np.float32) * 0.1, act)
+        res = O.round_to(rng.randn(M, N).astype(np.float32), act)
+        bias = O.round_to(rng.randn(N).astype(np.float32) * 0.1, act)
+        st_in = None
+        if with_stats:
+            st_in = torch.from_numpy((h.astype(np.float64) ** 2).reshape(M, -1, 16).sum(axis=2).astype(np.float32)).to(DEV)
+        xn = np.stack([O.rmsnorm_ref(h[m], w, 1e-5, act) for m in range(M)])
+        y = O.forward_gptq(xn, qweight, qzeros, scales, g_idx, bits, None if paired else bias, act, "fp16")
+        if paired:
+            out = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, in_glue=ops.GLUE_RMSNORM,
+                                    norm_weight=f32_to_torch(w, act, DEV), eps=1e-5, stats_in=st_in,
+                                    out_glue=ops.OUT_SILU_MUL_PAIRED, M=M)
+            ref = np.stack([O.silu_mul_ref(y[m, :inter], y[m, inter:], act) for m in range(M)])
+            assert out.shape == (M, inter)
+            assert_forward_close(torch_to_f32(out), ref, act, tag=(K, N, M, "paired"))
+        else:
+            st_out = torch.zeros((M, -(-N // 16)), dtype=torch.float32, device=DEV)
+            out = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, f32_to_torch(bias, act, DEV), K, N, gs, bits, sc.dtype,
+                                    in_glue=ops.GLUE_RMSNORM, norm_weight=f32_to_torch(w, act, DEV), eps=1e-5,
+                                    residual=f32_to_torch(res, act, DEV), stats_in=st_in, stats_out=st_out, M=M)
+            ref = O.residual_add_ref(res, y, act)
+            got = torch_to_f32(out)
+            assert_forward_close(got, ref, act, tag=(K, N, M, with_stats))
+            assert np.allclose(st_out.cpu().numpy(), (got.astype(np.float64) ** 2).reshape(M, -1, 16).sum(axis=2), rtol=1e-5)
+            # no glue at all == the plugin path's kernel on the same rows
+            plain = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, M=M)
+            gen = ops.gemm(f32_to_torch(h, act, DEV), qw_t, meta, None, None, N, gs, bits, sc.dtype)
+            assert torch.equal(plain, gen)
+    with pytest.raises(RuntimeError, match="M=5|1..4"):
+        ops.decode_linear(torch.zeros((5, 4096), dtype=TDT[act], device=DEV), qw_t, meta, None, 4096, 2048, gs, bits, sc.dtype, M=5)
+
+
 def test_decode_op_rejects_unsupported_shapes(ops):
     qweight, qzeros, scales, _ = synth_gptq(1, 4, 256, 64, 64)
     qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, 64, 4)

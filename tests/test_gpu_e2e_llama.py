@@ -46,8 +46,8 @@ def _build(desc_act: bool, fuse, dtype, family="llama"):
     torch.manual_seed(7)
     # the decoder-layer fast path needs shapes inside the decode op's pipeline (K = 1024 -> 8 chunks, 2816 -> 22 padded to 24)
     dims = dict(hidden_size=512, intermediate_size=1408)
-    if fuse == "layers":   # (act-order in the kernel needs whole 4-deep ring rounds: 16 chunks)
-        dims = dict(hidden_size=2048, intermediate_size=4096) if desc_act else dict(hidden_size=1024, intermediate_size=2816)
+    if fuse == "layers":   # (act-order in the kernel and the 2..4-row ops need whole 4-deep ring rounds: >= 16 chunks of K)
+        dims = dict(hidden_size=2048, intermediate_size=5632)
     common = dict(num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2, vocab_size=2048,
                   max_position_embeddings=128, tie_word_embeddings=False, **dims)
     if family == "qwen2":      # q/k/v carry a bias; same layer formula
@@ -145,10 +145,23 @@ def test_llama_decoder_layers_on_decode_ops_match_dense(desc_act, dtype, family)
     states = [L._gptqhip_fused["state"] for L in quant.model.layers]
     assert all(st is not None for st in states) and not any(L._gptqhip_fused["disabled"] for L in quant.model.layers)
     assert states[1].prev is states[0]          # layer 1 consumes layer 0's residual stream + statistics in place
-    # batch 2 at q_len 1 is not the fast path: same modules, HF's layer code
+    # up to four tokens per call stay on the fast path: two sequences at q_len 1 ...
     with torch.no_grad():
         ids2 = torch.randint(0, 2048, (2, 1), device="cuda")
         assert rel_err(quant(input_ids=ids2).logits.float().cpu().numpy(), dense(input_ids=ids2).logits.float().cpu().numpy()) < tol
+        assert desc_act or (2 in states[0].ops and 2 in states[1].ops)      # (no in-kernel permutation for M > 1: HF's path)
+        # ... or three new tokens of one sequence on top of its KV cache (speculative-decoding verification step)
+        o_d = dense(input_ids=ids, use_cache=True)
+        o_q = quant(input_ids=ids, use_cache=True)
+        nxt = torch.randint(0, 2048, (1, 3), device="cuda")
+        s_d = dense(input_ids=nxt, past_key_values=o_d.past_key_values, use_cache=True)
+        s_q = quant(input_ids=nxt, past_key_values=o_q.past_key_values, use_cache=True)
+        assert rel_err(s_q.logits.float().cpu().numpy(), s_d.logits.float().cpu().numpy()) < tol
+        assert desc_act or 3 in states[0].ops
+        # five tokens: HF's layer code through the same fused modules
+        ids5 = torch.randint(0, 2048, (1, 5), device="cuda")
+        assert rel_err(quant(input_ids=ids5).logits.float().cpu().numpy(), dense(input_ids=ids5).logits.float().cpu().numpy()) < tol
+        assert 5 not in states[0].ops
         out = quant.generate(input_ids=ids[:, :8], max_new_tokens=6, do_sample=False, pad_token_id=0)
     assert out.shape == (1, 14)
 
