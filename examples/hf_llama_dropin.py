@@ -119,6 +119,26 @@ def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=Fa
     res["eager_tokens_per_s"] = args.new_tokens / dt
     say(f"HF generate (eager, Python-bound): {args.new_tokens / dt:.1f} tokens/s")
 
+    # prefill: one 2048-token prompt through the same modules (the MFMA-tiled kernel; HF's attention / norms around it)
+    try:
+        n_prompt = 2048 if args.size != "tiny" else 256
+        pids = torch.randint(0, cfg.vocab_size, (1, n_prompt), device=dev)
+        with torch.no_grad():
+            for _ in range(2):
+                model(input_ids=pids, use_cache=False, logits_to_keep=1)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(3):
+                model(input_ids=pids, use_cache=False, logits_to_keep=1)
+            torch.cuda.synchronize()
+            dt = (time.time() - t0) / 3
+        res["prefill_tokens_per_s"] = n_prompt / dt
+        res["prefill_prompt_tokens"] = n_prompt
+        say(f"prefill of one {n_prompt}-token prompt: {n_prompt / dt:.0f} tokens/s ({dt * 1e3:.1f} ms)")
+    except Exception as e:  # noqa: BLE001
+        res["prefill_error"] = f"{type(e).__name__}: {str(e)[:200]}"
+        say(f"prefill leg skipped: {type(e).__name__}: {e}")
+
     # one HIP graph per decode step over a static KV cache
     try:
         from transformers import StaticCache

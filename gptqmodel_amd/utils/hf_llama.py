@@ -31,7 +31,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..nn_modules.qlinear import BaseQuantLinear
-from .model import (FusedSiblingView, _FusedGroup, deinterleave_gate_up, fuse_gate_up_interleaved, fuse_quant_linears)
+from .model import FusedSiblingView, _FusedGroup, fuse_gate_up_interleaved, fuse_quant_linears
 
 
 def _is_quant(m) -> bool:
@@ -175,9 +175,13 @@ def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, 
 
 
 def _mlp_forward(self, x):
-    """LlamaMLP.forward through the interleaved gate|up module (prefill / batched path)."""
-    g, u = deinterleave_gate_up(self.fused_gate_up.fused(x))
-    return self.down_proj(self.act_fn(g) * u)
+    """LlamaMLP.forward through the interleaved gate|up module (prefill / batched path).  gate and up are read as strided
+    views of the fused output ([.., inter/8, 2, 8]): no de-interleaving copies, the same two elementwise kernels as HF's
+    `act_fn(gate) * up`."""
+    y = self.fused_gate_up.fused(x)
+    v = y.view(*y.shape[:-1], y.shape[-1] // 16, 2, 8)
+    a = self.act_fn(v[..., 0, :]) * v[..., 1, :]
+    return self.down_proj(a.reshape(*y.shape[:-1], y.shape[-1] // 2))
 
 
 # decoder layers whose single-token arithmetic IS the Llama formula the fast path implements (RMSNorm `w * act(x * rsqrt(mean x^2
