@@ -41,7 +41,6 @@ struct SkinnyPlan {
     int chunks_per_split;  // chunks handled by one block
     int splits;            // grid.y (cross-block split-K)
     size_t slab_floats;    // fp32 partial slabs, 0 when splits == 1
-    int nt = 1;            // 16-column tiles per block: 2 = the wide-layer batch-1 kernel (one activation stage feeds two tiles)
 };
 
 struct TiledPlan {

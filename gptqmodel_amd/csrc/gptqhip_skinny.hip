@@ -816,203 +816,6 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
 
 
 // ------------------------------------------------------------------------------------------------
-// wide1_kernel: ONE row (M = 1) on WIDE layers (>= 1024 column tiles: fused gate_up, 70B qkv ...), two 16-column tiles per
-// block.  On such layers skinny_kernel runs 4 waves per 16-column tile: 7168 waves for Llama-3-8B's gate_up, whose launch
-// ramp alone is ~2 us (the dispatcher starts ~3000 waves per us, profiles/r02_decode_block_trace.txt), and every tile's
-// waves re-load and re-glue the same activation chunk.  Here a wave's ring stage carries the chunk of TWO adjacent tiles
-// (2 KiB of weights, two constant words) next to ONE activation pair: half the waves to launch, half the activation loads /
-// RMSNorm glue / statistics prologues per weight byte, and two independent dequant -> MFMA chains per wave.
-// Same straight-line ring (padded last round, counted waits), same epilogues (finish_outputs) as skinny_kernel<AM_ROW1>.
-template <int BITS, int ACT, int SCL, int D, int GLUE>
-__global__ __launch_bounds__(1024) void wide1_kernel(SkinnyParams p) {
-    constexpr int WPC = BITS == 4 ? 1 : 2;
-    constexpr int NT = 2;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int W = blockDim.x >> 6;
-    const int c = lane & 15, rq = lane >> 4;
-    const int tiles = (p.N + kTileN - 1) / kTileN;
-    const int t0 = blockIdx.x * NT;
-    const int c_end = p.chunks;   // no cross-block split-K on wide layers (the launcher guarantees splits == 1)
-
-    u4_t* aslot = reinterpret_cast<u4_t*>(reinterpret_cast<char*>(lds) + wave * 256);          // this wave's activation chunk
-    float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + W * 256);                // [W][NT][16]
-    float* scratch = red + W * NT * 16;                                                           // 1 + 16 floats
-    int* s_last = reinterpret_cast<int*>(scratch + 20);
-    const DequantConsts dk = make_dequant_consts<BITS>();
-
-    // reducer wave nt (< NT) finishes tile t0 + nt: its residual pair is requested up front (see skinny_kernel)
-    const int my_tile = t0 + (wave < NT ? wave : 0);
-    const bool tile_ok = wave < NT && my_tile < tiles;
-    uint32_t res_raw = 0u;
-    if (p.residual != nullptr && tile_ok && lane < 16) {
-        const int coln = my_tile * kTileN + lane;
-        res_raw = reinterpret_cast<const uint32_t*>(p.residual)[(coln < p.N ? coln : 0) >> 1];
-    }
-
-    struct WStage {
-        u4_t w[NT][WPC];
-        uint32_t meta[NT];
-        uint32_t xa[2];
-    } st[D];
-    const char* wbase[NT];
-    const uint32_t* mbase[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int t = t0 + nt < tiles ? t0 + nt : tiles - 1;   // odd tile count: the last block's second tile re-reads the first
-        wbase[nt] = reinterpret_cast<const char*>(p.qw) + (size_t)t * p.chunks * (WPC * 1024) + lane * 16;
-        mbase[nt] = p.meta + (size_t)t * p.G * 16 + c;
-    }
-    const char* xbase = reinterpret_cast<const char*>(p.x) + lane * 4;
-    int nxt = wave;   // next chunk this wave loads (wave-uniform)
-    auto load = [&](WStage& s) {
-        const int ch = nxt < c_end ? nxt : c_end - 1;   // padding chunks of the last ring round: clamped, skipped at compute time
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int h = 0; h < WPC; ++h)
-                s.w[nt][h] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wbase[nt] + (size_t)ch * (WPC * 1024) + h * 1024));
-            s.meta[nt] = mbase[nt][(size_t)(ch >> p.cpg_shift) * 16];
-        }
-        s.xa[0] = *reinterpret_cast<const uint32_t*>(xbase + (size_t)ch * 256);
-        if constexpr (GLUE == kGlueRmsNorm) {
-            s.xa[1] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p.glue_b) + lane * 4 + (size_t)ch * 256);
-        } else if constexpr (GLUE == kGlueSiluMul) {
-            s.xa[1] = *reinterpret_cast<const uint32_t*>(xbase + (size_t)p.K * 2 + (size_t)ch * 256);
-        }
-        nxt += W;
-    };
-
-    // ---- RMSNorm statistics + ring prologue (as skinny_kernel<AM_ROW1>) --------------------------------------------------
-    float glue_inv = 0.f;
-    if constexpr (GLUE == kGlueRmsNorm) {
-        if (p.stats_in != nullptr) {
-            float sv[8];
-            if (wave == 0) {
-                const int last = p.stats_n - 1;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int idx = lane + 64 * i;
-                    sv[i] = p.stats_in[idx < last ? idx : last];
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int d = 0; d < D; ++d) load(st[d]);
-            if (wave == 0) {
-                float ssum = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) ssum += (lane + 64 * i < p.stats_n) ? sv[i] : 0.f;
-#pragma unroll
-                for (int mk = 32; mk >= 1; mk >>= 1) ssum += __shfl_xor(ssum, mk, 64);
-                if (lane == 0) scratch[0] = rsqrtf(ssum / (float)p.K + p.eps);
-            }
-            __syncthreads();
-            glue_inv = scratch[0];
-        } else {
-            const u4_t* hs = reinterpret_cast<const u4_t*>(p.x);
-            const int n16 = p.K / 8;
-            float ss = 0.f;
-            for (int idx = (int)threadIdx.x; idx < n16; idx += (int)blockDim.x) {
-                const u4_t h = hs[idx];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a = bits16_to_f32<ACT>((uint16_t)(h[j] & 0xffffu)), b = bits16_to_f32<ACT>((uint16_t)(h[j] >> 16));
-                    ss = __builtin_fmaf(a, a, ss);
-                    ss = __builtin_fmaf(b, b, ss);
-                }
-            }
-#pragma unroll
-            for (int mk = 32; mk >= 1; mk >>= 1) ss += __shfl_xor(ss, mk, 64);
-            if (lane == 0) scratch[1 + wave] = ss;
-            __syncthreads();
-            float tot = 0.f;
-            for (int w = 0; w < W; ++w) tot += scratch[1 + w];
-            glue_inv = rsqrtf(tot / (float)p.K + p.eps);
-#pragma unroll
-            for (int d = 0; d < D; ++d) load(st[d]);
-        }
-    } else {
-#pragma unroll
-        for (int d = 0; d < D; ++d) load(st[d]);
-    }
-
-    f4_t acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = f4_t{0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](const WStage& s) {
-        if constexpr (GLUE == kGlueNone) {
-            reinterpret_cast<uint32_t*>(aslot)[lane] = s.xa[0];
-        } else {
-            reinterpret_cast<uint32_t*>(aslot)[lane] = glue_pair<ACT>(s.xa[0], s.xa[1], glue_inv, GLUE);
-        }
-        ColConst cc[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) cc[nt] = expand_meta<BITS, SCL>(s.meta[nt]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u4_t av = aslot[4 * j + rq];   // same-wave LDS accesses execute in order: no barrier after the write above
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                u4_t b;
-                if constexpr (BITS == 4) {
-                    b = dequant_word4<ACT, SCL>(s.w[nt][0][j], cc[nt], dk);
-                } else {
-                    b = dequant_word8<ACT, SCL>(s.w[nt][j >> 1][(j & 1) * 2], s.w[nt][j >> 1][(j & 1) * 2 + 1], cc[nt], dk);
-                }
-                acc[nt] = mfma16<ACT>(av, b, acc[nt]);
-            }
-        }
-    };
-    int cur = wave;
-    for (int it = D; it < p.n_mine; it += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            compute(st[d]);
-            load(st[d]);
-            cur += W;
-        }
-    }
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        if (cur < c_end) compute(st[d]);   // (only the last ring round can hold padding chunks: wave-uniform skip)
-        cur += W;
-    }
-
-    // ---- in-block reduction: accumulator row 0 (lanes 0..15, register 0) of every wave, per tile ---------------------------
-    if (lane < 16) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) red[(wave * NT + nt) * 16 + lane] = acc[nt][0];
-    }
-    __syncthreads();
-    float v = 0.f;
-    if (wave < NT && lane < 16) {
-        for (int w = 0; w < W; ++w) v += red[(w * NT + wave) * 16 + lane];
-    }
-    const int n = my_tile * kTileN + c;
-    const bool live = tile_ok && lane < 16 && n < p.N;
-    // reducer waves act as "wave 0" of their tile in the shared epilogue (no barriers in there when splits == 1)
-    finish_outputs<ACT>(p, v, live, 0, n, my_tile, 0, tile_ok ? 0 : 64, lane, res_raw, s_last);
-}
-
-template <int BITS, int ACT, int SCL>
-static int launch_wide1(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
-    const int tiles = ceil_div(p.N, kTileN);
-    const dim3 grid(ceil_div(tiles, 2), 1);
-    const dim3 block(64 * pl.waves);
-    const size_t lds_bytes = (size_t)pl.waves * 256 + (size_t)pl.waves * 2 * 16 * 4 + 20 * 4 + 16;
-    if (p.in_glue == kGlueRmsNorm) {
-        hipLaunchKernelGGL((wide1_kernel<BITS, ACT, SCL, 4, kGlueRmsNorm>), grid, block, lds_bytes, stream, p);
-    } else if (p.in_glue == kGlueSiluMul) {
-        hipLaunchKernelGGL((wide1_kernel<BITS, ACT, SCL, 4, kGlueSiluMul>), grid, block, lds_bytes, stream, p);
-    } else {
-        hipLaunchKernelGGL((wide1_kernel<BITS, ACT, SCL, 4, kGlueNone>), grid, block, lds_bytes, stream, p);
-    }
-    return check_hip(hipGetLastError(), "wide1_kernel launch");
-}
-
-// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 template <int BITS, int ACT, int SCL, int MT, int AM, int D>
@@ -1044,10 +847,6 @@ static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStr
 
 template <int BITS, int ACT, int SCL>
 static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
-    if (pl.nt == 2 && pl.mt == 1 && p.M == 1 && p.perm == nullptr && !p.exact_bf16 && pl.regular && pl.gpc == 1 && pl.depth == 4 &&
-        p.splits == 1) {
-        return launch_wide1<BITS, ACT, SCL>(p, pl, stream);
-    }
     if (pl.mt == 1 && p.M == 1 && p.perm != nullptr) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1P, 4>(p, pl, stream);
     if (pl.mt == 1 && p.M == 1 && pl.depth == 2) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1, 2>(p, pl, stream);
     if (pl.mt == 1 && p.M == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1, 4>(p, pl, stream);
@@ -1160,8 +959,6 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     pl.chunks_per_split = ceil_div(pl.chunks, s);
     pl.splits = ceil_div(pl.chunks, pl.chunks_per_split);
     pl.slab_floats = pl.splits > 1 ? (size_t)pl.splits * M * N : 0;
-    static const bool allow_wide = [] { const char* v = getenv("GPTQHIP_NO_WIDE"); return !(v && *v && *v != '0'); }();   // A/B switch
-    pl.nt = (allow_wide && M == 1 && tiles >= 1024 && pl.splits == 1 && pl.depth == 4 && pl.gpc == 1 && !in_kernel_perm) ? 2 : 1;
     pl.rounds = ceil_div(pl.chunks_per_split, pl.waves * pl.depth);
     const int virt_chunks = pl.rounds * pl.waves * pl.depth * pl.splits;   // incl. the padding of every block's last ring round
     pl.regular = (allow_pad ? (virt_chunks - pl.chunks) * 8 <= pl.chunks : virt_chunks == pl.chunks) && K % kChunkK == 0 &&
