@@ -215,7 +215,8 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
     """Reference path on the host cores: upstream's CPU test runs bf16 (tests/test_q4_torch.py:27,50) and
     flags fp16 CPU matmul as slow (:52-53); both are timed.  The thread count is swept on the actual sample (one decoder
     layer's 7 linears at M=1) and the best is used.  The torch.compile'd dequant upstream enables in post_init
-    (torch.py:215-216,259) is NOT timed: inductor needs a C++ toolchain run per shape that does not fit this bounded leg."""
+    (torch.py:215-216,259) is timed for C1 (bf16, M=1) in a subprocess with a hard time limit (inductor compiles for ~20-60 s);
+    `c1_ms.bf16_m1_compiled_dequant` is null when that does not finish."""
     from oracle.gptq_oracle import torch_cpu_forward_gptq
     torch.manual_seed(1234)
     ncpu = os.cpu_count() or 1
@@ -253,8 +254,10 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
             ms, _ = _time_cpu(lambda: torch_cpu_forward_gptq(x, *t, 4), budget_s * 0.05, 4)
             c1[f"{tag}_m{m}"] = round(ms, 3)
     torch.set_num_threads(default_threads)
+    c1["bf16_m1_compiled_dequant"], compiled_note = _cpu_compiled_c1(best, gs)
     return {
         "value": 1e3 / (per_layer * cfg["layers"]), "unit": "tokens/s", "cores": best, "kind": "port",
+        "c1_compiled_note": compiled_note,
         "sample": f"1 of {cfg['layers']} decoder layers (7 linears, M=1, bf16 like upstream's CPU test), {iters} passes, "
                   f"extrapolated x{cfg['layers']}; torch CPU port of BACKEND.TORCH (oracle/gptq_oracle.py), not the reference "
                   f"module itself; host os.cpu_count()={ncpu}",
@@ -264,6 +267,39 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
                                       "(null: fp16 CPU matmul at M>1 takes 2.6-183 s per call on such a host; not timed)",
         "leg_s": round(time.perf_counter() - t_start, 1),
     }
+
+
+def _cpu_compiled_c1(threads, gs, limit_s=150):
+    """C1 (4096x4096, bf16, M=1) with the dequant under torch.compile like upstream's post_init: (ms | None, note)."""
+    import subprocess
+    code = f"""
+import sys, time, torch
+sys.path.insert(0, {ROOT!r})
+import bench as B
+from oracle.gptq_oracle import torch_cpu_dequant_gptq, torch_cpu_forward_gptq
+torch.set_num_threads({threads})
+torch.manual_seed(1234)
+t = B._cpu_tensors(4096, 4096, {gs}, torch.bfloat16)
+x = (torch.randn(1, 4096) * 0.5).to(torch.bfloat16)
+deq = torch.compile(torch_cpu_dequant_gptq)
+t0 = time.perf_counter()
+torch_cpu_forward_gptq(x, *t, 4, dequant=deq)
+comp = time.perf_counter() - t0
+ms, _ = B._time_cpu(lambda: torch_cpu_forward_gptq(x, *t, 4, dequant=deq), 2.0, 4)
+print("RESULT", ms, comp)
+"""
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=limit_s, cwd="/tmp",
+                           env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
+        for line in r.stdout.splitlines():
+            if line.startswith("RESULT"):
+                _, ms, comp = line.split()
+                return round(float(ms), 3), f"torch.compile'd dequant (inductor, compile {float(comp):.0f} s), {threads} threads"
+        return None, f"torch.compile leg failed: {(r.stderr or r.stdout)[-200:]}"
+    except subprocess.TimeoutExpired:
+        return None, f"torch.compile leg exceeded {limit_s} s"
+    except Exception as e:  # noqa: BLE001
+        return None, f"torch.compile leg unavailable: {e}"
 
 
 def latest_pmc():

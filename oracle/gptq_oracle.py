@@ -253,10 +253,9 @@ def act_order_perm(g_idx: np.ndarray) -> np.ndarray:
 # torch-CPU restatement: the same op sequence as BACKEND.TORCH, multi-threaded aten, used ONLY as the
 # timed `cpu_baseline` ("port") in bench.py and cross-checked against the numpy oracle in tests.
 # ----------------------------------------------------------------------------------------------
-def torch_cpu_forward_gptq(x, qweight, qzeros, scales, g_idx, bits: int, bias=None):
-    """x [M,K] fp16|bf16 CPU tensor; packed tensors as in the checkpoint (v2 zeros).
-    Same aten op sequence as torch.py:700-717 + 326-347: shift-unpack to int8, mask, gather by g_idx,
-    (w - z) * s in scales dtype, cast, matmul, bias."""
+def torch_cpu_dequant_gptq(qweight, qzeros, scales, g_idx, bits: int):
+    """[K,N] weights in scales.dtype: the aten op sequence of torch.py:700-717 (shift-unpack to int8, mask, gather by g_idx,
+    (w - z) * s).  This is the function upstream wraps in torch.compile in post_init (torch.py:215-216,259)."""
     import torch
     pf = 32 // bits
     maxq = (1 << bits) - 1
@@ -267,7 +266,15 @@ def torch_cpu_forward_gptq(x, qweight, qzeros, scales, g_idx, bits: int, bias=No
     w = torch.bitwise_and(torch.bitwise_right_shift(qweight.unsqueeze(1).expand(-1, pf, -1), sh.view(1, pf, 1)).to(ddt), maxq)
     w = w.reshape(w.shape[0] * pf, w.shape[2])
     g = g_idx.long()
-    weights = scales[g] * (w - z[g])
+    return scales[g] * (w - z[g])
+
+
+def torch_cpu_forward_gptq(x, qweight, qzeros, scales, g_idx, bits: int, bias=None, dequant=torch_cpu_dequant_gptq):
+    """x [M,K] fp16|bf16 CPU tensor; packed tensors as in the checkpoint (v2 zeros).
+    Same aten op sequence as torch.py:700-717 + 326-347: dequant (above; `dequant` may be its torch.compile'd form), cast,
+    matmul, bias."""
+    import torch
+    weights = dequant(qweight, qzeros, scales, g_idx, bits)
     if weights.dtype != x.dtype:
         weights = weights.to(x.dtype)
     out = torch.matmul(x, weights)
