@@ -5,7 +5,8 @@
 non-attention work is glue between those launches -- two RMSNorms (6 small kernels each in eager HF), SiLU, the gate*up
 product and two residual adds: ~16 dependent launches per layer.  `fuse_llama_decoder_layers` keeps HF's module tree but
 
-  * fuses q/k/v into one module (views stand in for the three projections, as with fuse_siblings) and gate/up into ONE
+  * folds an act-order checkpoint's down_proj input permutation into gate / up's output columns (utils.model.
+    fold_act_order_into_producers: exact, removes down_proj's activation gather), fuses q/k/v into one module (views stand in for the three projections, as with fuse_siblings) and gate/up into ONE
     module with the columns interleaved in blocks of 8 (utils.model.fuse_gate_up_interleaved);
   * gives every decoder layer a decode fast path: when the layer is called with at most FOUR tokens (batch x q_len <= 4, eval:
     single-sequence decode, a few sequences, or speculative tokens of one), the layer runs as 4 decode ops (gptqhip_decode_linear: RMSNorm on the input of qkv / gate_up with the statistics handed
@@ -31,7 +32,8 @@ import torch.nn as nn
 
 from .. import ops
 from ..nn_modules.qlinear import BaseQuantLinear
-from .model import FusedSiblingView, _FusedGroup, fuse_gate_up_interleaved, fuse_quant_linears
+from .model import (FusedSiblingView, _FusedGroup, fold_act_order_into_producers, fuse_gate_up_interleaved,
+                    fuse_quant_linears)
 
 
 def _is_quant(m) -> bool:
@@ -246,6 +248,9 @@ def fuse_llama_decoder_layers(model: nn.Module, allow_unknown: bool = False) -> 
             continue
         try:
             qkv = fuse_quant_linears([attn.q_proj, attn.k_proj, attn.v_proj])
+            # act-order checkpoints: down_proj's input permutation moves into gate / up's column order (exact; only integer
+            # codes are re-ordered), so down_proj needs no activation gather -- neither the prefill pre-pass nor the in-kernel one
+            fold_act_order_into_producers(mlp.down_proj, [mlp.gate_proj, mlp.up_proj])
             gu = fuse_gate_up_interleaved(mlp.gate_proj, mlp.up_proj)
         except NotImplementedError as e:
             skipped.append((layer, f"siblings cannot share a launch: {e}"))

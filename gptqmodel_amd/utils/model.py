@@ -301,6 +301,77 @@ def deinterleave_gate_up(y: torch.Tensor):
     return v[..., 0, :].reshape(y.shape[:-1] + (-1,)), v[..., 1, :].reshape(y.shape[:-1] + (-1,))
 
 
+def _unpack_k(qweight: torch.Tensor, bits: int) -> torch.Tensor:
+    """K-packed int32 [K*bits/32, N] -> codes int32 [K, N] (row 32/bits*r + j = bits j*bits.. of word r; qlinear/__init__.py:827-865)."""
+    pf = 32 // bits
+    sh = torch.arange(0, 32, bits, dtype=torch.int32, device=qweight.device).view(1, pf, 1)
+    return ((qweight.unsqueeze(1) >> sh) & ((1 << bits) - 1)).reshape(qweight.shape[0] * pf, qweight.shape[1])
+
+
+def _pack_k(codes: torch.Tensor, bits: int) -> torch.Tensor:
+    pf = 32 // bits
+    v = codes.reshape(codes.shape[0] // pf, pf, codes.shape[1]).to(torch.int64)
+    sh = torch.arange(0, 32, bits, dtype=torch.int64, device=codes.device).view(1, pf, 1)
+    w = (v << sh).sum(dim=1) & 0xFFFFFFFF
+    return torch.where(w >= 2**31, w - 2**32, w).to(torch.int32)
+
+
+def _unpack_n(q: torch.Tensor, bits: int) -> torch.Tensor:
+    """N-packed int32 [R, N*bits/32] -> [R, N] (column 32/bits*c + j = bits j*bits.. of word c: the qzeros layout)."""
+    pf = 32 // bits
+    sh = torch.arange(0, 32, bits, dtype=torch.int32, device=q.device).view(1, 1, pf)
+    return ((q.unsqueeze(2) >> sh) & ((1 << bits) - 1)).reshape(q.shape[0], q.shape[1] * pf)
+
+
+def _pack_n(codes: torch.Tensor, bits: int) -> torch.Tensor:
+    pf = 32 // bits
+    v = codes.reshape(codes.shape[0], codes.shape[1] // pf, pf).to(torch.int64)
+    sh = torch.arange(0, 32, bits, dtype=torch.int64, device=codes.device).view(1, 1, pf)
+    w = (v << sh).sum(dim=2) & 0xFFFFFFFF
+    return torch.where(w >= 2**31, w - 2**32, w).to(torch.int32)
+
+
+def fold_act_order_into_producers(consumer: BaseQuantLinear, producers: List[BaseQuantLinear]) -> bool:
+    """Remove an act-order (desc_act) checkpoint's INPUT permutation from `consumer` by re-ordering the OUTPUT columns of the
+    quantised linears that produce its input through elementwise ops only -- Llama's down_proj(act(gate_proj(x)) * up_proj(x)):
+    with perm = stable argsort(consumer.g_idx),
+
+        consumer rows  k' <- perm[k']      (its packed rows are unpacked, gathered, re-packed; g_idx becomes k // group_size)
+        producer cols  j' <- perm[j']      (qweight / scales columns gathered, packed zero-points re-packed, bias gathered)
+
+    so  sum_k a[k] W[k,:]  is evaluated over the same terms in group order and the consumer needs NO gather any more: no x
+    permutation pre-pass in prefill (one extra read + write of [M, K]), no in-kernel permutation at decode.  Exact: only
+    integer codes move.  GPTQ checkpoint-layout modules BEFORE post_init(); returns False (nothing changed) when the consumer
+    has no act-order permutation or the modules do not fit (producer out_features != consumer in_features, adapters, AWQ)."""
+    g = getattr(consumer, "g_idx", None)
+    if g is None or g.numel() != consumer.in_features or getattr(consumer, "_ready", False):
+        return False
+    if any(getattr(p, "_ready", False) or p.out_features != consumer.in_features or getattr(p, "adapter", None) is not None
+           or p.qweight.shape[1] != p.out_features for p in producers) or getattr(consumer, "adapter", None) is not None:
+        return False
+    if consumer.qweight.shape[1] != consumer.out_features:      # (AWQ packs along N: no act-order there)
+        return False
+    k, gs = consumer.in_features, consumer.group_size
+    seq = torch.arange(k, device=g.device, dtype=torch.int64) // gs
+    gl = g.long()
+    if torch.equal(gl, seq):
+        return False
+    perm = torch.argsort(gl, stable=True)
+    if not torch.equal(gl[perm], seq):
+        return False                                            # unbalanced groups: the kernel layout cannot express it anyway
+    bits = consumer.bits
+    consumer.qweight.data = _pack_k(_unpack_k(consumer.qweight.data, bits)[perm], bits)
+    consumer.g_idx.data = seq.to(g.dtype)
+    for p in producers:
+        pp = perm.to(p.qweight.device)
+        p.qweight.data = p.qweight.data[:, pp].contiguous()
+        p.scales.data = p.scales.data[:, pp].contiguous()
+        p.qzeros.data = _pack_n(_unpack_n(p.qzeros.data, p.bits)[:, pp], p.bits)
+        if getattr(p, "bias", None) is not None:
+            p.bias.data = p.bias.data[pp].contiguous()
+    return True
+
+
 def fuse_siblings(parent: nn.Module, names: List[str]) -> Optional[_FusedGroup]:
     """Fuse parent.<names> (quant modules sharing their input) and replace them by views.  Returns the group, or None
     when fusion is not possible (the original modules are left untouched)."""

@@ -142,6 +142,8 @@ def test_llama_decoder_layers_on_decode_ops_match_dense(desc_act, dtype, family)
             assert rel_err(s_q.logits.float().cpu().numpy(), s_d.logits.float().cpu().numpy()) < tol
             pk_d, pk_q = s_d.past_key_values, s_q.past_key_values
             tok = s_d.logits[:, -1].argmax(-1, keepdim=True)
+    if desc_act:   # down_proj's act-order permutation was folded into gate / up: no gather left there, q|k|v and o keep theirs
+        assert all(L.mlp.down_proj.perm is None and L.self_attn.o_proj.perm is not None for L in quant.model.layers)
     states = [L._gptqhip_fused["state"] for L in quant.model.layers]
     assert all(st is not None for st in states) and not any(L._gptqhip_fused["disabled"] for L in quant.model.layers)
     assert states[1].prev is states[0]          # layer 1 consumes layer 0's residual stream + statistics in place

@@ -387,6 +387,45 @@ def test_interleave_cols_owns_its_storage():
     assert out[0].tolist() == list(range(0, 8)) + list(range(100, 108)) + list(range(8, 16)) + list(range(108, 116))
 
 
+def test_fold_act_order_into_producers_is_exact(kernels_available):
+    """down_proj's act-order input permutation folded into gate / up output columns: only integer codes move, so the
+    dequantised matrices are the permuted originals bit for bit, the consumer's g_idx becomes sequential, and the composite
+    y = (g(x) * u(x)) @ W_down is unchanged (checked on the dequantised matrices in float64)."""
+    import numpy as np
+    from helpers import synth_gptq
+    from oracle import gptq_oracle as O
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    from gptqmodel_amd.utils.model import fold_act_order_into_producers
+    for bits in (4, 8):
+        hidden, inter, gs = 128, 192, 32
+
+        def mod(seed, k, n, desc):
+            qweight, qzeros, scales, g_idx = synth_gptq(seed, bits, k, n, gs, desc_act=desc)
+            m = HipGptqLinear(bits=bits, group_size=gs, sym=False, desc_act=desc, in_features=k, out_features=n, bias=True,
+                              register_buffers=True)
+            m.load_state_dict({"qweight": torch.from_numpy(qweight), "qzeros": torch.from_numpy(qzeros),
+                               "scales": torch.from_numpy(scales).half(), "g_idx": torch.from_numpy(g_idx),
+                               "bias": (torch.arange(n).float() * 0.01 + seed).half()})
+            return m, O.dequant_gptq(qweight, qzeros, scales, g_idx, bits), g_idx
+
+        gate, w_gate, _ = mod(11, hidden, inter, True)
+        up, w_up, _ = mod(12, hidden, inter, True)
+        down, w_down, g_down = mod(13, inter, hidden, True)
+        b_gate = gate.bias.clone()
+        perm = np.argsort(g_down.astype(np.int64), kind="stable")
+        assert fold_act_order_into_producers(down, [gate, up])
+        deq = lambda m: O.dequant_gptq(m.qweight.numpy(), m.qzeros.numpy(), m.scales.float().numpy(), m.g_idx.numpy(), bits)
+        assert np.array_equal(deq(down), w_down[perm])
+        assert np.array_equal(deq(gate), w_gate[:, perm]) and np.array_equal(deq(up), w_up[:, perm])
+        assert np.array_equal(down.g_idx.numpy(), np.arange(inter) // gs)
+        assert torch.equal(gate.bias, b_gate[torch.from_numpy(perm)])
+        x = np.random.RandomState(0).randn(3, hidden)
+        before = ((x @ w_gate.astype(np.float64)) * (x @ w_up.astype(np.float64))) @ w_down.astype(np.float64)
+        after = ((x @ deq(gate).astype(np.float64)) * (x @ deq(up).astype(np.float64))) @ deq(down).astype(np.float64)
+        assert np.allclose(before, after, rtol=1e-12, atol=1e-9)
+        assert not fold_act_order_into_producers(down, [gate, up])      # nothing left to fold
+
+
 def test_gate_up_interleaved_fusion_layout(kernels_available):
     """fuse_gate_up_interleaved: output columns alternate in blocks of 8 (g0..7 u0..7 g8..15 ...) on the CHECKPOINT tensors
     (whole packed words move); the dequantised fused matrix is the column-interleave of the two, deinterleave undoes it."""
