@@ -46,13 +46,15 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--new-tokens", type=int, default=64)
     ap.add_argument("--no-fuse", action="store_true")
+    ap.add_argument("--batch", type=int, default=1, help="sequences decoded together (<= 4 stay on the decode-op fast path)")
     ap.add_argument("--siblings-only", action="store_true", help="fuse q/k/v and gate/up only (no decode-op layer fast path)")
     ap.add_argument("--quant-lm-head", action="store_true", help="also quantise lm_head (qcfg.lm_head upstream, loader.py:1376)")
     args = ap.parse_args()
-    run(args.size, args.dtype, args.new_tokens, not args.no_fuse, args.quant_lm_head, verbose=True, decode_ops=not args.siblings_only)
+    run(args.size, args.dtype, args.new_tokens, not args.no_fuse, args.quant_lm_head, verbose=True, decode_ops=not args.siblings_only,
+        batch=args.batch)
 
 
-def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=False, verbose=False, decode_ops=True):
+def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=False, verbose=False, decode_ops=True, batch=1):
     """Returns {"eager_tokens_per_s", "graph_tokens_per_s" | None, "build_s", ...}; bench.py reports it as `e2e`."""
     import types
     args = types.SimpleNamespace(size=size, dtype=dtype_name, new_tokens=new_tokens, no_fuse=not fuse, quant_lm_head=quant_lm_head)
@@ -108,7 +110,8 @@ def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=Fa
     say(f"built + quantised + packed + repacked {len(names)} linears ({nq} launches/token) in {time.time() - t0:.1f} s; "
         f"GPU memory {torch.cuda.memory_allocated() / 2**30:.2f} GiB")
 
-    ids = torch.randint(0, cfg.vocab_size, (1, 16), device=dev)
+    ids = torch.randint(0, cfg.vocab_size, (batch, 16), device=dev)
+    res["batch"] = batch
     with torch.no_grad():
         model.generate(input_ids=ids, max_new_tokens=4, do_sample=False, pad_token_id=0)  # warm-up
         torch.cuda.synchronize()
@@ -116,8 +119,8 @@ def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=Fa
         out = model.generate(input_ids=ids, max_new_tokens=args.new_tokens, do_sample=False, pad_token_id=0)
         torch.cuda.synchronize()
         dt = time.time() - t0
-    res["eager_tokens_per_s"] = args.new_tokens / dt
-    say(f"HF generate (eager, Python-bound): {args.new_tokens / dt:.1f} tokens/s")
+    res["eager_tokens_per_s"] = batch * args.new_tokens / dt
+    say(f"HF generate (eager, Python-bound): {batch * args.new_tokens / dt:.1f} tokens/s (batch {batch})")
 
     # prefill: one 2048-token prompt through the same modules (the MFMA-tiled kernel; HF's attention / norms around it)
     try:
@@ -166,8 +169,8 @@ def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=Fa
                     s_pos.add_(1)
                 stream.synchronize()
                 dt = time.time() - t0
-        res["graph_tokens_per_s"] = args.new_tokens / dt
-        say(f"graph-replayed decode step (static KV cache): {args.new_tokens / dt:.1f} tokens/s")
+        res["graph_tokens_per_s"] = batch * args.new_tokens / dt
+        say(f"graph-replayed decode step (static KV cache): {batch * args.new_tokens / dt:.1f} tokens/s (batch {batch})")
     except Exception as e:  # transformers API drift must not hide the eager result above
         res["graph_tokens_per_s"] = None
         res["graph_error"] = f"{type(e).__name__}: {str(e)[:200]}"
