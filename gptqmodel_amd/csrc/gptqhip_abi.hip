@@ -391,6 +391,18 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
                          ws ? reinterpret_cast<int*>(ws + L.counters_off) : nullptr, reinterpret_cast<hipStream_t>(stream));
 }
 
+int gptqhip_decode_linear_seq(const gptqhip_decode_op* const* ops, int n, gptqhip_stream_t stream) {
+    if (!ops || n < 0) {
+        set_error("gptqhip_decode_linear_seq: null op list");
+        return GPTQHIP_EINVAL;
+    }
+    for (int i = 0; i < n; ++i) {
+        const int rc = gptqhip_decode_linear(ops[i], stream);
+        if (rc) return rc;
+    }
+    return GPTQHIP_OK;
+}
+
 int gptqhip_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* g_idx,
                     void* out, int K, int N, int group_size, int bits, int scale_dtype, int out_dtype,
                     gptqhip_stream_t stream) {

@@ -231,6 +231,19 @@ def launch_decode_op(op: "_lib.DecodeOp", device: torch.device) -> None:
     _lib.check(rc, "gptqhip_decode_linear")
 
 
+def bind_decode_seq(op_list):
+    """ctypes array of pointers to bound decode ops, for launch_decode_seq (keeps the structs alive through the array)."""
+    arr = (ctypes.POINTER(_lib.DecodeOp) * len(op_list))(*[ctypes.pointer(o) for o in op_list])
+    arr._ops = list(op_list)
+    return arr
+
+
+def launch_decode_seq(seq, device: torch.device) -> None:
+    """Enqueue a dependent run of bound decode ops with ONE host call (gptqhip_decode_linear_seq)."""
+    rc = _lib.load().gptqhip_decode_linear_seq(ctypes.cast(seq, ctypes.c_void_p), len(seq), _stream(device))
+    _lib.check(rc, "gptqhip_decode_linear_seq")
+
+
 def decode_linear(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, bias: Optional[torch.Tensor], K: int,
                   N: int, group_size: int, bits: int, scale_dtype: torch.dtype, **kw) -> torch.Tensor:
     """One-shot convenience wrapper (tests): out[N] of a batch-1 decode op with optional fused glue."""

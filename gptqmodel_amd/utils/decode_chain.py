@@ -5,7 +5,8 @@ RMSNorm / SiLU*mul / residual-add torch kernels between them -- ~20 dependent la
 kernel boundary of 2-3 us (measured: 437 tokens/s for the Llama-3-8B linear stack, profiles/r02_*).  This helper builds
 the same computation from the modules' already-relayouted tensors as 4 launches per layer: sibling projections fused
 (utils.model.fuse_siblings) and the glue fused into the GEMV (input RMSNorm / SiLU*mul, residual-add epilogue).
-All ops are bound once (raw-pointer structs); a step is 4*L ctypes calls, or one HIP graph replay after capture.
+All ops are bound once (raw-pointer structs); a step is ONE host call (gptqhip_decode_linear_seq: 870 tokens/s for the 8B stack
+without any graph), or one HIP graph replay after capture.
 
 Per layer (h = residual stream [hidden], activation dtype):
     qkv = rmsnorm(h; w_in) @ Wqkv                       in_glue RMSNORM
@@ -106,13 +107,13 @@ class DecodeStep:
                                                    out_glue=oglue, stats_in=s_in, stats_out=s_out, perm=perm))
             h_in, st_in = h2, st2
         self.out = h_in
+        self._seq = ops.bind_decode_seq(self.ops)
 
     def run(self) -> torch.Tensor:
-        """Enqueue one decode step on the current stream.  Capture-safe: wrap in torch.cuda.graph() to replay a token as
-        one graph launch."""
+        """Enqueue one decode step on the current stream (ONE host call for the whole chain).  Capture-safe: wrap in
+        torch.cuda.graph() to replay a token as one graph launch."""
         with torch.cuda.device(self.device):
-            for op in self.ops:
-                ops.launch_decode_op(op, self.device)
+            ops.launch_decode_seq(self._seq, self.device)
         return self.out
 
 

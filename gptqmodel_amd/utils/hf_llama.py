@@ -105,8 +105,11 @@ class _LayerDecodeState:
                  out_glue=ops.OUT_SILU_MUL_PAIRED),
             bind(down, self.act, self.h2, residual=self.h1, stats_out=self.st2),
         )
-        self.ops[M] = bound
-        return bound
+        # o_proj -> gate_up -> down_proj run back to back: one host call each way
+        tail_chain = ops.bind_decode_seq([bound[2], bound[4], bound[5]]) if chain_ok else None
+        tail_first = ops.bind_decode_seq([bound[3], bound[4], bound[5]])
+        self.ops[M] = bound + (tail_chain, tail_first)
+        return self.ops[M]
 
 
 def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
@@ -143,7 +146,7 @@ def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, 
         if M == 1:
             fd["disabled"] = True
         return original()
-    op_qkv_chain, op_qkv_first, op_o_chain, op_o_first, op_gu, op_down = st.ops_for(M)
+    op_qkv_chain, op_qkv_first, _, _, _, _, tail_chain, tail_first = st.ops_for(M)
     dev = hidden_states.device
     attn = self.self_attn
     bsz, q_len = hidden_states.shape[0], hidden_states.shape[1]
@@ -157,8 +160,11 @@ def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, 
         # ---- HF's attention between the projections (LlamaAttention.forward, projections removed) ----------------------------
         q_dim, kv_dim, hd = st.q_dim, st.kv_dim, attn.head_dim
         qkv = st.qkv_out[:M]
-        q = qkv[:, :q_dim].reshape(bsz, q_len, -1, hd).transpose(1, 2)
-        k = qkv[:, q_dim:q_dim + kv_dim].reshape(bsz, q_len, -1, hd).transpose(1, 2)
+        q = qkv[:, :q_dim].reshape(bsz, q_len, -1, hd)
+        k = qkv[:, q_dim:q_dim + kv_dim].reshape(bsz, q_len, -1, hd)
+        if fd["qk_norm"]:          # Qwen3-style per-head RMSNorm on q / k (HF's own modules)
+            q, k = attn.q_norm(q), attn.k_norm(k)
+        q, k = q.transpose(1, 2), k.transpose(1, 2)
         v = qkv[:, q_dim + kv_dim:].reshape(bsz, q_len, -1, hd).transpose(1, 2)
         cos, sin = position_embeddings
         q, k = fd["rotary"](q, k, cos, sin)
@@ -170,9 +176,7 @@ def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, 
         attn_out, _ = interface(attn, q, k, v, attention_mask, dropout=0.0, scaling=attn.scaling, **kwargs)
         st.attn_in[:M].copy_(attn_out.reshape(M, -1))
         # ---- o_proj + residual, MLP ---------------------------------------------------------------------------------------------
-        ops.launch_decode_op(op_o_chain if chained else op_o_first, dev)
-        ops.launch_decode_op(op_gu, dev)
-        ops.launch_decode_op(op_down, dev)
+        ops.launch_decode_seq(tail_chain if chained else tail_first, dev)
     return st.h2[:M].view(hidden_states.shape)
 
 
@@ -187,10 +191,11 @@ def _mlp_forward(self, x):
 
 
 # decoder layers whose single-token arithmetic IS the Llama formula the fast path implements (RMSNorm `w * act(x * rsqrt(mean x^2
-# + eps))`, rotary on q / k straight after the projections, SiLU MLP, plain residual adds).  Architectures with per-head q/k norms
-# (Qwen3, OLMo2), (1 + w) norms or GELU (Gemma), parallel residuals etc. are NOT in this list and are left untouched.
-_KNOWN_ATTENTION = ("LlamaAttention", "MistralAttention", "Qwen2Attention")
-_KNOWN_NORMS = ("LlamaRMSNorm", "MistralRMSNorm", "Qwen2RMSNorm")
+# + eps))`, rotary on q / k after the projections (Qwen3: after its per-head q_norm / k_norm, applied through HF's own modules),
+# SiLU MLP, plain residual adds).  Architectures with (1 + w) norms or GELU (Gemma), post-norms (OLMo2), parallel residuals etc.
+# are NOT in this list and are left untouched.
+_KNOWN_ATTENTION = ("LlamaAttention", "MistralAttention", "Qwen2Attention", "Qwen3Attention")
+_KNOWN_NORMS = ("LlamaRMSNorm", "MistralRMSNorm", "Qwen2RMSNorm", "Qwen3RMSNorm")
 
 
 def fuse_llama_decoder_layers(model: nn.Module, allow_unknown: bool = False) -> Tuple[List[nn.Module], List[Tuple[nn.Module, str]]]:
@@ -242,7 +247,8 @@ def fuse_llama_decoder_layers(model: nn.Module, allow_unknown: bool = False) -> 
             continue
         known = (type(attn).__name__ in _KNOWN_ATTENTION and type(layer.input_layernorm).__name__ in _KNOWN_NORMS
                  and type(layer.post_attention_layernorm).__name__ in _KNOWN_NORMS)
-        if any(hasattr(attn, a) for a in ("q_norm", "k_norm")) or (not known and not allow_unknown):
+        qk_norm = hasattr(attn, "q_norm") and hasattr(attn, "k_norm")
+        if (qk_norm and type(attn).__name__ != "Qwen3Attention" and not allow_unknown) or (not known and not allow_unknown):
             skipped.append((layer, f"{type(attn).__name__} / {type(layer.input_layernorm).__name__}: not a known Llama-formula layer"))
             prev = None
             continue
@@ -267,9 +273,12 @@ def fuse_llama_decoder_layers(model: nn.Module, allow_unknown: bool = False) -> 
         mlp.fused_gate_up = gu_group
         del mlp.gate_proj, mlp.up_proj
         mlp.forward = types.MethodType(_mlp_forward, mlp)
+        import sys
+        amod = sys.modules.get(type(attn).__module__)     # the model family's own rotary / eager-attention functions
         layer._gptqhip_fused = {"hidden": in_f, "state": None, "prev": prev, "disabled": False, "workspace": workspace,
-                                "orig_forward": layer.forward, "rotary": rotary, "eager_attention": eager_attention,
-                                "sliding_window": getattr(attn, "sliding_window", None) is not None,
+                                "orig_forward": layer.forward, "rotary": getattr(amod, "apply_rotary_pos_emb", rotary),
+                                "eager_attention": getattr(amod, "eager_attention_forward", eager_attention),
+                                "sliding_window": getattr(attn, "sliding_window", None) is not None, "qk_norm": qk_norm,
                                 "interfaces": ALL_ATTENTION_FUNCTIONS}
         layer.forward = types.MethodType(_layer_forward, layer)
         fused.append(layer)

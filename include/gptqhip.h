@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 9
+#define GPTQHIP_ABI_VERSION 10
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -171,6 +171,9 @@ typedef struct gptqhip_decode_op {
                                     M > 1 (a few sequences, or speculative tokens of one): in_glue NONE | RMSNORM, perm NULL.   */
 } gptqhip_decode_op;
 int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream);
+/* The same for n ops in order on one stream (one host call per dependent run of ops: o_proj -> gate_up -> down_proj of a
+ * decoder layer); stops at the first error. */
+int gptqhip_decode_linear_seq(const gptqhip_decode_op* const* ops, int n, gptqhip_stream_t stream);
 /* 1 if gptqhip_decode_linear supports a [K,N] layer with this group size (has_perm: with an act-order
  * permutation; M: rows, 1..4), else 0. */
 int gptqhip_decode_supported(int K, int N, int group_size, int has_perm, int M);

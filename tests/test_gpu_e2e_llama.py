@@ -56,6 +56,12 @@ def _build(desc_act: bool, fuse, dtype, family="llama"):
         for layer in dense.model.layers:   # (random-init biases are zero: make them matter)
             for n in ("q_proj", "k_proj", "v_proj"):
                 getattr(layer.self_attn, n).bias.data.normal_(0, 0.05)
+    elif family == "qwen3":    # per-head q_norm / k_norm between the projections and rotary
+        from transformers import Qwen3Config, Qwen3ForCausalLM
+        dense = Qwen3ForCausalLM(Qwen3Config(head_dim=dims["hidden_size"] // 8, **common)).to(dtype).cuda().eval()
+        for layer in dense.model.layers:
+            layer.self_attn.q_norm.weight.data.normal_(1.0, 0.1)
+            layer.self_attn.k_norm.weight.data.normal_(1.0, 0.1)
     elif family == "mistral":
         from transformers import MistralConfig, MistralForCausalLM
         dense = MistralForCausalLM(MistralConfig(sliding_window=64, **common)).to(dtype).cuda().eval()
@@ -120,7 +126,7 @@ def test_llama_prefill_and_decode_match_dense_dequantised_model(desc_act, fuse, 
 
 @pytest.mark.parametrize("desc_act,dtype,family", [(False, torch.float16, "llama"), (True, torch.float16, "llama"),
                                                    (False, torch.bfloat16, "llama"), (False, torch.float16, "qwen2"),
-                                                   (False, torch.float16, "mistral")])
+                                                   (False, torch.float16, "mistral"), (False, torch.float16, "qwen3")])
 def test_llama_decoder_layers_on_decode_ops_match_dense(desc_act, dtype, family):
     """fuse_llama_decoder_layers: prefill (HF path through the fused modules) and single-token KV-cache decode (4 decode ops
     per layer around HF's attention) against the dense model holding the dequantised weights; the fast path must have run."""
