@@ -17,7 +17,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libgptqhip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # every symbol include/gptqhip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -57,7 +57,7 @@ class DecodeOp(ctypes.Structure):
                 ("out", _vp), ("workspace", _vp), ("workspace_bytes", _sz), ("stats_in", _vp), ("stats_out", _vp),
                 ("perm", _vp), ("eps", _c.c_float),
                 ("K", _i), ("N", _i), ("group_size", _i), ("bits", _i), ("act_dtype", _i), ("scale_dtype", _i),
-                ("in_glue", _i), ("out_glue", _i), ("stats_n", _i), ("M", _i)]
+                ("in_glue", _i), ("out_glue", _i), ("stats_n", _i), ("flags", _i), ("M", _i)]
 
 
 _lock = threading.Lock()

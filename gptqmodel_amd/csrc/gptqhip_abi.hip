@@ -366,6 +366,7 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
     char* ws = reinterpret_cast<char*>(op->workspace);
     GemmArgs a;
     a.x = op->x;
+    a.exact_bf16 = (op->flags & GPTQHIP_GEMM_EXACT_BF16) ? 1 : 0;
     a.perm = op->perm;
     a.qweight = op->qweight_t;
     a.meta = op->meta;

@@ -288,8 +288,8 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
 }
 
 template <int BITS, int ACT, int GPC, int AM>
-__host__ __device__ constexpr bool kExactBf16() {
-    return BITS == 4 && ACT == kBF16 && GPC == 1 && (AM == AM_ROW1 || AM == AM_ROW1P || AM == AM_ROW4);
+__host__ __device__ constexpr bool kExactBf16() {   // (historic name: the opt-in exact-arithmetic path exists for fp16 too)
+    return BITS == 4 && GPC == 1 && (AM == AM_ROW1 || AM == AM_ROW1P || AM == AM_ROW4);
 }
 
 template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int GLUE = 0>
@@ -341,19 +341,24 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
         // max|y| measured) away from the reference's rounding chain -- inside the reference's own acceptance for other
         // kernels (atol 8e-3 + rtol 0.15, tests/kernels/test_gptq.py:255,321-360) but outside this repo's default
         // gate, hence a flag and not the default.
+        // fp16 activations (round 2, GPTQHIP_GEMM_EXACT on any activation dtype): the same with (nibble | 0x6400) = 1024 + q and
+        // a fragment of fp16 ones; fp16 x fp16 products are exact in fp32 too.  Replaces 13 VALU per word by 7 (+ 8 per chunk);
+        // differs from the reference's chain by single output ulps (the per-weight fp16 rounding it skips is ~2^-12 relative).
         const uint32_t mw = st.meta[0];
         const float s = bits16_to_f32<SCL>((uint16_t)(mw & 0xffffu));
-        const float zc = 128.f + (float)((mw >> 16) & 0xFu);
-        const u4_t ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+        const float zc = (ACT == kBF16 ? 128.f : 1024.f) + (float)((mw >> 16) & 0xFu);
+        const uint32_t one2 = ACT == kBF16 ? 0x3F803F80u : 0x3C003C00u;
+        const uint32_t magic = ACT == kBF16 ? dk.magic_bf : dk.magic;
+        const u4_t ones = {one2, one2, one2, one2};
         f4_t ag = {0.f, 0.f, 0.f, 0.f}, sg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t w = st.w[0][j];
             u4_t b;
-            b.x = and_or(w, dk.lo, dk.magic_bf);        // k0,k1
-            b.y = and_or(w >> 4, dk.lo, dk.magic_bf);   // k2,k3
-            b.z = and_or(w >> 8, dk.lo, dk.magic_bf);   // k4,k5
-            b.w = and_or(w >> 12, dk.lo, dk.magic_bf);  // k6,k7
+            b.x = and_or(w, dk.lo, magic);        // k0,k1
+            b.y = and_or(w >> 4, dk.lo, magic);   // k2,k3
+            b.z = and_or(w >> 8, dk.lo, magic);   // k4,k5
+            b.w = and_or(w >> 12, dk.lo, magic);  // k6,k7
             const u4_t av = aslot[abase + 4 * j + rq];
             ag = mfma16<ACT>(av, b, ag);
             sg = mfma16<ACT>(av, ones, sg);

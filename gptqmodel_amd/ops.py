@@ -189,12 +189,13 @@ def make_decode_op(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor,
                    norm_weight: Optional[torch.Tensor] = None, eps: float = 1e-5, residual: Optional[torch.Tensor] = None,
                    workspace: Optional[torch.Tensor] = None, out_glue: int = OUT_NONE,
                    stats_in: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None,
-                   perm: Optional[torch.Tensor] = None, M: int = 1) -> "_lib.DecodeOp":
+                   perm: Optional[torch.Tensor] = None, M: int = 1, exact: bool = False) -> "_lib.DecodeOp":
     """Fill a struct gptqhip_decode_op (include/gptqhip.h) from tensors.  The struct only holds raw pointers: the caller
     keeps the tensors alive (DecodeStep does) -- binding once and re-launching costs no per-call Python work.
     `workspace`: the stream's scratch (workspace_for); taken from the CURRENT stream when omitted.
     `perm`: the module's act-order permutation (int32 [K]); applied to the glued input inside the kernel.
-    `M`: rows (1..4): x [M,K], out / residual [M,N], stats_in [M, K/16], stats_out [M, ceil(N/16)], all contiguous."""
+    `M`: rows (1..4): x [M,K], out / residual [M,N], stats_in [M, K/16], stats_out [M, ceil(N/16)], all contiguous.
+    `exact`: the opt-in exact-arithmetic dequant (GPTQHIP_GEMM_EXACT, include/gptqhip.h)."""
     _require_cuda(x, qweight_t, meta, bias, out, norm_weight, residual, workspace, stats_in, stats_out, perm)
     if not 1 <= M <= 4:
         raise RuntimeError("decode op: M must be 1..4")
@@ -222,7 +223,8 @@ def make_decode_op(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor,
     p = lambda t: 0 if t is None else t.data_ptr()
     return _lib.DecodeOp(p(qweight_t), p(meta), p(bias), p(x), p(norm_weight), p(residual), p(out), p(workspace),
                          workspace.numel(), p(stats_in), p(stats_out), p(perm), float(eps), K, N, group_size, bits, _DT[x.dtype],
-                         _DT[scale_dtype], int(in_glue), int(out_glue), tiles_in if stats_in is not None else 0, int(M))
+                         _DT[scale_dtype], int(in_glue), int(out_glue), tiles_in if stats_in is not None else 0,
+                         2 if exact else 0, int(M))
 
 
 def launch_decode_op(op: "_lib.DecodeOp", device: torch.device) -> None:

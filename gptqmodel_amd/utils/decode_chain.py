@@ -57,7 +57,8 @@ def _lin_tensors(lin, dtype):
 
 class DecodeStep:
     def __init__(self, layers: Sequence[DecodeLayer], hidden: int, q_dim: int, dtype: torch.dtype, eps: float = 1e-5,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, exact: bool = False):
+        """exact: the opt-in exact-arithmetic dequant (GPTQHIP_GEMM_EXACT; not the reference's per-weight rounding chain)."""
         if not layers:
             raise ValueError("no layers")
         self.layers = list(layers)
@@ -104,7 +105,7 @@ class DecodeStep:
                 self._keep.extend([qw, meta, bias, nw, perm])
                 self.ops.append(ops.make_decode_op(x, qw, meta, bias, out, K, N, lin.group_size, lin.bits, sdt, in_glue=glue,
                                                    norm_weight=nw, eps=eps, residual=res, workspace=self.workspace,
-                                                   out_glue=oglue, stats_in=s_in, stats_out=s_out, perm=perm))
+                                                   out_glue=oglue, stats_in=s_in, stats_out=s_out, perm=perm, exact=exact))
             h_in, st_in = h2, st2
         self.out = h_in
         self._seq = ops.bind_decode_seq(self.ops)
