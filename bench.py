@@ -539,19 +539,20 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
         del g
     except Exception as e:  # noqa: BLE001
         res.append({"config": "C2", "mode": "independent launches", "error": str(e)[:300]})
-    # opt-in exact-arithmetic dequant (GPTQHIP_GEMM_EXACT): NOT the default and not the headline -- it skips the reference's
-    # per-weight rounding (single output ulps away from its chain); shows what the bit-faithful dequant costs
-    try:
-        from gptqmodel_amd.utils.decode_chain import DecodeStep as _DSx
-        st = _DSx(layers, cfg["hidden"], cfg["q"], dtype, exact=True)
-        st.x_in.copy_((torch.randn(cfg["hidden"], device=dev, generator=gen) * 0.5).to(dtype))
-        ms, g = time_graph(st.run, stream, 100, 10)
-        res.append(decode_entry("C2", "decode chain with the OPT-IN exact-arithmetic dequant (GPTQHIP_GEMM_EXACT; leaves the reference's "
-                                "per-weight rounding chain by single output ulps -- not the default, not the headline)", cfg, ms, n_launch,
-                                extra={"mode": "chain, exact-arithmetic opt-in"}))
-        del g, st
-    except Exception as e:  # noqa: BLE001
-        res.append({"config": "C2", "mode": "chain, exact-arithmetic opt-in", "error": str(e)[:300]})
+    # opt-in exact-arithmetic dequant (GPTQHIP_GEMM_EXACT_BF16; bf16 activations only): NOT the default and not the headline -- it
+    # skips the reference's per-weight rounding (up to 2 output ulps away from its chain)
+    if dtype == torch.bfloat16:
+        try:
+            from gptqmodel_amd.utils.decode_chain import DecodeStep as _DSx
+            st = _DSx(layers, cfg["hidden"], cfg["q"], dtype, exact=True)
+            st.x_in.copy_((torch.randn(cfg["hidden"], device=dev, generator=gen) * 0.5).to(dtype))
+            ms, g = time_graph(st.run, stream, 100, 10)
+            res.append(decode_entry("C2", "bf16 decode chain with the OPT-IN exact-arithmetic dequant (GPTQHIP_GEMM_EXACT_BF16; leaves the "
+                                    "reference's per-weight rounding chain -- not the default, not the headline)", cfg, ms, n_launch,
+                                    extra={"mode": "chain, exact-arithmetic opt-in"}))
+            del g, st
+        except Exception as e:  # noqa: BLE001
+            res.append({"config": "C2", "mode": "chain, exact-arithmetic opt-in", "error": str(e)[:300]})
     # headline-model prefill (one decoder layer at M=8192, desc_act=False) -- the TFLOPS half of the metric
     L0 = layers[0]
     lins = [L0.qkv, L0.o, L0.gate_up, L0.down]

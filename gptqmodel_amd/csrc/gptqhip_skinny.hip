@@ -288,8 +288,12 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
 }
 
 template <int BITS, int ACT, int GPC, int AM>
-__host__ __device__ constexpr bool kExactBf16() {   // (historic name: the opt-in exact-arithmetic path exists for fp16 too)
-    return BITS == 4 && GPC == 1 && (AM == AM_ROW1 || AM == AM_ROW1P || AM == AM_ROW4);
+__host__ __device__ constexpr bool kExactBf16() {
+    // bf16 activations only.  The same form for fp16 ((nibble | 0x6400) = 1024 + q) was built and measured in round 2: as a runtime
+    // branch it slowed the DEFAULT fp16 kernels by 2 % on narrow layers and gained 2.8 % when on; as separate instantiations it
+    // left the default alone and ran 5 % SLOWER than it -- the bit-faithful fp16 dequant (13 VALU per word) is not what holds
+    // decode back, so there is no fp16 variant.
+    return BITS == 4 && ACT == kBF16 && GPC == 1 && (AM == AM_ROW1 || AM == AM_ROW1P || AM == AM_ROW4);
 }
 
 template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int GLUE = 0>
@@ -341,15 +345,11 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
         // max|y| measured) away from the reference's rounding chain -- inside the reference's own acceptance for other
         // kernels (atol 8e-3 + rtol 0.15, tests/kernels/test_gptq.py:255,321-360) but outside this repo's default
         // gate, hence a flag and not the default.
-        // fp16 activations (round 2, GPTQHIP_GEMM_EXACT on any activation dtype): the same with (nibble | 0x6400) = 1024 + q and
-        // a fragment of fp16 ones; fp16 x fp16 products are exact in fp32 too.  Replaces 13 VALU per word by 7 (+ 8 per chunk);
-        // differs from the reference's chain by single output ulps (the per-weight fp16 rounding it skips is ~2^-12 relative).
         const uint32_t mw = st.meta[0];
         const float s = bits16_to_f32<SCL>((uint16_t)(mw & 0xffffu));
-        const float zc = (ACT == kBF16 ? 128.f : 1024.f) + (float)((mw >> 16) & 0xFu);
-        const uint32_t one2 = ACT == kBF16 ? 0x3F803F80u : 0x3C003C00u;
-        const uint32_t magic = ACT == kBF16 ? dk.magic_bf : dk.magic;
-        const u4_t ones = {one2, one2, one2, one2};
+        const float zc = 128.f + (float)((mw >> 16) & 0xFu);
+        const uint32_t magic = dk.magic_bf;
+        const u4_t ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
         f4_t ag = {0.f, 0.f, 0.f, 0.f}, sg = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

@@ -104,14 +104,13 @@ int gptqhip_repack_tiled(const int32_t* qweight, const int32_t* qzeros, const vo
  *   flags    GPTQHIP_GEMM_PARTIAL_F32: `out` is float32 [M,N] and receives the UNROUNDED fp32 accumulators (bias
  *            must be NULL) -- the partial sums a row-parallel (K-sharded) tensor-parallel layer all-reduces before
  *            rounding once, so TP reproduces the single-GPU rounding chain.
- *            GPTQHIP_GEMM_EXACT (= GPTQHIP_GEMM_EXACT_BF16; opt-in, default off): 4-bit weights, group_size % 128 == 0,
- *            M <= 4: accumulate the exact products s*(q-z)*x instead of first rounding every weight to the scale /
- *            activation dtype like torch.py:326-335 does (7 instead of 13-16 VALU per packed word).  The result is the
- *            exact-arithmetic value: single output ulps (fp16) / up to 2 output ulps (bf16) away from the reference's
- *            rounding chain; ignored where the fast form does not exist (8-bit, sub-128 groups, M > 4). */
+ *            GPTQHIP_GEMM_EXACT_BF16 (opt-in, default off): bf16 activations, 4-bit weights, group_size % 128 == 0,
+ *            M <= 4: accumulate the exact products s*(q-z)*x instead of first rounding every weight to bf16 like
+ *            torch.py:326-335 does (gfx950 has no packed bf16 VALU; 7 instead of 16 VALU per packed word).  The result is
+ *            the exact-arithmetic value, up to 2 output ulps away from the reference's chain; ignored elsewhere
+ *            (fp16 activations included: measured there, it does not pay -- DESIGN.md 4.1.1). */
 #define GPTQHIP_GEMM_PARTIAL_F32 1
 #define GPTQHIP_GEMM_EXACT_BF16 2
-#define GPTQHIP_GEMM_EXACT GPTQHIP_GEMM_EXACT_BF16   /* round 2: the same opt-in for fp16 activations */
 int gptqhip_gemm(const void* x, const uint32_t* qweight_t, const uint32_t* meta,
                  const int32_t* perm, const void* bias, void* out,
                  void* workspace, size_t workspace_bytes,
@@ -169,7 +168,7 @@ typedef struct gptqhip_decode_op {
                                     kernel, or NULL.  Needs K * 2 bytes <= 44 KiB (else gather first).                */
     float eps;
     int K, N, group_size, bits, act_dtype, scale_dtype, in_glue, out_glue, stats_n;
-    int flags;                   /* 0 or GPTQHIP_GEMM_EXACT_BF16 (= GPTQHIP_GEMM_EXACT: the opt-in exact-arithmetic dequant)          */
+    int flags;                   /* 0 or GPTQHIP_GEMM_EXACT_BF16 (the opt-in exact-arithmetic dequant, bf16 activations)                */
     int M;                       /* rows (1..4): x [M,K], residual / out [M,N], stats_in [M][stats_n], stats_out [M][ceil(N/16)].
                                     M > 1 (a few sequences, or speculative tokens of one): in_glue NONE | RMSNORM, perm NULL.   */
 } gptqhip_decode_op;
