@@ -281,6 +281,10 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
     } else if constexpr (is_rows<AM>()) {
 #pragma unroll
         for (int i = 0; i < row_quads<AM, MT>(); ++i) st.x.a[i] = *reinterpret_cast<const u4_t*>(xsrc + lo.x[i]);
+        if constexpr (AM == AM_ROWSH && MT == 1 && GLUE == kGlueRmsNorm) {
+            // decode op on 5..8 rows: the norm-weight segment rides in the stage's last (unused: quads 2, 3 are skipped) register
+            st.x.a[3] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (xsrc - tb.x) + tb.c4 * 4u);
+        }
     }
     cu.w += (size_t)stride_chunks * (WPC * 1024);
     cu.x += (size_t)stride_chunks * 256;
@@ -299,7 +303,7 @@ __host__ __device__ constexpr bool kExactBf16() {
 template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int GLUE = 0>
 __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st, const SkinnyParams& p, int chunk,
                                               int lane, u4_t* aslot, const DequantConsts& dk, f4_t (&acc)[MT],
-                                              const uint16_t* xbuf = nullptr, float inv = 0.f) {
+                                              const uint16_t* xbuf = nullptr, float inv = 0.f, float inv2 = 0.f) {
     const int c = lane & 15;
     const int rq = lane >> 4;
     int abase = 0;  // u4 index of this lane's fragment row inside the wave's LDS slot
@@ -330,8 +334,18 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
         abase = (c < p.M ? c : 0) << 4;  // lanes of unused rows re-read row 0: a broadcast, no extra bank traffic
     } else if constexpr (is_rows<AM>()) {
         // rows of skipped quads keep whatever the slot held: they only feed output rows >= M, which nobody stores
+        if constexpr (AM == AM_ROWSH && MT == 1 && GLUE == kGlueRmsNorm) {
 #pragma unroll
-        for (int i = 0; i < row_quads<AM, MT>(); ++i) aslot[(4 * i + rq) * kRowsPitch + c] = st.x.a[i];
+            for (int i = 0; i < 2; ++i) {   // row 4 i + rq with its own 1/rms (inv: rows 0..3, inv2: rows 4..7)
+                u4_t g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = glue_pair<ACT>(st.x.a[i][j], st.x.a[3][j], i == 0 ? inv : inv2, GLUE);
+                aslot[(4 * i + rq) * kRowsPitch + c] = g;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < row_quads<AM, MT>(); ++i) aslot[(4 * i + rq) * kRowsPitch + c] = st.x.a[i];
+        }
     }
     if (kExactBf16<BITS, ACT, GPC, AM>() && p.exact_bf16) {
         // OPT-IN (GPTQHIP_GEMM_EXACT_BF16; block-uniform branch).  bf16 activations, 4-bit codes, one group per chunk,
@@ -431,17 +445,20 @@ __device__ __forceinline__ void finish_outputs(const SkinnyParams& p, float v, b
     } else if (p.out_glue == kOutSiluMul || p.stats_out != nullptr) {
         // decode op (M <= 4) epilogues that combine a tile's 16 outputs of one row: reducer wave w holds row w in lanes 0..15
         // (accumulator register w of the lanes with rq == 0) and runs them wave-uniformly so the lane shuffles are legal
-        if (wave < p.M) {
+        if (wave < 4 && wave < p.M) {
+            // reducer wave w: lanes 0..15 hold row w, lanes 16..31 row w + 4 (live when < M); all shuffles below stay inside a
+            // 16-lane group
             const int tiles = (p.N + kTileN - 1) / kTileN;
+            const int c16 = lane & 15;
             float y = round_through<ACT>(v);
             if (p.bias != nullptr && live) y = round_through<ACT>(y + load16_as_f32<ACT>(p.bias, (size_t)n));
             if (p.out_glue == kOutSiluMul) {
-                // interleaved gate|up tile (fuse_gate_up_interleaved): lanes 0..7 hold gate columns j, lanes 8..15 the matching
-                // up columns; HF LlamaMLP: act(silu(gate)) * up, each rounded in the activation dtype
+                // interleaved gate|up tile (fuse_gate_up_interleaved): lanes 0..7 of a group hold gate columns j, lanes 8..15 the
+                // matching up columns; HF LlamaMLP: act(silu(gate)) * up, each rounded in the activation dtype
                 const float up = __shfl_down(y, 8, 64);
                 const float a = round_through<ACT>(y / (1.0f + __expf(-y))) * up;
-                const int j = tile * 8 + lane;
-                if (live && lane < 8 && j < p.N / 2) reinterpret_cast<uint16_t*>(p.out)[(size_t)m * (p.N / 2) + j] = f32_to_16<ACT>(a);
+                const int j = tile * 8 + c16;
+                if (live && c16 < 8 && j < p.N / 2) reinterpret_cast<uint16_t*>(p.out)[(size_t)m * (p.N / 2) + j] = f32_to_16<ACT>(a);
             } else {
                 if (p.residual != nullptr) y = bits16_to_f32<ACT>((uint16_t)(res_raw >> ((lane & 1) * 16))) + y;
                 const float h = round_through<ACT>(y);
@@ -449,7 +466,7 @@ __device__ __forceinline__ void finish_outputs(const SkinnyParams& p, float v, b
                 float sq = live ? h * h : 0.f;  // RMSNorm statistic of the NEXT op: fixed shuffle tree over the 16 columns
 #pragma unroll
                 for (int mk = 8; mk >= 1; mk >>= 1) sq += __shfl_xor(sq, mk, 64);
-                if (lane == 0) p.stats_out[(size_t)wave * tiles + tile] = sq;
+                if (c16 == 0 && m < p.M) p.stats_out[(size_t)m * tiles + tile] = sq;
             }
         }
     } else if (live) {
@@ -501,11 +518,12 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     // decode op: the residual of this tile's row-0 outputs (reducer lanes = wave 0, lanes 0..15) is requested up front as
     // the aligned 32-bit pair holding the column (no zero-extension ALU op behind the load -> no early wait), used in the
     // epilogue; glue_inv = RMSNorm's rsqrt(mean(h^2) + eps)
-    float glue_inv = 0.f;
+    float glue_inv = 0.f, glue_inv2 = 0.f;   // (glue_inv2: rows 4..7 of the 5..8-row decode op)
     uint32_t res_raw = 0u;
-    if (p.residual != nullptr && wave < p.M && lane < 16) {   // (decode op: M <= 4, reducer wave w holds output row w)
-        const int coln = tile * kTileN + lane;
-        res_raw = reinterpret_cast<const uint32_t*>(p.residual)[((size_t)wave * p.N + (coln < p.N ? coln : 0)) >> 1];
+    if (p.residual != nullptr && wave < 4 && lane < 32 && wave + 4 * rq < p.M) {
+        // (decode op: M <= 8; reducer wave w holds output rows w (lanes 0..15) and w + 4 (lanes 16..31))
+        const int coln = tile * kTileN + c;
+        res_raw = reinterpret_cast<const uint32_t*>(p.residual)[((size_t)(wave + 4 * rq) * p.N + (coln < p.N ? coln : 0)) >> 1];
     }
 
     // D-deep register ring: every load of a chunk (weights, constants, activations) is issued D chunks ahead,
@@ -630,56 +648,69 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
                     reinterpret_cast<u4_t*>(xbuf)[idx] = glued(xs[idx], gv);
                 }
                 __syncthreads();
-            } else if constexpr (AM == AM_ROW4 && GLUE == kGlueRmsNorm) {
-                // decode op on up to four rows: wave w (< M) owns row w's RMSNorm statistic -- the producer's per-tile sums of
-                // squares (eight clamped loads per lane, in front of the weight ring), or a wave-local reduction of the row when
-                // there is no producer (first op of a step) -- and shares 1/rms through LDS
+            } else if constexpr ((AM == AM_ROW4 || (AM == AM_ROWSH && MT == 1)) && GLUE == kGlueRmsNorm) {
+                // decode op on up to eight rows: wave w (< 4) owns the RMSNorm statistics of rows w and w + 4 -- the producer's
+                // per-tile sums of squares (eight clamped loads per lane and row, in front of the weight ring), or a wave-local
+                // reduction of the row when there is no producer (first op of a step) -- and shares 1/rms through LDS
                 float* scratch = reinterpret_cast<float*>(xbuf);
-                const bool mine = wave < p.M;
-                float sv[8];
+                constexpr int RPW = AM == AM_ROW4 ? 1 : 2;   // rows per wave
+                float sv[RPW][8];
                 if (p.stats_in != nullptr) {
-                    if (mine) {
-                        const float* srow = p.stats_in + (size_t)wave * p.stats_n;
-                        const int last = p.stats_n - 1;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const int idx = lane + 64 * i;
-                            sv[i] = srow[idx < last ? idx : last];
+                    for (int r = 0; r < RPW; ++r) {
+                        const int row = wave + 4 * r;
+                        if (wave < 4 && row < p.M) {
+                            const float* srow = p.stats_in + (size_t)row * p.stats_n;
+                            const int last = p.stats_n - 1;
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const int idx = lane + 64 * i;
+                                sv[r][i] = srow[idx < last ? idx : last];
+                            }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
-                    if (mine) {
-                        float ssum = 0.f;
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) ssum += (lane + 64 * i < p.stats_n) ? sv[i] : 0.f;
+                    for (int r = 0; r < RPW; ++r) {
+                        const int row = wave + 4 * r;
+                        if (wave < 4 && row < p.M) {
+                            float ssum = 0.f;
 #pragma unroll
-                        for (int mk = 32; mk >= 1; mk >>= 1) ssum += __shfl_xor(ssum, mk, 64);
-                        if (lane == 0) scratch[wave] = rsqrtf(ssum / (float)p.K + p.eps);
+                            for (int i = 0; i < 8; ++i) ssum += (lane + 64 * i < p.stats_n) ? sv[r][i] : 0.f;
+#pragma unroll
+                            for (int mk = 32; mk >= 1; mk >>= 1) ssum += __shfl_xor(ssum, mk, 64);
+                            if (lane == 0) scratch[row] = rsqrtf(ssum / (float)p.K + p.eps);
+                        }
                     }
                 } else {
-                    if (mine) {
-                        const u4_t* hs = reinterpret_cast<const u4_t*>(p.x) + (size_t)wave * (p.K / 8);
-                        float ss = 0.f;
-                        for (int idx = lane; idx < p.K / 8; idx += 64) {
-                            const u4_t h = hs[idx];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float a = bits16_to_f32<ACT>((uint16_t)(h[j] & 0xffffu)), b = bits16_to_f32<ACT>((uint16_t)(h[j] >> 16));
-                                ss = __builtin_fmaf(a, a, ss);
-                                ss = __builtin_fmaf(b, b, ss);
+                    for (int r = 0; r < RPW; ++r) {
+                        const int row = wave + 4 * r;
+                        if (wave < 4 && row < p.M) {
+                            const u4_t* hs = reinterpret_cast<const u4_t*>(p.x) + (size_t)row * (p.K / 8);
+                            float ss = 0.f;
+                            for (int idx = lane; idx < p.K / 8; idx += 64) {
+                                const u4_t h = hs[idx];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const float a = bits16_to_f32<ACT>((uint16_t)(h[j] & 0xffffu)), b = bits16_to_f32<ACT>((uint16_t)(h[j] >> 16));
+                                    ss = __builtin_fmaf(a, a, ss);
+                                    ss = __builtin_fmaf(b, b, ss);
+                                }
                             }
-                        }
 #pragma unroll
-                        for (int mk = 32; mk >= 1; mk >>= 1) ss += __shfl_xor(ss, mk, 64);
-                        if (lane == 0) scratch[wave] = rsqrtf(ss / (float)p.K + p.eps);
+                            for (int mk = 32; mk >= 1; mk >>= 1) ss += __shfl_xor(ss, mk, 64);
+                            if (lane == 0) scratch[row] = rsqrtf(ss / (float)p.K + p.eps);
+                        }
                     }
 #pragma unroll
                     for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
                 }
                 __syncthreads();
                 glue_inv = scratch[rq < p.M ? rq : 0];
+                if constexpr (AM == AM_ROWSH) glue_inv2 = scratch[4 + rq < p.M ? 4 + rq : 0];
             } else if (GLUE == kGlueRmsNorm && p.stats_in != nullptr) {
                 // RMSNorm statistics handed over by the op that produced h (one partial per 16-column tile: its epilogue's
                 // sum of out^2).  ONE wave per block sums them in a fixed order -- eight clamped loads per lane issued in
@@ -752,7 +783,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
             for (int it = D; it < n_mine; it += D) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE>(st[d], p, cur, lane, aslot, dk, acc, xbuf, glue_inv);
+                    compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE>(st[d], p, cur, lane, aslot, dk, acc, xbuf, glue_inv, glue_inv2);
                     load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
                     cur += W;
                 }
@@ -760,7 +791,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 // (only the last ring round can hold padding chunks: wave-uniform skip)
-                if (cur < c_end) compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE>(st[d], p, cur, lane, aslot, dk, acc, xbuf, glue_inv);
+                if (cur < c_end) compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE>(st[d], p, cur, lane, aslot, dk, acc, xbuf, glue_inv, glue_inv2);
                 cur += W;
             }
         }
@@ -829,11 +860,12 @@ static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStr
     const dim3 block(64 * pl.waves);
     constexpr int kSlot = slot_bytes<AM, MT>() > MT * 1024 ? slot_bytes<AM, MT>() : MT * 1024;
     const size_t lds_bytes = (size_t)pl.waves * kSlot + 16 + (AM == AM_ROW1P ? (size_t)p.K * 2 + 80 : 64);
-    if constexpr ((AM == AM_ROW1 && MT == 1 && (D == 4 || D == 2)) || (AM == AM_ROW1P && MT == 1 && D == 4) || (AM == AM_ROW4 && MT == 1 && D == 4)) {
+    if constexpr ((AM == AM_ROW1 && MT == 1 && (D == 4 || D == 2)) || (AM == AM_ROW1P && MT == 1 && D == 4) || (AM == AM_ROW4 && MT == 1 && D == 4) ||
+                  (AM == AM_ROWSH && MT == 1 && D == 2)) {
         if (p.in_glue != kGlueNone) {  // decode op with input glue: regular single-group-per-chunk plans only (ABI checks)
             if (p.in_glue == kGlueRmsNorm) {
                 hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueRmsNorm>), grid, block, lds_bytes, stream, p);
-            } else if constexpr (AM != AM_ROW4) {
+            } else if constexpr (AM != AM_ROW4 && AM != AM_ROWSH) {
                 hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueSiluMul>), grid, block, lds_bytes, stream, p);
             } else {
                 set_error("decode op: SiLU*mul INPUT glue exists for one row only (use the paired gate_up epilogue)");

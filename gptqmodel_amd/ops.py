@@ -180,7 +180,7 @@ OUT_NONE, OUT_SILU_MUL_PAIRED, OUT_PARTIAL_F32 = 0, 1, 2
 
 def decode_supported(K: int, N: int, group_size: int, has_perm: bool = False, M: int = 1) -> bool:
     """True when gptqhip_decode_linear handles a [K,N] layer (regular pipeline; has_perm: with an act-order permutation
-    applied in the kernel; M: rows 1..4), else use gemm()."""
+    applied in the kernel; M: rows 1..8), else use gemm()."""
     return bool(_lib.load().gptqhip_decode_supported(K, N, group_size, 1 if has_perm else 0, M))
 
 
@@ -194,11 +194,11 @@ def make_decode_op(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor,
     keeps the tensors alive (DecodeStep does) -- binding once and re-launching costs no per-call Python work.
     `workspace`: the stream's scratch (workspace_for); taken from the CURRENT stream when omitted.
     `perm`: the module's act-order permutation (int32 [K]); applied to the glued input inside the kernel.
-    `M`: rows (1..4): x [M,K], out / residual [M,N], stats_in [M, K/16], stats_out [M, ceil(N/16)], all contiguous.
+    `M`: rows (1..8): x [M,K], out / residual [M,N], stats_in [M, K/16], stats_out [M, ceil(N/16)], all contiguous.
     `exact`: the opt-in exact-arithmetic dequant (GPTQHIP_GEMM_EXACT, include/gptqhip.h)."""
     _require_cuda(x, qweight_t, meta, bias, out, norm_weight, residual, workspace, stats_in, stats_out, perm)
-    if not 1 <= M <= 4:
-        raise RuntimeError("decode op: M must be 1..4")
+    if not 1 <= M <= 8:
+        raise RuntimeError("decode op: M must be 1..8")
     if perm is not None and (perm.dtype != torch.int32 or perm.numel() != K or not perm.is_contiguous()):
         raise RuntimeError("decode op: perm must be a contiguous int32 [K] tensor")
     want_out = torch.float32 if out_glue == OUT_PARTIAL_F32 else x.dtype

@@ -8,7 +8,7 @@ product and two residual adds: ~16 dependent launches per layer.  `fuse_llama_de
   * folds an act-order checkpoint's down_proj input permutation into gate / up's output columns (utils.model.
     fold_act_order_into_producers: exact, removes down_proj's activation gather), fuses q/k/v into one module (views stand in for the three projections, as with fuse_siblings) and gate/up into ONE
     module with the columns interleaved in blocks of 8 (utils.model.fuse_gate_up_interleaved);
-  * gives every decoder layer a decode fast path: when the layer is called with at most FOUR tokens (batch x q_len <= 4, eval:
+  * gives every decoder layer a decode fast path: when the layer is called with at most EIGHT tokens (batch x q_len <= 8, eval:
     single-sequence decode, a few sequences, or speculative tokens of one), the layer runs as 4 decode ops (gptqhip_decode_linear: RMSNorm on the input of qkv / gate_up with the statistics handed
     over by the op that produced the residual stream, SiLU*mul in the gate_up epilogue, residual add + next statistics in
     the o / down epilogue) around HF's own rotary / KV-cache update / attention call.  Everything else (prefill, batches,
@@ -40,7 +40,7 @@ def _is_quant(m) -> bool:
     return isinstance(m, BaseQuantLinear) and getattr(m, "adapter", None) is None
 
 
-MAX_ROWS = 4   # tokens per call on the fast path (gptqhip_decode_op.M): a few sequences at q_len 1, or speculative tokens of one
+MAX_ROWS = 8   # tokens per call on the fast path (gptqhip_decode_op.M): a few sequences at q_len 1, or speculative tokens of one
 
 
 class _LayerDecodeState:

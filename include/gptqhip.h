@@ -169,7 +169,7 @@ typedef struct gptqhip_decode_op {
     float eps;
     int K, N, group_size, bits, act_dtype, scale_dtype, in_glue, out_glue, stats_n;
     int flags;                   /* 0 or GPTQHIP_GEMM_EXACT_BF16 (the opt-in exact-arithmetic dequant, bf16 activations)                */
-    int M;                       /* rows (1..4): x [M,K], residual / out [M,N], stats_in [M][stats_n], stats_out [M][ceil(N/16)].
+    int M;                       /* rows (1..8): x [M,K], residual / out [M,N], stats_in [M][stats_n], stats_out [M][ceil(N/16)].
                                     M > 1 (a few sequences, or speculative tokens of one): in_glue NONE | RMSNORM, perm NULL.   */
 } gptqhip_decode_op;
 int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream);
@@ -177,7 +177,7 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream);
  * decoder layer); stops at the first error. */
 int gptqhip_decode_linear_seq(const gptqhip_decode_op* const* ops, int n, gptqhip_stream_t stream);
 /* 1 if gptqhip_decode_linear supports a [K,N] layer with this group size (has_perm: with an act-order
- * permutation; M: rows, 1..4), else 0. */
+ * permutation; M: rows, 1..8), else 0. */
 int gptqhip_decode_supported(int K, int N, int group_size, int has_perm, int M);
 
 /* Materialise W[K,N] from the CHECKPOINT layout in `out_dtype` (= scales dtype in the reference).  Replaces

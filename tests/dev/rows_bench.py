@@ -11,7 +11,7 @@ NL = 24
 stream = torch.cuda.Stream()
 SHAPES = [("qkv", 4096, 6144, True, False, False), ("o", 4096, 4096, False, True, False),
           ("gate_up", 4096, 28672, True, False, True), ("down", 14336, 4096, False, True, False)]
-for M in (1, 2, 3, 4):
+for M in (1, 2, 4, 6, 8):
     tot = 0.0
     line = [f"M={M}"]
     for name, K, N, rms, res, paired in SHAPES:

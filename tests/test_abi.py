@@ -74,9 +74,9 @@ def test_decode_op_shape_predicate_is_host_logic(lib):
     # act-order in the kernel: 4-deep ring only, and the x row must fit in LDS next to the wave slots
     assert lib.gptqhip_decode_supported(4096, 4096, 128, 1, 1) == 1 and lib.gptqhip_decode_supported(14336, 4096, 128, 1, 1) == 1
     assert lib.gptqhip_decode_supported(1024, 1024, 128, 1, 1) == 0 and lib.gptqhip_decode_supported(28672, 8192, 128, 1, 1) == 0
-    # up to four rows (no permutation there); five are gptqhip_gemm's business
-    assert lib.gptqhip_decode_supported(4096, 28672, 128, 0, 4) == 1 and lib.gptqhip_decode_supported(14336, 4096, 128, 0, 3) == 1
-    assert lib.gptqhip_decode_supported(4096, 4096, 128, 0, 5) == 0 and lib.gptqhip_decode_supported(4096, 4096, 128, 1, 2) == 0
+    # up to eight rows (no permutation there); nine are gptqhip_gemm's business
+    assert lib.gptqhip_decode_supported(4096, 28672, 128, 0, 4) == 1 and lib.gptqhip_decode_supported(14336, 4096, 128, 0, 8) == 1
+    assert lib.gptqhip_decode_supported(4096, 4096, 128, 0, 9) == 0 and lib.gptqhip_decode_supported(4096, 4096, 128, 1, 2) == 0
 
 
 def test_argument_validation_reports_errors_without_a_gpu(lib):

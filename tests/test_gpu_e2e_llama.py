@@ -166,10 +166,13 @@ def test_llama_decoder_layers_on_decode_ops_match_dense(desc_act, dtype, family)
         s_q = quant(input_ids=nxt, past_key_values=o_q.past_key_values, use_cache=True)
         assert rel_err(s_q.logits.float().cpu().numpy(), s_d.logits.float().cpu().numpy()) < tol
         assert desc_act or 3 in states[0].ops
-        # five tokens: HF's layer code through the same fused modules
-        ids5 = torch.randint(0, 2048, (1, 5), device="cuda")
-        assert rel_err(quant(input_ids=ids5).logits.float().cpu().numpy(), dense(input_ids=ids5).logits.float().cpu().numpy()) < tol
-        assert 5 not in states[0].ops
+        # six tokens (two sequences x three): still the decode ops; nine: HF's layer code through the same fused modules
+        ids6 = torch.randint(0, 2048, (2, 3), device="cuda")
+        assert rel_err(quant(input_ids=ids6).logits.float().cpu().numpy(), dense(input_ids=ids6).logits.float().cpu().numpy()) < tol
+        assert desc_act or 6 in states[0].ops
+        ids9 = torch.randint(0, 2048, (1, 9), device="cuda")
+        assert rel_err(quant(input_ids=ids9).logits.float().cpu().numpy(), dense(input_ids=ids9).logits.float().cpu().numpy()) < tol
+        assert 9 not in states[0].ops
         out = quant.generate(input_ids=ids[:, :8], max_new_tokens=6, do_sample=False, pad_token_id=0)
     assert out.shape == (1, 14)
 
