@@ -1,4 +1,6 @@
-"""dev: per-block timeline of the decode kernel (trace build, tests/dev/ablate.sh 16): which CU ran which block, when."""
+"""dev: per-block timeline of the decode kernel: which CU ran which block, when.  Needs the trace hooks (GPTQHIP_ABLATE & 16:
+gptqhip_dev_set_trace + wall_clock64 / HW_ID stamps) that lived in csrc/gptqhip_skinny.hip at commit 1701c9f ("Experiment (kept in
+history): decode1_kernel"); profiles/r02_decode_block_trace.txt is its output."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch, numpy as np
