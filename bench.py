@@ -12,8 +12,17 @@ is the quantised-linear stack of a token, which is what the metric name says.  T
 as ONE HIP graph per token.  value = tokens/s (x N for --gpus N: the 8B model fits one GPU, ranks are independent
 replicas, no data-path collective -- SURVEY.md 8e).
 
+Launching: `python bench.py --gpus N ...` with no WORLD_SIZE in the environment SPAWNS the N ranks itself (it re-executes under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`), rank r bound to GPU r, RCCL process
+group; launched under torchrun by somebody else it uses the environment it finds and insists that WORLD_SIZE == --gpus.  Either
+way ONE JSON line comes out with n_gpus = N and ranks_seen = an all-reduce of ones over the process group.  For N > 1 the line
+keeps the 8B replica headline (so N = 1 agrees with the single-GPU record) and carries configs[] = [{"config": "C5", "tp": N, ...}]:
+the Llama-3-70B decode step tensor-parallel over the same N ranks (bench_tp.tp_decode_entry), i.e. one scaling sweep of this
+command also yields the 70B strong-scaling curve BASELINE.json's metric names.
+
 Extra objects on the JSON line (tier contract):
-  roofline      dominant kernel = gptqhip::gemv1_kernel (batch-1 fused dequant-GEMV); achieved = algorithmic bytes per
+  roofline      dominant kernel = gptqhip::skinny_kernel (batch-1 fused dequant-GEMV, decode-op instantiation with the layer glue
+                fused); achieved = algorithmic bytes per
                 launch (K*N/2 + G*N*2 + G*N/2 + M*(K+N)*2, averaged over the launches) / average launch
                 duration measured with HIP events on the launch stream over the timed region.  traffic = HBM bytes per
                 launch from the committed rocprofv3 --pmc passes (traffic_source says which file; it is NOT measured in
@@ -25,7 +34,9 @@ Extra objects on the JSON line (tier contract):
                 lm_head) decoding through the plugin classes: eager generate() and one HIP graph per decode step.
   cpu_baseline  the oracle's torch-CPU PORT of BACKEND.TORCH (oracle/gptq_oracle.py:torch_cpu_forward_gptq) on this
                 host's cores, thread count swept, rank 0 at N=1 only: C1 (single 4096x4096 linear, M in {1,32,2048}, fp16 and
-                bf16) and one decoder layer at M=1 extrapolated to tokens/s.
+                bf16), the AWQ leg (C4: the AwqTorchLinear op sequence, torch_awq.py:157-195, bf16, M in {1,32}), one decoder layer
+                at M=1 extrapolated to tokens/s, and the model-level figure from the per-shape timings; `measured` / `extrapolated`
+                say which numbers are which.
 """
 from __future__ import annotations
 
@@ -253,10 +264,50 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
             x = (torch.randn(m, k) * 0.5).to(dt)
             ms, _ = _time_cpu(lambda: torch_cpu_forward_gptq(x, *t, 4), budget_s * 0.05, 4)
             c1[f"{tag}_m{m}"] = round(ms, 3)
+    # per-shape C1-style timings (each linear of the model on its own, warm, M=1, bf16): the model-level figure they add up to is
+    # the trustworthy CPU number -- the 7-linear layer pass above streams 218 M codes through the caches per pass and reads ~2x
+    # slower than the sum of its parts
+    per_shape = {}
+    for name, kk, nn in layer_shapes(cfg):
+        key = f"{kk}x{nn}"
+        if key in per_shape:
+            continue
+        t = _cpu_tensors(kk, nn, gs, torch.bfloat16)
+        x = (torch.randn(1, kk) * 0.5).to(torch.bfloat16)
+        ms, _ = _time_cpu(lambda: torch_cpu_forward_gptq(x, *t, 4), budget_s * 0.04, 3)
+        per_shape[key] = round(ms, 3)
+        del t
+    model_ms = cfg["layers"] * sum(per_shape[f"{kk}x{nn}"] for _, kk, nn in layer_shapes(cfg))
+    # C4: the AWQ reference path (AwqTorchLinear.forward op sequence, torch_awq.py:157-195 + dequantize_gemm) on a 4096x4096 layer
+    from oracle.gptq_oracle import torch_cpu_forward_awq
+    c4 = {}
+    qw = torch.randint(-2**31, 2**31 - 1, (k, n // 8), dtype=torch.int32)
+    qz = torch.randint(-2**31, 2**31 - 1, (k // gs, n // 8), dtype=torch.int32)
+    sc = (torch.rand((k // gs, n)) * 0.01 + 0.005).to(torch.bfloat16)
+    for m in (1, 32):
+        x = (torch.randn(m, k) * 0.5).to(torch.bfloat16)
+        ms, _ = _time_cpu(lambda: torch_cpu_forward_awq(x, qw, qz, sc, gs), budget_s * 0.05, 4)
+        c4[f"bf16_m{m}"] = round(ms, 3)
+    del qw, qz, sc
     torch.set_num_threads(default_threads)
     c1["bf16_m1_compiled_dequant"], compiled_note = _cpu_compiled_c1(best, gs)
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
     return {
         "value": 1e3 / (per_layer * cfg["layers"]), "unit": "tokens/s", "cores": best, "kind": "port",
+        "cpu_model": cpu_model, "torch": torch.__version__,
+        "measured": ["ms_per_layer (one decoder layer's 7 linears, M=1)", "threads_swept", "c1_ms", "c4_awq_ms", "per_shape_ms"],
+        "extrapolated": ["value = 1000 / (ms_per_layer x layers)", "model_tokens_per_s_from_per_shape = 1000 / (layers x sum of per_shape_ms)"],
+        "per_shape_ms": per_shape, "per_shape_workload": "each distinct linear shape of the model alone, warm, M=1, bf16, best_threads",
+        "model_tokens_per_s_from_per_shape": 1e3 / model_ms,
+        "c4_awq_ms": c4, "c4_workload": "AWQ reference path: AwqTorchLinear.forward op sequence (oracle torch_cpu_forward_awq: column "
+                                         "unpack, AWQ reverse order, (w - z) * s, matmul) on 4096x4096 g128 asym, bf16, best_threads",
+        "trust": "c1_ms / c4_awq_ms / per_shape_ms are warm single-layer timings and the figures to compare with; `value` (layer pass "
+                 "x layers) includes the cache thrash of streaming 7 layers' codes per pass and reads ~2x lower",
         "c1_compiled_note": compiled_note,
         "sample": f"1 of {cfg['layers']} decoder layers (7 linears, M=1, bf16 like upstream's CPU test), {iters} passes, "
                   f"extrapolated x{cfg['layers']}; torch CPU port of BACKEND.TORCH (oracle/gptq_oracle.py), not the reference "
@@ -317,6 +368,39 @@ def latest_pmc():
         return None, f"unavailable ({e})"
 
 
+def spawn_command(gpus, environ, argv):
+    """The command that launches `gpus` ranks of this script, or None when this process IS a rank already (WORLD_SIZE set by a
+    launcher) or a single rank is wanted.  Pure function of its arguments (tests/test_host_logic.py)."""
+    if gpus <= 1 or "WORLD_SIZE" in environ:
+        return None
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def handshake(rank, local_rank, world):
+    """--handshake-only: rendezvous + one all-reduce of ones (RCCL with one GPU per rank, else gloo); rank 0 prints the JSON line."""
+    backend = "gloo"
+    dev = "cpu"
+    if torch.cuda.is_available() and torch.cuda.device_count() >= world and not os.environ.get("GPTQHIP_BENCH_SHARE_GPU"):
+        backend, dev = "nccl", torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+    seen = 1
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend) if backend == "gloo" else dist.init_process_group(backend, device_id=dev)
+        ones = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ones)
+        seen = int(ones.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "handshake", "n_gpus": world, "ranks_seen": seen, "backend": backend}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -334,16 +418,35 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the configs[] array (C3/C4/C5 legs)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end HF Llama-3-8B-shaped decode leg (`e2e` key)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--tp-steps", type=int, default=30, help="timed steps of the C5 tp=N entry appended when N > 1")
+    ap.add_argument("--handshake-only", action="store_true",
+                    help="launch / rendezvous check only: spawn the ranks, all-reduce ones, print {n_gpus, ranks_seen}; needs no GPU "
+                         "(gloo when CUDA is unavailable) -- tests/test_host_logic.py uses it to prove --gpus is honoured")
     args = ap.parse_args()
 
+    cmd = spawn_command(args.gpus, os.environ, sys.argv[1:])
+    if cmd is not None:
+        # `python bench.py --gpus N` outside torchrun: become the launcher of N ranks (one process per GPU)
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / peer mappings across processes need it here
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         "(or without torchrun: bench.py spawns the ranks itself)")
+    if args.handshake_only:
+        return handshake(rank, local_rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     # GPTQHIP_BENCH_SHARE_GPU=1 (smoke-testing the N > 1 code path on a one-GPU box, tests/dev): every rank uses cuda:0 and
     # the process group runs on gloo (RCCL refuses two ranks on one device); the numbers of such a run mean nothing.
     share = bool(os.environ.get("GPTQHIP_BENCH_SHARE_GPU")) and world > 1
+    if not share and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible "
+                         "(GPTQHIP_BENCH_SHARE_GPU=1 runs the N > 1 code paths with all ranks on GPU 0: a smoke switch, not a measurement)")
     dev_index = 0 if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -356,10 +459,17 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    ranks_seen = 1
+    if dist is not None:
+        ones = torch.ones(1, dtype=torch.int32, device="cpu" if share else dev)
+        dist.all_reduce(ones)                                  # over RCCL unless the smoke switch put every rank on one GPU
+        ranks_seen = int(ones.item())
 
     if args.model == "llama3-70b":
         from bench_tp import run_70b   # tensor-parallel 70B leg lives in its own file
-        run_70b(args, rank, local_rank, world, dev, dist)
+        run_70b(args, rank, local_rank, world, dev, dist, ranks_seen=ranks_seen)
+        if dist is not None:
+            dist.destroy_process_group()
         return
 
     from gptqmodel_amd.utils.decode_chain import DecodeStep
@@ -423,12 +533,26 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
-    tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([wall], device="cpu" if share else dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
     ms_per_step = wall * 1e3 / args.steps
     value = world * args.steps / wall   # replicas add up
+
+    tp_entry = None
+    if world > 1 and not args.no_configs:
+        # BASELINE configs[4] on the SAME ranks: the 70B decode step tensor-parallel over all of them (every rank takes part)
+        del step, graph
+        layers.clear()
+        torch.cuda.empty_cache()
+        step = graph = None
+        try:
+            from bench_tp import tp_decode_entry
+            tp_entry = tp_decode_entry(args, rank, world, dev, dist, args.tp_steps, 5,
+                                       log=(lambda m: print(m, file=sys.stderr, flush=True)) if rank == 0 else None)
+        except Exception as e:  # noqa: BLE001
+            tp_entry = {"config": "C5", "tp": world, "error": f"{type(e).__name__}: {str(e)[:300]}"}
 
     if rank == 0:
         traffic, traffic_source = latest_pmc()
@@ -440,7 +564,7 @@ def main():
         out = {
             "metric": "llama3_8b_gptq_int4_g128_decode_linear_stack_tokens_per_s",
             "value": value, "unit": "tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if dtype == torch.float16 else "bf16", "data": "synthetic",
             "config": {"workload": "Llama-3-8B GPTQ int4 g128 desc_act=False batch=1 decode: the 224 quantised linears of a token "
@@ -456,11 +580,16 @@ def main():
                                  "dependent-launch gap)"},
             "gemm_tflops_equiv": step_flops * value / world / 1e12,
         }
+        if tp_entry is not None:
+            out["configs"] = [tp_entry]
+        if share:
+            out["note"] = "GPTQHIP_BENCH_SHARE_GPU=1: every rank ran on GPU 0 over gloo -- a launch / code-path smoke run, NOT a measurement"
         if world == 1 and not args.no_configs:
             out["configs"] = extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, ms_per_step, n_launch)
             if out["configs"] and out["configs"][-1].get("config") == "_prefill_headline":
                 out["prefill"] = out["configs"].pop()
-        del layers, step, graph
+        layers.clear()
+        step = graph = None
         torch.cuda.empty_cache()
         if world == 1 and not args.no_e2e and not args.no_configs:
             # the whole model, not just the quantised linears: HF LlamaForCausalLM with Llama-3-8B shapes (random init), real

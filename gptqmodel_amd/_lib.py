@@ -17,7 +17,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libgptqhip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # every symbol include/gptqhip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -41,6 +41,7 @@ SIGNATURES = {
     "gptqhip_comm_free": (_i, [_vp]),
     "gptqhip_comm_status": (_i, [_vp, _c.POINTER(_c.c_uint32)]),
     "gptqhip_allreduce_oneshot": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "gptqhip_allgather_select": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "gptqhip_dequant": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_dequant_tiled": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_repack_awq": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -48,6 +49,7 @@ SIGNATURES = {
     "gptqhip_pack_gptq": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "gptqhip_pack_gptq_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "gptqhip_gather_cols": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "gptqhip_rmsnorm_gather": (_i, [_vp, _vp, _vp, _vp, _i, _i, _c.c_float, _i, _vp]),
     "gptqhip_set_tuning": (_i, [_i, _i, _i]),
 }
 

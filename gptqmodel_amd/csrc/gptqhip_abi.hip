@@ -300,7 +300,7 @@ int gptqhip_decode_supported(int K, int N, int group_size, int has_perm, int M) 
     // the decode op rides on the skinny kernel's regular batch-1 pipeline (straight-line counted-wait ring, one group
     // constant per 128-row chunk): same predicate as the planner's
     if (K <= 0 || N <= 0 || group_size <= 0 || K % group_size != 0 || K % 32 != 0 || N % 8 != 0) return 0;
-    if (M < 1 || M > 8 || (M > 1 && has_perm)) return 0;
+    if (M < 1 || M > 16 || (M > 1 && has_perm)) return 0;
     const SkinnyPlan pl = plan_skinny(M, K, N, group_size, 0, 0, has_perm != 0);
     if (has_perm && !(pl.depth == 4 && (size_t)K * 2 <= kInKernelPermMaxRowBytes)) return 0;
     return (pl.regular && pl.gpc == 1 && pl.mt == 1) ? 1 : 0;
@@ -344,8 +344,8 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
         return GPTQHIP_EINVAL;
     }
     const int M = op->M;
-    if (M < 1 || M > 8 || (M > 1 && (op->perm || op->in_glue == GPTQHIP_GLUE_SILU_MUL))) {
-        set_error("gptqhip_decode_linear: M=%d outside 1..8, or M > 1 with perm / SiLU*mul input glue", M);
+    if (M < 1 || M > 16 || (M > 1 && (op->perm || op->in_glue == GPTQHIP_GLUE_SILU_MUL))) {
+        set_error("gptqhip_decode_linear: M=%d outside 1..16, or M > 1 with perm / SiLU*mul input glue", M);
         return GPTQHIP_EINVAL;
     }
     const SkinnyPlan pl = plan_skinny(M, op->K, op->N, op->group_size, g_force_split, g_force_waves, op->perm != nullptr);
@@ -542,6 +542,20 @@ int gptqhip_gather_cols(const void* x, const int32_t* perm, void* out, int M, in
         return GPTQHIP_EINVAL;
     }
     return launch_gather_cols(x, perm, out, M, K, reinterpret_cast<hipStream_t>(stream));
+}
+
+int gptqhip_rmsnorm_gather(const void* h, const void* weight, const int32_t* perm, void* out, int M, int K, float eps, int act_dtype,
+                           gptqhip_stream_t stream) {
+    if (M == 0) return GPTQHIP_OK;
+    if (!h || !weight || !out || M < 0 || K <= 0 || K % 8 != 0 || K > 16384 || h == out) {
+        set_error("gptqhip_rmsnorm_gather: bad args (K a multiple of 8 up to 16384, out must not alias h)");
+        return GPTQHIP_EINVAL;
+    }
+    if (act_dtype != GPTQHIP_FP16 && act_dtype != GPTQHIP_BF16) {
+        set_error("gptqhip_rmsnorm_gather: act_dtype must be GPTQHIP_FP16/BF16");
+        return GPTQHIP_EINVAL;
+    }
+    return launch_rmsnorm_gather(h, weight, perm, out, M, K, eps, act_dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

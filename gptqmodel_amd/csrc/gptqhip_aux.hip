@@ -380,6 +380,152 @@ int launch_gather_cols(const void* x, const int32_t* perm, void* out, int M, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// RMSNorm (+ act-order gather) in ONE pass over the activations: out[m, k'] = w[p] * act(h32[m, p] * rsqrt(mean_k h32[m, k]^2 + eps)),
+// p = perm[k'] (perm NULL: p = k').  HF LlamaRMSNorm semantics (fp32 statistics, the normalised value rounded to the activation
+// dtype, then the product with the weight rounded once) -- the caller of the quantised q|k|v and gate|up projections.  An
+// act-order checkpoint's prefill otherwise pays a separate gather pass over x per linear (one extra read + write of [M, K]:
+// -10 % at 4096^2, M = 65536) on top of eager HF's six small RMSNorm kernels with fp32 temporaries; here the permuted,
+// normalised x leaves the kernel that had to read h anyway.  Same structure as gather_cols_lds_kernel: R rows per pass staged
+// in LDS, every HBM access a coalesced 16-byte piece, the random access happens on-chip.  HBM-bound: M * K * 4 bytes.
+// ---------------------------------------------------------------------------------------------
+template <int ACT, int R, int IT>
+__global__ __launch_bounds__(256) void rmsnorm_gather_kernel(const uint16_t* __restrict__ h, const uint16_t* __restrict__ weight,
+                                                             const int32_t* __restrict__ perm, uint16_t* __restrict__ out, int M, int K,
+                                                             float eps) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t rows[];  // [R][K] normalised rows, then [K] the norm weight
+    __shared__ float red[4][R];
+    uint16_t* wl = rows + (size_t)R * K;
+    const int k8 = K / 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < k8; i += 256) reinterpret_cast<u4_t*>(wl)[i] = reinterpret_cast<const u4_t*>(weight)[i];
+    for (int m0 = blockIdx.x * R; m0 < M; m0 += gridDim.x * R) {
+        u4_t stage[R][IT];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int m = m0 + r < M ? m0 + r : M - 1;
+            const u4_t* src = reinterpret_cast<const u4_t*>(h + (size_t)m * K);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int i = threadIdx.x + it * 256;
+                stage[r][it] = i < k8 ? src[i] : u4_t{0u, 0u, 0u, 0u};
+            }
+        }
+        // statistics: fp32 sum of squares per row, fixed order (thread pieces, shuffle tree, four waves)
+        float ss[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float a = 0.f;
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = bits16_to_f32<ACT>((uint16_t)(stage[r][it][j] & 0xffffu)), hi = bits16_to_f32<ACT>((uint16_t)(stage[r][it][j] >> 16));
+                    a = __builtin_fmaf(lo, lo, a);
+                    a = __builtin_fmaf(hi, hi, a);
+                }
+#pragma unroll
+            for (int mk = 32; mk >= 1; mk >>= 1) a += __shfl_xor(a, mk, 64);
+            ss[r] = a;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) red[wave][r] = ss[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float inv = rsqrtf((red[0][r] + red[1][r] + red[2][r] + red[3][r]) / (float)K + eps);
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int i = threadIdx.x + it * 256;
+                if (i < k8) {
+                    u4_t v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float lo = bits16_to_f32<ACT>((uint16_t)(stage[r][it][j] & 0xffffu)), hi = bits16_to_f32<ACT>((uint16_t)(stage[r][it][j] >> 16));
+                        v[j] = (uint32_t)f32_to_16<ACT>(lo * inv) | ((uint32_t)f32_to_16<ACT>(hi * inv) << 16);
+                    }
+                    reinterpret_cast<u4_t*>(rows + (size_t)r * K)[i] = v;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = threadIdx.x + it * 256;
+            if (i < k8) {
+                int src[8];
+                if (perm != nullptr) {
+                    const u4_t p0 = *reinterpret_cast<const u4_t*>(perm + 8 * i);
+                    const u4_t p1 = *reinterpret_cast<const u4_t*>(perm + 8 * i + 4);
+                    src[0] = p0.x; src[1] = p0.y; src[2] = p0.z; src[3] = p0.w;
+                    src[4] = p1.x; src[5] = p1.y; src[6] = p1.z; src[7] = p1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) src[e] = 8 * i + e;
+                }
+                float w8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w8[e] = bits16_to_f32<ACT>(wl[src[e]]);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (m0 + r < M) {
+                        const uint16_t* row = rows + (size_t)r * K;
+                        u4_t v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float a = w8[2 * j] * bits16_to_f32<ACT>(row[src[2 * j]]);
+                            const float b = w8[2 * j + 1] * bits16_to_f32<ACT>(row[src[2 * j + 1]]);
+                            v[j] = (uint32_t)f32_to_16<ACT>(a) | ((uint32_t)f32_to_16<ACT>(b) << 16);
+                        }
+                        reinterpret_cast<u4_t*>(out + (size_t)(m0 + r) * K)[i] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_rmsnorm_gather(const void* h, const void* weight, const int32_t* perm, void* out, int M, int K, float eps, int act_dtype,
+                          hipStream_t stream) {
+    const uint16_t* hs = reinterpret_cast<const uint16_t*>(h);
+    const uint16_t* ws = reinterpret_cast<const uint16_t*>(weight);
+    uint16_t* os = reinterpret_cast<uint16_t*>(out);
+    const int it = ceil_div(K / 8, 256);  // 16-byte pieces per thread and row
+    const int r = K <= 8192 ? 4 : 2;      // rows per pass
+    const int passes = ceil_div(M, r);
+    const dim3 grid(passes < 2048 ? passes : 2048);
+    const size_t lds = (size_t)(r + 1) * K * 2;
+#define GPTQHIP_RMSG(A_, R_, IT_)                                                                                       \
+    do {                                                                                                                  \
+        auto kern = rmsnorm_gather_kernel<A_, R_, IT_>;                                                                   \
+        if (lds > 64 * 1024) {                                                                                            \
+            int rc_ = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), \
+                                "rmsnorm_gather: LDS size");                                                              \
+            if (rc_) return rc_;                                                                                          \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, hs, ws, perm, os, M, K, eps);                              \
+    } while (0)
+#define GPTQHIP_RMSG_A(R_, IT_)                                      \
+    do {                                                             \
+        if (act_dtype == kFP16) GPTQHIP_RMSG(kFP16, R_, IT_);        \
+        else GPTQHIP_RMSG(kBF16, R_, IT_);                           \
+    } while (0)
+    if (r == 4) {
+        if (it <= 1) GPTQHIP_RMSG_A(4, 1);
+        else if (it <= 2) GPTQHIP_RMSG_A(4, 2);
+        else GPTQHIP_RMSG_A(4, 4);
+    } else {
+        if (it <= 6) GPTQHIP_RMSG_A(2, 6);
+        else GPTQHIP_RMSG_A(2, 8);
+    }
+#undef GPTQHIP_RMSG_A
+#undef GPTQHIP_RMSG
+    return check_hip(hipGetLastError(), "rmsnorm_gather launch");
+}
+
+// ---------------------------------------------------------------------------------------------
 // embedding gather-dequant from the tiled layout: one thread per (token, column).  Reads one packed word per output
 // element (8x read amplification on a tokens x dim problem that is tiny next to the table itself) instead of
 // materialising the whole [vocab, dim] table like the reference does.

@@ -4,21 +4,34 @@
 // memory, so the exchange is ONE kernel with no intermediate hop:
 //
 //   push    rank r stores its fp32 partial vector into slot [parity][r] of EVERY rank's communication buffer (peer-mapped
-//           through IPC handles; 7 remote + 1 local 16-byte system-scope stores per 4 elements), drains them, then raises
-//           flag [parity][r][block] = epoch in every buffer;
-//   wait    each block polls its OWN buffer's `world` flags (local memory, one lane per source rank, bounded);
+//           through IPC handles; 7 remote + 1 local 16-byte system-scope write-through stores per 4 elements); every storing
+//           wave then executes a system-scope RELEASE fence (buffer_wbl2 sc0 sc1 + s_waitcnt vmcnt(0): all its stores have been
+//           acknowledged by the destination), the block meets at a barrier, and `world` lanes raise flag [parity][r][block] =
+//           epoch in every buffer with a system-scope store-RELEASE;
+//   wait    each block polls its OWN buffer's `world` flags (local memory, one lane per source rank), bounded by the 100 MHz
+//           wall clock (CommHeader::timeout_ticks), then executes a system-scope ACQUIRE fence (buffer_inv sc0 sc1) before the
+//           block barrier that lets the other waves read the slots (which they do with system-scope loads);
 //   reduce  sums the `world` slots in RANK ORDER (every rank adds the same numbers in the same order: bit-identical results on
 //           all ranks, unlike a ring whose association depends on the rank), then the reference's rounding chain in the same
 //           pass: y = act(sum); y = act(y + bias); out = act(residual + y)  (torch.py:337-342 + the caller's residual add).
+//
+// The flag edge is therefore a textbook message-passing pattern in the HSA / LLVM-AMDGPU memory model: data stores
+// happen-before the release store of the flag (same wave: program order + fence; other waves: fence, workgroup barrier, release
+// store), the acquire side observes the flag and then the data.  A wait that exceeds its bound does NOT reduce stale slots: the
+// block writes NaN to its part of `out` (and of stats_out) and sets the sticky status word (gptqhip_comm_status), so a lost peer
+// is loud -- downstream activations become NaN -- instead of silently corrupt.
 //
 // Epochs are counted in device memory (one word per block, owned by that block), so a captured launch replays correctly;
 // slots are double-buffered by epoch parity: a rank can only enter call t+2 after every peer has pushed call t+1, i.e. has
 // finished reading call t.  The buffers are allocated UNCACHED (fine-grained) by gptqhip_comm_alloc so that neither the
 // writer's nor the reader's L2 can hold a stale line; all cross-rank accesses are system-scope.
 //
-// No reference interface is replaced: the reference has no tensor parallelism.  NOT yet run across more than one
-// physical GPU (the build / test boxes have one): tests/test_gpu_comm.py drives the protocol with two processes that share
-// GPU 0 through real IPC mappings.
+// No reference interface is replaced: the reference has no tensor parallelism.  Hardware status: the build / test
+// boxes have ONE GPU; tests/test_gpu_comm.py drives the protocol with two processes that share GPU 0 through real IPC mappings
+// (incl. a 10^5-epoch back-to-back stress with per-epoch payloads).  utils.xgmi_allreduce.OneShotAllReduce.self_test() validates a
+// freshly built communicator against the process group's own collective before anybody relies on it, and bench.py falls back to
+// RCCL when that fails -- the first contact with real xGMI links is therefore checked at run time.
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/gptqhip.h"
@@ -30,17 +43,24 @@ namespace gptqhip {
 constexpr int kCommMaxWorld = 8;
 constexpr int kCommMaxBlocks = 64;
 constexpr int kCommBlockFloats = 1024;  // 256 threads x 4 floats
-constexpr unsigned kCommMaxSpins = 1u << 22;
+constexpr unsigned long long kCommDefaultTimeoutTicks = 10ull * 100000000ull;   // 10 s of the 100 MHz wall clock
 
 struct CommHeader {
     uint32_t epoch[kCommMaxBlocks];                          // owned by block b of the LOCAL rank
     uint32_t status;                                         // |= 1 when a bounded wait gave up
-    uint32_t pad[63];
+    uint32_t timeout_lo, timeout_hi;                         // wait bound in wall-clock ticks (100 MHz), set by gptqhip_comm_alloc
+    uint32_t gepoch;                                         // all-gather calls (gptqhip_allgather_select): their own epoch, flags and
+    uint32_t gflags[2][kCommMaxWorld];                       //   slot region, so the two collectives never alias each other's parity
+    uint32_t pad[44];
     uint32_t flags[2][kCommMaxWorld][kCommMaxBlocks];        // written by peers
 };
 
 __host__ __device__ inline size_t comm_data_offset() { return (sizeof(CommHeader) + 255) / 256 * 256; }
 __host__ __device__ inline size_t comm_slot_floats(int n_max) { return (size_t)(n_max + kCommBlockFloats - 1) / kCommBlockFloats * kCommBlockFloats; }
+// all-gather region behind the all-reduce slots: [2 parities][world ranks] slots of n_max 16-bit elements each
+__host__ __device__ inline size_t comm_gather_offset(int n_max) { return comm_data_offset() + (size_t)2 * kCommMaxWorld * comm_slot_floats(n_max) * sizeof(float); }
+__host__ __device__ inline size_t comm_gslot_bytes(int n_max) { return ((size_t)n_max * 2 + 255) / 256 * 256; }
+static_assert(sizeof(CommHeader) == (64 + 64 + 2 * 8 * 64) * 4, "CommHeader layout");
 
 struct PeerTable {
     char* base[kCommMaxWorld];
@@ -67,14 +87,23 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const float* __r
                                                                 const void* __restrict__ residual, void* __restrict__ out,
                                                                 float* __restrict__ stats_out) {
     __shared__ uint32_t s_epoch;
+    __shared__ uint32_t s_lost;
     const int b = blockIdx.x, tid = threadIdx.x;
     CommHeader* mine = reinterpret_cast<CommHeader*>(peers.base[rank]);
-    if (tid == 0) s_epoch = __hip_atomic_load(&mine->epoch[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
+    if (tid == 0) {
+        s_epoch = __hip_atomic_load(&mine->epoch[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
+        s_lost = 0u;
+    }
     __syncthreads();
     const uint32_t e = s_epoch;
     const int par = (int)(e & 1u);
     const int i = b * kCommBlockFloats + tid * 4;  // n % 4 == 0 (checked by the host)
     const bool live = i < n;
+
+    // bias / residual do not depend on the peers: requested up front as aligned 8-byte words, their latency hides under the push
+    u2_t braw = {0u, 0u}, rraw = {0u, 0u};
+    if (live && bias != nullptr) braw = *reinterpret_cast<const u2_t*>(reinterpret_cast<const uint16_t*>(bias) + i);
+    if (live && residual != nullptr) rraw = *reinterpret_cast<const u2_t*>(reinterpret_cast<const uint16_t*>(residual) + i);
 
     // ---- push -------------------------------------------------------------------------------------------------------
     if (live) {
@@ -84,25 +113,32 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const float* __r
             store16_system(dst, v);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its remote writes
+    // every storing wave: system-scope release fence (write-back + wait until its remote stores are acknowledged) ...
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     __syncthreads();
+    // ... then the flag, itself a system-scope store-release (ordered after everything the barrier collected)
     if (tid < world) {
         CommHeader* peer = reinterpret_cast<CommHeader*>(peers.base[tid]);
-        __hip_atomic_store(&peer->flags[par][rank][b], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&peer->flags[par][rank][b], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 
     // ---- wait: lane q polls "rank q has pushed block b of this epoch" in the LOCAL buffer ---------------------------------
     if (tid < world) {
+        const unsigned long long limit = (unsigned long long)mine->timeout_lo | ((unsigned long long)mine->timeout_hi << 32);
+        const unsigned long long t0 = wall_clock64();
         unsigned spins = 0;
         while (__hip_atomic_load(&mine->flags[par][tid][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
-            if (++spins > kCommMaxSpins) {
+            if ((++spins & 255u) == 0u && wall_clock64() - t0 > limit) {
                 atomicOr(&mine->status, 1u);
+                atomicOr(&s_lost, 1u);
                 break;
             }
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(2);
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: nothing read below may come from a line cached before the flags
     __syncthreads();
+    const bool lost = s_lost != 0u;
 
     // ---- reduce in rank order + the reference's rounding chain ----------------------------------------------------------
     float sq = 0.f;
@@ -114,8 +150,9 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float y = round_through<ACT>(s[j]);
-            if (bias != nullptr) y = round_through<ACT>(y + load16_as_f32<ACT>(bias, (size_t)i + j));
-            if (residual != nullptr) y = load16_as_f32<ACT>(residual, (size_t)i + j) + y;
+            if (bias != nullptr) y = round_through<ACT>(y + bits16_to_f32<ACT>((uint16_t)(braw[j >> 1] >> ((j & 1) * 16))));
+            if (residual != nullptr) y = bits16_to_f32<ACT>((uint16_t)(rraw[j >> 1] >> ((j & 1) * 16))) + y;
+            if (lost) y = __builtin_nanf("");   // a peer never arrived: poison, do not publish a sum of stale slots
             r[j] = f32_to_16<ACT>(y);
             const float h = bits16_to_f32<ACT>(r[j]);
             sq = __builtin_fmaf(h, h, sq);
@@ -134,6 +171,65 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(const float* __r
     if (tid == 0) __hip_atomic_store(&mine->epoch[b], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// One-shot ALL-GATHER + select for act-order row-parallel shards: a row shard cut from the GLOBALLY group-sorted
+// rows (utils.tp.shard_gptq_row(act_order="global_sort"), the Marlin rule gptqmodel/utils/marlin.py:296-305,368-372) needs the input
+// features index[0..n_out) of the FULL activation vector, which is scattered over all ranks' column shards (attention heads).  Same
+// protocol as above with its own epoch / flags / slots: every rank pushes its n_local 16-bit elements into every rank's buffer,
+// release -> flag -> acquire, then out[j] = full[index[j]] straight from the local slots (index NULL: the whole vector).  One block:
+// the message is <= 16 KB and every output element may come from any rank.
+__global__ __launch_bounds__(256) void allgather_select_kernel(const uint16_t* __restrict__ x_local, PeerTable peers, int rank, int world,
+                                                               int n_local, size_t gather_off, size_t gslot_bytes,
+                                                               const int32_t* __restrict__ index, int n_out, uint16_t* __restrict__ out,
+                                                               uint32_t nan_bits) {
+    __shared__ uint32_t s_epoch;
+    __shared__ uint32_t s_lost;
+    const int tid = threadIdx.x;
+    CommHeader* mine = reinterpret_cast<CommHeader*>(peers.base[rank]);
+    if (tid == 0) {
+        s_epoch = __hip_atomic_load(&mine->gepoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
+        s_lost = 0u;
+    }
+    __syncthreads();
+    const uint32_t e = s_epoch;
+    const int par = (int)(e & 1u);
+    for (int i = tid * 8; i < n_local; i += 256 * 8) {   // n_local % 8 == 0 (host-checked): 16 bytes per lane
+        const u4_t v = *reinterpret_cast<const u4_t*>(x_local + i);
+        for (int p = 0; p < world; ++p) {
+            char* slot = peers.base[p] + gather_off + ((size_t)par * kCommMaxWorld + rank) * gslot_bytes;
+            store16_system(reinterpret_cast<float*>(slot + (size_t)i * 2), __builtin_bit_cast(f4_t, v));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (tid < world) {
+        CommHeader* peer = reinterpret_cast<CommHeader*>(peers.base[tid]);
+        __hip_atomic_store(&peer->gflags[par][rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long limit = (unsigned long long)mine->timeout_lo | ((unsigned long long)mine->timeout_hi << 32);
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        while (__hip_atomic_load(&mine->gflags[par][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
+            if ((++spins & 255u) == 0u && wall_clock64() - t0 > limit) {
+                atomicOr(&mine->status, 1u);
+                atomicOr(&s_lost, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __syncthreads();
+    const bool lost = s_lost != 0u;
+    const char* slots = peers.base[rank] + gather_off + (size_t)par * kCommMaxWorld * gslot_bytes;
+    for (int j = tid; j < n_out; j += 256) {
+        const int src = index != nullptr ? index[j] : j;
+        const int r = src / n_local, off = src - r * n_local;
+        uint16_t* q = reinterpret_cast<uint16_t*>(const_cast<char*>(slots) + (size_t)r * gslot_bytes) + off;
+        const uint16_t v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        out[j] = lost ? (uint16_t)nan_bits : v;
+    }
+    if (tid == 0) __hip_atomic_store(&mine->gepoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace gptqhip
 
 using namespace gptqhip;
@@ -142,7 +238,7 @@ extern "C" {
 
 size_t gptqhip_comm_bytes(int world, int n_max) {
     if (world < 1 || world > kCommMaxWorld || n_max <= 0 || (size_t)n_max > (size_t)kCommMaxBlocks * kCommBlockFloats) return 0;
-    return comm_data_offset() + (size_t)2 * kCommMaxWorld * comm_slot_floats(n_max) * sizeof(float);
+    return comm_gather_offset(n_max) + (size_t)2 * kCommMaxWorld * comm_gslot_bytes(n_max);
 }
 
 int gptqhip_comm_alloc(size_t bytes, void** dev_ptr, unsigned char* handle_out) {
@@ -161,6 +257,16 @@ int gptqhip_comm_alloc(size_t bytes, void** dev_ptr, unsigned char* handle_out) 
     if (rc) return rc;
     rc = check_hip(hipMemset(p, 0, bytes), "gptqhip_comm_alloc: hipMemset");
     if (rc) return rc;
+    {
+        // wait bound of the kernels that poll this buffer (GPTQHIP_COMM_TIMEOUT_MS, default 10 s; 100 MHz wall clock)
+        unsigned long long ticks = kCommDefaultTimeoutTicks;
+        const char* v = getenv("GPTQHIP_COMM_TIMEOUT_MS");
+        if (v && *v && atoll(v) > 0) ticks = (unsigned long long)atoll(v) * 100000ull;
+        const uint32_t t[2] = {(uint32_t)ticks, (uint32_t)(ticks >> 32)};
+        rc = check_hip(hipMemcpy(&reinterpret_cast<CommHeader*>(p)->timeout_lo, t, sizeof(t), hipMemcpyHostToDevice),
+                       "gptqhip_comm_alloc: timeout");
+        if (rc) return rc;
+    }
     rc = check_hip(hipDeviceSynchronize(), "gptqhip_comm_alloc: sync");
     if (rc) return rc;
     hipIpcMemHandle_t h;
@@ -214,6 +320,10 @@ int gptqhip_allreduce_oneshot(const float* partial, void* const* peer_bufs, int 
         set_error("gptqhip_allreduce_oneshot: act_dtype must be GPTQHIP_FP16/BF16");
         return GPTQHIP_EINVAL;
     }
+    if (((uintptr_t)partial & 15u) || ((uintptr_t)out & 7u) || ((uintptr_t)bias & 7u) || ((uintptr_t)residual & 7u)) {
+        set_error("gptqhip_allreduce_oneshot: partial must be 16-byte aligned, out / bias / residual 8-byte aligned");
+        return GPTQHIP_EINVAL;
+    }
     PeerTable t;
     for (int p = 0; p < kCommMaxWorld; ++p) t.base[p] = p < world ? reinterpret_cast<char*>(peer_bufs[p]) : nullptr;
     for (int p = 0; p < world; ++p) {
@@ -230,6 +340,36 @@ int gptqhip_allreduce_oneshot(const float* partial, void* const* peer_bufs, int 
         hipLaunchKernelGGL((allreduce_oneshot_kernel<kBF16>), grid, block, 0, s, partial, t, rank, world, n, comm_slot_floats(n_max), bias, residual, out, stats_out);
     }
     return check_hip(hipGetLastError(), "allreduce_oneshot_kernel launch");
+}
+
+int gptqhip_allgather_select(const void* x_local, void* const* peer_bufs, int rank, int world, int n_local, int n_max,
+                             const int32_t* index, int n_out, void* out, int act_dtype, gptqhip_stream_t stream) {
+    if (!x_local || !peer_bufs || !out || world < 1 || world > kCommMaxWorld || rank < 0 || rank >= world || n_local <= 0 ||
+        n_local % 8 != 0 || n_local > n_max || n_out <= 0 || gptqhip_comm_bytes(world, n_max) == 0 || ((uintptr_t)x_local & 15u)) {
+        set_error("gptqhip_allgather_select: bad arguments (world <= %d, n_local %% 8 == 0, n_local <= n_max, x_local 16-byte aligned)",
+                  kCommMaxWorld);
+        return GPTQHIP_EINVAL;
+    }
+    if (index == nullptr && n_out != n_local * world) {
+        set_error("gptqhip_allgather_select: without an index the output is the whole vector (n_out = n_local * world)");
+        return GPTQHIP_EINVAL;
+    }
+    if (act_dtype != GPTQHIP_FP16 && act_dtype != GPTQHIP_BF16) {
+        set_error("gptqhip_allgather_select: act_dtype must be GPTQHIP_FP16/BF16");
+        return GPTQHIP_EINVAL;
+    }
+    PeerTable t;
+    for (int p = 0; p < kCommMaxWorld; ++p) t.base[p] = p < world ? reinterpret_cast<char*>(peer_bufs[p]) : nullptr;
+    for (int p = 0; p < world; ++p) {
+        if (!t.base[p]) {
+            set_error("gptqhip_allgather_select: peer buffer %d is NULL", p);
+            return GPTQHIP_EINVAL;
+        }
+    }
+    hipLaunchKernelGGL(allgather_select_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const uint16_t*>(x_local), t, rank, world, n_local, comm_gather_offset(n_max), comm_gslot_bytes(n_max),
+                       index, n_out, reinterpret_cast<uint16_t*>(out), act_dtype == GPTQHIP_FP16 ? 0x7E00u : 0x7FC0u);
+    return check_hip(hipGetLastError(), "allgather_select_kernel launch");
 }
 
 }  // extern "C"

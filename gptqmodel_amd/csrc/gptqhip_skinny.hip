@@ -90,8 +90,8 @@ __device__ __forceinline__ uint32_t glue_pair(uint32_t a, uint32_t b, float inv,
         r0 = b0 * round_through<ACT>(a0 * inv);
         r1 = b1 * round_through<ACT>(a1 * inv);
     } else {
-        r0 = round_through<ACT>(a0 / (1.0f + __expf(-a0))) * b0;
-        r1 = round_through<ACT>(a1 / (1.0f + __expf(-a1))) * b1;
+        r0 = round_through<ACT>(a0 / (1.0f + expf(-a0))) * b0;   // expf, not __expf: HF evaluates SiLU with the accurate exp
+        r1 = round_through<ACT>(a1 / (1.0f + expf(-a1))) * b1;
     }
     return (uint32_t)f32_to_16<ACT>(r0) | ((uint32_t)f32_to_16<ACT>(r1) << 16);
 }
@@ -132,7 +132,9 @@ __host__ __device__ constexpr int row_quads() {  // 4-row groups actually loaded
 
 template <int AM, int MT>
 struct AStage {
-    u4_t a[AM == AM_ROW4 ? 2 : 4 * MT];   // AM_ROW4: [1] = the norm-weight segment of the decode op's RMSNorm glue, unused otherwise
+    // AM_ROW4: [1] = the norm-weight segment of the decode op's RMSNorm glue; AM_ROWS with MT == 1 (decode op on 9..16 rows): [4] =
+    // the same (AM_ROWSH keeps it in the unused quad [3]); unused -- and never allocated -- otherwise
+    u4_t a[AM == AM_ROW4 ? 2 : (AM == AM_ROWS && MT == 1 ? 5 : 4 * MT)];
 };
 template <int MT>
 struct AStage<AM_ROW1, MT> {
@@ -281,15 +283,20 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
     } else if constexpr (is_rows<AM>()) {
 #pragma unroll
         for (int i = 0; i < row_quads<AM, MT>(); ++i) st.x.a[i] = *reinterpret_cast<const u4_t*>(xsrc + lo.x[i]);
-        if constexpr (AM == AM_ROWSH && MT == 1 && GLUE == kGlueRmsNorm) {
-            // decode op on 5..8 rows: the norm-weight segment rides in the stage's last (unused: quads 2, 3 are skipped) register
-            st.x.a[3] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (xsrc - tb.x) + tb.c4 * 4u);
+        if constexpr (is_rows<AM>() && MT == 1 && GLUE == kGlueRmsNorm) {
+            // decode op on 5..8 rows: the norm-weight segment rides in the stage's last (unused: quads 2, 3 are skipped) register;
+            // on 9..16 rows (AM_ROWS) in a fifth one
+            st.x.a[AM == AM_ROWSH ? 3 : 4] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (xsrc - tb.x) + tb.c4 * 4u);
         }
     }
     cu.w += (size_t)stride_chunks * (WPC * 1024);
     cu.x += (size_t)stride_chunks * 256;
     cu.chunk += stride_chunks;
 }
+
+struct GlueInv {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};   // RMSNorm 1/rms of rows rq, 4 + rq, 8 + rq, 12 + rq (the lane's row of each loaded quad)
+};
 
 template <int BITS, int ACT, int GPC, int AM>
 __host__ __device__ constexpr bool kExactBf16() {
@@ -303,7 +310,8 @@ __host__ __device__ constexpr bool kExactBf16() {
 template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int GLUE = 0>
 __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st, const SkinnyParams& p, int chunk,
                                               int lane, u4_t* aslot, const DequantConsts& dk, f4_t (&acc)[MT],
-                                              const uint16_t* xbuf = nullptr, float inv = 0.f, float inv2 = 0.f) {
+                                              const uint16_t* xbuf = nullptr, const GlueInv& gi = GlueInv{}) {
+    const float inv = gi.v[0];
     const int c = lane & 15;
     const int rq = lane >> 4;
     int abase = 0;  // u4 index of this lane's fragment row inside the wave's LDS slot
@@ -334,12 +342,12 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
         abase = (c < p.M ? c : 0) << 4;  // lanes of unused rows re-read row 0: a broadcast, no extra bank traffic
     } else if constexpr (is_rows<AM>()) {
         // rows of skipped quads keep whatever the slot held: they only feed output rows >= M, which nobody stores
-        if constexpr (AM == AM_ROWSH && MT == 1 && GLUE == kGlueRmsNorm) {
+        if constexpr (MT == 1 && GLUE == kGlueRmsNorm) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {   // row 4 i + rq with its own 1/rms (inv: rows 0..3, inv2: rows 4..7)
+            for (int i = 0; i < row_quads<AM, MT>(); ++i) {   // row 4 i + rq with its own 1/rms (gi.v[i])
                 u4_t g;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = glue_pair<ACT>(st.x.a[i][j], st.x.a[3][j], i == 0 ? inv : inv2, GLUE);
+                for (int j = 0; j < 4; ++j) g[j] = glue_pair<ACT>(st.x.a[i][j], st.x.a[AM == AM_ROWSH ? 3 : 4][j], gi.v[i], GLUE);
                 aslot[(4 * i + rq) * kRowsPitch + c] = g;
             }
         } else {
@@ -443,11 +451,11 @@ __device__ __forceinline__ void finish_outputs(const SkinnyParams& p, float v, b
     if (live && p.out_f32) {
         reinterpret_cast<float*>(p.out)[(size_t)m * p.N + n] = v;
     } else if (p.out_glue == kOutSiluMul || p.stats_out != nullptr) {
-        // decode op (M <= 4) epilogues that combine a tile's 16 outputs of one row: reducer wave w holds row w in lanes 0..15
+        // decode op (M <= 16) epilogues that combine a tile's 16 outputs of one row: reducer wave w holds row w in lanes 0..15
         // (accumulator register w of the lanes with rq == 0) and runs them wave-uniformly so the lane shuffles are legal
         if (wave < 4 && wave < p.M) {
-            // reducer wave w: lanes 0..15 hold row w, lanes 16..31 row w + 4 (live when < M); all shuffles below stay inside a
-            // 16-lane group
+            // reducer wave w: lanes 0..15 hold row w, lanes 16..31 row w + 4, 32..47 row w + 8, 48..63 row w + 12 (live when < M);
+            // all shuffles below stay inside a 16-lane group
             const int tiles = (p.N + kTileN - 1) / kTileN;
             const int c16 = lane & 15;
             float y = round_through<ACT>(v);
@@ -456,7 +464,7 @@ __device__ __forceinline__ void finish_outputs(const SkinnyParams& p, float v, b
                 // interleaved gate|up tile (fuse_gate_up_interleaved): lanes 0..7 of a group hold gate columns j, lanes 8..15 the
                 // matching up columns; HF LlamaMLP: act(silu(gate)) * up, each rounded in the activation dtype
                 const float up = __shfl_down(y, 8, 64);
-                const float a = round_through<ACT>(y / (1.0f + __expf(-y))) * up;
+                const float a = round_through<ACT>(y / (1.0f + expf(-y))) * up;
                 const int j = tile * 8 + c16;
                 if (live && c16 < 8 && j < p.N / 2) reinterpret_cast<uint16_t*>(p.out)[(size_t)m * (p.N / 2) + j] = f32_to_16<ACT>(a);
             } else {
@@ -481,8 +489,11 @@ __device__ __forceinline__ void finish_outputs(const SkinnyParams& p, float v, b
 
 // (Measured and dropped in round 2: a sched_barrier after every stage's loads, which keeps hipcc from sinking the four dwordx4
 // weight loads of a ring round to the end of the round -- per-shape times moved by < 1.5 % either way, other waves cover.)
-template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int D, int GLUE = 0>
-__global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
+// LB: threads the block may have.  17..32 rows (MT == 2) hold 32 activation registers per ring stage: under the 128-VGPR budget
+// of a 1024-thread block every such instantiation spilled 24-60 registers to scratch (round-2 ISA audit); they are built with
+// LB = 512 (<= 8 waves per block, 256-VGPR budget) instead and the planner picks <= 8 waves for them.
+template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int D, int GLUE = 0, int LB = (MT == 2 ? 512 : 1024)>
+__global__ __launch_bounds__(LB) void skinny_kernel(SkinnyParams p) {
     // ONE dynamic LDS array (16-B aligned base, no statics in front of it): per-wave activation slots during the K
     // loop, then the split-K reduction buffer red[W][MT*4][64]; the last 16 bytes hold the "last arriver" flag.
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -518,10 +529,11 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
     // decode op: the residual of this tile's row-0 outputs (reducer lanes = wave 0, lanes 0..15) is requested up front as
     // the aligned 32-bit pair holding the column (no zero-extension ALU op behind the load -> no early wait), used in the
     // epilogue; glue_inv = RMSNorm's rsqrt(mean(h^2) + eps)
-    float glue_inv = 0.f, glue_inv2 = 0.f;   // (glue_inv2: rows 4..7 of the 5..8-row decode op)
+    GlueInv ginv;                            // (v[1..3]: rows 4.. of the 5..16-row decode op)
+    float& glue_inv = ginv.v[0];
     uint32_t res_raw = 0u;
-    if (p.residual != nullptr && wave < 4 && lane < 32 && wave + 4 * rq < p.M) {
-        // (decode op: M <= 8; reducer wave w holds output rows w (lanes 0..15) and w + 4 (lanes 16..31))
+    if (p.residual != nullptr && wave < 4 && wave + 4 * rq < p.M) {
+        // (decode op: M <= 16; reducer wave w holds output rows w (lanes 0..15), w + 4 (lanes 16..31), w + 8, w + 12)
         const int coln = tile * kTileN + c;
         res_raw = reinterpret_cast<const uint32_t*>(p.residual)[((size_t)(wave + 4 * rq) * p.N + (coln < p.N ? coln : 0)) >> 1];
     }
@@ -648,12 +660,12 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
                     reinterpret_cast<u4_t*>(xbuf)[idx] = glued(xs[idx], gv);
                 }
                 __syncthreads();
-            } else if constexpr ((AM == AM_ROW4 || (AM == AM_ROWSH && MT == 1)) && GLUE == kGlueRmsNorm) {
-                // decode op on up to eight rows: wave w (< 4) owns the RMSNorm statistics of rows w and w + 4 -- the producer's
-                // per-tile sums of squares (eight clamped loads per lane and row, in front of the weight ring), or a wave-local
-                // reduction of the row when there is no producer (first op of a step) -- and shares 1/rms through LDS
+            } else if constexpr ((AM == AM_ROW4 || (is_rows<AM>() && MT == 1)) && GLUE == kGlueRmsNorm) {
+                // decode op on up to sixteen rows: wave w (< 4) owns the RMSNorm statistics of rows w, w + 4, w + 8, w + 12 -- the
+                // producer's per-tile sums of squares (eight clamped loads per lane and row, in front of the weight ring), or a
+                // wave-local reduction of the row when there is no producer (first op of a step) -- and shares 1/rms through LDS
                 float* scratch = reinterpret_cast<float*>(xbuf);
-                constexpr int RPW = AM == AM_ROW4 ? 1 : 2;   // rows per wave
+                constexpr int RPW = AM == AM_ROW4 ? 1 : (AM == AM_ROWSH ? 2 : 4);   // rows per wave
                 float sv[RPW][8];
                 if (p.stats_in != nullptr) {
 #pragma unroll
@@ -709,8 +721,8 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
                     for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
                 }
                 __syncthreads();
-                glue_inv = scratch[rq < p.M ? rq : 0];
-                if constexpr (AM == AM_ROWSH) glue_inv2 = scratch[4 + rq < p.M ? 4 + rq : 0];
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) ginv.v[r] = scratch[4 * r + rq < p.M ? 4 * r + rq : 0];
             } else if (GLUE == kGlueRmsNorm && p.stats_in != nullptr) {
                 // RMSNorm statistics handed over by the op that produced h (one partial per 16-column tile: its epilogue's
                 // sum of out^2).  ONE wave per block sums them in a fixed order -- eight clamped loads per lane issued in
@@ -783,7 +795,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
             for (int it = D; it < n_mine; it += D) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE>(st[d], p, cur, lane, aslot, dk, acc, xbuf, glue_inv, glue_inv2);
+                    compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE>(st[d], p, cur, lane, aslot, dk, acc, xbuf, ginv);
                     load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
                     cur += W;
                 }
@@ -791,7 +803,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 // (only the last ring round can hold padding chunks: wave-uniform skip)
-                if (cur < c_end) compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE>(st[d], p, cur, lane, aslot, dk, acc, xbuf, glue_inv, glue_inv2);
+                if (cur < c_end) compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE>(st[d], p, cur, lane, aslot, dk, acc, xbuf, ginv);
                 cur += W;
             }
         }
@@ -854,18 +866,22 @@ __global__ __launch_bounds__(1024) void skinny_kernel(SkinnyParams p) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int BITS, int ACT, int SCL, int MT, int AM, int D>
+template <int BITS, int ACT, int SCL, int MT, int AM, int D, int LB = (MT == 2 ? 512 : 1024)>
 static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
+    if (64 * pl.waves > LB) {
+        set_error("skinny_kernel: %d waves per block exceed the instantiation's %d-thread bound", pl.waves, LB);
+        return -22;
+    }
     const dim3 grid(ceil_div(p.N, kTileN), p.splits);
     const dim3 block(64 * pl.waves);
     constexpr int kSlot = slot_bytes<AM, MT>() > MT * 1024 ? slot_bytes<AM, MT>() : MT * 1024;
     const size_t lds_bytes = (size_t)pl.waves * kSlot + 16 + (AM == AM_ROW1P ? (size_t)p.K * 2 + 80 : 64);
     if constexpr ((AM == AM_ROW1 && MT == 1 && (D == 4 || D == 2)) || (AM == AM_ROW1P && MT == 1 && D == 4) || (AM == AM_ROW4 && MT == 1 && D == 4) ||
-                  (AM == AM_ROWSH && MT == 1 && D == 2)) {
+                  (is_rows<AM>() && MT == 1 && D == 2)) {
         if (p.in_glue != kGlueNone) {  // decode op with input glue: regular single-group-per-chunk plans only (ABI checks)
             if (p.in_glue == kGlueRmsNorm) {
                 hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueRmsNorm>), grid, block, lds_bytes, stream, p);
-            } else if constexpr (AM != AM_ROW4 && AM != AM_ROWSH) {
+            } else if constexpr (AM != AM_ROW4 && !is_rows<AM>()) {
                 hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueSiluMul>), grid, block, lds_bytes, stream, p);
             } else {
                 set_error("decode op: SiLU*mul INPUT glue exists for one row only (use the paired gate_up epilogue)");
@@ -875,9 +891,13 @@ static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStr
         }
     }
     if (pl.gpc == 1) {
-        hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D>), grid, block, lds_bytes, stream, p);
+        hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, 0, LB>), grid, block, lds_bytes, stream, p);
+    } else if constexpr (AM != AM_ROW1P) {
+        hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 4, AM, D, 0, LB>), grid, block, lds_bytes, stream, p);
     } else {
-        hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 4, AM, D>), grid, block, lds_bytes, stream, p);
+        // (gptqhip_gemm / gptqhip_decode_linear only pick the in-kernel permutation for one group constant per chunk)
+        set_error("skinny_kernel: the in-kernel act-order variant needs group_size %% 128 == 0");
+        return -22;
     }
     return check_hip(hipGetLastError(), "skinny_kernel launch");
 }
@@ -890,8 +910,11 @@ static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStre
     if (pl.mt == 1 && p.M <= 4) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW4, 4>(p, pl, stream);
     if (pl.mt == 1 && p.M <= 8) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROWSH, 2>(p, pl, stream);
     if (pl.mt == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROWS, 2>(p, pl, stream);
+#ifdef GPTQHIP_MT2_AB   // dev A/B build only (tests/dev): the round-2 plan, 16 waves per block under a 1024-thread bound (spills)
+    if (pl.mt == 2 && pl.waves > 8 && p.M <= 24) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWSH, 2, 1024>(p, pl, stream);
+    if (pl.mt == 2 && pl.waves > 8) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWS, 2, 1024>(p, pl, stream);
+#endif
     if (pl.mt == 2 && p.M <= 24) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWSH, 2>(p, pl, stream);
-    if (pl.mt == 2) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWS, 2>(p, pl, stream);
     return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWS, 2>(p, pl, stream);  // (callers chunk M to <= 32 rows)
 }
 
@@ -975,14 +998,22 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
         if (best > 0 && (best >= waves || pl.chunks / (waves * pl.depth) * (waves * pl.depth) != pl.chunks)) waves = best;
     }
     if (pl.mt == 2) {
-        // 17..32 rows: 16 waves per block beat the 8 round 1 capped it at (8.5 KiB of LDS per wave for the padded activation
-        // tile: 136 KiB, one block per CU) on every shape: 4096^2 M=32 10.4 -> 7.8 us, gate_up 49.2 -> 43.6 us
-        // (also where 16 does not divide the chunks into whole ring rounds: K=14336 runs the generic path at 19.9 us vs
-        // 21.0 on 8 regular waves and 23.5 on 14)
-        waves = 16;
+        // 17..32 rows: 32 activation registers per ring stage.  Round 2 ran 16 waves per block (1024-thread bound = 128 VGPRs:
+        // every instantiation spilled 24-60 registers); the instantiations are now bounded to 512 threads (256-VGPR budget, no
+        // scratch) and the plan is the largest wave count <= 8 that gives whole ring rounds.
+        static const bool ab16 = [] { const char* v = getenv("GPTQHIP_MT2_WAVES16"); return v && *v && *v != '0'; }();
+        if (ab16) {
+            waves = 16;   // (only meaningful in a -DGPTQHIP_MT2_AB dev build)
+        } else {
+            waves = 8;
+            for (int w = 8; w >= 4; --w) {
+                if (pl.chunks % (w * pl.depth) == 0) { waves = w; break; }
+            }
+        }
     }
     if (waves < 4 * pl.mt) waves = 4 * pl.mt;
     if (force_waves > 0) waves = force_waves < 4 * pl.mt ? 4 * pl.mt : force_waves;
+    if (pl.mt == 2 && waves > 8 && !getenv("GPTQHIP_MT2_WAVES16")) waves = 8;
     pl.waves = waves;
     // cross-block split-K costs a publish + ticket + re-read round trip (~1.5-2 us measured): only worth it
     // when the tiles alone leave most of the chip idle AND there is a long K range to share

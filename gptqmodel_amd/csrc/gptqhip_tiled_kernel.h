@@ -61,19 +61,39 @@ struct BStage {
     uint32_t meta[TPW][GPC];
 };
 
+// B loads go through buffer (MUBUF) instructions: ONE per-lane 32-bit offset register (lane * 16, or (lane & 15) * 4 for the
+// group constants) + a wave-uniform scalar offset per (tile, chunk).  With flat/global addressing hipcc hoisted one 64-bit VGPR
+// pointer per (tile, tensor) out of the chunk loop and re-added the chunk offset with 64-bit vector adds; on the 256-row tile those
+// 8+ registers did not fit beside the 128 accumulators and came back as scratch reloads with a FULL vmcnt drain in the main loop
+// (profiles/r03_isa_audit.txt).  The descriptors cover the whole tensors (< 2 GiB each: checked by the launcher).
+struct BSrc {
+    __amdgpu_buffer_rsrc_t qw, meta;
+    uint32_t l16, c4;   // per-lane byte offsets
+};
+__device__ __forceinline__ BSrc make_b_src(const TiledParams& p, int lane, size_t qw_bytes, size_t meta_bytes) {
+    BSrc b;
+    b.qw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.qw), 0, (int)qw_bytes, 0x00020000);
+    b.meta = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(p.meta), 0, (int)meta_bytes, 0x00020000);
+    b.l16 = (uint32_t)lane * 16u;
+    b.c4 = (uint32_t)(lane & 15) * 4u;
+    return b;
+}
+
 template <int BITS, int GPC, int TPW>
-__device__ __forceinline__ void load_b(BStage<BITS, GPC, TPW>& st, const TiledParams& p, int tile0, int chunk, int lane) {
+__device__ __forceinline__ void load_b(BStage<BITS, GPC, TPW>& st, const TiledParams& p, const BSrc& bs, int tile0, int chunk) {
     constexpr int WPC = BITS == 4 ? 1 : 2;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         int tile = tile0 + t;
         tile = tile < p.tiles ? tile : p.tiles - 1;  // ragged N: clamp (those columns are never stored)
-        const u4_t* src = reinterpret_cast<const u4_t*>(p.qw) + ((size_t)tile * p.chunks + chunk) * (WPC * 64) + lane;
+        const uint32_t soff = (uint32_t)(tile * p.chunks + chunk) * (uint32_t)(WPC * 1024);
 #pragma unroll
-        for (int h = 0; h < WPC; ++h) st.w[t][h] = src[h * 64];
-        const uint32_t* mb = p.meta + (size_t)tile * p.G * 16 + (lane & 15);
+        for (int h = 0; h < WPC; ++h) st.w[t][h] = __builtin_amdgcn_raw_buffer_load_b128(bs.qw, bs.l16, soff + h * 1024, 0);
+        const uint32_t mrow = (uint32_t)(tile * p.G);
 #pragma unroll
-        for (int j = 0; j < GPC; ++j) st.meta[t][j] = mb[tiled_group_of(p, chunk * kChunkK + j * (kChunkK / GPC)) * 16];
+        for (int j = 0; j < GPC; ++j)
+            st.meta[t][j] = __builtin_amdgcn_raw_buffer_load_b32(bs.meta, bs.c4,
+                                                                 (mrow + (uint32_t)tiled_group_of(p, chunk * kChunkK + j * (kChunkK / GPC))) * 64u, 0);
     }
 }
 
@@ -116,8 +136,8 @@ template <int BM, int NT, int I>
 __device__ __forceinline__ void stage_a_piece(const ATileSrc& a, char* lds_buf, int chunk, int wave) {
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int r0 = (I * (NT / 64) + wave) * 4;  // wave-uniform first row of this 1 KiB piece (r0 & 15 == 4*wave & 15)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(a.rsrc, (lptr_t)(lds_buf + r0 * 256), 16, a.voff + I * a.piece_step,
-                                             chunk * (kChunkK * 2), 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a.rsrc, (lptr_t)(lds_buf + r0 * 256), 16, a.voff,
+                                             chunk * (kChunkK * 2) + I * a.piece_step, 0, 0);
 }
 
 template <int BM, int NT>
@@ -210,6 +230,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     f4_t acc[MT][TPW];
     const DequantConsts dk = make_dequant_consts<BITS>();
     BStage<BITS, GPC, TPW> bst[D];
+    const BSrc bsrc = make_b_src(p, lane, (size_t)p.tiles * p.chunks * (BITS == 4 ? 1024 : 2048), (size_t)p.tiles * p.G * 64);
 
     const int c_begin = blockIdx.z * p.chunks_per_split;
     const int c_end = min(p.chunks, c_begin + p.chunks_per_split);
@@ -230,7 +251,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         constexpr int s = decltype(sc)::value;
         const int ck = min(chunk, c_end - 1);
         stage_a_dma<BM, NT>(t.a, lds_all + s * (BM * 256), ck, wave);
-        load_b<BITS, GPC, TPW>(bst[s], p, t.tile0, ck, lane);
+        load_b<BITS, GPC, TPW>(bst[s], p, bsrc, t.tile0, ck);
     };
     auto prologue = [&](const TileCtx& t) __attribute__((always_inline)) {
         static_for<D - 1>([&](auto dc) { issue(dc, t, c_begin + decltype(dc)::value); });
@@ -295,7 +316,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
             lds_read_b128<(i % MT) * 4096>(abuf[0][i], aaddr[i / MT]);
         });
         const int ck = min(chunk + D - 1, c_end - 1);
-        if constexpr (kIssue) load_b<BITS, GPC, TPW>(bst[si], p, t.tile0, ck, lane);
+        if constexpr (kIssue) load_b<BITS, GPC, TPW>(bst[si], p, bsrc, t.tile0, ck);
         __builtin_amdgcn_sched_barrier(0);
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -486,6 +507,10 @@ inline int launch_tiled_out(const TiledParams& p, int bm, hipStream_t stream) {
     // loads in flight across the epilogue.  Split-K launches have few tiles by construction: one tile per block.
     const int ntiles = ceil_div(p.N, kTiledBN) * ceil_div(p.M, bm);
     const dim3 grid(p.splits == 1 && ntiles > 256 ? 256 : ntiles, 1, p.splits);
+    if ((size_t)p.tiles * p.chunks * (BITS == 4 ? 1024 : 2048) >= ((size_t)1 << 31) || (size_t)p.tiles * p.G * 64 >= ((size_t)1 << 31)) {
+        set_error("tiled kernel: packed weights of one layer must stay below 2 GiB (32-bit buffer offsets)");
+        return -22;  // GPTQHIP_EINVAL
+    }
     {
         // 256-row tiles for every variant.  The 8-bit and per-K-step-group-constant stages spill 11-14 VGPRs beside the 128
         // accumulator registers (profiles/r02_tiled_bm256_isa.txt) and are STILL 19-36 % faster than on 128-row tiles

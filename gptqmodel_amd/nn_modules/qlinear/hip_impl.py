@@ -169,6 +169,23 @@ def make_hip_classes(ns, module_name: str):
                 out = out.to(in_dtype)
             return out.reshape(out_shape)
 
+        def forward_pregathered(self, x: torch.Tensor) -> torch.Tensor:
+            """forward() for an input whose features are ALREADY in this module's kernel row order (x_in[..., self.perm]; any
+            x when the module has no act-order permutation): the act-order gather pass of forward() is skipped.  Used by the
+            prefill path of utils.hf_llama, where ops.rmsnorm_gather emits the normalised activations in that order."""
+            if not self._ready:
+                raise RuntimeError("HipGptqLinear.forward_pregathered called before post_init()")
+            if self.adapter:
+                raise NotImplementedError("forward_pregathered: adapters see the un-permuted input; use forward()")
+            from gptqmodel_amd import ops
+            out_shape = x.shape[:-1] + (self.out_features,)
+            x2, in_dtype = flatten_input(x, self.in_features)
+            out = ops.gemm(x2, self.qweight, self.meta, self._bias_for(x2.dtype, x2.device), None, self.out_features,
+                           self.group_size, self.bits, self._scale_dtype, exact_bf16=self.EXACT_BF16_DECODE)
+            if out.dtype != in_dtype:
+                out = out.to(in_dtype)
+            return out.reshape(out_shape)
+
         def pack_block(self, linear: torch.nn.Module, scales: torch.Tensor, zeros: torch.Tensor, g_idx: torch.Tensor,
                        block_in: int = 8192, workers: int = 1):
             """Quantise-and-pack a float Linear into this module's checkpoint-layout buffers ON THE DEVICE; same

@@ -180,7 +180,7 @@ OUT_NONE, OUT_SILU_MUL_PAIRED, OUT_PARTIAL_F32 = 0, 1, 2
 
 def decode_supported(K: int, N: int, group_size: int, has_perm: bool = False, M: int = 1) -> bool:
     """True when gptqhip_decode_linear handles a [K,N] layer (regular pipeline; has_perm: with an act-order permutation
-    applied in the kernel; M: rows 1..8), else use gemm()."""
+    applied in the kernel; M: rows 1..16), else use gemm()."""
     return bool(_lib.load().gptqhip_decode_supported(K, N, group_size, 1 if has_perm else 0, M))
 
 
@@ -194,11 +194,11 @@ def make_decode_op(x: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor,
     keeps the tensors alive (DecodeStep does) -- binding once and re-launching costs no per-call Python work.
     `workspace`: the stream's scratch (workspace_for); taken from the CURRENT stream when omitted.
     `perm`: the module's act-order permutation (int32 [K]); applied to the glued input inside the kernel.
-    `M`: rows (1..8): x [M,K], out / residual [M,N], stats_in [M, K/16], stats_out [M, ceil(N/16)], all contiguous.
+    `M`: rows (1..16): x [M,K], out / residual [M,N], stats_in [M, K/16], stats_out [M, ceil(N/16)], all contiguous.
     `exact`: the opt-in exact-arithmetic dequant (GPTQHIP_GEMM_EXACT, include/gptqhip.h)."""
     _require_cuda(x, qweight_t, meta, bias, out, norm_weight, residual, workspace, stats_in, stats_out, perm)
-    if not 1 <= M <= 8:
-        raise RuntimeError("decode op: M must be 1..8")
+    if not 1 <= M <= 16:
+        raise RuntimeError("decode op: M must be 1..16")
     if perm is not None and (perm.dtype != torch.int32 or perm.numel() != K or not perm.is_contiguous()):
         raise RuntimeError("decode op: perm must be a contiguous int32 [K] tensor")
     want_out = torch.float32 if out_glue == OUT_PARTIAL_F32 else x.dtype
@@ -384,6 +384,29 @@ def gather_cols(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(x.device):
         rc = lib.gptqhip_gather_cols(_ptr(x), _ptr(perm), _ptr(out), M, K, _stream(x.device))
     _lib.check(rc, "gptqhip_gather_cols")
+    return out
+
+
+def rmsnorm_gather(h: torch.Tensor, weight: torch.Tensor, eps: float, perm: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """HF LlamaRMSNorm over the last dimension fused with an act-order gather: out[.., k'] = weight[p] * act(h32[.., p] * rsqrt(mean
+    h32^2 + eps)), p = perm[k'] (perm None: plain RMSNorm).  Feed the result to HipGptqLinear.forward_pregathered of the q|k|v or
+    gate|up module whose `perm` this is: the linear then needs no gather pass of its own."""
+    lib = _lib.load()
+    _require_cuda(h, weight)
+    if h.dtype not in _DT or weight.dtype != h.dtype or not h.is_contiguous() or not weight.is_contiguous():
+        raise RuntimeError("rmsnorm_gather: h and weight must be contiguous fp16 / bf16 tensors of the same dtype")
+    K = h.shape[-1]
+    M = h.numel() // K
+    if weight.numel() != K or (perm is not None and (perm.dtype != torch.int32 or perm.numel() != K or not perm.is_contiguous())):
+        raise RuntimeError("rmsnorm_gather: weight / perm must have K elements (perm int32)")
+    if out is None:
+        out = torch.empty_like(h)
+    elif out.shape != h.shape or out.dtype != h.dtype or not out.is_contiguous() or out.data_ptr() == h.data_ptr():
+        raise RuntimeError("rmsnorm_gather: out must be a distinct contiguous tensor like h")
+    with torch.cuda.device(h.device):
+        rc = lib.gptqhip_rmsnorm_gather(_ptr(h), _ptr(weight), _ptr(perm), _ptr(out), M, K, float(eps), _DT[h.dtype], _stream(h.device))
+    _lib.check(rc, "gptqhip_rmsnorm_gather")
     return out
 
 

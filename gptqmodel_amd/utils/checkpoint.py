@@ -1,0 +1,231 @@
+"""On-disk GPTQ / AWQ checkpoints on either side of the quantised-linear path: the part of the reference's load flow that hands
+tensors to the QuantLinear classes, and the inverse for tests / tools.
+
+Reference flow being mirrored (gptqmodel/models/loader.py): `QuantizeConfig.from_pretrained` (quantization/config.py:3022-3043:
+quantize_config.json, else quant_config.json, else config.json["quantization_config"]; key synonyms :1504-1525) ->
+`make_quant` (loader.py:1092 -> utils/model.py:398) -> safetensors shards into the module buffers (loader.py:1646
+`load_checkpoint_in_model...`) -> v1 -> v2 zero-point conversion for kernels with REQUIRES_FORMAT_V2 (loader.py:1658-1675,
+utils/model.py:750-844) -> `gptqmodel_post_init` (loader.py:1804).  The model zoo, tokenizer handling, device maps, lazy /
+offloaded loading and every other checkpoint format stay with the reference (out of scope); this file is the minimum
+a caller needs to go from a checkpoint DIRECTORY to post_init()ed HIP modules inside an already constructed HF model, and it is what
+tests/test_gpu_checkpoint.py round-trips.
+
+On-disk conventions: GPTQ `format: "gptq"` stores zero-points minus one (v1); `gptq_v2` stores them as
+is.  safetensors shards + `model.safetensors.index.json` (`weight_map`: tensor name -> shard file) as written by transformers.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Iterable, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .backend import BACKEND
+from .const import FORMAT, METHOD
+
+QUANT_CONFIG_FILENAMES = ("quantize_config.json", "quant_config.json", "config.json")     # quantization/config.py:73-74
+# quantization/config.py:1504-1525
+_SYNONYMS = {"w_bit": "bits", "wbits": "bits", "q_group_size": "group_size", "version": "format", "checkpoint_format": "format",
+             "quant_method": "method"}
+_SYNONYMS_NEGATED = {"zero_point": "sym"}
+SAFETENSORS_INDEX = "model.safetensors.index.json"
+SAFETENSORS_SINGLE = "model.safetensors"
+
+
+def normalize_quantize_config(raw: Dict) -> Dict:
+    """Canonical keys of a quantize_config payload (the subset that reaches the kernel constructor: SURVEY.md appendix A):
+    bits, group_size, desc_act, sym, format, method, pack_dtype, dynamic, lm_head, meta.  Synonyms as in the reference; AWQ's
+    `zero_point` is the NEGATION of sym; `is_marlin_format` is rejected like the reference does (config.py:67-68)."""
+    if "is_marlin_format" in raw:
+        raise ValueError("quantize_config: `is_marlin_format` is a hard-deprecated key (quantization/config.py:67-68)")
+    cfg: Dict = {}
+    for key, val in raw.items():
+        if key in _SYNONYMS_NEGATED:
+            cfg[_SYNONYMS_NEGATED[key]] = not bool(val)
+        else:
+            cfg[_SYNONYMS.get(key, key)] = val
+    method = str(cfg.get("method", "gptq")).lower()
+    fmt = cfg.get("format")
+    if fmt is None:
+        fmt = "gemm" if method == "awq" else "gptq"
+    out = {
+        "bits": int(cfg["bits"]),
+        "group_size": int(cfg.get("group_size", 128)),
+        "desc_act": bool(cfg.get("desc_act", False)),
+        "sym": bool(cfg.get("sym", True)),
+        "format": str(fmt).lower(),
+        "method": method,
+        "pack_dtype": str(cfg.get("pack_dtype", "int32")).replace("torch.", ""),
+        "dynamic": cfg.get("dynamic"),
+        "lm_head": bool(cfg.get("lm_head", False)),
+        "meta": cfg.get("meta") or {},
+    }
+    if out["bits"] not in (2, 3, 4, 8):
+        raise ValueError(f"quantize_config: bits={out['bits']}")
+    if out["group_size"] != -1 and out["group_size"] <= 0:
+        raise ValueError(f"quantize_config: group_size={out['group_size']}")
+    return out
+
+
+def read_quantize_config(ckpt_dir: str) -> Dict:
+    """quantize_config.json | quant_config.json | config.json["quantization_config"], first one found (config.py:3022-3043)."""
+    for name in QUANT_CONFIG_FILENAMES:
+        path = os.path.join(ckpt_dir, name)
+        if os.path.exists(path):
+            with open(path, "r", encoding="utf-8") as f:
+                raw = json.load(f)
+            if name == "config.json":
+                if "quantization_config" not in raw:
+                    continue
+                raw = raw["quantization_config"]
+            return normalize_quantize_config(raw)
+    raise ValueError("no quantize_config.json, quant_config.json or config.json[quantization_config] in " + ckpt_dir)
+
+
+def _shard_map(ckpt_dir: str) -> Dict[str, str]:
+    """tensor name -> shard file (model.safetensors.index.json, or the single model.safetensors)."""
+    from safetensors import safe_open
+    idx = os.path.join(ckpt_dir, SAFETENSORS_INDEX)
+    if os.path.exists(idx):
+        with open(idx, "r", encoding="utf-8") as f:
+            return dict(json.load(f)["weight_map"])
+    single = os.path.join(ckpt_dir, SAFETENSORS_SINGLE)
+    if not os.path.exists(single):
+        raise ValueError(f"no {SAFETENSORS_INDEX} / {SAFETENSORS_SINGLE} in {ckpt_dir}")
+    with safe_open(single, framework="pt") as f:
+        return {k: SAFETENSORS_SINGLE for k in f.keys()}
+
+
+def quantized_module_names(weight_map: Iterable[str]) -> List[str]:
+    """Modules that are quantised in the checkpoint = those that own a `.qweight` tensor."""
+    return sorted(k[: -len(".qweight")] for k in weight_map if k.endswith(".qweight"))
+
+
+def load_quantized_checkpoint(model: nn.Module, ckpt_dir: str, device="cuda", backend: BACKEND = BACKEND.AUTO,
+                              fuse_decoder_layers: bool = False, dtype: Optional[torch.dtype] = None) -> nn.Module:
+    """Turn an already constructed HF model (any weights; typically built from the checkpoint's config.json) into the quantised
+    model stored in `ckpt_dir`, on the HIP backend: make_quant -> every tensor of the safetensors shards into its parameter /
+    buffer -> v1 -> v2 zero-points -> (optional) utils.hf_llama.fuse_llama_decoder_layers -> gptqmodel_post_init.  Raises on
+    missing / unexpected / mis-shaped tensors -- a silently half-loaded model is worse than an error."""
+    from safetensors import safe_open
+    from .model import convert_gptq_v1_to_v2_format, gptqmodel_post_init, make_quant
+    cfg = read_quantize_config(ckpt_dir)
+    if cfg["method"] not in ("gptq", "awq"):
+        raise NotImplementedError(f"quant method `{cfg['method']}` is outside this backend (GPTQ / AWQ only)")
+    fmt = {"gptq": FORMAT.GPTQ, "gptq_v2": FORMAT.GPTQ_V2, "gemm": FORMAT.GEMM}.get(cfg["format"])
+    if fmt is None:
+        raise NotImplementedError(f"checkpoint format `{cfg['format']}` is outside this backend (gptq, gptq_v2, AWQ gemm)")
+    method = METHOD.GPTQ if cfg["method"] == "gptq" else METHOD.AWQ
+    weight_map = _shard_map(ckpt_dir)
+    names = quantized_module_names(weight_map)
+    if not names:
+        raise ValueError("the checkpoint holds no quantised (.qweight) tensors")
+    if dtype is None:
+        dtype = next((p.dtype for p in model.parameters() if p.dtype in (torch.float16, torch.bfloat16)), torch.float16)
+    make_quant(model, names, bits=cfg["bits"], group_size=cfg["group_size"], desc_act=cfg["desc_act"], sym=cfg["sym"],
+               backend=backend, format=fmt, quant_method=method, dynamic=cfg["dynamic"], dtype=dtype)
+    model.to(device)
+    targets = dict(model.named_parameters())
+    targets.update(dict(model.named_buffers()))
+    seen = set()
+    by_file: Dict[str, List[str]] = {}
+    for name, fname in weight_map.items():
+        by_file.setdefault(fname, []).append(name)
+    for fname, keys in sorted(by_file.items()):
+        with safe_open(os.path.join(ckpt_dir, fname), framework="pt") as f:
+            for key in keys:
+                t = f.get_tensor(key)
+                if key not in targets:
+                    if key.endswith(".g_idx") or key.endswith(".bias"):
+                        # optional tensors of a quant module that this module instance does not register (e.g. no bias)
+                        raise ValueError(f"checkpoint tensor `{key}` has no counterpart in the model")
+                    raise ValueError(f"unexpected checkpoint tensor `{key}`")
+                dst = targets[key]
+                if tuple(dst.shape) != tuple(t.shape):
+                    raise ValueError(f"`{key}`: checkpoint shape {tuple(t.shape)} != module shape {tuple(dst.shape)}")
+                with torch.no_grad():
+                    dst.copy_(t.to(device=dst.device, dtype=dst.dtype if dst.dtype.is_floating_point else t.dtype))
+                seen.add(key)
+    quant_owned = [k for k in targets if any(k.startswith(n + ".") for n in names)]
+    missing = [k for k in quant_owned if k not in seen and not k.endswith((".meta", ".perm"))]
+    if missing:
+        raise ValueError(f"the checkpoint lacks tensors of quantised modules: {missing[:8]}")
+    if fmt == FORMAT.GPTQ:
+        # on-disk v1 (zero - 1) -> runtime v2, for every kernel that asks for it (loader.py:1658-1675)
+        convert_gptq_v1_to_v2_format(model, bits=cfg["bits"])
+    if fuse_decoder_layers:
+        from .hf_llama import fuse_llama_decoder_layers
+        fuse_llama_decoder_layers(model)
+    gptqmodel_post_init(model, use_act_order=cfg["desc_act"])
+    model.eval()
+    return model
+
+
+def _v2_to_v1_qzeros(qzeros: torch.Tensor, bits: int) -> torch.Tensor:
+    """Runtime (v2) zero-points -> on-disk `format: gptq` (v1, zero - 1 per field): the inverse of utils/model.py:814-818 /
+    the reference writer's convert_gptq_v2_to_v1_format.  Fields wrap modulo 2^bits like the reference's integer subtraction."""
+    pf = 32 // bits
+    mask = (1 << bits) - 1
+    sh = torch.arange(0, 32, bits, dtype=torch.int64, device=qzeros.device)
+    z = (qzeros.to(torch.int64).unsqueeze(-1) >> sh) & mask
+    w = (((z - 1) & mask) << sh).sum(dim=-1) & 0xFFFFFFFF
+    assert z.shape[-1] == pf
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+
+
+def save_quantized_checkpoint(model: nn.Module, ckpt_dir: str, quantize_config: Dict, max_shard_bytes: int = 1 << 30) -> List[str]:
+    """Write `model` (HIP quant modules still in the CHECKPOINT layout, i.e. before post_init) in the on-disk layout:
+    safetensors shards of at most max_shard_bytes + model.safetensors.index.json + quantize_config.json.  `format: "gptq"`
+    stores v1 zero-points like the reference's writer.  Returns the shard file names.  (Saving a post_init()ed model is refused by
+    the modules themselves: the kernel layout is not a checkpoint layout.)"""
+    from safetensors.torch import save_file
+    from ..nn_modules.qlinear import BaseQuantLinear
+    cfg = normalize_quantize_config(quantize_config)
+    os.makedirs(ckpt_dir, exist_ok=True)
+    state = {}
+    v1_owners = set()
+    for name, mod in model.named_modules():
+        if isinstance(mod, BaseQuantLinear):
+            if getattr(mod, "_ready", False):
+                raise RuntimeError(f"`{name}` is already post_init()ed: save from the checkpoint-layout model")
+            if cfg["format"] == "gptq" and hasattr(mod, "qzero_format") and mod.qzero_format() == 2:
+                v1_owners.add(name)
+    for key, t in model.state_dict().items():
+        t = t.detach()
+        if key.endswith(".qzeros") and key[: -len(".qzeros")] in v1_owners:
+            t = _v2_to_v1_qzeros(t, cfg["bits"])
+        state[key] = t.to("cpu").contiguous()
+    shards: List[Dict[str, torch.Tensor]] = [{}]
+    size = 0
+    for key in sorted(state):
+        nbytes = state[key].numel() * state[key].element_size()
+        if shards[-1] and size + nbytes > max_shard_bytes:
+            shards.append({})
+            size = 0
+        shards[-1][key] = state[key]
+        size += nbytes
+    files, weight_map = [], {}
+    for i, sh in enumerate(shards):
+        fname = SAFETENSORS_SINGLE if len(shards) == 1 else f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors"
+        save_file(sh, os.path.join(ckpt_dir, fname), metadata={"format": "pt"})
+        files.append(fname)
+        for key in sh:
+            weight_map[key] = fname
+    if len(shards) > 1:
+        total = sum(t.numel() * t.element_size() for t in state.values())
+        with open(os.path.join(ckpt_dir, SAFETENSORS_INDEX), "w", encoding="utf-8") as f:
+            json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=1)
+    payload = {"bits": cfg["bits"], "group_size": cfg["group_size"], "desc_act": cfg["desc_act"], "sym": cfg["sym"],
+               "lm_head": cfg["lm_head"], "quant_method": cfg["method"], "checkpoint_format": cfg["format"], "pack_dtype": cfg["pack_dtype"],
+               "meta": dict(cfg["meta"], quantizer=cfg["meta"].get("quantizer", ["gptqmodel_amd:test-writer"]))}
+    if cfg["dynamic"]:
+        payload["dynamic"] = cfg["dynamic"]
+    with open(os.path.join(ckpt_dir, "quantize_config.json"), "w", encoding="utf-8") as f:
+        json.dump(payload, f, indent=1)
+    return files
+
+
+__all__ = ["read_quantize_config", "normalize_quantize_config", "load_quantized_checkpoint", "save_quantized_checkpoint",
+           "quantized_module_names"]

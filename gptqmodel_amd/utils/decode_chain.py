@@ -36,11 +36,15 @@ class DecodeLayer:
     """The four (fused) quantised linears of one decoder layer + its two RMSNorm weights."""
 
     def __init__(self, qkv, o, gate_up, down, input_norm: torch.Tensor, post_norm: torch.Tensor,
-                 o_bias: Optional[torch.Tensor] = None, down_bias: Optional[torch.Tensor] = None):
+                 o_bias: Optional[torch.Tensor] = None, down_bias: Optional[torch.Tensor] = None,
+                 o_input_index: Optional[torch.Tensor] = None):
         self.qkv, self.o, self.gate_up, self.down = qkv, o, gate_up, down
         self.input_norm, self.post_norm = input_norm, post_norm
         # tensor parallel only: the FULL-layer bias of the row-parallel o / down projections (added once, after the reduction)
         self.o_bias, self.down_bias = o_bias, down_bias
+        # tensor parallel + act-order o_proj only (utils.tp.shard_gptq_row(act_order="global_sort")["input_index"]): the features of
+        # the FULL attention output this rank's sorted rows consume
+        self.o_input_index = o_input_index
 
 
 def _lin_tensors(lin, dtype):
@@ -132,7 +136,14 @@ class TPDecodeStep:
 
     The rounding points are those of the reference's single-GPU module chain (round the full linear output once, then add the
     residual), so tp=N differs from tp=1 only by the fp32 association of the K-shards' partial sums.  Every rank holds the
-    same h1 / h2 bit for bit (the reduction order is the rank order on every rank)."""
+    same h1 / h2 bit for bit (the reduction order is the rank order on every rank).
+
+    Act-order (desc_act=True) checkpoints (the rule of gptqmodel/utils/marlin.py:296-305,368-372 -- row shards
+    are cut from the globally group-sorted rows): the column shards keep their input permutation and the decode op applies it in
+    the kernel; down_proj's permutation is folded into the column OWNERSHIP of gate / up (utils.tp.shard_mlp_act_order: exact, no
+    exchange); o_proj's rows need attention-output features owned by other ranks, so ONE one-shot all-gather + select kernel
+    (gptqhip_allgather_select) sits in front of it (DecodeLayer.o_input_index) -- 80 extra 16 KB exchanges per 70B token instead
+    of the module path's all_gather + index_select per layer."""
 
     def __init__(self, layers: Sequence[DecodeLayer], hidden: int, q_dim_local: int, dtype: torch.dtype, comm, eps: float = 1e-5,
                  device: Optional[torch.device] = None):
@@ -153,22 +164,23 @@ class TPDecodeStep:
             for lin in (L.qkv, L.o, L.gate_up, L.down):
                 need = max(need, ops.workspace_bytes(1, lin.in_features, lin.out_features, lin.group_size, lin.bits, False))
         self.workspace = torch.zeros(max(need, 1 << 20), dtype=torch.uint8, device=dev)
-        self._keep, self.steps = [], []   # steps: ("op", struct) | ("ar", residual, bias, out, stats_out)
+        self._keep, self.steps = [], []   # steps: ("op", struct) | ("ar", residual, bias, out, stats_out) | ("ag", x_local, index, out)
+        self.o_in = None                  # act-order o_proj shards: the gathered + selected attention-output features
 
         def bind(lin, x, out, glue, nw, oglue, s_in):
             qw, meta, bias, sdt, perm = _lin_tensors(lin, dtype)
-            if perm is not None:
-                raise NotImplementedError("TPDecodeStep: act-order shards need the row-parallel input exchange of "
-                                          "utils.tp.RowParallelQuantLinear; use the module path")
             K, N = lin.in_features, lin.out_features
+            if oglue == ops.OUT_PARTIAL_F32 and perm is not None:
+                raise NotImplementedError("TPDecodeStep: a row-parallel shard must have sequential groups -- cut it with "
+                                          "utils.tp.shard_gptq_row(act_order='global_sort') / shard_mlp_act_order")
             if oglue == ops.OUT_PARTIAL_F32 and bias is not None:
                 raise ValueError("row-parallel shards must not carry a bias: pass the layer bias as DecodeLayer.o_bias / down_bias")
-            if not ops.decode_supported(K, N, lin.group_size):
+            if not ops.decode_supported(K, N, lin.group_size, perm is not None):
                 raise NotImplementedError(f"decode chain: shard shape K={K} N={N} group_size={lin.group_size} unsupported")
-            self._keep.extend([qw, meta, bias, nw])
+            self._keep.extend([qw, meta, bias, nw, perm])
             self.steps.append(("op", ops.make_decode_op(x, qw, meta, bias, out, K, N, lin.group_size, lin.bits, sdt, in_glue=glue,
                                                         norm_weight=nw, eps=eps, workspace=self.workspace, out_glue=oglue,
-                                                        stats_in=s_in)))
+                                                        stats_in=s_in, perm=perm)))
 
         h_in, st_in = self.x_in, None
         for li, L in enumerate(self.layers):
@@ -178,7 +190,18 @@ class TPDecodeStep:
                 raise ValueError("row-parallel shard shapes do not match hidden / q_dim_local")
             h1, h2, st1, st2 = self.h[li, 0], self.h[li, 1], self.stats[li, 0], self.stats[li, 1]
             bind(L.qkv, h_in, self.qkv_out, ops.GLUE_RMSNORM, L.input_norm, ops.OUT_NONE, st_in)
-            bind(L.o, self.qkv_out, self.partial, ops.GLUE_NONE, None, ops.OUT_PARTIAL_F32, None)   # stand-in attention: a = q_r
+            o_in = self.qkv_out                                                                     # stand-in attention: a = q_r
+            if L.o_input_index is not None:
+                # act-order o_proj shard: its sorted rows consume features of the FULL attention output
+                idx = L.o_input_index.to(device=dev, dtype=torch.int32).contiguous()
+                if idx.numel() != q_dim_local:
+                    raise ValueError("o_input_index must select q_dim_local features")
+                if self.o_in is None:
+                    self.o_in = torch.zeros(q_dim_local, dtype=dtype, device=dev)
+                self._keep.append(idx)
+                self.steps.append(("ag", self.qkv_out[:q_dim_local], idx, self.o_in))
+                o_in = self.o_in
+            bind(L.o, o_in, self.partial, ops.GLUE_NONE, None, ops.OUT_PARTIAL_F32, None)
             self.steps.append(("ar", h_in, L.o_bias, h1, st1))
             bind(L.gate_up, h1, self.gu_out, ops.GLUE_RMSNORM, L.post_norm, ops.OUT_SILU_MUL_PAIRED, st1)
             bind(L.down, self.gu_out, self.partial, ops.GLUE_NONE, None, ops.OUT_PARTIAL_F32, None)
@@ -191,10 +214,17 @@ class TPDecodeStep:
             for st in self.steps:
                 if st[0] == "op":
                     ops.launch_decode_op(st[1], self.device)
+                elif st[0] == "ag":
+                    self.comm.gather_select(st[1], st[2], out=st[3])
                 else:
                     _, res, bias, out, stats = st
                     self.comm(self.partial, self.dtype, bias=bias, residual=res, out=out, stats_out=stats)
         return self.out
+
+    def check(self) -> None:
+        """Host-side health check at a synchronisation point (not inside a captured region): raises when a peer wait of this
+        rank's communicator timed out (the affected outputs were poisoned with NaN by the kernel)."""
+        self.comm.check_status()
 
 
 __all__ = ["DecodeLayer", "DecodeStep", "TPDecodeStep"]

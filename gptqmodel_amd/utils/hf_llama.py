@@ -8,16 +8,26 @@ product and two residual adds: ~16 dependent launches per layer.  `fuse_llama_de
   * folds an act-order checkpoint's down_proj input permutation into gate / up's output columns (utils.model.
     fold_act_order_into_producers: exact, removes down_proj's activation gather), fuses q/k/v into one module (views stand in for the three projections, as with fuse_siblings) and gate/up into ONE
     module with the columns interleaved in blocks of 8 (utils.model.fuse_gate_up_interleaved);
-  * gives every decoder layer a decode fast path: when the layer is called with at most EIGHT tokens (batch x q_len <= 8, eval:
+  * gives every decoder layer a decode fast path: when the layer is called with at most SIXTEEN tokens (batch x q_len <= 16, eval:
     single-sequence decode, a few sequences, or speculative tokens of one), the layer runs as 4 decode ops (gptqhip_decode_linear: RMSNorm on the input of qkv / gate_up with the statistics handed
     over by the op that produced the residual stream, SiLU*mul in the gate_up epilogue, residual add + next statistics in
-    the o / down epilogue) around HF's own rotary / KV-cache update / attention call.  Everything else (prefill, batches,
-    training-mode calls) takes HF's original path through the same fused modules.
+    the o / down epilogue) around HF's own rotary / KV-cache update / attention call;
+  * gives it a prefill path for more tokens than that (eval, no grad): the two RMSNorms run as ONE HIP kernel each
+    (ops.rmsnorm_gather instead of eager HF's six small kernels with fp32 temporaries) that, for act-order checkpoints, writes
+    the normalised activations already in the q|k|v / gate|up kernels' row order -- those two linears then run without their
+    own x-gather pass (o_proj keeps its pre-pass: its input comes from attention; down_proj's was folded away at load time).
+    Training-mode calls, calls with forward hooks on the layer's sub-modules and anything unexpected take HF's original path
+    through the same fused modules.
 
 The fast path binds raw pointers once per layer (buffers owned by the layer), so a decode step is capture-safe and costs 4
-ctypes calls per layer on the host.  It follows transformers' `LlamaAttention.forward` of the installed version
-(>= 4.48 attention-interface API); `fuse_llama_decoder_layers` verifies the attributes it relies on and leaves a layer
-untouched (returns it in `skipped`) when something does not match.
+ctypes calls per layer on the host.  It mirrors `LlamaAttention.forward` / `LlamaDecoderLayer.forward` of transformers >= 4.56 /
+5.x: `past_key_values` keyword, `Cache.update(k, v, layer_idx)`, the decoder layer returning a bare tensor.
+`fuse_llama_decoder_layers` VERIFIES that contract on the installed classes (signature + source inspection, `_hf_contract`)
+and leaves a layer untouched (returns it in `skipped` with the reason) when anything does not match -- older releases (4.48 -
+4.55: `past_key_value` in **kwargs, tuple return, cache_kwargs) would otherwise run with a silently stale KV cache.
+
+Aliasing: the fast path returns a view of a per-layer buffer that the next decode step overwrites; when the decoder layer
+itself carries forward hooks (transformers records `output_hidden_states` through them) a clone is returned instead.
 
 Reference behaviour preserved: each op's arithmetic is the reference's TorchLinear.forward chain (torch.py:326-347) composed
 with HF's LlamaRMSNorm / LlamaMLP / residual formulas -- tests/test_gpu_e2e_llama.py compares logits with the unfused model.
@@ -40,7 +50,7 @@ def _is_quant(m) -> bool:
     return isinstance(m, BaseQuantLinear) and getattr(m, "adapter", None) is None
 
 
-MAX_ROWS = 8   # tokens per call on the fast path (gptqhip_decode_op.M): a few sequences at q_len 1, or speculative tokens of one
+MAX_ROWS = 16   # tokens per call on the fast path (gptqhip_decode_op.M): a few sequences at q_len 1, or speculative tokens of one
 
 
 class _LayerDecodeState:
@@ -124,9 +134,16 @@ def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, 
 
     hidden = fd["hidden"]
     M = hidden_states.numel() // hidden
-    if (M < 1 or M > MAX_ROWS or hidden_states.dim() != 3 or hidden_states.shape[-1] != hidden or self.training
+    if (M < 1 or hidden_states.dim() != 3 or hidden_states.shape[-1] != hidden or self.training
             or not hidden_states.is_cuda or position_embeddings is None or fd["disabled"]
-            or (torch.is_grad_enabled() and hidden_states.requires_grad)):
+            or (torch.is_grad_enabled() and hidden_states.requires_grad)
+            or kwargs.get("output_attentions") or _has_hooks(self.self_attn, self.mlp, self.input_layernorm, self.post_attention_layernorm)
+            or "attentions" in _capture_keys(self.self_attn)):
+        # (user hooks / attention-weight capture on the sub-modules the fast paths bypass: HF's own code runs them)
+        return original()
+    if M > MAX_ROWS:
+        if fd["prefill"] is not None and hidden_states.dtype in (torch.float16, torch.bfloat16):
+            return _prefill_forward(self, fd, hidden_states, attention_mask, past_key_values, position_embeddings, kwargs)
         return original()
     st: Optional[_LayerDecodeState] = fd["state"]
     if st is None or st.dtype != hidden_states.dtype:
@@ -171,13 +188,114 @@ def _layer_forward(self, hidden_states, attention_mask=None, position_ids=None, 
         if past_key_values is not None:
             k, v = past_key_values.update(k, v, attn.layer_idx)
         interface = fd["interfaces"].get_interface(attn.config._attn_implementation, fd["eager_attention"])
-        if fd["sliding_window"]:   # Mistral / Qwen2 hand their window to the attention interface
-            kwargs = dict(kwargs, sliding_window=attn.sliding_window)
+        window = _sliding_window(attn) if fd["sliding_window"] else None
+        if window is not None:     # Mistral / Qwen2 / Qwen3 hand their window to the attention interface
+            kwargs = dict(kwargs, sliding_window=window)
         attn_out, _ = interface(attn, q, k, v, attention_mask, dropout=0.0, scaling=attn.scaling, **kwargs)
         st.attn_in[:M].copy_(attn_out.reshape(M, -1))
         # ---- o_proj + residual, MLP ---------------------------------------------------------------------------------------------
         ops.launch_decode_seq(tail_chain if chained else tail_first, dev)
-    return st.h2[:M].view(hidden_states.shape)
+    out = st.h2[:M].view(hidden_states.shape)
+    # a view of the layer's persistent buffer: anything that RECORDS it across steps (transformers captures
+    # output_hidden_states through forward hooks on the decoder layer) must get its own copy
+    return out.clone() if (_has_hooks(self) or "hidden_states" in _capture_keys(self)) else out
+
+
+def _is_hf_capture_hook(fn) -> bool:
+    # transformers >= 4.56 installs its output recorders as PERMANENT forward hooks on every decoder layer / attention module the
+    # first time the model runs (utils/output_capturing.py); they are inert unless a collector is active (_capture_keys)
+    return getattr(fn, "__name__", "") == "output_capturing_hook" and "output_capturing" in getattr(fn, "__module__", "")
+
+
+def _has_hooks(*mods) -> bool:
+    """Forward (pre-)hooks other than transformers' own inert output recorders."""
+    return any(m._forward_pre_hooks or any(not _is_hf_capture_hook(h) for h in m._forward_hooks.values()) for m in mods)
+
+
+def _capture_keys(module):
+    """Output kinds transformers is recording during this call ("hidden_states", "attentions", ...): the keys of its active
+    collector; when that machinery is not importable (other releases), every kind a recorder hook on `module` could serve."""
+    try:
+        from transformers.utils.output_capturing import _active_collector
+        col = _active_collector.get()
+        return () if col is None else tuple(col.keys())
+    except Exception:  # noqa: BLE001
+        return ("hidden_states", "attentions") if module._forward_hooks else ()
+
+
+def _sliding_window(attn):
+    """The window HF's own attention forward hands to the attention interface: Qwen2 / Qwen3 keep it as `self.sliding_window`,
+    Mistral reads `getattr(self.config, "sliding_window", None)` (modeling_mistral.py), Llama passes none."""
+    if hasattr(attn, "sliding_window"):
+        return attn.sliding_window
+    return getattr(attn.config, "sliding_window", None)
+
+
+def _prefill_forward(self, fd, hidden_states, attention_mask, past_key_values, position_embeddings, kwargs):
+    """LlamaDecoderLayer.forward for more than MAX_ROWS tokens (eval): HF's layer with the two RMSNorms as one HIP kernel each,
+    fused with the act-order gather of the projection that consumes them (module docstring)."""
+    attn, mlp = self.self_attn, self.mlp
+    qkv_lin, gu_lin = attn.fused_q_proj_k_proj_v_proj.fused, mlp.fused_gate_up.fused
+    group = attn.fused_q_proj_k_proj_v_proj
+    dt = hidden_states.dtype
+    pf = fd["prefill"]
+    if pf.get("dtype") != dt:
+        pf.update(dtype=dt, w_in=self.input_layernorm.weight.detach().to(dt).contiguous(),
+                  w_post=self.post_attention_layernorm.weight.detach().to(dt).contiguous(),
+                  eps_in=float(getattr(self.input_layernorm, "variance_epsilon", 1e-6)),
+                  eps_post=float(getattr(self.post_attention_layernorm, "variance_epsilon", 1e-6)))
+    bsz, q_len = hidden_states.shape[0], hidden_states.shape[1]
+    h = hidden_states.contiguous()
+    xn = ops.rmsnorm_gather(h, pf["w_in"], pf["eps_in"], getattr(qkv_lin, "perm", None))
+    qkv = qkv_lin.forward_pregathered(xn)
+    del xn
+    q_dim, kv_dim, hd = group.sizes[0], group.sizes[1], attn.head_dim
+    q = qkv[..., :q_dim].reshape(bsz, q_len, -1, hd)
+    k = qkv[..., q_dim:q_dim + kv_dim].reshape(bsz, q_len, -1, hd)
+    if fd["qk_norm"]:
+        q, k = attn.q_norm(q), attn.k_norm(k)
+    q, k = q.transpose(1, 2), k.transpose(1, 2)
+    v = qkv[..., q_dim + kv_dim:].reshape(bsz, q_len, -1, hd).transpose(1, 2)
+    cos, sin = position_embeddings
+    q, k = fd["rotary"](q, k, cos, sin)
+    if past_key_values is not None:
+        k, v = past_key_values.update(k, v, attn.layer_idx)
+    interface = fd["interfaces"].get_interface(attn.config._attn_implementation, fd["eager_attention"])
+    window = _sliding_window(attn) if fd["sliding_window"] else None
+    if window is not None:
+        kwargs = dict(kwargs, sliding_window=window)
+    attn_out, _ = interface(attn, q, k, v, attention_mask, dropout=0.0, scaling=attn.scaling, **kwargs)
+    del qkv, q, k, v
+    h1 = h + attn.o_proj(attn_out.reshape(bsz, q_len, -1).contiguous())
+    xn = ops.rmsnorm_gather(h1, pf["w_post"], pf["eps_post"], getattr(gu_lin, "perm", None))
+    y = gu_lin.forward_pregathered(xn)
+    del xn
+    yv = y.view(*y.shape[:-1], y.shape[-1] // 16, 2, 8)
+    a = mlp.act_fn(yv[..., 0, :]) * yv[..., 1, :]
+    del y, yv
+    return h1 + mlp.down_proj(a.reshape(bsz, q_len, -1))
+
+
+def _hf_contract(layer) -> Optional[str]:
+    """None when the installed transformers' decoder layer / attention follow the calling convention the fast paths mirror
+    (module docstring), else the reason.  Signature + source inspection of the CLASSES (the instance's forward may already be
+    wrapped by accelerate / hooks)."""
+    import inspect
+    try:
+        lsig = inspect.signature(type(layer).forward).parameters
+        asig = inspect.signature(type(layer.self_attn).forward).parameters
+        lsrc = inspect.getsource(type(layer).forward)
+        asrc = inspect.getsource(type(layer.self_attn).forward)
+    except (OSError, TypeError, ValueError) as e:
+        return f"cannot inspect the installed transformers classes ({e})"
+    for name in ("past_key_values", "position_embeddings"):
+        if name not in lsig or name not in asig:
+            return f"transformers' {type(layer).__name__}/{type(layer.self_attn).__name__}.forward take no `{name}` keyword (transformers >= 4.56 needed)"
+    if "return hidden_states" not in lsrc or "outputs = (hidden_states,)" in lsrc or "return outputs" in lsrc:
+        return f"{type(layer).__name__}.forward does not return the bare hidden-states tensor (transformers >= 4.56 needed)"
+    if "cache_kwargs" in asrc or ".update(key_states, value_states, self.layer_idx)" not in asrc:
+        return f"{type(layer.self_attn).__name__}.forward does not call Cache.update(k, v, layer_idx) (cache_kwargs / StaticCache-era API)"
+    return None
 
 
 def _mlp_forward(self, x):
@@ -245,6 +363,11 @@ def fuse_llama_decoder_layers(model: nn.Module, allow_unknown: bool = False) -> 
             skipped.append((layer, "attention module does not follow the attention-interface layout"))
             prev = None
             continue
+        why = _hf_contract(layer)
+        if why is not None:
+            skipped.append((layer, why))
+            prev = None
+            continue
         known = (type(attn).__name__ in _KNOWN_ATTENTION and type(layer.input_layernorm).__name__ in _KNOWN_NORMS
                  and type(layer.post_attention_layernorm).__name__ in _KNOWN_NORMS)
         qk_norm = hasattr(attn, "q_norm") and hasattr(attn, "k_norm")
@@ -278,8 +401,14 @@ def fuse_llama_decoder_layers(model: nn.Module, allow_unknown: bool = False) -> 
         layer._gptqhip_fused = {"hidden": in_f, "state": None, "prev": prev, "disabled": False, "workspace": workspace,
                                 "orig_forward": layer.forward, "rotary": getattr(amod, "apply_rotary_pos_emb", rotary),
                                 "eager_attention": getattr(amod, "eager_attention_forward", eager_attention),
-                                "sliding_window": getattr(attn, "sliding_window", None) is not None, "qk_norm": qk_norm,
-                                "interfaces": ALL_ATTENTION_FUNCTIONS}
+                                # families whose attention forward hands a window to the interface (the VALUE is resolved per call)
+                                "sliding_window": type(attn).__name__ != "LlamaAttention" and (
+                                    hasattr(attn, "sliding_window") or hasattr(attn.config, "sliding_window")),
+                                "qk_norm": qk_norm, "interfaces": ALL_ATTENTION_FUNCTIONS,
+                                # prefill path (ops.rmsnorm_gather + forward_pregathered): GPTQ modules only (AWQ has no
+                                # forward_pregathered: no act-order there) and hidden sizes the norm kernel stages in LDS
+                                "prefill": ({} if hasattr(qkv, "forward_pregathered") and hasattr(gu, "forward_pregathered")
+                                            and in_f % 8 == 0 and in_f <= 16384 else None)}
         layer.forward = types.MethodType(_layer_forward, layer)
         fused.append(layer)
         prev = layer

@@ -393,7 +393,10 @@ def dequantize_model(model: nn.Module, device="cpu", dtype: torch.dtype = torch.
     """Replace every HIP QuantLinear by an nn.Linear holding its dequantised weights -- the mirror of the reference's
     dequantize_model (nn_modules/qlinear/torch.py:736-761, which does this for TorchLinear and moves the weights to CPU
     fp16).  The [K,N] weights come from the device dequant kernels (bit-exact with dequantize_weight()).  Fused sibling
-    groups (fuse_siblings) are split back into one nn.Linear per original projection."""
+    groups (fuse_siblings) are split back into one nn.Linear per original projection; decoder layers rewritten by
+    utils.hf_llama.fuse_llama_decoder_layers get HF's own forward back, their interleaved gate|up module is de-interleaved into
+    gate_proj / up_proj again (an act-order down_proj folded into them stays folded: gate / up columns and down_proj rows were
+    re-ordered consistently, the MLP computes the same function)."""
     from ..nn_modules.qlinear.hip_awq import HipAwqLinear
     from ..nn_modules.qlinear.hip_gptq import HipGptqLinear, HipQuantEmbeddings
 
@@ -404,12 +407,28 @@ def dequantize_model(model: nn.Module, device="cpu", dtype: torch.dtype = torch.
             lin.bias = nn.Parameter(bias.detach().to(device=device, dtype=dtype), requires_grad=False)
         return lin
 
+    for layer in list(model.modules()):   # decoder layers of fuse_llama_decoder_layers: back to HF's own code path
+        fd = getattr(layer, "_gptqhip_fused", None)
+        if isinstance(fd, dict) and "orig_forward" in fd:
+            layer.forward = fd["orig_forward"]
+            del layer._gptqhip_fused
     for name, module in list(model.named_modules()):
         parent_name, _, child = name.rpartition(".")
         live = dict(model.named_modules())
         if parent_name and parent_name not in live:
             continue  # child of a fused group that was already replaced
         parent = live[parent_name] if parent_name else model
+        if isinstance(module, _FusedGroup) and getattr(module.fused, "gate_up_interleaved", False):
+            # fuse_gate_up_interleaved: columns alternate in blocks of 8 (g0..7 u0..7 g8..15 ...); there are no sibling views
+            w = module.fused.dequantize_weight()
+            b = module.fused.bias
+            wg, wu = deinterleave_gate_up(w)
+            bg, bu = (None, None) if b is None else deinterleave_gate_up(b[None])
+            parent.gate_proj = to_linear(wg, None if bg is None else bg[0])
+            parent.up_proj = to_linear(wu, None if bu is None else bu[0])
+            parent.__dict__.pop("forward", None)      # the instance-level _mlp_forward: the class's own forward is back
+            delattr(parent, child)
+            continue
         if isinstance(module, _FusedGroup):
             w = module.fused.dequantize_weight()
             b = module.fused.bias

@@ -108,6 +108,37 @@ def shard_gptq_row(t: Dict[str, torch.Tensor], rank: int, world: int, bits: int,
     return out
 
 
+def select_gptq_columns(t: Dict[str, torch.Tensor], cols: torch.Tensor, bits: int) -> Dict[str, torch.Tensor]:
+    """The GPTQ checkpoint tensors of the output columns `cols` (int64, any order, len % (32 / bits) == 0): qweight / scales / bias
+    columns gathered, the N-packed zero-points unpacked, gathered and re-packed.  Exact: only integer codes move."""
+    pf = 32 // bits
+    if cols.numel() % pf != 0:
+        raise ValueError(f"column selection must keep whole packed zero-point words ({pf} columns)")
+    cols = cols.to(t["qweight"].device)
+    sh = torch.arange(0, 32, bits, dtype=torch.int32, device=cols.device).view(1, 1, pf)
+    z = ((t["qzeros"].unsqueeze(2) >> sh) & ((1 << bits) - 1)).reshape(t["qzeros"].shape[0], -1)[:, cols]
+    zw = (z.reshape(z.shape[0], -1, pf).to(torch.int64) << sh.to(torch.int64)).sum(dim=2) & 0xFFFFFFFF
+    return {"qweight": t["qweight"][:, cols].contiguous(), "qzeros": torch.where(zw >= 2 ** 31, zw - 2 ** 32, zw).to(torch.int32),
+            "scales": t["scales"][:, cols].contiguous(), "g_idx": t["g_idx"].clone() if t.get("g_idx") is not None else None,
+            "bias": t["bias"][cols].contiguous() if t.get("bias") is not None else None}
+
+
+def shard_mlp_act_order(gate: Dict[str, torch.Tensor], up: Dict[str, torch.Tensor], down: Dict[str, torch.Tensor], rank: int,
+                        world: int, bits: int, group_size: int):
+    """Tensor-parallel shards of a Llama MLP whose down_proj is an act-order (desc_act) checkpoint, WITHOUT an activation
+    exchange: down_proj's rows are sorted by group globally and sliced (shard_gptq_row(act_order="global_sort"), the Marlin rule
+    gptqmodel/utils/marlin.py:296-305,368-372); rank r's rows then need the intermediate features perm[k0:k1] -- and since
+    gate_proj / up_proj are column-parallel and connected to down_proj by elementwise ops only, rank r simply OWNS exactly those
+    columns of gate / up, in that order (the column-parallel assignment is free).  Returns (gate_r, up_r, down_r); down_r carries
+    no input_index, its local g_idx is sequential.  gate / up keep their own (input-side) g_idx."""
+    down_r = shard_gptq_row(down, rank, world, bits, group_size, act_order="global_sort")
+    idx = down_r.pop("input_index", None)
+    if idx is None:   # down_proj has no act-order permutation: the plain contiguous split
+        k0, k1 = _bounds(down["qweight"].shape[0] * (32 // bits), rank, world, max(group_size, 32), "in_features")
+        idx = torch.arange(k0, k1, dtype=torch.int64)
+    return select_gptq_columns(gate, idx, bits), select_gptq_columns(up, idx, bits), down_r
+
+
 def shard_awq_column(t, rank, world):
     n = t["scales"].shape[1]
     n0, n1 = _bounds(n, rank, world, 8, "out_features")

@@ -6,7 +6,13 @@ all_gather_object), afterwards a call is ONE kernel launch on the current stream
     out = comm(partial_fp32, out_dtype=torch.float16, bias=None, residual=h)     # every rank, same sequence of calls
 
 Used by RowParallelQuantLinear(..., comm=comm) for small messages (batch-1 decode: 32 KB at hidden 8192); larger ones keep
-dist.all_reduce (RCCL spreads bandwidth-bound messages over the 7 xGMI links).  NOT yet run across physical GPUs."""
+dist.all_reduce (RCCL spreads bandwidth-bound messages over the 7 xGMI links).
+
+Trust model: the build / test boxes have ONE GPU (two processes share it through real IPC mappings in tests/test_gpu_comm.py),
+so a communicator proves itself where it runs: `self_test()` pushes distinct payloads through the kernel -- single calls and a
+back-to-back burst with no host synchronisation in between -- and compares every result BIT FOR BIT with the rank-ordered sum
+obtained through the process group's own all_gather; callers (bench.py, bench_tp.py) fall back to dist.all_reduce when it
+returns False.  A peer that never arrives poisons the output with NaN and sets the sticky status word (`check_status()`)."""
 from __future__ import annotations
 
 import ctypes
@@ -75,6 +81,103 @@ class OneShotAllReduce:
                                                        ops._stream(partial.device))
         _lib.check(rc, "gptqhip_allreduce_oneshot")
         return out
+
+    def gather_select(self, x_local: torch.Tensor, index: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One-shot all-gather of every rank's 16-bit vector x_local [n_local] (same length on all ranks) + select:
+        out[j] = concat_r(x_r)[index[j]] (index int32 device tensor; None: the whole vector).  The input exchange of an act-order
+        row-parallel shard (utils.tp.shard_gptq_row(act_order="global_sort")); one kernel, capture-safe."""
+        if x_local.dtype not in (torch.float16, torch.bfloat16) or not x_local.is_cuda or not x_local.is_contiguous():
+            raise RuntimeError("gather_select: x_local must be a contiguous fp16 / bf16 device tensor")
+        n_local = x_local.numel()
+        if n_local % 8 != 0 or n_local > self.n_max:
+            raise RuntimeError(f"gather_select: {n_local} elements per rank (multiple of 8, max {self.n_max})")
+        if index is not None and (index.dtype != torch.int32 or not index.is_cuda or not index.is_contiguous()):
+            raise RuntimeError("gather_select: index must be a contiguous int32 device tensor")
+        n_out = n_local * self.world if index is None else index.numel()
+        if out is None:
+            out = torch.empty(n_out, dtype=x_local.dtype, device=x_local.device)
+        elif out.dtype != x_local.dtype or out.numel() < n_out or not out.is_contiguous():
+            raise RuntimeError("gather_select: out must be a contiguous tensor of x_local's dtype with >= n_out elements")
+        with torch.cuda.device(x_local.device):
+            rc = _lib.load().gptqhip_allgather_select(x_local.data_ptr(), self._peers, self.rank, self.world, n_local, self.n_max,
+                                                      0 if index is None else index.data_ptr(), n_out, out.data_ptr(),
+                                                      ops._DT[x_local.dtype], ops._stream(x_local.device))
+        _lib.check(rc, "gptqhip_allgather_select")
+        return out
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _gather(self, t: torch.Tensor):
+        """All ranks' copies of device tensor t (through the process group, whatever its backend)."""
+        if self.world == 1:
+            return [t.clone()]
+        if dist.get_backend(self.group) == "gloo":
+            parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, t.cpu(), group=self.group)
+            return [p.to(t.device) for p in parts]
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t.contiguous(), group=self.group)
+        return parts
+
+    def self_test(self, calls: int = 8, burst: int = 512, n: Optional[int] = None) -> bool:
+        """Validate this communicator on the hardware it runs on (collective: every rank calls it).  `calls` single
+        all-reduces with fresh random payloads (+ residual) and one burst of `burst` back-to-back launches whose payloads change
+        every epoch (no host synchronisation inside the burst: the device-side epoch / parity protocol is what is being tested),
+        each compared bit for bit with the rank-ordered fp32 sum of the all_gather'ed inputs.  Returns True only if every rank
+        saw every result right and no wait timed out."""
+        dev = self.device
+        n = int(n or self.n_max)
+        n -= n % 16
+        ok = True
+        try:
+            with torch.cuda.device(dev):
+                for it in range(calls):
+                    g = torch.Generator(device=dev)
+                    g.manual_seed(7919 * it + self.rank)
+                    part = torch.randn(n, device=dev, generator=g) * 3.0
+                    gr = torch.Generator(device=dev)
+                    gr.manual_seed(104729 + it)
+                    res = torch.randn(n, device=dev, generator=gr).to(torch.float16)
+                    parts = self._gather(part)
+                    want = parts[0].clone()
+                    for p in parts[1:]:
+                        want = want + p
+                    want = (res.float() + want.to(torch.float16).float()).to(torch.float16)
+                    got = self(part, out_dtype=torch.float16, residual=res)
+                    torch.cuda.synchronize(dev)
+                    ok = ok and bool(torch.equal(got, want))
+                    xl = torch.randn(512, device=dev, generator=g).to(torch.float16)
+                    idx = torch.randperm(512 * self.world, device=dev, generator=gr)[:640].to(torch.int32)
+                    full = torch.cat(self._gather(xl))
+                    sel = self.gather_select(xl, idx)
+                    torch.cuda.synchronize(dev)
+                    ok = ok and bool(torch.equal(sel, full[idx.long()]))
+                # burst: payload of epoch t = base_r + t (exact in fp32 for these magnitudes); mismatches counted on the device
+                g = torch.Generator(device=dev)
+                g.manual_seed(31337 + self.rank)
+                base = torch.randn(n, device=dev, generator=g).to(torch.float16).float()   # 11 significant bits: base + t is exact
+                bases = self._gather(base)
+                bad = torch.zeros((), dtype=torch.int64, device=dev)
+                part = torch.empty(n, device=dev)
+                out = torch.empty(n, device=dev, dtype=torch.float16)
+                for t in range(burst):
+                    torch.add(base, float(t % 64), out=part)
+                    self(part, out_dtype=torch.float16, out=out)
+                    want = bases[0] + float(t % 64)
+                    for b_ in bases[1:]:
+                        want = want + (b_ + float(t % 64))
+                    bad += (out != want.to(torch.float16)).sum()
+                torch.cuda.synchronize(dev)
+                ok = ok and int(bad.item()) == 0
+            self.check_status()
+        except Exception:  # noqa: BLE001 -- a failing self test must not take the caller down: it answers False
+            ok = False
+        if self.world > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            if dist.get_backend(self.group) != "gloo":
+                flag = flag.to(dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            ok = bool(int(flag.item()) == 1)
+        return ok
 
     def check_status(self) -> None:
         st = ctypes.c_uint32(0)

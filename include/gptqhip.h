@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 11
+#define GPTQHIP_ABI_VERSION 12
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -169,7 +169,7 @@ typedef struct gptqhip_decode_op {
     float eps;
     int K, N, group_size, bits, act_dtype, scale_dtype, in_glue, out_glue, stats_n;
     int flags;                   /* 0 or GPTQHIP_GEMM_EXACT_BF16 (the opt-in exact-arithmetic dequant, bf16 activations)                */
-    int M;                       /* rows (1..8): x [M,K], residual / out [M,N], stats_in [M][stats_n], stats_out [M][ceil(N/16)].
+    int M;                       /* rows (1..16): x [M,K], residual / out [M,N], stats_in [M][stats_n], stats_out [M][ceil(N/16)].
                                     M > 1 (a few sequences, or speculative tokens of one): in_glue NONE | RMSNORM, perm NULL.   */
 } gptqhip_decode_op;
 int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream);
@@ -177,7 +177,7 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream);
  * decoder layer); stops at the first error. */
 int gptqhip_decode_linear_seq(const gptqhip_decode_op* const* ops, int n, gptqhip_stream_t stream);
 /* 1 if gptqhip_decode_linear supports a [K,N] layer with this group size (has_perm: with an act-order
- * permutation; M: rows, 1..8), else 0. */
+ * permutation; M: rows, 1..16), else 0. */
 int gptqhip_decode_supported(int K, int N, int group_size, int has_perm, int M);
 
 /* Materialise W[K,N] from the CHECKPOINT layout in `out_dtype` (= scales dtype in the reference).  Replaces
@@ -226,6 +226,16 @@ int gptqhip_pack_gptq_host(const float* weight, const float* scales, const int32
  * (ExllamaV2 gathers A through q_perm: gptqmodel_ext/exllamav2/cuda/q_gemm_kernel_gptq.cuh:79-90). */
 int gptqhip_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, gptqhip_stream_t stream);
 
+/* RMSNorm fused with the act-order gather, for the PREFILL of act-order (desc_act) checkpoints:
+ *     out[m, k'] = weight[p] * act(h32[m, p] * rsqrt(mean_k(h32[m, k]^2) + eps)),   p = perm[k']   (perm NULL: p = k')
+ * HF LlamaRMSNorm arithmetic (fp32 statistics, the normalised value rounded to the activation dtype, the product with the weight
+ * rounded once).  The callers of the q|k|v and gate|up QuantLinears are RMSNorms; their siblings share one g_idx, so the
+ * normalised x can leave the norm kernel already in the kernel's row order and gptqhip_gemm runs with perm = NULL -- the separate
+ * x gather per linear (ExllamaV2 does it while staging A: gptqmodel_ext/exllamav2/cuda/q_gemm_kernel_gptq.cuh:79-90) disappears.
+ * h, out [M,K] act dtype (out must not alias h), weight [K] act dtype, K % 8 == 0, K <= 16384. */
+int gptqhip_rmsnorm_gather(const void* h, const void* weight, const int32_t* perm, void* out, int M, int K, float eps, int act_dtype,
+                           gptqhip_stream_t stream);
+
 /* ONE-SHOT ALL-REDUCE for the tensor-parallel decode step (gptqmodel_amd/csrc/gptqhip_comm.hip).  The reference has no
  * tensor parallelism and no collectives -- nothing upstream is replaced; this is the MI355X design for the 70B
  * config's 160 latency-bound all-reduces per token (32 KB each at batch 1): every rank pushes its fp32 partial vector straight
@@ -241,8 +251,19 @@ int gptqhip_gather_cols(const void* x, const int32_t* perm, void* out, int M, in
  *   gptqhip_allreduce_oneshot(partial[n] fp32, peer_bufs[world] (HOST array of device pointers, own buffer at [rank]), rank, world,
  *                             n (% 4 == 0), n_max (as allocated), bias|NULL, residual|NULL, out[n] act dtype,
  *                             stats_out[ceil(n/16)]|NULL (per-16 sums of out^2: the next decode op's RMSNorm statistic), act_dtype, stream)
+ *   gptqhip_allgather_select(x_local[n_local] act dtype, peer_bufs, rank, world, n_local (% 8 == 0, the same on every rank), n_max,
+ *                            index[n_out] int32 | NULL, n_out, out[n_out], act_dtype, stream)
+ *                                      one-shot ALL-GATHER of the ranks' 16-bit vectors + select: out[j] = concat_r(x_r)[index[j]]
+ *                                      (index NULL: the whole vector, n_out = n_local * world).  The input exchange of an act-order
+ *                                      row-parallel shard cut from globally group-sorted rows (the rule of
+ *                                      gptqmodel/utils/marlin.py:296-305,368-372): its rows need input features scattered over all
+ *                                      ranks' column shards.  Own epoch / flags / slots inside the same buffer.
+ * Ordering: data stores (system scope, write-through) -> system-scope release fence per wave -> block barrier -> flag store-release;
+ * the waiter polls its own buffer, then a system-scope acquire fence.  A wait that exceeds its bound (GPTQHIP_COMM_TIMEOUT_MS at
+ * gptqhip_comm_alloc time, default 10 s) writes NaN to the block's outputs and sets the sticky status word: a lost peer is loud.
  * Every rank must issue the same sequence of calls.  Status: exercised by two processes sharing one GPU through real IPC
- * mappings (tests/test_gpu_comm.py); not yet run across physical GPUs. */
+ * mappings incl. a 10^5-epoch stress (tests/test_gpu_comm.py); OneShotAllReduce.self_test() validates a communicator against the
+ * process group's own collective on whatever hardware it runs on. */
 #define GPTQHIP_IPC_HANDLE_BYTES 64
 size_t gptqhip_comm_bytes(int world, int n_max);
 int gptqhip_comm_alloc(size_t bytes, void** dev_ptr, unsigned char* handle_out);
@@ -253,6 +274,8 @@ int gptqhip_comm_status(void* own_buf, uint32_t* status_out);
 int gptqhip_allreduce_oneshot(const float* partial, void* const* peer_bufs, int rank, int world, int n, int n_max,
                               const void* bias, const void* residual, void* out, float* stats_out, int act_dtype,
                               gptqhip_stream_t stream);
+int gptqhip_allgather_select(const void* x_local, void* const* peer_bufs, int rank, int world, int n_local, int n_max,
+                             const int32_t* index, int n_out, void* out, int act_dtype, gptqhip_stream_t stream);
 
 /* Tuning hook (benchmarks / tests): force the cross-block split-K factor and the waves per block of the skinny
  * kernel (0 = heuristic), or the kernel family (0 auto, 1 skinny, 2 tiled-prefill).  The overrides are THREAD-LOCAL

@@ -283,6 +283,38 @@ def torch_cpu_forward_gptq(x, qweight, qzeros, scales, g_idx, bits: int, bias=No
     return out
 
 
+def torch_cpu_dequant_awq(qweight, qzeros, scales, group_size: int, bits: int = 4):
+    """[K,N] weights in scales.dtype: the aten op sequence of `dequantize_gemm` (quantization/awq/utils/packing_utils.py:106-121):
+    column-wise shift-unpack of qweight [K,N/8] and qzeros [G,N/8] to int8 (:14-30), the AWQ_REVERSE_ORDER column gather (:46-61,
+    order :10), the overflow mask, repeat_interleave of scales / zeros over the group (:117-118), (w - z) * s."""
+    import torch
+    pf = 32 // bits
+    sh = torch.arange(0, 32, bits)
+    iw = torch.bitwise_right_shift(qweight[:, :, None], sh[None, None, :]).to(torch.int8).view(qweight.shape[0], -1)
+    iz = torch.bitwise_right_shift(qzeros[:, :, None], sh[None, None, :]).to(torch.int8).view(qzeros.shape[0], -1)
+    rev = torch.arange(iw.shape[-1], dtype=torch.int32).view(-1, pf)[:, AWQ_REVERSE_ORDER].reshape(-1)
+    iw, iz = iw[:, rev], iz[:, rev]
+    iw = torch.bitwise_and(iw, (1 << bits) - 1)
+    iz = torch.bitwise_and(iz, (1 << bits) - 1)
+    return (iw - iz.repeat_interleave(group_size, dim=0)) * scales.repeat_interleave(group_size, dim=0)
+
+
+def torch_cpu_forward_awq(x, qweight, qzeros, scales, group_size: int, bias=None, bits: int = 4):
+    """x [M,K] fp16|bf16 CPU tensor, AWQ GEMM-layout tensors.  Same aten op sequence as AwqTorchLinear.forward
+    (nn_modules/qlinear/torch_awq.py:157-195): scales cast to the compute dtype (:149-155), dequantize_gemm, contiguous weight in
+    the compute dtype, matmul, out-of-place bias add.  Timed as the C4 `cpu_baseline` leg in bench.py ("port")."""
+    import torch
+    if scales.dtype != x.dtype:
+        scales = scales.to(x.dtype)
+    weight = torch_cpu_dequant_awq(qweight, qzeros, scales, group_size, bits)
+    if weight.dtype != x.dtype or not weight.is_contiguous():
+        weight = weight.to(x.dtype).contiguous()
+    out = torch.matmul(x, weight)
+    if bias is not None:
+        out = out + bias.to(out.dtype)
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # Decoder-layer glue between the quantised linears -- NOT part of the reference repo: these restate what the reference's
 # CALLER (HF transformers LlamaDecoderLayer: LlamaRMSNorm.forward, LlamaMLP.forward, the two residual adds) computes between

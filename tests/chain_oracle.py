@@ -1,0 +1,94 @@
+"""Oracle composition of a Llama-style decode chain over GPTQ checkpoint tensors, single GPU or tensor parallel (numpy only; test
+infrastructure shared by the CPU and GPU tests).  Every linear = the oracle's forward (dequantise, matmul, ONE rounding:
+gptqmodel/nn_modules/qlinear/torch.py:326-347); row-parallel shards contribute unrounded fp32 partial sums added in rank order before
+that rounding; HF's RMSNorm / SiLU*mul / residual formulas (oracle rmsnorm_ref / silu_mul_ref / residual_add_ref)."""
+import numpy as np
+import torch
+
+from oracle import gptq_oracle as O
+
+
+def deq(t, bits=4):
+    return O.dequant_gptq(t["qweight"], t["qzeros"], t["scales"], t["g_idx"], bits)
+
+
+def oracle_chain(x, layers, act, eps):
+    """layers[li] = dict(w_in, w_post, ranks=[dict(q, k, v, o, o_index|None, gate, up, down)]) of numpy checkpoint tensors.  The
+    reference's module chain: every linear = forward_gptq (dequantise, matmul, ONE rounding); row-parallel shards contribute
+    unrounded fp32 partial sums added in rank order before that rounding; HF's RMSNorm / SiLU*mul / residual formulas."""
+    h = x.copy()
+    for L in layers:
+        xn = O.rmsnorm_ref(h, L["w_in"], eps, act)[None]
+        a_full = np.concatenate([O.matmul_round(xn, deq(r["q"]), None, act)[0] for r in L["ranks"]])    # stand-in attention: a = q
+        part = None
+        for r in L["ranks"]:
+            a_r = a_full[r["o_index"]] if r["o_index"] is not None else O.matmul_round(xn, deq(r["q"]), None, act)[0]
+            p = a_r[None].astype(np.float32) @ deq(r["o"])
+            part = p if part is None else part + p
+        h = O.residual_add_ref(h[None], O.round_to(part, act), act)[0]
+        xn = O.rmsnorm_ref(h, L["w_post"], eps, act)[None]
+        part = None
+        for r in L["ranks"]:
+            a_r = O.silu_mul_ref(O.matmul_round(xn, deq(r["gate"]), None, act), O.matmul_round(xn, deq(r["up"]), None, act), act)
+            p = a_r.astype(np.float32) @ deq(r["down"])
+            part = p if part is None else part + p
+        h = O.residual_add_ref(h[None], O.round_to(part, act), act)[0]
+    return h
+
+
+def np_tensors(seed, K, N, gs, g_idx=None):
+    """Zero-mean sym checkpoint tensors (codes symmetric around the zero-point 8: a chain of them keeps fp16 activations bounded)."""
+    rng = np.random.RandomState(seed)
+    w = rng.randint(-2**31, 2**31, size=(K // 8, N), dtype=np.int64).astype(np.int32)
+    w = w | (((~(w | (w >> 1) | (w >> 2) | (w >> 3))) & 0x11111111) << 3)
+    qz = np.full((K // gs, N // 8), -2004318072, dtype=np.int32)
+    sc = O.round_to(rng.rand(K // gs, N).astype(np.float32) * 0.01 + 0.005, "fp16")
+    gi = (np.arange(K) // gs).astype(np.int32) if g_idx is None else g_idx
+    return {"qweight": w, "qzeros": qz, "scales": sc, "g_idx": gi, "bias": None}
+
+
+def to_torch(t):
+    return {k: (None if v is None else (torch.from_numpy(v).half() if k == "scales" else torch.from_numpy(v))) for k, v in t.items()}
+
+
+def to_np(t):
+    return {k: (None if v is None else (v.float().numpy() if k == "scales" else v.numpy())) for k, v in t.items() if k != "input_index"}
+
+
+def cat_cols(ts):
+    return {"qweight": np.concatenate([t["qweight"] for t in ts], axis=1), "qzeros": np.concatenate([t["qzeros"] for t in ts], axis=1),
+            "scales": np.concatenate([t["scales"] for t in ts], axis=1), "g_idx": ts[0]["g_idx"], "bias": None}
+
+
+def build_layers(world, n_layers, hidden, inter, q_dim, kv_dim, gs, desc_act, seed=0):
+    """Full-model checkpoint tensors + their TP shards.  Returns (oracle layer list, per-rank shard tensors [rank][layer]); every
+    oracle layer also carries the un-sharded tensors under "full"."""
+    from gptqmodel_amd.utils import tp
+    rng = np.random.RandomState(1000 + seed)
+    layers, shards = [], [[] for _ in range(world)]
+    for li in range(n_layers):
+        gi_h = (rng.permutation(hidden) // gs).astype(np.int32) if desc_act else None       # shared by q|k|v and by gate|up
+        gi_h2 = (rng.permutation(hidden) // gs).astype(np.int32) if desc_act else None
+        gi_q = (rng.permutation(q_dim) // gs).astype(np.int32) if desc_act else None
+        gi_i = (rng.permutation(inter) // gs).astype(np.int32) if desc_act else None
+        s = seed * 100 + li * 10
+        full = {"q": np_tensors(s + 1, hidden, q_dim, gs, gi_h), "k": np_tensors(s + 2, hidden, kv_dim, gs, gi_h),
+                "v": np_tensors(s + 3, hidden, kv_dim, gs, gi_h), "o": np_tensors(s + 4, q_dim, hidden, gs, gi_q),
+                "gate": np_tensors(s + 5, hidden, inter, gs, gi_h2), "up": np_tensors(s + 6, hidden, inter, gs, gi_h2),
+                "down": np_tensors(s + 7, inter, hidden, gs, gi_i)}
+        w_in = O.round_to(1.0 + 0.1 * rng.randn(hidden).astype(np.float32), "fp16")
+        w_post = O.round_to(1.0 + 0.1 * rng.randn(hidden).astype(np.float32), "fp16")
+        ranks = []
+        for r in range(world):
+            tt = {k: to_torch(v) for k, v in full.items()}
+            sh = {n: to_np(tp.shard_gptq_column(tt[n], r, world, 4)) for n in ("q", "k", "v")}
+            o_t = tp.shard_gptq_row(tt["o"], r, world, 4, gs, act_order="global_sort" if desc_act else "reject")
+            g_t, u_t, d_t = tp.shard_mlp_act_order(tt["gate"], tt["up"], tt["down"], r, world, 4, gs)
+            sh.update(o=to_np(o_t), gate=to_np(g_t), up=to_np(u_t), down=to_np(d_t),
+                      o_index=o_t["input_index"].numpy() if "input_index" in o_t else None)
+            ranks.append(sh)
+            shards[r].append(sh)
+        layers.append({"w_in": w_in, "w_post": w_post, "ranks": ranks, "full": full})
+    return layers, shards
+
+

@@ -74,9 +74,30 @@ def test_decode_op_shape_predicate_is_host_logic(lib):
     # act-order in the kernel: 4-deep ring only, and the x row must fit in LDS next to the wave slots
     assert lib.gptqhip_decode_supported(4096, 4096, 128, 1, 1) == 1 and lib.gptqhip_decode_supported(14336, 4096, 128, 1, 1) == 1
     assert lib.gptqhip_decode_supported(1024, 1024, 128, 1, 1) == 0 and lib.gptqhip_decode_supported(28672, 8192, 128, 1, 1) == 0
-    # up to eight rows (no permutation there); nine are gptqhip_gemm's business
+    # up to sixteen rows (no permutation there); seventeen are gptqhip_gemm's business
     assert lib.gptqhip_decode_supported(4096, 28672, 128, 0, 4) == 1 and lib.gptqhip_decode_supported(14336, 4096, 128, 0, 8) == 1
-    assert lib.gptqhip_decode_supported(4096, 4096, 128, 0, 9) == 0 and lib.gptqhip_decode_supported(4096, 4096, 128, 1, 2) == 0
+    for K, N in yes[:8]:
+        assert lib.gptqhip_decode_supported(K, N, 128, 0, 9) == 1 and lib.gptqhip_decode_supported(K, N, 128, 0, 16) == 1, (K, N)
+    assert lib.gptqhip_decode_supported(4096, 4096, 128, 0, 17) == 0 and lib.gptqhip_decode_supported(4096, 4096, 128, 1, 2) == 0
+
+
+def test_comm_buffer_sizes_and_collective_argument_checks(lib):
+    """The one-shot collectives' host logic: buffer size = header + 2 x 8 all-reduce slots + 2 x 8 all-gather slots, argument
+    validation before anything touches a GPU."""
+    assert lib.gptqhip_comm_bytes(9, 8192) == 0 and lib.gptqhip_comm_bytes(2, 0) == 0 and lib.gptqhip_comm_bytes(2, 70000) == 0
+    b1, b2 = lib.gptqhip_comm_bytes(2, 8192), lib.gptqhip_comm_bytes(8, 8192)
+    assert b1 == b2 >= 2 * 8 * 8192 * 4 + 2 * 8 * 8192 * 2          # sized for the maximum world: any group size shares a layout
+    one = ctypes.c_void_p(256)
+    peers = (ctypes.c_void_p * 2)(256, 512)
+    assert lib.gptqhip_allreduce_oneshot(one, peers, 0, 2, 1001, 8192, None, None, one, None, 0, None) == -22     # n % 4
+    assert lib.gptqhip_allreduce_oneshot(one, peers, 2, 2, 1024, 8192, None, None, one, None, 0, None) == -22     # rank >= world
+    assert lib.gptqhip_allreduce_oneshot(ctypes.c_void_p(260), peers, 0, 2, 1024, 8192, None, None, one, None, 0, None) == -22   # alignment
+    assert b"aligned" in lib.gptqhip_last_error()
+    assert lib.gptqhip_allgather_select(one, peers, 0, 2, 1001, 8192, None, 2002, one, 0, None) == -22             # n_local % 8
+    assert lib.gptqhip_allgather_select(one, peers, 0, 2, 1024, 8192, None, 1000, one, 0, None) == -22             # no index: whole vector
+    assert lib.gptqhip_rmsnorm_gather(one, one, None, one, 4, 4096, 1e-5, 0, None) == -22                          # out aliases h
+    assert lib.gptqhip_rmsnorm_gather(one, ctypes.c_void_p(512), None, ctypes.c_void_p(1024), 4, 4100, 1e-5, 0, None) == -22
+    assert lib.gptqhip_rmsnorm_gather(one, one, None, one, 0, 4096, 1e-5, 0, None) == 0                            # empty batch
 
 
 def test_argument_validation_reports_errors_without_a_gpu(lib):

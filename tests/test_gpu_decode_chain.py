@@ -141,10 +141,10 @@ def test_decode_op_act_order_in_kernel_perm_with_glue(ops, act):
         ops.decode_linear(torch.zeros(K, dtype=TDT[act], device=DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, perm=perm)
 
 
-@pytest.mark.parametrize("M", [2, 3, 4, 5, 7, 8])
+@pytest.mark.parametrize("M", [2, 3, 4, 5, 7, 8, 9, 12, 13, 16])
 @pytest.mark.parametrize("act", ["fp16", "bf16"])
-def test_decode_op_rows_2_to_8(ops, M, act):
-    """The decode op on up to eight rows (a few sequences, or speculative tokens of one): per-row RMSNorm statistics (from the
+def test_decode_op_rows_2_to_16(ops, M, act):
+    """The decode op on up to sixteen rows (a few sequences, or speculative tokens of one): per-row RMSNorm statistics (from the
     producer and reduced in the kernel), per-row residual + stats_out, the paired SiLU*mul epilogue, bias, cross-block split-K
     and a padded plan -- each against the oracle composed with HF's glue formulas, row by row."""
     gs, bits = 128, 4
@@ -192,8 +192,8 @@ def test_decode_op_rows_2_to_8(ops, M, act):
             plain = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, M=M)
             gen = ops.gemm(f32_to_torch(h, act, DEV), qw_t, meta, None, None, N, gs, bits, sc.dtype)
             assert torch.equal(plain, gen)
-    with pytest.raises(RuntimeError, match="1..8"):
-        ops.decode_linear(torch.zeros((9, 4096), dtype=TDT[act], device=DEV), qw_t, meta, None, 4096, 2048, gs, bits, sc.dtype, M=9)
+    with pytest.raises(RuntimeError, match="1..16"):
+        ops.decode_linear(torch.zeros((17, 4096), dtype=TDT[act], device=DEV), qw_t, meta, None, 4096, 2048, gs, bits, sc.dtype, M=17)
 
 
 def test_decode_op_rejects_unsupported_shapes(ops):

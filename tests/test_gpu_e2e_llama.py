@@ -24,7 +24,7 @@ def _rtn(weight: torch.Tensor, group_size: int, bits: int):
     wmax, wmin = w.amax(dim=2), w.amin(dim=2)
     maxq = (1 << bits) - 1
     scales = ((wmax - wmin).clamp(min=1e-5) / maxq).half().float()
-    zeros = torch.round(-wmin / scales).clamp(0, maxq)
+    zeros = torch.round(-wmin / scales).clamp(1, maxq)   # >= 1: representable in the v1 on-disk format (zero - 1 per field)
     return scales, zeros
 
 
@@ -46,7 +46,7 @@ def _build(desc_act: bool, fuse, dtype, family="llama"):
     torch.manual_seed(7)
     # the decoder-layer fast path needs shapes inside the decode op's pipeline (K = 1024 -> 8 chunks, 2816 -> 22 padded to 24)
     dims = dict(hidden_size=512, intermediate_size=1408)
-    if fuse == "layers":   # (act-order in the kernel and the 2..4-row ops need whole 4-deep ring rounds: >= 16 chunks of K)
+    if fuse in ("layers", "layers_dims_only"):   # (act-order in the kernel and the 2..4-row ops need whole 4-deep ring rounds: >= 16 chunks of K)
         dims = dict(hidden_size=2048, intermediate_size=5632)
     common = dict(num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2, vocab_size=2048,
                   max_position_embeddings=128, tie_word_embeddings=False, **dims)
@@ -93,11 +93,14 @@ def _build(desc_act: bool, fuse, dtype, family="llama"):
         from gptqmodel_amd.utils.hf_llama import fuse_llama_decoder_layers
         fused, skipped = fuse_llama_decoder_layers(quant)
         assert len(fused) == 2 and not skipped
+    elif fuse == "layers_dims_only":
+        pass   # the decode-op-friendly shapes, modules left unfused (tests/test_gpu_checkpoint.py fuses after loading from disk)
     elif fuse:
         for layer in quant.model.layers:
             assert fuse_siblings(layer.self_attn, ["q_proj", "k_proj", "v_proj"]) is not None
             assert fuse_siblings(layer.mlp, ["gate_proj", "up_proj"]) is not None
-    gptqmodel_post_init(quant)
+    import gptqmodel_amd.utils.model as _m
+    _m.gptqmodel_post_init(quant)      # (looked up at call time: test_gpu_checkpoint.py swaps it to keep the checkpoint layout)
     return dense, quant
 
 
@@ -138,7 +141,9 @@ def test_llama_decoder_layers_on_decode_ops_match_dense(desc_act, dtype, family)
         o_d = dense(input_ids=ids, use_cache=True)
         o_q = quant(input_ids=ids, use_cache=True)
         assert rel_err(o_q.logits.float().cpu().numpy(), o_d.logits.float().cpu().numpy()) < tol
-        assert all(L._gptqhip_fused["state"] is None for L in quant.model.layers)     # 20 tokens: HF's path
+        assert all(L._gptqhip_fused["state"] is None for L in quant.model.layers)     # 20 tokens: not the decode ops ...
+        # ... but the prefill path: ops.rmsnorm_gather (fused with the act-order gather) + forward_pregathered
+        assert all(L._gptqhip_fused["prefill"].get("dtype") == dtype for L in quant.model.layers)
         pk_d, pk_q = o_d.past_key_values, o_q.past_key_values
         tok = o_d.logits[:, -1].argmax(-1, keepdim=True)
         for _ in range(8):
@@ -166,13 +171,14 @@ def test_llama_decoder_layers_on_decode_ops_match_dense(desc_act, dtype, family)
         s_q = quant(input_ids=nxt, past_key_values=o_q.past_key_values, use_cache=True)
         assert rel_err(s_q.logits.float().cpu().numpy(), s_d.logits.float().cpu().numpy()) < tol
         assert desc_act or 3 in states[0].ops
-        # six tokens (two sequences x three): still the decode ops; nine: HF's layer code through the same fused modules
-        ids6 = torch.randint(0, 2048, (2, 3), device="cuda")
-        assert rel_err(quant(input_ids=ids6).logits.float().cpu().numpy(), dense(input_ids=ids6).logits.float().cpu().numpy()) < tol
-        assert desc_act or 6 in states[0].ops
-        ids9 = torch.randint(0, 2048, (1, 9), device="cuda")
-        assert rel_err(quant(input_ids=ids9).logits.float().cpu().numpy(), dense(input_ids=ids9).logits.float().cpu().numpy()) < tol
-        assert 9 not in states[0].ops
+        # six tokens (two sequences x three), nine, sixteen (two x eight): still the decode ops; seventeen: the prefill path
+        for shape in ((2, 3), (1, 9), (3, 4), (2, 8)):
+            idn = torch.randint(0, 2048, shape, device="cuda")
+            assert rel_err(quant(input_ids=idn).logits.float().cpu().numpy(), dense(input_ids=idn).logits.float().cpu().numpy()) < tol
+            assert desc_act or shape[0] * shape[1] in states[0].ops
+        ids17 = torch.randint(0, 2048, (1, 17), device="cuda")
+        assert rel_err(quant(input_ids=ids17).logits.float().cpu().numpy(), dense(input_ids=ids17).logits.float().cpu().numpy()) < tol
+        assert 17 not in states[0].ops
         out = quant.generate(input_ids=ids[:, :8], max_new_tokens=6, do_sample=False, pad_token_id=0)
     assert out.shape == (1, 14)
 
@@ -185,3 +191,64 @@ def test_llama_generate_runs_on_quantised_model():
     assert out.shape == (1, 16)
     n_launch_modules = sum(1 for m in quant.modules() if type(m).__name__ == "HipGptqLinear")
     assert n_launch_modules == 2 * 4  # fused qkv, o, fused gate_up, down per layer
+
+
+def test_fused_decoder_layers_hidden_state_capture_and_dequantize_model():
+    """(1) output_hidden_states across decode steps: the fast path returns a view of a per-layer buffer, so what transformers
+    records through its forward hooks must be a copy -- the states of step 1 stay intact after step 2.  (2) forward hooks on a
+    sub-module the fast path bypasses send the layer through HF's own code (the hook fires).  (3) dequantize_model on a model
+    rewritten by fuse_llama_decoder_layers: HF's forward restored, the interleaved gate|up module split back into gate_proj /
+    up_proj, logits equal to the dense twin."""
+    from gptqmodel_amd.utils.model import dequantize_model
+    dense, quant = _build(True, "layers", torch.float16)
+    torch.manual_seed(3)
+    ids = torch.randint(0, 2048, (1, 6), device="cuda")
+    with torch.no_grad():
+        o_q = quant(input_ids=ids, use_cache=True)
+        o_d = dense(input_ids=ids, use_cache=True)
+        tok = o_d.logits[:, -1].argmax(-1, keepdim=True)
+        s1 = quant(input_ids=tok, past_key_values=o_q.past_key_values, use_cache=True, output_hidden_states=True)
+        d1 = dense(input_ids=tok, past_key_values=o_d.past_key_values, use_cache=True, output_hidden_states=True)
+        kept = [h.clone() for h in s1.hidden_states]
+        tok2 = d1.logits[:, -1].argmax(-1, keepdim=True)
+        quant(input_ids=tok2, past_key_values=s1.past_key_values, use_cache=True, output_hidden_states=True)
+        assert all(torch.equal(a, b) for a, b in zip(kept, s1.hidden_states)), "recorded hidden states alias a reused buffer"
+        for a, b in zip(s1.hidden_states, d1.hidden_states):
+            assert rel_err(a.float().cpu().numpy(), b.float().cpu().numpy()) < 2e-2
+        fired = []
+        hk = quant.model.layers[0].mlp.register_forward_hook(lambda m, i, o: fired.append(1))
+        quant(input_ids=tok)
+        hk.remove()
+        assert fired, "a forward hook on a bypassed sub-module must be honoured (HF path)"
+        want = dense(input_ids=ids).logits
+        dequantize_model(quant, device="cuda", dtype=torch.float16)
+        assert not any(type(m).__name__ == "HipGptqLinear" for m in quant.modules())
+        assert all(isinstance(L.mlp.gate_proj, nn.Linear) and isinstance(L.mlp.up_proj, nn.Linear) and not hasattr(L, "_gptqhip_fused")
+                   for L in quant.model.layers)
+        got = quant(input_ids=ids).logits
+        assert rel_err(got.float().cpu().numpy(), want.float().cpu().numpy()) < 2e-2
+
+
+def test_hf_contract_check_rejects_older_calling_conventions():
+    """fuse_llama_decoder_layers verifies the transformers calling convention its fast paths mirror: classes with the
+    4.48-4.55 convention (`past_key_value` in kwargs, tuple return, cache_kwargs) must be skipped with a reason, not run with a
+    silently stale KV cache.  Pure host logic, but it needs the quant modules, hence a GPU test."""
+    from gptqmodel_amd.utils import hf_llama
+
+    class OldAttn(nn.Module):
+        def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_value=None, **kwargs):
+            cache_kwargs = {}
+            return hidden_states, None
+
+    class OldLayer(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.self_attn = OldAttn()
+
+        def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, position_embeddings=None, **kwargs):
+            outputs = (hidden_states,)
+            return outputs
+
+    assert "past_key_values" in hf_llama._hf_contract(OldLayer())
+    dense, quant = _build(False, False, torch.float16)
+    assert hf_llama._hf_contract(dense.model.layers[0]) is None

@@ -130,6 +130,13 @@ SHAPES = [
     (4096, 1024, 32, 20),    # ... two row tiles
     (14336, 256, 14336, 1),  # group_size == K with K / 128 not a power of two (per-channel checkpoints, group_size = -1)
     (11008, 256, 11008, 5),
+    (4096, 1024, 128, 9),    # 9..16 rows: one MFMA row tile, all four row quads staged
+    (4096, 1024, 128, 16),
+    (4096, 1024, 128, 24),   # 17..32 rows: the 512-thread-bounded two-row-tile instantiations (no scratch; round-3 ISA audit)
+    (4096, 1024, 128, 32),
+    (14336, 512, 128, 32),
+    (2048, 2048, 64, 24),
+    (11008, 256, 128, 17),
     (64, 32, 32, 4),         # the reference's own unit-test shape (K < one 128-row chunk, N = 2 tiles)
     (96, 8, 32, 1),          # ragged everywhere: K % 128 != 0, N < one tile
 ]

@@ -1,0 +1,359 @@
+"""Round-3 GPU parity tests: the RMSNorm + act-order gather kernel, the accurate SiLU of the glue, a TWO-LAYER decode chain against
+the ORACLE composition (not against another HIP path), the one-shot collectives under stress / loss of a peer, and the
+tensor-parallel act-order chain on two ranks against the oracle composition of the same shards."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import assert_forward_close, f32_to_torch, rel_err, synth_gptq, torch_to_bits, torch_to_f32
+from chain_oracle import build_layers as _build_layers, cat_cols as _cat_cols, oracle_chain as _oracle_chain
+from oracle import gptq_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TDT = {"fp16": torch.float16, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gptqmodel_amd import ops as _ops
+    return _ops
+
+
+def _ulps16(got_bits: np.ndarray, ref_bits: np.ndarray) -> np.ndarray:
+    """Distance in representable 16-bit floats (sign-magnitude -> ordered integers)."""
+    def order(b):
+        b = b.astype(np.int32)
+        return np.where(b & 0x8000, -(b & 0x7FFF), b & 0x7FFF)
+    return np.abs(order(got_bits) - order(ref_bits))
+
+
+@pytest.mark.parametrize("act", ["fp16", "bf16"])
+@pytest.mark.parametrize("K,M,with_perm", [(4096, 37, True), (4096, 5, False), (8192, 9, True), (14336, 3, True), (2048, 300, True),
+                                           (512, 1, False)])
+def test_rmsnorm_gather_vs_hf_formula(ops, act, K, M, with_perm):
+    """ops.rmsnorm_gather == LlamaRMSNorm (oracle restatement) followed by the act-order column gather.  The fp32 sum of squares is
+    associated differently from numpy's, so 1/rms may differ in its last fp32 bit: a handful of elements may land on the other
+    side of a 16-bit rounding boundary (<= 1 ulp, <= 0.1 % of the elements); everything else is bit-exact."""
+    rng = np.random.RandomState(K + M)
+    h = O.round_to(rng.randn(M, K).astype(np.float32) * (0.5 + np.arange(M)[:, None] % 7), act)
+    w = O.round_to(1.0 + 0.1 * rng.randn(K).astype(np.float32), act)
+    perm = rng.permutation(K).astype(np.int32) if with_perm else None
+    out = ops.rmsnorm_gather(f32_to_torch(h, act, DEV), f32_to_torch(w, act, DEV), 1e-5,
+                             None if perm is None else torch.from_numpy(perm).to(DEV))
+    ref = np.stack([O.rmsnorm_ref(h[m], w, 1e-5, act) for m in range(M)])
+    if perm is not None:
+        ref = ref[:, perm]
+    got_b = torch_to_bits(out)
+    ref_b = torch_to_bits(f32_to_torch(ref, act))
+    d = _ulps16(got_b, ref_b)
+    assert d.max() <= 1, f"max distance {d.max()} ulps"
+    assert (d > 0).mean() <= 1e-3, f"{(d > 0).mean():.2e} of the elements differ"
+    # gather consistency is exact: the permuted output is a permutation of the un-permuted one, bit for bit
+    if perm is not None:
+        plain = ops.rmsnorm_gather(f32_to_torch(h, act, DEV), f32_to_torch(w, act, DEV), 1e-5)
+        assert torch.equal(out, plain[:, torch.from_numpy(perm).long().to(DEV)])
+
+
+def test_rmsnorm_gather_feeds_forward_pregathered(ops):
+    """The prefill path's pair: rmsnorm_gather(h, w, perm) -> forward_pregathered == forward(rmsnorm(h)) of an act-order module,
+    bit for bit (the gather moved from the linear's pre-pass into the norm kernel)."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    K, N, gs, M = 4096, 1024, 128, 70
+    qweight, qzeros, scales, g_idx = synth_gptq(5, 4, K, N, gs, desc_act=True)
+    lin = HipGptqLinear(bits=4, group_size=gs, sym=False, desc_act=True, in_features=K, out_features=N, bias=False, register_buffers=False)
+    lin.qweight, lin.qzeros = torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV)
+    lin.scales, lin.g_idx, lin.bias = f32_to_torch(scales, "fp16", DEV), torch.from_numpy(g_idx).to(DEV), None
+    lin.qzero_format(format=2)
+    lin.eval()
+    lin.post_init()
+    assert lin.perm is not None
+    rng = np.random.RandomState(1)
+    h = f32_to_torch(rng.randn(M, K).astype(np.float32), "fp16", DEV)
+    w = f32_to_torch(1.0 + 0.1 * rng.randn(K).astype(np.float32), "fp16", DEV)
+    a = lin.forward_pregathered(ops.rmsnorm_gather(h, w, 1e-5, lin.perm))
+    b = lin(ops.rmsnorm_gather(h, w, 1e-5))
+    assert torch.equal(a, b)
+    xn = np.stack([O.rmsnorm_ref(torch_to_f32(h)[m], torch_to_f32(w), 1e-5, "fp16") for m in range(M)])
+    assert_forward_close(torch_to_f32(a), O.forward_gptq(xn, qweight, qzeros, scales, g_idx, 4, None, "fp16", "fp16"), "fp16")
+
+
+@pytest.mark.parametrize("act", ["fp16", "bf16"])
+def test_silu_mul_epilogue_elementwise_large_arguments(ops, act):
+    """SiLU in the glue is evaluated with the accurate expf (HF: x * sigmoid(x) in fp32, rounded to the activation dtype), pinned
+    ELEMENT-WISE on gate values spanning |x| <= 20: the paired gate|up epilogue against the oracle's silu_mul_ref on
+    the DEVICE's own pre-activation values, <= 1 ulp, >= 99.9 % bit-exact."""
+    gs, K, inter = 128, 4096, 1024
+    N = 2 * inter
+    qweight, qzeros, scales, g_idx = synth_gptq(91, 4, K, N, gs)
+    scales = O.round_to(scales * 6.0, "fp16")          # widen the output range: gate values reach |x| ~ 20
+    order = np.stack([np.arange(inter).reshape(-1, 8), inter + np.arange(inter).reshape(-1, 8)], axis=1).reshape(-1)
+    qw_i = np.ascontiguousarray(qweight[:, order])
+    qz_i = O.pack_cols(O.unpack_cols(qzeros, 4)[:, order], 4)
+    sc_i = f32_to_torch(np.ascontiguousarray(scales[:, order]), "fp16", DEV)
+    qw_t, meta = ops.repack_tiled(torch.from_numpy(qw_i).to(DEV), torch.from_numpy(qz_i).to(DEV), sc_i, None, gs, 4)
+    x = f32_to_torch(np.random.RandomState(2).randn(4, K).astype(np.float32), act, DEV)
+    pre = ops.decode_linear(x, qw_t, meta, None, K, N, gs, 4, sc_i.dtype, M=4)                       # interleaved gate|up, no glue
+    out = ops.decode_linear(x, qw_t, meta, None, K, N, gs, 4, sc_i.dtype, M=4, out_glue=ops.OUT_SILU_MUL_PAIRED)
+    p = torch_to_f32(pre).reshape(4, inter // 8, 2, 8)
+    gate, up = p[:, :, 0, :].reshape(4, inter), p[:, :, 1, :].reshape(4, inter)
+    assert np.abs(gate).max() > 12.0, "test input does not reach large SiLU arguments"
+    ref = O.silu_mul_ref(gate, up, act)
+    d = _ulps16(torch_to_bits(out)[:, :inter], torch_to_bits(f32_to_torch(ref, act)))
+    assert d.max() <= 1 and (d > 0).mean() <= 1e-3, (int(d.max()), float((d > 0).mean()))
+
+
+def _module(t, gs, dtype, desc_act):
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    K, N = t["qweight"].shape[0] * 8, t["qweight"].shape[1]
+    m = HipGptqLinear(bits=4, group_size=gs, sym=True, desc_act=desc_act, in_features=K, out_features=N, bias=False, register_buffers=False)
+    m.qweight, m.qzeros = torch.from_numpy(t["qweight"]).to(DEV), torch.from_numpy(t["qzeros"]).to(DEV)
+    m.scales, m.g_idx, m.bias = torch.from_numpy(t["scales"]).to(dtype).to(DEV), torch.from_numpy(t["g_idx"]).to(DEV), None
+    m.qzero_format(format=2)
+    m.eval()
+    return m
+
+
+def _decode_layers(shard_list, layers, gs, dtype, desc_act):
+    """DecodeLayer objects (HIP modules, post_init()ed) of ONE rank's shards."""
+    from gptqmodel_amd.utils.decode_chain import DecodeLayer
+    from gptqmodel_amd.utils.model import fuse_gate_up_interleaved
+    out = []
+    for sh, L in zip(shard_list, layers):
+        qkv = _module(_cat_cols([sh["q"], sh["k"], sh["v"]]), gs, dtype, desc_act)
+        o = _module(sh["o"], gs, dtype, False)
+        gu = fuse_gate_up_interleaved(_module(sh["gate"], gs, dtype, desc_act), _module(sh["up"], gs, dtype, desc_act))
+        down = _module(sh["down"], gs, dtype, False)
+        for m in (qkv, o, gu, down):
+            m.post_init()
+        out.append(DecodeLayer(qkv, o, gu, down, torch.from_numpy(L["w_in"]).to(dtype).to(DEV), torch.from_numpy(L["w_post"]).to(dtype).to(DEV),
+                               o_input_index=None if sh["o_index"] is None else torch.from_numpy(sh["o_index"])))
+    return out
+
+
+# two layers = eight chained linears + four norms: each linear's output is within ~1e-3 (norm-wise) of the oracle's, single 16-bit
+# ulps on some elements that the next RMSNorm / residual carries on -- the chain-level bar is 3e-3 of max |h|
+CHAIN_TOL = 3e-3
+
+
+@pytest.mark.parametrize("desc_act", [False, True])
+def test_two_layer_chain_vs_oracle_composition(desc_act):
+    """DecodeStep (the chain bench.py times) on two layers against the ORACLE's composition of the same eight linears + glue --
+    not against another HIP path (VERDICT r2 'parity thin spots')."""
+    from gptqmodel_amd.utils.decode_chain import DecodeStep
+    hidden, inter, q_dim, kv_dim, gs = 2048, 4096, 2048, 512, 128
+    layers, shards = _build_layers(1, 2, hidden, inter, q_dim, kv_dim, gs, desc_act, seed=3)
+    step_layers = _decode_layers(shards[0], layers, gs, torch.float16, desc_act)
+    if desc_act:
+        # DecodeStep has no exchange step: o_proj runs from the UN-sorted checkpoint tensors with the module's own in-kernel
+        # permutation (the "shard" of a one-rank group is the whole group-sorted layer + an input index = that permutation; the
+        # oracle composition multiplies the same terms)
+        from gptqmodel_amd.utils.decode_chain import DecodeLayer
+        rebuilt = []
+        for L, OL in zip(step_layers, layers):
+            assert L.o_input_index is not None
+            o_mod = _module(OL["full"]["o"], gs, torch.float16, True)
+            o_mod.post_init()
+            assert o_mod.perm is not None and L.qkv.perm is not None and L.down.perm is None
+            rebuilt.append(DecodeLayer(L.qkv, o_mod, L.gate_up, L.down, L.input_norm, L.post_norm))
+        step_layers = rebuilt
+    step = DecodeStep(step_layers, hidden, q_dim, torch.float16)
+    for i in range(3):
+        x = O.round_to(np.random.RandomState(70 + i).randn(hidden).astype(np.float32) * 0.5, "fp16")
+        step.x_in.copy_(f32_to_torch(x, "fp16", DEV))
+        got = torch_to_f32(step.run())
+        torch.cuda.synchronize()
+        ref = _oracle_chain(x, layers, "fp16", 1e-5)
+        assert np.isfinite(got).all()
+        e = rel_err(got, ref)
+        assert e <= CHAIN_TOL, f"two-layer chain vs oracle composition: rel err {e:.3e}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# collectives: stress, gather-select, a lost peer
+# ---------------------------------------------------------------------------------------------------------------------
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    return dev
+
+
+def _stress_worker(rank, world, port, ret, epochs):
+    dev = _init(rank, world, port)
+    try:
+        from gptqmodel_amd.utils.xgmi_allreduce import OneShotAllReduce
+        n = 8192
+        comm = OneShotAllReduce(n, dev)
+        ok = comm.self_test(calls=4, burst=256)
+        # 10^5 back-to-back epochs: a captured graph of 100 all-reduces whose payload changes EVERY epoch (base_r + a device-side
+        # counter), replayed 1000 times with no host synchronisation in between; mismatches are counted on the device, bit-exactly
+        bases = [torch.randn(n, generator=torch.Generator().manual_seed(500 + r)).half().float().to(dev) for r in range(world)]
+        counter = torch.zeros((), device=dev)
+        bad = torch.zeros((), dtype=torch.int64, device=dev)
+        part = torch.empty(n, device=dev)
+        out = torch.empty(n, device=dev, dtype=torch.float16)
+        res = torch.randn(n, generator=torch.Generator().manual_seed(9)).half().to(dev)
+
+        def one():
+            counter.add_(1.0)
+            counter.remainder_(251.0)          # payloads stay exactly representable: |base| < 8, counter < 251
+            torch.add(bases[rank], counter, out=part)
+            comm(part, out_dtype=torch.float16, residual=res, out=out)
+            want = bases[0] + counter
+            for b in bases[1:]:
+                want = want + (b + counter)
+            want = (res.float() + want.half().float()).half()
+            bad.add_((out != want).sum())
+
+        s = torch.cuda.Stream()
+        per_graph = 100
+        with torch.cuda.stream(s):
+            one()
+            s.synchronize()
+            dist.barrier()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                for _ in range(per_graph):
+                    one()
+            for _ in range(epochs // per_graph):
+                g.replay()
+            s.synchronize()
+        comm.check_status()
+        ok = ok and int(bad.item()) == 0
+        # gather + select: every rank's 16-bit vector, any subset / order of the concatenation
+        for it in range(6):
+            n_local = (1024, 4096, 8, 2048, 512, 8192)[it]
+            xl = torch.randn(n_local, generator=torch.Generator().manual_seed(40 * it + rank)).half()
+            allx = [torch.empty(n_local, dtype=torch.float16) for _ in range(world)]
+            dist.all_gather(allx, xl)
+            full = torch.cat(allx)
+            idx = torch.randperm(n_local * world, generator=torch.Generator().manual_seed(it))[:max(8, n_local // 2 + 8 * it)].to(torch.int32)
+            got = comm.gather_select(xl.to(dev), idx.to(dev))
+            whole = comm.gather_select(xl.to(dev))
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(got.cpu(), full[idx.long()]) and torch.equal(whole.cpu(), full)
+        comm.check_status()
+        comm.close()
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_oneshot_collectives_stress_1e5_epochs_two_processes_one_gpu():
+    world = 2
+    port = 33100 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    mp.spawn(_stress_worker, args=(world, port, ret, int(os.environ.get("GPTQHIP_STRESS_EPOCHS", "100000"))), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def _lost_peer_worker(rank, world, port, ret):
+    os.environ["GPTQHIP_COMM_TIMEOUT_MS"] = "300"
+    dev = _init(rank, world, port)
+    try:
+        from gptqmodel_amd.utils.xgmi_allreduce import OneShotAllReduce
+        comm = OneShotAllReduce(4096, dev)
+        part = torch.ones(4096, device=dev)
+        ok = torch.equal(comm(part, out_dtype=torch.float16).cpu(), torch.full((4096,), float(world), dtype=torch.float16))
+        dist.barrier()
+        if rank == 0:
+            # rank 1 never makes this call: the wait gives up after 300 ms, the output is poisoned and the status word set
+            stats = torch.zeros(4096 // 16, device=dev)
+            out = comm(part, out_dtype=torch.float16, stats_out=stats)
+            torch.cuda.synchronize()
+            ok = ok and bool(torch.isnan(out).all()) and bool(torch.isnan(stats).all())
+            try:
+                comm.check_status()
+                ok = False
+            except RuntimeError:
+                pass
+        dist.barrier()
+        torch.cuda.synchronize()
+        ret[rank] = bool(ok)
+        # (no comm.close(): rank 0's communicator is deliberately out of step)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_oneshot_allreduce_lost_peer_poisons_output():
+    world = 2
+    port = 35100 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    mp.spawn(_lost_peer_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tensor-parallel act-order chain, two ranks, against the oracle composition of the same shards
+# ---------------------------------------------------------------------------------------------------------------------
+def _tp_oracle_worker(rank, world, port, ret, desc_act):
+    dev = _init(rank, world, port)
+    try:
+        from gptqmodel_amd.utils.decode_chain import TPDecodeStep
+        from gptqmodel_amd.utils.xgmi_allreduce import OneShotAllReduce
+        hidden, inter, q_dim, kv_dim, gs = 2048, 4096, 2048, 512, 128
+        layers, shards = _build_layers(world, 2, hidden, inter, q_dim, kv_dim, gs, desc_act, seed=5)
+        dl = _decode_layers(shards[rank], layers, gs, torch.float16, desc_act)
+        if desc_act:
+            assert all(L.o_input_index is not None and L.qkv.perm is not None and L.gate_up.perm is not None and L.down.perm is None
+                       for L in dl)
+        comm = OneShotAllReduce(hidden, dev)
+        step = TPDecodeStep(dl, hidden, q_dim // world, torch.float16, comm)
+        ok = True
+        errs = []
+        for i in range(3):
+            x = O.round_to(np.random.RandomState(90 + i).randn(hidden).astype(np.float32) * 0.5, "fp16")
+            step.x_in.copy_(f32_to_torch(x, "fp16", dev))
+            got = step.run().clone()
+            torch.cuda.synchronize()
+            step.check()
+            ref = _oracle_chain(x, layers, "fp16", 1e-5)
+            e = rel_err(torch_to_f32(got), ref)
+            errs.append(e)
+            ok = ok and bool(torch.isfinite(got).all()) and e <= CHAIN_TOL
+            both = [torch.empty(hidden, dtype=torch.float16) for _ in range(world)]
+            dist.all_gather(both, got.cpu())
+            ok = ok and all(torch.equal(both[0], b) for b in both)     # rank-ordered reduction: identical bits on every rank
+        # graph replay with the exchange steps inside
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            step.run()
+            s.synchronize()
+            dist.barrier()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                out = step.run()
+            first = None
+            for _ in range(5):
+                g.replay()
+                s.synchronize()
+                first = out.clone() if first is None else first
+                ok = ok and torch.equal(out, first)
+        step.check()
+        comm.close()
+        ret[rank] = (bool(ok), [float(e) for e in errs])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("desc_act", [False, True])
+def test_tp2_chain_two_layers_vs_oracle_composition(desc_act):
+    """TPDecodeStep on two ranks (two processes, one GPU, real IPC mappings): column shards with the in-kernel act-order
+    permutation, down_proj's permutation folded into gate / up's column ownership, o_proj behind the one-shot all-gather + select,
+    fp32 partial sums reduced in rank order -- against the ORACLE composition of the same shards."""
+    world = 2
+    port = 37100 + (os.getpid() % 2000) + (500 if desc_act else 0)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    mp.spawn(_tp_oracle_worker, args=(world, port, ret, desc_act), nprocs=world, join=True)
+    assert all(v[0] for v in dict(ret).values()) and len(ret) == world, dict(ret)

@@ -160,3 +160,45 @@ def test_reference_selection_tests_still_pass_with_overlay(overlaid_tree):
         os.path.join(overlaid_tree, "tests", "kernels", "test_qlinear_hierarchy.py"))
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=overlaid_tree)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+def test_reference_quantize_config_parses_what_the_repo_writes(tmp_path):
+    """The quantize_config.json written by utils.checkpoint.save_quantized_checkpoint (and the legacy-alias forms its reader
+    accepts) parsed by the REAL reference's QuantizeConfig.from_pretrained (quantization/config.py:3022): the keys that reach the
+    kernel constructor must agree field by field with utils.checkpoint.read_quantize_config."""
+    import json
+    script = r'''
+import json, os, sys
+sys.path.insert(0, {root!r})
+os.environ["CUDA_VISIBLE_DEVICES"] = ""
+from oracle.ref_import import load_reference
+load_reference()
+from gptqmodel.quantization.config import QuantizeConfig
+from gptqmodel_amd.utils.checkpoint import read_quantize_config
+out = []
+for d in {dirs!r}:
+    q = QuantizeConfig.from_pretrained(d)
+    ours = read_quantize_config(d)
+    fmt = getattr(q.format, "value", q.format)
+    meth = getattr(q.method, "value", q.method) if hasattr(q, "method") else getattr(q.quant_method, "value", q.quant_method)
+    out.append({{"ref": [int(q.bits), int(q.group_size), bool(q.desc_act), bool(q.sym), str(fmt).lower(), str(meth).lower()],
+                 "ours": [ours["bits"], ours["group_size"], ours["desc_act"], ours["sym"], ours["format"], ours["method"]]}})
+print("RESULT " + json.dumps(out))
+'''
+    payloads = [
+        {"bits": 4, "group_size": 128, "desc_act": True, "sym": False, "lm_head": False, "quant_method": "gptq", "checkpoint_format": "gptq",
+         "pack_dtype": "int32", "meta": {"quantizer": ["gptqmodel_amd:test-writer"]}},                       # what the writer emits
+        {"bits": 8, "group_size": 32, "desc_act": False, "sym": True, "quant_method": "gptq", "checkpoint_format": "gptq_v2"},
+        {"w_bit": 4, "q_group_size": 64, "zero_point": True, "version": "gemm", "quant_method": "awq"},       # AutoAWQ-style keys
+    ]
+    dirs = []
+    for i, pl in enumerate(payloads):
+        d = tmp_path / f"c{i}"
+        d.mkdir()
+        (d / "quantize_config.json").write_text(json.dumps(pl))
+        dirs.append(str(d))
+    r = subprocess.run([sys.executable, "-c", script.format(root=ROOT, dirs=dirs)], capture_output=True, text=True, timeout=600, cwd="/tmp")
+    line = next((ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")), None)
+    assert line is not None, (r.stdout[-800:], r.stderr[-1500:])
+    for res in json.loads(line[7:]):
+        assert res["ref"] == res["ours"], res

@@ -157,3 +157,42 @@ def test_awq_shards_tile_the_matrix():
     wr = np.concatenate([O.dequant_awq(c["qweight"].numpy(), c["qzeros"].numpy(), c["scales"].float().numpy(), gs)
                          for c in (tp.shard_awq_row(t, r, 2, gs) for r in range(2))], axis=0)
     assert np.array_equal(wc, full) and np.array_equal(wr, full)
+
+
+def test_shard_mlp_act_order_needs_no_exchange():
+    """down_proj's act-order permutation folded into the column OWNERSHIP of gate / up (tp.shard_mlp_act_order): every rank's
+    (gate_r, up_r) produce exactly the intermediate features its group-sorted down_proj rows consume, in that order -- so the
+    sum over ranks of down_r(act(gate_r(x)) * up_r(x)) is the full MLP over the same terms (dequantised shards tile the
+    permuted matrices bit for bit), with no all-gather (gptqmodel/utils/marlin.py:296-305,368-372)."""
+    bits, gs, H, I = 4, 64, 256, 512
+    gate, up = _tensors(21, bits, H, I, gs), _tensors(22, bits, H, I, gs)
+    # gate / up themselves are act-order checkpoints on their INPUT side (shared permutation, like real GPTQ siblings)
+    gi = torch.from_numpy((np.random.RandomState(5).permutation(H) // gs).astype(np.int32))
+    gate["g_idx"], up["g_idx"] = gi, gi.clone()
+    down = _tensors(23, bits, I, H, gs, bias=False)
+    down["g_idx"] = torch.from_numpy((np.random.RandomState(6).permutation(I) // gs).astype(np.int32))
+    deq = lambda t: O.dequant_gptq(t["qweight"].numpy(), t["qzeros"].numpy(), t["scales"].float().numpy(), t["g_idx"].numpy(), bits)
+    wg, wu, wd = deq(gate), deq(up), deq(down)
+    perm = O.act_order_perm(down["g_idx"].numpy())
+    for world in (2, 4):
+        sh = [tp.shard_mlp_act_order(gate, up, down, r, world, bits, gs) for r in range(world)]
+        k = I // world
+        for r, (g_r, u_r, d_r) in enumerate(sh):
+            assert "input_index" not in d_r
+            assert np.array_equal(d_r["g_idx"].numpy(), np.arange(k) // gs)
+            cols = perm[r * k:(r + 1) * k]
+            assert np.array_equal(deq(g_r), wg[:, cols]) and np.array_equal(deq(u_r), wu[:, cols])
+            assert np.array_equal(deq(d_r), wd[cols])
+            assert torch.equal(g_r["bias"], gate["bias"][torch.from_numpy(cols)])
+        # the MLP through the shards == the full MLP (fp32 association of the K-shards aside)
+        x = O.round_to(np.random.RandomState(8).randn(2, H).astype(np.float32) * 0.5, "fp16")
+        full = O.matmul_round(O.silu_mul_ref(O.matmul_round(x, wg, gate["bias"].float().numpy(), "fp16"),
+                                             O.matmul_round(x, wu, up["bias"].float().numpy(), "fp16"), "fp16"), wd, None, "fp16")
+        part = sum(O.silu_mul_ref(O.matmul_round(x, deq(g_r), g_r["bias"].float().numpy(), "fp16"),
+                                  O.matmul_round(x, deq(u_r), u_r["bias"].float().numpy(), "fp16"), "fp16") @ deq(d_r)
+                   for g_r, u_r, d_r in sh)
+        assert np.abs(O.round_to(part, "fp16") - full).max() <= 1e-3 * np.abs(full).max()
+    # a down_proj without act-order degenerates to the plain contiguous split
+    down_seq = _tensors(23, bits, I, H, gs, bias=False)
+    g_r, u_r, d_r = tp.shard_mlp_act_order(gate, up, down_seq, 1, 2, bits, gs)
+    assert np.array_equal(deq(g_r), wg[:, I // 2:]) and np.array_equal(deq(d_r), deq(down_seq)[I // 2:])
