@@ -353,6 +353,51 @@ print("RESULT", ms, comp)
         return None, f"torch.compile leg unavailable: {e}"
 
 
+def live_pmc(dtype_flag, limit_s=170):
+    """--live-pmc: HBM bytes per decode launch measured NOW on this box: two separate `rocprofv3 --kernel-trace --pmc <counter>`
+    passes (MI355X_MICROARCH.md: counters in their own run, no other trace domains) over a 3-step eager run of this same script,
+    FETCH_SIZE doubled (the guide's gfx950 correction for wide coalesced reads) + WRITE_SIZE.  (bytes | None, source string)."""
+    import csv
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "live PMC unavailable (no rocprofv3)"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        td = tempfile.mkdtemp(prefix="gptqhip_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", td, "-o", "bench", "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-configs", "--no-graph", "--dtype", dtype_flag]
+        try:
+            pr = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp", start_new_session=True,
+                                  env=dict(os.environ, TMPDIR="/tmp"))
+            try:
+                pr.wait(timeout=limit_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)        # the process group WE started, nothing else
+                pr.wait()
+                return None, f"live PMC pass {counter} exceeded {limit_s} s"
+            rows = []
+            for root, _, files in os.walk(td):
+                for fn in files:
+                    if fn.endswith("counter_collection.csv"):
+                        with open(os.path.join(root, fn)) as f:
+                            rows += [float(r["Counter_Value"]) for r in csv.DictReader(f)
+                                     if "skinny_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if not rows:
+                return None, f"live PMC pass {counter} produced no skinny_kernel rows"
+            vals[counter] = sum(rows) / len(rows)
+        except Exception as e:  # noqa: BLE001
+            return None, f"live PMC failed: {str(e)[:120]}"
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    tr = 2.0 * 1024.0 * vals["FETCH_SIZE"] + 1024.0 * vals["WRITE_SIZE"]
+    return tr, ("measured live in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 3 eager steps of this "
+                "command on this box; FETCH_SIZE x2 = the guide's gfx950 correction, KB -> bytes)")
+
+
 def latest_pmc():
     """(traffic bytes per launch | None, source string).  Read from the committed rocprofv3 --pmc summary of the SAME bench
     command (profiles/*_pmc_summary.json, gfx950 FETCH_SIZE correction applied there); not measured in this run."""
@@ -419,6 +464,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end HF Llama-3-8B-shaped decode leg (`e2e` key)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--tp-steps", type=int, default=30, help="timed steps of the C5 tp=N entry appended when N > 1")
+    ap.add_argument("--live-pmc", action="store_true",
+                    help="measure roofline.traffic live (two short rocprofv3 --pmc passes of this script, ~1-2 min) instead of reading "
+                         "the committed profiles/*_pmc_summary.json")
     ap.add_argument("--handshake-only", action="store_true",
                     help="launch / rendezvous check only: spawn the ranks, all-reduce ones, print {n_gpus, ranks_seen}; needs no GPU "
                          "(gloo when CUDA is unavailable) -- tests/test_host_logic.py uses it to prove --gpus is honoured")
@@ -540,6 +588,7 @@ def main():
     ms_per_step = wall * 1e3 / args.steps
     value = world * args.steps / wall   # replicas add up
 
+    used_graph = graph is not None
     tp_entry = None
     if world > 1 and not args.no_configs:
         # BASELINE configs[4] on the SAME ranks: the 70B decode step tensor-parallel over all of them (every rank takes part)
@@ -555,7 +604,14 @@ def main():
             tp_entry = {"config": "C5", "tp": world, "error": f"{type(e).__name__}: {str(e)[:300]}"}
 
     if rank == 0:
-        traffic, traffic_source = latest_pmc()
+        traffic, traffic_source = (None, "")
+        if args.live_pmc and world == 1:
+            traffic, traffic_source = live_pmc(args.dtype)
+        if traffic is None:
+            note = traffic_source
+            traffic, traffic_source = latest_pmc()
+            if note:
+                traffic_source += f" [{note}]"
         launch_us = ev_ms * 1e3 / (args.steps * n_launch)   # average launch duration incl. whatever the ops do not overlap
         bytes_per_launch = step_bytes / n_launch
         achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
@@ -572,7 +628,7 @@ def main():
                                    "SiLU*mul, residual adds fused into the ops; attention stand-in = q), M=1, random packed weights",
                        "parallelism": f"replicas x{world}", "mode": mode,
                        "linears_per_step": n_linear, "launches_per_step": n_launch, "fused_siblings": True,
-                       "graph": graph is not None, "replicas": world, "weight_bytes_per_token": step_bytes},
+                       "graph": used_graph, "replicas": world, "weight_bytes_per_token": step_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel, "bytes_per_launch": bytes_per_launch, "avg_launch_us": launch_us,

@@ -49,12 +49,15 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="sequences decoded together (<= 4 stay on the decode-op fast path)")
     ap.add_argument("--siblings-only", action="store_true", help="fuse q/k/v and gate/up only (no decode-op layer fast path)")
     ap.add_argument("--quant-lm-head", action="store_true", help="also quantise lm_head (qcfg.lm_head upstream, loader.py:1376)")
+    ap.add_argument("--desc-act", action="store_true", help="act-order checkpoint: g_idx = a random permutation per input tensor "
+                                                             "(shared by q|k|v and by gate|up like a real GPTQ act-order checkpoint)")
     args = ap.parse_args()
     run(args.size, args.dtype, args.new_tokens, not args.no_fuse, args.quant_lm_head, verbose=True, decode_ops=not args.siblings_only,
-        batch=args.batch)
+        batch=args.batch, desc_act=args.desc_act)
 
 
-def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=False, verbose=False, decode_ops=True, batch=1):
+def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=False, verbose=False, decode_ops=True, batch=1,
+        desc_act=False):
     """Returns {"eager_tokens_per_s", "graph_tokens_per_s" | None, "build_s", ...}; bench.py reports it as `e2e`."""
     import types
     args = types.SimpleNamespace(size=size, dtype=dtype_name, new_tokens=new_tokens, no_fuse=not fuse, quant_lm_head=quant_lm_head)
@@ -78,13 +81,24 @@ def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=Fa
              (".layers." in n or (args.quant_lm_head and n == "lm_head"))]
     mods = dict(model.named_modules())
     floats = {n: mods[n] for n in names}
-    make_quant(model, names, bits=4, group_size=128, desc_act=False, sym=False, backend=BACKEND.AUTO, format=FORMAT.GPTQ,
+    make_quant(model, names, bits=4, group_size=128, desc_act=desc_act, sym=False, backend=BACKEND.AUTO, format=FORMAT.GPTQ,
                dtype=dtype)
     mods = dict(model.named_modules())
+    res["desc_act"] = desc_act
+    perms = {}
     for n in names:
         lin, qm = floats[n], mods[n]
-        scales, zeros = rtn(lin.weight.data, 128, 4)
-        qm.pack(lin, scales, zeros, (torch.arange(lin.in_features) // 128).to(torch.int32))
+        if desc_act:
+            key = (n.rsplit(".", 1)[0], lin.in_features)          # siblings that share an input share the permutation
+            if key not in perms:
+                perms[key] = (torch.randperm(lin.in_features) // 128).to(torch.int32)
+            g_idx = perms[key]
+            order = torch.argsort(g_idx.long(), stable=True).to(lin.weight.device)
+            scales, zeros = rtn(lin.weight.data[:, order], 128, 4)  # group g = the columns whose g_idx == g
+        else:
+            g_idx = (torch.arange(lin.in_features) // 128).to(torch.int32)
+            scales, zeros = rtn(lin.weight.data, 128, 4)
+        qm.pack(lin, scales, zeros, g_idx)
     del floats
     res["layer_path"] = "per-module launches"
     if not args.no_fuse and decode_ops:

@@ -245,12 +245,16 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     a.perm = fused_perm ? perm : nullptr;
     a.exact_bf16 = (flags & GPTQHIP_GEMM_EXACT_BF16) ? 1 : 0;
 
-    // measured crossover (profiles/r02_mid_m_sweep.txt, after the round-2 planners): the MFMA-tiled kernel (64-row tiles,
-    // split-K) wins above 32 rows, and above 16 rows on wide layers (N >= 8192, e.g. fused gate_up: 25.4 vs 38.3 us at M=24;
-    // at M=16 the decode kernel still leads 23.5 vs 25.0) where every 16-column block of the skinny kernel re-stages the whole
-    // activation tile
+    // measured crossover (profiles/r03_mid_m_sweep.txt, after the round-3 change of the 17..32-row decode instantiations to 512-thread
+    // blocks): the MFMA-tiled kernel (64-row tiles, split-K) wins above 32 rows -- above 48 on small layers (K < 8192 and N < 6144:
+    // 4096^2 at M=48 13.6 us in two decode launches vs 14.4 us tiled), above 16 rows on wide layers (N >= 8192, e.g. fused gate_up:
+    // 24.7 vs 36.9 us at M=24; at M=16 the decode kernel still leads 23.1 vs 25.6) where every 16-column block of the skinny kernel
+    // re-stages the whole activation tile, and above 24 rows on long-K layers (K >= 8192: 14336x4096 at M=32 18.2 vs 19.5 us)
     const bool wide = N >= 8192 && M > 16;
-    const bool use_tiled = (g_force_kernel == 2) || (g_force_kernel == 0 && (M > kSkinnyMaxM || wide));
+    const bool long_k = K >= 8192 && M > 24;
+    const bool small_layer = K < 8192 && N < 6144;
+    const int skinny_max = small_layer ? 48 : kSkinnyMaxM;
+    const bool use_tiled = (g_force_kernel == 2) || (g_force_kernel == 0 && (M > skinny_max || wide || long_k));
     if (use_tiled) {
         a.x = xin;
         a.out = out;

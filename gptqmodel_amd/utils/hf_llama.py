@@ -34,6 +34,7 @@ with HF's LlamaRMSNorm / LlamaMLP / residual formulas -- tests/test_gpu_e2e_llam
 """
 from __future__ import annotations
 
+import os
 import types
 from typing import List, Optional, Tuple
 
@@ -407,8 +408,10 @@ def fuse_llama_decoder_layers(model: nn.Module, allow_unknown: bool = False) -> 
                                 "qk_norm": qk_norm, "interfaces": ALL_ATTENTION_FUNCTIONS,
                                 # prefill path (ops.rmsnorm_gather + forward_pregathered): GPTQ modules only (AWQ has no
                                 # forward_pregathered: no act-order there) and hidden sizes the norm kernel stages in LDS
+                                # (GPTQHIP_HF_PREFILL=0: A/B switch, keeps HF's own layer code for prefill)
                                 "prefill": ({} if hasattr(qkv, "forward_pregathered") and hasattr(gu, "forward_pregathered")
-                                            and in_f % 8 == 0 and in_f <= 16384 else None)}
+                                            and in_f % 8 == 0 and in_f <= 16384 and os.environ.get("GPTQHIP_HF_PREFILL", "1") != "0"
+                                            else None)}
         layer.forward = types.MethodType(_layer_forward, layer)
         fused.append(layer)
         prev = layer

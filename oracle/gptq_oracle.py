@@ -329,9 +329,12 @@ def rmsnorm_ref(h_f32: np.ndarray, weight_f32: np.ndarray, eps: float, act_dtype
 
 
 def silu_mul_ref(gate_f32: np.ndarray, up_f32: np.ndarray, act_dtype: str) -> np.ndarray:
-    """LlamaMLP: act_fn(gate) * up with act_fn = SiLU evaluated in fp32 and rounded to the activation dtype."""
+    """LlamaMLP: act_fn(gate) * up with act_fn = SiLU evaluated in fp32 (aten computes half / bfloat16 SiLU in float opmath:
+    x / (1 + exp(-x)) with the fp32 exp, so exp(-x) overflows to inf for x < -88.7 and the result is -0, not a 1e-37 denormal-ish
+    value a float64 evaluation would produce) and rounded to the activation dtype."""
     g = np.asarray(gate_f32, np.float32)
-    s = round_to((g.astype(np.float64) / (1.0 + np.exp(-g.astype(np.float64)))).astype(np.float32), act_dtype)
+    with np.errstate(over="ignore"):
+        s = round_to(g / (np.float32(1.0) + np.exp(-g)), act_dtype)
     return round_to(s * np.asarray(up_f32, np.float32), act_dtype)
 
 

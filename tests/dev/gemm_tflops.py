@@ -1,22 +1,22 @@
 """Dev tool: dequant-GEMM TFLOPS of the prefill kernel (methodology of the reference's
 scripts/benchmark_marlin_a100.py: tflops = 2*M*K*N / t, random int32 qweight, warmup then timed iters)."""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from gptqmodel_amd import ops
 dev = "cuda"
 DT = torch.bfloat16 if "bf16" in sys.argv else torch.float16
 def run(M, K, N, gs=128, iters=20):
     qw = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=dev)
     qz = torch.randint(-2**31, 2**31 - 1, (K // gs, N // 8), dtype=torch.int32, device=dev)
-    sc = (torch.rand((K // gs, N), device=dev) * 0.01 + 0.005).half()
+    sc = (torch.rand((K // gs, N), device=dev) * 0.01 + 0.005).to(torch.bfloat16 if "bf16s" in sys.argv else torch.float16)
     qw_t, meta = ops.repack_tiled(qw, qz, sc, None, gs, 4)
     x = (torch.randn(M, K, device=dev) * 0.5).to(DT)
     out = torch.empty((M, N), dtype=DT, device=dev)
-    for _ in range(25): ops.gemm(x, qw_t, meta, None, None, N, gs, 4, torch.float16, out=out)
+    for _ in range(25): ops.gemm(x, qw_t, meta, None, None, N, gs, 4, sc.dtype, out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters): ops.gemm(x, qw_t, meta, None, None, N, gs, 4, torch.float16, out=out)
+    for _ in range(iters): ops.gemm(x, qw_t, meta, None, None, N, gs, 4, sc.dtype, out=out)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     return ms, 2.0 * M * K * N / ms / 1e9

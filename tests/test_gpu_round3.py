@@ -38,7 +38,8 @@ def _ulps16(got_bits: np.ndarray, ref_bits: np.ndarray) -> np.ndarray:
 def test_rmsnorm_gather_vs_hf_formula(ops, act, K, M, with_perm):
     """ops.rmsnorm_gather == LlamaRMSNorm (oracle restatement) followed by the act-order column gather.  The fp32 sum of squares is
     associated differently from numpy's, so 1/rms may differ in its last fp32 bit: a handful of elements may land on the other
-    side of a 16-bit rounding boundary (<= 1 ulp, <= 0.1 % of the elements); everything else is bit-exact."""
+    side of a 16-bit rounding boundary -- 1 ulp in the normalised value, which the product with a weight > 1 can turn into 2 ulps of
+    the output (<= 2 ulps, <= 0.1 % of the elements); everything else is bit-exact."""
     rng = np.random.RandomState(K + M)
     h = O.round_to(rng.randn(M, K).astype(np.float32) * (0.5 + np.arange(M)[:, None] % 7), act)
     w = O.round_to(1.0 + 0.1 * rng.randn(K).astype(np.float32), act)
@@ -51,7 +52,7 @@ def test_rmsnorm_gather_vs_hf_formula(ops, act, K, M, with_perm):
     got_b = torch_to_bits(out)
     ref_b = torch_to_bits(f32_to_torch(ref, act))
     d = _ulps16(got_b, ref_b)
-    assert d.max() <= 1, f"max distance {d.max()} ulps"
+    assert d.max() <= 2, f"max distance {d.max()} ulps"
     assert (d > 0).mean() <= 1e-3, f"{(d > 0).mean():.2e} of the elements differ"
     # gather consistency is exact: the permuted output is a permutation of the un-permuted one, bit for bit
     if perm is not None:
