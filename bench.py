@@ -754,6 +754,55 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
         res.append(prefill_entry("C3", "GPTQ int4 g128 desc_act=True, M=65536, 4096x28672 (fused gate_up)", [agu], 65536, dtype, dev,
                                  iters=2))
         del agu
+        # C3 the way a MODEL runs it (utils/hf_llama prefill path): one decoder layer of the act-order checkpoint at M = 65536 -- the
+        # RMSNorm in front of q|k|v and of gate|up is ONE HIP kernel that writes the normalised activations already in the linear's
+        # row order (ops.rmsnorm_gather -> forward_pregathered: no x-gather pass for those two), o_proj keeps its gather pre-pass
+        # (its input comes from attention), down_proj's permutation is folded into gate / up at load time (no gather)
+        from gptqmodel_amd import ops as _ops
+        m_c3 = 65536
+        lq = make_gptq(4096, cfg["q"] + 2 * cfg["kv"], gs, dev, gen, dtype, desc_act=True)
+        lo = make_gptq(cfg["q"], 4096, gs, dev, gen, dtype, desc_act=True)
+        lg = make_gptq(4096, 2 * cfg["inter"], gs, dev, gen, dtype, desc_act=True)
+        ld = make_gptq(cfg["inter"], 4096, gs, dev, gen, dtype, desc_act=False)      # (act-order folded into gate / up)
+        hh = (torch.randn((m_c3, 4096), device=dev, generator=gen) * 0.5).to(dtype)
+        a_in = (torch.randn((m_c3, cfg["q"]), device=dev, generator=gen) * 0.5).to(dtype)
+        m_in = (torch.randn((m_c3, cfg["inter"]), device=dev, generator=gen) * 0.5).to(dtype)
+        nw1 = (1.0 + 0.1 * torch.randn(4096, device=dev, generator=gen)).to(dtype)
+
+        def c3_layer(fused):
+            if fused:
+                lq.forward_pregathered(_ops.rmsnorm_gather(hh, nw1, 1e-5, lq.perm))
+            else:
+                lq(_ops.rmsnorm_gather(hh, nw1, 1e-5))
+            lo(a_in)
+            if fused:
+                lg.forward_pregathered(_ops.rmsnorm_gather(hh, nw1, 1e-5, lg.perm))
+            else:
+                lg(_ops.rmsnorm_gather(hh, nw1, 1e-5))
+            ld(m_in)
+
+        flops = sum(2.0 * m_c3 * l.in_features * l.out_features for l in (lq, lo, lg, ld))
+        for fused, what in ((True, "RMSNorm fused with the act-order gather of q|k|v and gate|up (rmsnorm_gather -> forward_pregathered), "
+                                   "o_proj with its gather pre-pass, down_proj folded"),
+                            (False, "the same layer with a separate x-gather pass in front of every act-order linear (round-2 path; the "
+                                    "two RMSNorm kernels included as well)")):
+            c3_layer(fused)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(2):
+                c3_layer(fused)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 2
+            tf = flops / ms / 1e9
+            res.append({"config": "C3", "workload": f"one Llama-3-8B decoder layer of a desc_act=True checkpoint at M={m_c3} (4 quantised "
+                                                    f"linears + 2 RMSNorm kernels in the timed region): {what}",
+                        "value": tf, "unit": "TFLOP/s", "ms": ms, "flops_counted": "the 4 GEMMs only",
+                        "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
+                                     "kernel": "gptqhip::tiled_kernel (+ rmsnorm_gather_kernel, gather_cols)"}})
+        del lq, lo, lg, ld, hh, a_in, m_in
+        torch.cuda.empty_cache()
         # the same checkpoint kind at batch-1 decode: the act-order permutation is applied inside the decode op
         from gptqmodel_amd.utils.decode_chain import DecodeStep as _DS
         act_layers = build_stack(cfg, lambda k, n: make_gptq(k, n, gs, dev, gen, dtype, desc_act=True), dev, gen, dtype)

@@ -61,6 +61,7 @@ int check_hip(hipError_t e, const char* what) {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 constexpr int kSkinnyMaxM = 32;  // above: the MFMA-tiled kernel (split-K when its grid is small)
+constexpr int kSkinnyMaxRows4 = 64;  // rows one decode-kernel launch takes with 4-bit weights (MT = 4 instantiations)
 constexpr size_t kCounterBytes = 64 * 1024;  // 16384 arrival counters
 
 struct WorkspaceLayout {
@@ -80,10 +81,15 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
     L.gather_bytes = has_perm ? align_up((size_t)M * K * 2, 256) : 0;
     L.slabs_off = L.gather_off + L.gather_bytes;
     const int mchunk = M < kSkinnyMaxM ? M : kSkinnyMaxM;
+    const int mchunk4 = M < kSkinnyMaxRows4 ? M : kSkinnyMaxRows4;   // (4-bit: up to 64 rows per launch, planned without cross-block split)
     // worst case over the split heuristics: the skinny plan for one row-chunk
     // the SAME plans gptqhip_gemm will make for this (shape, group_size, bits): both sides call these planners with
     // identical arguments, so the layout cannot drift from the launch
-    size_t floats = plan_skinny(mchunk, K, N, group_size, g_force_split, g_force_waves).slab_floats;
+    size_t floats = plan_skinny(mchunk, K, N, group_size, g_force_split, g_force_waves, false, bits).slab_floats;
+    {
+        const size_t f4 = plan_skinny(mchunk4, K, N, group_size, g_force_split, g_force_waves, false, bits).slab_floats;
+        if (f4 > floats) floats = f4;
+    }
     if (M > 16 || g_force_kernel == 2) {
         const TiledPlan tp = plan_tiled(M, K, N, group_size, bits, g_force_waves, g_force_split);
         if (tp.slab_floats > floats) floats = tp.slab_floats;
@@ -245,16 +251,16 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     a.perm = fused_perm ? perm : nullptr;
     a.exact_bf16 = (flags & GPTQHIP_GEMM_EXACT_BF16) ? 1 : 0;
 
-    // measured crossover (profiles/r03_mid_m_sweep.txt, after the round-3 change of the 17..32-row decode instantiations to 512-thread
-    // blocks): the MFMA-tiled kernel (64-row tiles, split-K) wins above 32 rows -- above 48 on small layers (K < 8192 and N < 6144:
-    // 4096^2 at M=48 13.6 us in two decode launches vs 14.4 us tiled), above 16 rows on wide layers (N >= 8192, e.g. fused gate_up:
-    // 24.7 vs 36.9 us at M=24; at M=16 the decode kernel still leads 23.1 vs 25.6) where every 16-column block of the skinny kernel
-    // re-stages the whole activation tile, and above 24 rows on long-K layers (K >= 8192: 14336x4096 at M=32 18.2 vs 19.5 us)
+    // measured crossover (profiles/r03_mid_m_sweep.txt, round 3: split-ring pipeline for 17..64 rows, 33..64 rows in one launch with
+    // 4-bit weights): the decode kernel leads up to 64 rows on layers with K < 8192 and N < 8192 (4096^2 at M=64 10.7 us vs 15.8 us
+    // tiled; 4096x6144 18.1 vs 18.4), up to 32 rows on long-K layers (14336x4096: 18.4 vs 18.1 us at M=32, 24.6 vs 19.2 at M=40), and
+    // up to 16 rows on wide layers (N >= 8192, e.g. fused gate_up: 28.4 vs 25.6 us at M=24) where every 16-column block of the decode
+    // kernel re-stages the whole activation tile.  Everything above goes to the MFMA-tiled kernel (64-row tiles, split-K).
     const bool wide = N >= 8192 && M > 16;
-    const bool long_k = K >= 8192 && M > 24;
-    const bool small_layer = K < 8192 && N < 6144;
-    const int skinny_max = small_layer ? 48 : kSkinnyMaxM;
-    const bool use_tiled = (g_force_kernel == 2) || (g_force_kernel == 0 && (M > skinny_max || wide || long_k));
+    const int skinny_max = (bits == 4 && K < 8192 && N < 8192) ? kSkinnyMaxRows4 : kSkinnyMaxM;
+    const bool use_tiled = (g_force_kernel == 2) || (g_force_kernel == 0 && (M > skinny_max || wide));
+    // rows per decode-kernel launch: 32, or 64 with 4-bit weights (one launch, the weights are streamed once)
+    const int rows_per_launch = bits == 4 ? kSkinnyMaxRows4 : kSkinnyMaxM;
     if (use_tiled) {
         a.x = xin;
         a.out = out;
@@ -288,12 +294,12 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         return launch_tiled(a, tp, slabs, stream);
     }
     // skinny kernel, kSkinnyMaxM rows per launch
-    for (int m0 = 0; m0 < M; m0 += kSkinnyMaxM) {
-        const int mc = (M - m0) < kSkinnyMaxM ? (M - m0) : kSkinnyMaxM;
+    for (int m0 = 0; m0 < M; m0 += rows_per_launch) {
+        const int mc = (M - m0) < rows_per_launch ? (M - m0) : rows_per_launch;
         a.x = reinterpret_cast<const char*>(xin) + (size_t)m0 * K * 2;
         a.out = reinterpret_cast<char*>(out) + (size_t)m0 * N * (partial_f32 ? 4 : 2);
         a.M = mc;
-        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves, fused_perm);
+        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves, fused_perm, bits);
         rc = launch_skinny(a, pl, slabs, counters, stream);
         if (rc) return rc;
     }

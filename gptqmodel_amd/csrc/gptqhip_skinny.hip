@@ -31,6 +31,16 @@
 #endif
 namespace gptqhip {
 
+// Threads a block may have (the instantiation's __launch_bounds__): 1024 (16 waves, 128 VGPRs) up to 16 rows, 512 (8 waves) for
+// 17..64 rows.  Measured in round 3 (profiles/r03_mid_m_sweep.txt): with the split-ring pipeline the 17..32-row instantiations
+// need only 88-132 VGPRs and COULD run 16 waves, but 8 waves per block are as fast on 4096^2 / 14336x4096 and 7-25 % faster on
+// 4096x6144 / 4096x28672 (twice the blocks per CU re-stage twice the activation tiles).  profiles/r03_isa_audit.txt has the table.
+template <int BITS, int MT>
+__host__ __device__ constexpr int skinny_launch_bound() {
+    return MT >= 2 ? 512 : 1024;
+}
+static int skinny_max_waves(int bits, int mt) { (void)bits; return mt >= 2 ? 8 : 16; }
+
 struct SkinnyParams {
     const void* x;
     const int32_t* perm;   // act-order row permutation applied to x inside the kernel (AM_ROW1P), else nullptr
@@ -171,6 +181,8 @@ struct TileBases {
     const char* x;         // activations
     uint32_t lane16;       // lane * 16
     uint32_t c4;           // (lane & 15) * 4
+    __amdgpu_buffer_rsrc_t xrsrc;  // 17..64-row instantiations: descriptor over the M valid rows of x
+    uint32_t quad_stride;          //   bytes between row quads (4 rows)
 };
 
 template <int BITS, int GPC, int MT, int AM>
@@ -230,10 +242,12 @@ struct Cursor {
 
 template <int MT, int AM>
 struct LaneOffs {
-    uint32_t x[is_rows<AM>() ? 4 * MT : 1];  // byte offsets of this lane's activation loads
+    uint32_t x[is_rows<AM>() && MT == 1 ? 4 : 1];  // byte offsets of this lane's activation loads
 };
 
-template <int BITS, int GPC, int MT, int AM, int GLUE = 0>
+// LOAD_W / LOAD_A: the split-ring pipeline of the 17..64-row instantiations (kSplitRing) loads the weight stage and the activation
+// stage through two cursors; everything else loads both through one.
+template <int BITS, int GPC, int MT, int AM, int GLUE = 0, bool LOAD_W = true, bool LOAD_A = true>
 __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, const SkinnyParams& p, const TileBases& tb,
                                                 const LaneOffs<MT, AM>& lo, Cursor& cu, int stride_chunks) {
     constexpr int WPC = BITS == 4 ? 1 : 2;
@@ -242,6 +256,7 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
     const char* wsrc = cu.w - back * (WPC * 1024);
     const char* xsrc = cu.x - back * 256;
     const int ch = cu.chunk - (int)back;
+    if constexpr (LOAD_W) {
 #pragma unroll
     for (int h = 0; h < WPC; ++h)
         st.w[h] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wsrc + h * 1024 + tb.lane16));
@@ -260,7 +275,10 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
             st.meta[j] = *reinterpret_cast<const uint32_t*>(mrow + tb.c4);
         }
     }
-    if constexpr (AM == AM_ROW1) {
+    }   // LOAD_W
+    if constexpr (!LOAD_A) {
+        // (weights only)
+    } else if constexpr (AM == AM_ROW1) {
 #if GPTQHIP_ABLATE & 2
         st.x.a[0] = 0x3c003c00u;
 #else
@@ -280,6 +298,13 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
         if constexpr (GLUE == kGlueRmsNorm) {   // the same 16-byte weight segment for all four rows
             st.x.a[1] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (xsrc - tb.x) + tb.c4 * 4u);
         }
+    } else if constexpr (is_rows<AM>() && MT >= 2) {
+        // 17..64 rows: buffer loads -- ONE per-lane offset register (row quad 0) + a scalar offset per quad and chunk instead of
+        // 4 * MT offset registers; rows >= M are outside the descriptor and come back as zeros (no clamps)
+        const uint32_t soff = (uint32_t)(xsrc - tb.x);
+#pragma unroll
+        for (int i = 0; i < row_quads<AM, MT>(); ++i)
+            st.x.a[i] = __builtin_amdgcn_raw_buffer_load_b128(tb.xrsrc, lo.x[0], soff + (uint32_t)i * tb.quad_stride, 0);
     } else if constexpr (is_rows<AM>()) {
 #pragma unroll
         for (int i = 0; i < row_quads<AM, MT>(); ++i) st.x.a[i] = *reinterpret_cast<const u4_t*>(xsrc + lo.x[i]);
@@ -292,6 +317,11 @@ __device__ __forceinline__ void load_stage_fast(Stage<BITS, GPC, MT, AM>& st, co
     cu.w += (size_t)stride_chunks * (WPC * 1024);
     cu.x += (size_t)stride_chunks * 256;
     cu.chunk += stride_chunks;
+}
+
+template <int MT, int AM, int GLUE>
+__host__ __device__ constexpr bool kSplitRing() {
+    return MT >= 2 && (AM == AM_ROWS || AM == AM_ROWSH) && GLUE == 0;
 }
 
 struct GlueInv {
@@ -307,7 +337,9 @@ __host__ __device__ constexpr bool kExactBf16() {
     return BITS == 4 && ACT == kBF16 && GPC == 1 && (AM == AM_ROW1 || AM == AM_ROW1P || AM == AM_ROW4);
 }
 
-template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int GLUE = 0>
+// PHASE 0: the whole stage; 1: only park the stage's activations in the wave's LDS slot; 2: only dequantise + multiply (the
+// activations are in the slot already) -- the split-ring pipeline (kSplitRing) runs 1 and 2 on different register stages.
+template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int GLUE = 0, int PHASE = 0>
 __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st, const SkinnyParams& p, int chunk,
                                               int lane, u4_t* aslot, const DequantConsts& dk, f4_t (&acc)[MT],
                                               const uint16_t* xbuf = nullptr, const GlueInv& gi = GlueInv{}) {
@@ -340,7 +372,7 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
             aslot[lane] = st.x.a[0];
         }
         abase = (c < p.M ? c : 0) << 4;  // lanes of unused rows re-read row 0: a broadcast, no extra bank traffic
-    } else if constexpr (is_rows<AM>()) {
+    } else if constexpr (is_rows<AM>() && PHASE != 2) {
         // rows of skipped quads keep whatever the slot held: they only feed output rows >= M, which nobody stores
         if constexpr (MT == 1 && GLUE == kGlueRmsNorm) {
 #pragma unroll
@@ -355,6 +387,7 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
             for (int i = 0; i < row_quads<AM, MT>(); ++i) aslot[(4 * i + rq) * kRowsPitch + c] = st.x.a[i];
         }
     }
+    if constexpr (PHASE == 1) return;
     if (kExactBf16<BITS, ACT, GPC, AM>() && p.exact_bf16) {
         // OPT-IN (GPTQHIP_GEMM_EXACT_BF16; block-uniform branch).  bf16 activations, 4-bit codes, one group per chunk,
         // at most 4 rows: gfx950 has no packed bf16 VALU, so the per-weight dequant (cvt, mul, cvt_pk: 28 VALU per word)
@@ -491,8 +524,9 @@ __device__ __forceinline__ void finish_outputs(const SkinnyParams& p, float v, b
 // weight loads of a ring round to the end of the round -- per-shape times moved by < 1.5 % either way, other waves cover.)
 // LB: threads the block may have.  17..32 rows (MT == 2) hold 32 activation registers per ring stage: under the 128-VGPR budget
 // of a 1024-thread block every such instantiation spilled 24-60 registers to scratch (round-2 ISA audit); they are built with
-// LB = 512 (<= 8 waves per block, 256-VGPR budget) instead and the planner picks <= 8 waves for them.
-template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int D, int GLUE = 0, int LB = (MT == 2 ? 512 : 1024)>
+// LB = 512 (<= 8 waves per block, 256-VGPR budget) instead and the planner picks <= 8 waves for them.  33..64 rows (MT == 4, round 3:
+// one launch -- the weights are read ONCE -- instead of two 32-row launches) live in the same 512-thread budget.
+template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int D, int GLUE = 0, int LB = skinny_launch_bound<BITS, MT>()>
 __global__ __launch_bounds__(LB) void skinny_kernel(SkinnyParams p) {
     // ONE dynamic LDS array (16-B aligned base, no statics in front of it): per-wave activation slots during the K
     // loop, then the split-K reduction buffer red[W][MT*4][64]; the last 16 bytes hold the "last arriver" flag.
@@ -523,6 +557,10 @@ __global__ __launch_bounds__(LB) void skinny_kernel(SkinnyParams p) {
     tb.x = reinterpret_cast<const char*>(p.x);
     tb.lane16 = (uint32_t)lane * 16u;
     tb.c4 = (uint32_t)c * 4u;
+    if constexpr (MT >= 2) {
+        tb.xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.M * p.K * 2, 0x00020000);
+        tb.quad_stride = (uint32_t)p.K * 8u;
+    }
     u4_t* aslot = reinterpret_cast<u4_t*>(reinterpret_cast<char*>(lds) + wave * slot_bytes<AM, MT>());
     const DequantConsts dk = make_dequant_consts<BITS>();
 
@@ -556,6 +594,8 @@ __global__ __launch_bounds__(LB) void skinny_kernel(SkinnyParams p) {
             } else if constexpr (AM == AM_ROW4) {
                 const int row = rq < p.M ? rq : 0;
                 lo.x[0] = (uint32_t)row * (uint32_t)p.K * 2u + (uint32_t)c * 16u;
+            } else if constexpr (is_rows<AM>() && MT >= 2) {
+                lo.x[0] = (uint32_t)rq * (uint32_t)p.K * 2u + (uint32_t)c * 16u;   // (row quad i: + i * quad_stride through the scalar offset)
             } else if constexpr (is_rows<AM>()) {
 #pragma unroll
                 for (int i = 0; i < row_quads<AM, MT>(); ++i) {
@@ -788,10 +828,47 @@ __global__ __launch_bounds__(LB) void skinny_kernel(SkinnyParams p) {
                 float tot = 0.f;
                 for (int w = 0; w < W; ++w) tot += scratch[w];
                 glue_inv = rsqrtf(tot / (float)p.K + p.eps);
+            } else if constexpr (kSplitRing<MT, AM, GLUE>()) {
+                // 17..64 rows: the weight ring stays D deep, the ACTIVATION stage (32 / 64 registers) is ONE deep -- st[0].x only: as
+                // soon as a chunk's activations are parked in LDS the next chunk's (L2-resident) rows are requested into the same
+                // registers and arrive under this chunk's dequant + MFMAs.  D activation stages needed 152-251 VGPRs at 32 rows
+                // (<= 8 waves per block) and spilled at 64.
+                Cursor ca = cu;    // (the first chunk's activations are requested FIRST: they are waited for first)
+                load_stage_fast<BITS, GPC, MT, AM, GLUE, false, true>(st[0], p, tb, lo, ca, W);
+#pragma unroll
+                for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM, GLUE, true, false>(st[d], p, tb, lo, cu, W);
             } else {
 #pragma unroll
                 for (int d = 0; d < D; ++d) load_stage_fast<BITS, GPC, MT, AM, GLUE>(st[d], p, tb, lo, cu, W);
             }
+            if constexpr (kSplitRing<MT, AM, GLUE>()) {
+                Cursor ca;     // the activation cursor runs one chunk ahead of the chunk being multiplied
+                ca.w = nullptr;
+                ca.x = tb.x + (size_t)(cur + W) * 256;
+                ca.chunk = cur + W;
+                ca.end = c_end;
+                for (int it = D; it < n_mine; it += D) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE, 1>(st[0], p, cur, lane, aslot, dk, acc, xbuf, ginv);
+                        load_stage_fast<BITS, GPC, MT, AM, GLUE, false, true>(st[0], p, tb, lo, ca, W);
+                        compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE, 2>(st[d], p, cur, lane, aslot, dk, acc, xbuf, ginv);
+                        load_stage_fast<BITS, GPC, MT, AM, GLUE, true, false>(st[d], p, tb, lo, cu, W);
+                        cur += W;
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    // (only the last ring round can hold padding chunks: wave-uniform skip; the activation prefetch past the end is
+                    // clamped to the last real chunk like the weight loads)
+                    if (cur < c_end) {
+                        compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE, 1>(st[0], p, cur, lane, aslot, dk, acc, xbuf, ginv);
+                        if (d + 1 < D) load_stage_fast<BITS, GPC, MT, AM, GLUE, false, true>(st[0], p, tb, lo, ca, W);
+                        compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE, 2>(st[d], p, cur, lane, aslot, dk, acc, xbuf, ginv);
+                    }
+                    cur += W;
+                }
+            } else {
             for (int it = D; it < n_mine; it += D) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
@@ -806,6 +883,7 @@ __global__ __launch_bounds__(LB) void skinny_kernel(SkinnyParams p) {
                 if (cur < c_end) compute_stage<BITS, ACT, SCL, MT, GPC, AM, GLUE>(st[d], p, cur, lane, aslot, dk, acc, xbuf, ginv);
                 cur += W;
             }
+            }
         }
     } else {
         // generic: any chunk count per wave (ragged K, forced geometry); conservative waits
@@ -814,6 +892,14 @@ __global__ __launch_bounds__(LB) void skinny_kernel(SkinnyParams p) {
                 reinterpret_cast<u4_t*>(xbuf)[idx] = reinterpret_cast<const u4_t*>(p.x)[idx];
             __syncthreads();
         }
+        if constexpr (kSplitRing<MT, AM, GLUE>()) {
+            // 17..64 rows off the regular pipeline (ragged K, forced geometry -- rare): one stage at a time, no prefetch ring, so
+            // that this fallback does not dictate the instantiation's register budget (D activation stages = 64-128 VGPRs)
+            for (int cur = c_begin + wave; cur < c_end; cur += W) {
+                load_stage<BITS, GPC, MT, AM>(st[0], p, tb, cur, lane);
+                compute_stage<BITS, ACT, SCL, MT, GPC, AM>(st[0], p, cur, lane, aslot, dk, acc, xbuf);
+            }
+        } else {
         {
             int nxt = c_begin + wave;
 #pragma unroll
@@ -833,6 +919,7 @@ __global__ __launch_bounds__(LB) void skinny_kernel(SkinnyParams p) {
                 }
             }
         }
+        }
     }
 
 #if GPTQHIP_ABLATE & 8
@@ -848,6 +935,26 @@ __global__ __launch_bounds__(LB) void skinny_kernel(SkinnyParams p) {
     }
     __syncthreads();
 
+    if constexpr (MT == 4) {
+        // 33..64 rows: 16 accumulator registers per lane, at most 8 waves -> reducer wave w owns registers w, w + W, ...; no decode
+        // op glue and no cross-block split-K here (the planner keeps splits == 1), just the reference's rounding chain
+        const int n4 = tile * kTileN + c;
+        for (int r = wave; r < 4 * MT; r += W) {
+            float v4 = 0.f;
+            for (int w = 0; w < W; ++w) v4 += red[w][r][lane];
+            const int m4 = 16 * (r >> 2) + 4 * rq + (r & 3);
+            if (m4 < p.M && n4 < p.N) {
+                if (p.out_f32) {
+                    reinterpret_cast<float*>(p.out)[(size_t)m4 * p.N + n4] = v4;
+                } else {
+                    float y = round_through<ACT>(v4);
+                    if (p.bias != nullptr) y = y + load16_as_f32<ACT>(p.bias, (size_t)n4);
+                    reinterpret_cast<uint16_t*>(p.out)[(size_t)m4 * p.N + n4] = f32_to_16<ACT>(y);
+                }
+            }
+        }
+        return;
+    }
     // wave w < 4*MT owns accumulator register (mt = w>>2, i = w&3): row m = 16*mt + 4*rq + i, column n
     const bool reducer = wave < 4 * MT;
     const int m = 16 * (wave >> 2) + 4 * rq + (wave & 3);
@@ -866,7 +973,7 @@ __global__ __launch_bounds__(LB) void skinny_kernel(SkinnyParams p) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int BITS, int ACT, int SCL, int MT, int AM, int D, int LB = (MT == 2 ? 512 : 1024)>
+template <int BITS, int ACT, int SCL, int MT, int AM, int D, int LB = skinny_launch_bound<BITS, MT>()>
 static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
     if (64 * pl.waves > LB) {
         set_error("skinny_kernel: %d waves per block exceed the instantiation's %d-thread bound", pl.waves, LB);
@@ -910,20 +1017,23 @@ static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStre
     if (pl.mt == 1 && p.M <= 4) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW4, 4>(p, pl, stream);
     if (pl.mt == 1 && p.M <= 8) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROWSH, 2>(p, pl, stream);
     if (pl.mt == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROWS, 2>(p, pl, stream);
-#ifdef GPTQHIP_MT2_AB   // dev A/B build only (tests/dev): the round-2 plan, 16 waves per block under a 1024-thread bound (spills)
-    if (pl.mt == 2 && pl.waves > 8 && p.M <= 24) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWSH, 2, 1024>(p, pl, stream);
-    if (pl.mt == 2 && pl.waves > 8) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWS, 2, 1024>(p, pl, stream);
-#endif
     if (pl.mt == 2 && p.M <= 24) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWSH, 2>(p, pl, stream);
-    return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWS, 2>(p, pl, stream);  // (callers chunk M to <= 32 rows)
+    if (pl.mt == 2) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWS, 2>(p, pl, stream);
+    if constexpr (BITS == 4) {   // 33..64 rows in one launch (4-bit only: the 8-bit register stage does not fit beside 64 activation registers)
+        if (p.M <= 56) return launch_skinny_gpc<BITS, ACT, SCL, 4, AM_ROWSH, 2>(p, pl, stream);
+        return launch_skinny_gpc<BITS, ACT, SCL, 4, AM_ROWS, 2>(p, pl, stream);   // (callers chunk M to <= 64 rows)
+    } else {
+        set_error("skinny_kernel: more than 32 rows per launch need 4-bit weights");
+        return -22;
+    }
 }
 
-SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm) {
+SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm, int bits) {
     static const bool allow_depth2 = [] { const char* v = getenv("GPTQHIP_NO_DEPTH2"); return !(v && *v && *v != '0'); }();
     static const bool allow_pad = [] { const char* v = getenv("GPTQHIP_NO_PAD"); return !(v && *v && *v != '0'); }();   // A/B switch
     SkinnyPlan pl;
     const int mtiles = ceil_div(M, 16);
-    pl.mt = mtiles <= 1 ? 1 : 2;  // gptqhip_gemm feeds at most 32 rows per launch
+    pl.mt = mtiles <= 1 ? 1 : (mtiles <= 2 ? 2 : 4);  // gptqhip_gemm feeds at most 32 rows per launch (64 for 4-bit narrow layers)
     pl.gpc = (group_size % kChunkK == 0) ? 1 : 4;
     pl.chunks = ceil_div(K, kChunkK);
     const int tiles = ceil_div(N, kTileN);
@@ -997,23 +1107,20 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
         }
         if (best > 0 && (best >= waves || pl.chunks / (waves * pl.depth) * (waves * pl.depth) != pl.chunks)) waves = best;
     }
-    if (pl.mt == 2) {
-        // 17..32 rows: 32 activation registers per ring stage.  Round 2 ran 16 waves per block (1024-thread bound = 128 VGPRs:
-        // every instantiation spilled 24-60 registers); the instantiations are now bounded to 512 threads (256-VGPR budget, no
-        // scratch) and the plan is the largest wave count <= 8 that gives whole ring rounds.
-        static const bool ab16 = [] { const char* v = getenv("GPTQHIP_MT2_WAVES16"); return v && *v && *v != '0'; }();
-        if (ab16) {
-            waves = 16;   // (only meaningful in a -DGPTQHIP_MT2_AB dev build)
-        } else {
-            waves = 8;
-            for (int w = 8; w >= 4; --w) {
-                if (pl.chunks % (w * pl.depth) == 0) { waves = w; break; }
-            }
+    if (pl.mt >= 2) {
+        // 17..64 rows (split-ring pipeline: the activation stage is one deep).  Round 2 ran 16 waves per block with two activation
+        // stages in registers (1024-thread bound = 128 VGPRs: every instantiation spilled 24-60 registers); the waves per block are
+        // now bounded by the instantiation's launch bound and the plan is the largest count that gives whole ring rounds
+        const int cap = skinny_max_waves(bits, pl.mt);
+        waves = cap < 8 ? cap : 8;
+        for (int w = cap; w >= 4; --w) {
+            if (pl.chunks % (w * pl.depth) == 0) { waves = w; break; }
         }
     }
-    if (waves < 4 * pl.mt) waves = 4 * pl.mt;
-    if (force_waves > 0) waves = force_waves < 4 * pl.mt ? 4 * pl.mt : force_waves;
-    if (pl.mt == 2 && waves > 8 && !getenv("GPTQHIP_MT2_WAVES16")) waves = 8;
+    const int min_waves = pl.mt == 4 ? 4 : 4 * pl.mt;   // (MT == 4: reducer waves loop over the accumulator registers)
+    if (waves < min_waves) waves = min_waves;
+    if (force_waves > 0) waves = force_waves < min_waves ? min_waves : force_waves;
+    if (pl.mt >= 2 && waves > skinny_max_waves(bits, pl.mt)) waves = skinny_max_waves(bits, pl.mt);
     pl.waves = waves;
     // cross-block split-K costs a publish + ticket + re-read round trip (~1.5-2 us measured): only worth it
     // when the tiles alone leave most of the chip idle AND there is a long K range to share
@@ -1024,6 +1131,7 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     if (max_s < 1) max_s = 1;
     if (s > max_s) s = max_s;
     if (force_split > 0) s = force_split < pl.chunks ? force_split : pl.chunks;
+    if (pl.mt == 4) s = 1;   // no cross-block split-K for the 33..64-row instantiations (their epilogue is the plain one)
     pl.chunks_per_split = ceil_div(pl.chunks, s);
     pl.splits = ceil_div(pl.chunks, pl.chunks_per_split);
     pl.slab_floats = pl.splits > 1 ? (size_t)pl.splits * M * N : 0;

@@ -137,6 +137,12 @@ SHAPES = [
     (14336, 512, 128, 32),
     (2048, 2048, 64, 24),
     (11008, 256, 128, 17),
+    (4096, 1024, 128, 48),   # 33..64 rows in ONE decode-kernel launch (4-bit, narrow layers): four row tiles, split-ring pipeline
+    (4096, 1024, 128, 64),
+    (14336, 512, 128, 57),
+    (2048, 2048, 64, 40),
+    (1056, 256, 32, 50),     # ... off the regular pipeline (K % 128 != 0): the no-ring fallback of those instantiations
+    (4096, 4096, 128, 33),
     (64, 32, 32, 4),         # the reference's own unit-test shape (K < one 128-row chunk, N = 2 tiles)
     (96, 8, 32, 1),          # ragged everywhere: K % 128 != 0, N < one tile
 ]

@@ -358,3 +358,30 @@ def test_tp2_chain_two_layers_vs_oracle_composition(desc_act):
     ret = ctx.Manager().dict()
     mp.spawn(_tp_oracle_worker, args=(world, port, ret, desc_act), nprocs=world, join=True)
     assert all(v[0] for v in dict(ret).values()) and len(ret) == world, dict(ret)
+
+
+@pytest.mark.parametrize("act", ["fp16", "bf16"])
+@pytest.mark.parametrize("M", [33, 47, 56, 57, 64])
+def test_rows_33_to_64_one_launch_bias_and_partial_f32(ops, act, M):
+    """33..64 rows with 4-bit weights on a narrow layer: ONE decode-kernel launch (four row tiles; the weights are streamed once).
+    Rounded output with bias against the oracle, and the unrounded fp32 partial sums (tensor-parallel row shards) against the
+    prefill kernel's."""
+    K, N, gs = 4096, 768, 128
+    qweight, qzeros, scales, g_idx = synth_gptq(400 + M, 4, K, N, gs)
+    rng = np.random.RandomState(M)
+    x = O.round_to(rng.randn(M, K).astype(np.float32) * 0.5, act)
+    bias = O.round_to(rng.randn(N).astype(np.float32) * 0.1, act)
+    sc = f32_to_torch(scales, "fp16", DEV)
+    qw_t, meta = ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV), sc, None, gs, 4)
+    xt = f32_to_torch(x, act, DEV)
+    try:
+        ops.set_tuning(0, 1, 0)        # the decode kernel family
+        out = ops.gemm(xt, qw_t, meta, f32_to_torch(bias, act, DEV), None, N, gs, 4, sc.dtype)
+        part = ops.gemm(xt, qw_t, meta, None, None, N, gs, 4, sc.dtype, partial_f32=True)
+        ops.set_tuning(0, 2, 0)        # the prefill kernel family
+        part_t = ops.gemm(xt, qw_t, meta, None, None, N, gs, 4, sc.dtype, partial_f32=True)
+    finally:
+        ops.set_tuning(0, 0, 0)
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, bias, act, "fp16")
+    assert_forward_close(torch_to_f32(out), ref, act, tag=M)
+    assert part.dtype == torch.float32 and rel_err(part.cpu().numpy(), part_t.cpu().numpy()) <= 1e-5
