@@ -155,6 +155,55 @@ def shard_awq_row(t, rank, world, group_size):
             "scales": t["scales"][g0:g1].contiguous(), "bias": None}
 
 
+# messages above this many bytes of fp32 partial sums take the two-step exchange below (prefill); smaller ones are latency-bound
+TWO_STEP_MIN_BYTES = 1 << 20
+
+
+def reduce_round_gather(partial: torch.Tensor, out_dtype: torch.dtype, bias: Optional[torch.Tensor] = None,
+                        group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """sum over ranks of the fp32 partials -> ONE rounding to out_dtype (+ bias) -> the full result on every rank, for the
+    bandwidth-bound prefill messages (M x hidden fp32: 1 GiB at M = 32768, hidden 8192) -- SURVEY.md 5 / 8e: a single ring is capped
+    by one xGMI link, so the exchange is spread over ALL links:
+
+        1. all-to-all: the partial is cut into `world` row slabs; rank r receives slab r of every rank -- on the fully connected xGMI
+           fabric every pair of GPUs has its own link, so the (world - 1) / world of the message that has to move travels over all
+           7 links of a GPU at once (a reduce-scatter without a ring);
+        2. rank r adds its `world` slabs in RANK ORDER (bit-identical whoever computes it), rounds ONCE like the reference (torch.py:
+           337-342), adds the bias;
+        3. all-gather of the 16-bit slabs: the second half of the exchange moves 2 bytes per element, not 4 -- a fp32 all-reduce moves
+           8 bytes per element over the links, this 6.
+
+    Same rounding chain as RowParallelQuantLinear's all-reduce path (sum in fp32, round once); the fp32 association differs (rank
+    order here, RCCL's choice there).  Works on any backend with all_to_all_single / all_gather_into_tensor (RCCL; gloo in the CPU
+    tests)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    shape = partial.shape
+    n = shape[-1]
+    p2 = partial.reshape(-1, n)
+    m = p2.shape[0]
+    if world == 1:
+        out = p2.to(out_dtype)
+        if bias is not None:
+            out = out + bias.to(device=out.device, dtype=out_dtype)
+        return out.reshape(shape)
+    rows = -(-m // world)                      # rows per slab (the last slabs are zero-padded)
+    if rows * world != m:
+        pad = torch.zeros((rows * world - m, n), dtype=p2.dtype, device=p2.device)
+        p2 = torch.cat([p2, pad], dim=0)
+    recv = torch.empty_like(p2)                # [world, rows, n]: slab `rank` of every rank, in rank order
+    dist.all_to_all_single(recv, p2.contiguous(), group=group)
+    slabs = recv.view(world, rows, n)
+    acc = slabs[0].clone()
+    for r in range(1, world):
+        acc += slabs[r]                        # rank order: every rank would compute the same bits for this slab
+    mine = acc.to(out_dtype)
+    if bias is not None:
+        mine = mine + bias.to(device=mine.device, dtype=out_dtype)
+    full = torch.empty((world * rows, n), dtype=out_dtype, device=mine.device)
+    dist.all_gather_into_tensor(full, mine.contiguous(), group=group)
+    return full[:m].reshape(shape)
+
+
 class ColumnParallelQuantLinear(nn.Module):
     """y_local = local(x): rank r owns output columns [r*N/w, (r+1)*N/w).  No communication unless gather_output."""
 
@@ -176,13 +225,17 @@ class ColumnParallelQuantLinear(nn.Module):
 
 class RowParallelQuantLinear(nn.Module):
     """x arrives sharded along K (the output of a column-parallel layer).  Each rank computes fp32 partial sums over
-    its K-slice, ONE all-reduce(sum) over xGMI combines them, then the reference's rounding chain runs once:
-    y = round(sum) ; y = round(y + bias)   (torch.py:337-342)."""
+    its K-slice, ONE exchange over xGMI combines them, then the reference's rounding chain runs once:
+    y = round(sum) ; y = round(y + bias)   (torch.py:337-342).  Three message regimes: decode vectors (<= comm.n_max elements) through
+    the one-shot peer-to-peer kernel when a communicator is given; mid-size messages through dist.all_reduce; prefill messages
+    (>= 1 MiB of partials) through reduce_round_gather (all-to-all + rank-ordered sum + 16-bit all-gather: every link busy, 6 instead
+    of 8 bytes per element on the wire)."""
 
     def __init__(self, local: nn.Module, bias: Optional[torch.Tensor] = None, group: Optional[dist.ProcessGroup] = None,
-                 input_index: Optional[torch.Tensor] = None, comm=None):
+                 input_index: Optional[torch.Tensor] = None, comm=None, two_step: bool = True):
         super().__init__()
         self.local = local
+        self.two_step = two_step    # large (prefill) messages: reduce_round_gather instead of a fp32 all-reduce
         self.group = group
         self.bias = bias
         # utils.xgmi_allreduce.OneShotAllReduce: small (decode) messages go through ONE peer-to-peer kernel that also applies
@@ -212,6 +265,10 @@ class RowParallelQuantLinear(nn.Module):
             if bias is not None and partial.dim() > 1 and partial.numel() != bias.numel():
                 bias = bias.expand(partial.shape).contiguous()
             return self.comm(partial.contiguous(), out_dtype=odt, bias=bias)
+        if (self.two_step and dist.is_initialized() and dist.get_world_size(self.group) > 1
+                and partial.numel() * 4 >= TWO_STEP_MIN_BYTES):
+            # bandwidth-bound (prefill) message: all-to-all + rank-ordered sum + one rounding + 16-bit all-gather over all links
+            return reduce_round_gather(partial, odt, self.bias, self.group)
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=self.group)
         out = partial.to(x_shard.dtype if x_shard.dtype in (torch.float16, torch.bfloat16) else torch.float16)

@@ -82,6 +82,18 @@ def _worker(rank, world, port, ret):
         y_a_full = OracleLocal(down_a, bits, gs)(h_full)
         err_a = (y_a.float() - y_a_full.float()).abs().max().item() / y_a_full.float().abs().max().item()
         assert err_a <= 1e-3, err_a
+        # prefill-sized message: the two-step exchange (all-to-all, rank-ordered sum, one rounding + bias, 16-bit all-gather) against the
+        # fp32 all-reduce path -- same partials, same single rounding; M = 1031 rows (not a multiple of the world size: padded slab)
+        xb = torch.from_numpy(O.round_to(np.random.RandomState(17).randn(1031, I // world).astype(np.float32) * 0.5, "fp16")).half()
+        loc = OracleLocal(tp.shard_gptq_row(down, rank, world, bits, gs), bits, gs)
+        assert 1031 * H * 4 >= tp.TWO_STEP_MIN_BYTES
+        y2 = tp.RowParallelQuantLinear(loc, bias=down["bias"])(xb)
+        y1 = tp.RowParallelQuantLinear(loc, bias=down["bias"], two_step=False)(xb)
+        assert y2.shape == y1.shape == (1031, H) and y2.dtype == torch.float16
+        assert torch.equal(y2, y1), "two ranks: a + b in rank order == the all-reduce's sum, so the paths must agree bit for bit"
+        both = [torch.empty_like(y2) for _ in range(world)]
+        dist.all_gather(both, y2)
+        assert torch.equal(both[0], both[1])
         ret[rank] = err
     finally:
         dist.destroy_process_group()
