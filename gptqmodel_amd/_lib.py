@@ -17,7 +17,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libgptqhip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # every symbol include/gptqhip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -40,6 +40,7 @@ SIGNATURES = {
     "gptqhip_comm_close": (_i, [_vp]),
     "gptqhip_comm_free": (_i, [_vp]),
     "gptqhip_comm_status": (_i, [_vp, _c.POINTER(_c.c_uint32)]),
+    "gptqhip_comm_set_timeout": (_i, [_vp, _c.c_uint]),
     "gptqhip_allreduce_oneshot": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "gptqhip_allgather_select": (_i, [_vp, _c.POINTER(_vp), _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "gptqhip_dequant": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -256,7 +256,15 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     // tiled; 4096x6144 18.1 vs 18.4), up to 32 rows on long-K layers (14336x4096: 18.4 vs 18.1 us at M=32, 24.6 vs 19.2 at M=40), and
     // up to 16 rows on wide layers (N >= 8192, e.g. fused gate_up: 28.4 vs 25.6 us at M=24) where every 16-column block of the decode
     // kernel re-stages the whole activation tile.  Everything above goes to the MFMA-tiled kernel (64-row tiles, split-K).
-    const bool wide = N >= 8192 && M > 16;
+    // wide layers (N >= 8192): up to 16 rows the decode kernel (its wide-layer form where plannable: several column tiles per block
+    // share one staging of the activation tile -- 4096x28672 at M=16 23.7 -> 16.7 us, 8192x57344 80.5 -> 53.2, lm_head 87.4 -> 55.6);
+    // 17..32 rows too when K < 8192 and N < 65536 (4096x28672 at M=32 32.4 -> 24.4 us vs 27.3 us tiled, 4096x8192 11.9 -> 8.7 vs 13.0;
+    // but 8192x10240 22.6 vs 20.8 tiled, 4096x128256 91.9 vs 80.7); above that the tiled kernel (4096x28672 at M=48: 28.7 vs 39.0 us).
+    // profiles/r03_wide_layers.txt
+    bool wide = N >= 8192 && M > 16;
+    if (wide && M <= 32 && K < 8192 && N < 65536 && g_force_kernel == 0 &&
+        plan_skinny(M, K, N, group_size, g_force_split, g_force_waves, false, bits, true).nt > 1)
+        wide = false;
     const int skinny_max = (bits == 4 && K < 8192 && N < 8192) ? kSkinnyMaxRows4 : kSkinnyMaxM;
     const bool use_tiled = (g_force_kernel == 2) || (g_force_kernel == 0 && (M > skinny_max || wide));
     // rows per decode-kernel launch: 32, or 64 with 4-bit weights (one launch, the weights are streamed once)
@@ -299,7 +307,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         a.x = reinterpret_cast<const char*>(xin) + (size_t)m0 * K * 2;
         a.out = reinterpret_cast<char*>(out) + (size_t)m0 * N * (partial_f32 ? 4 : 2);
         a.M = mc;
-        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves, fused_perm, bits);
+        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves, fused_perm, bits, true);
         rc = launch_skinny(a, pl, slabs, counters, stream);
         if (rc) return rc;
     }

@@ -308,6 +308,17 @@ int gptqhip_comm_status(void* own_buf, uint32_t* status_out) {
                      "gptqhip_comm_status");
 }
 
+int gptqhip_comm_set_timeout(void* own_buf, unsigned int timeout_ms) {
+    if (!own_buf || timeout_ms == 0) {
+        set_error("gptqhip_comm_set_timeout: bad arguments");
+        return GPTQHIP_EINVAL;
+    }
+    const unsigned long long ticks = (unsigned long long)timeout_ms * 100000ull;     // 100 MHz wall clock
+    const uint32_t t[2] = {(uint32_t)ticks, (uint32_t)(ticks >> 32)};
+    return check_hip(hipMemcpy(&reinterpret_cast<CommHeader*>(own_buf)->timeout_lo, t, sizeof(t), hipMemcpyHostToDevice),
+                     "gptqhip_comm_set_timeout");
+}
+
 int gptqhip_allreduce_oneshot(const float* partial, void* const* peer_bufs, int rank, int world, int n, int n_max, const void* bias,
                               const void* residual, void* out, float* stats_out, int act_dtype, gptqhip_stream_t stream) {
     if (!partial || !peer_bufs || !out || world < 1 || world > kCommMaxWorld || rank < 0 || rank >= world || n <= 0 || n % 4 != 0 ||

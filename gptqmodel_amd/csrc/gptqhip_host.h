@@ -41,6 +41,7 @@ struct SkinnyPlan {
     int chunks_per_split;  // chunks handled by one block
     int splits;            // grid.y (cross-block split-K)
     size_t slab_floats;    // fp32 partial slabs, 0 when splits == 1
+    int nt = 1;            // column tiles per block: 4 (2 for 33..64 rows) = the wide-layer kernel (skinny_wide_kernel), else 1
 };
 
 struct TiledPlan {
@@ -56,7 +57,8 @@ void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
 // in_kernel_perm: the plan is for the batch-1 act-order variant (AM_ROW1P), which only exists with the 4-deep ring
-SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm = false, int bits = 4);
+SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm = false, int bits = 4,
+                       bool allow_wide = false);
 int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* counters, hipStream_t stream);
 
 TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_variant, int force_split);

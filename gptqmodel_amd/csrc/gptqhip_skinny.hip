@@ -970,6 +970,187 @@ __global__ __launch_bounds__(LB) void skinny_kernel(SkinnyParams p) {
 
 
 
+
+// ------------------------------------------------------------------------------------------------
+// Wide layers (N >= 8192 columns: fused gate_up, lm_head, the 70B projections) at 5..32 rows.  skinny_kernel gives every 16-column tile its own
+// block, so each of the N/16 blocks stages the WHOLE activation tile (M x K) from L2 through LDS: 1792 x 256 KiB = 460 MB of
+// on-chip traffic for 61 MB of weights on a Llama-3-8B gate_up at M = 32 (profiles/r03_mid_m_sweep.txt: 32 us where the weights
+// stream in 14.6 us at M = 1).  Here a block owns NT = 4 (2) adjacent column tiles: per 128-row chunk a wave parks its activation
+// rows in LDS ONCE, reads each K-step's A fragments ONCE and multiplies them with the four tiles' dequantised words (4 KiB of
+// weights per ring stage and wave instead of 1).  Same ingredients as the split-ring pipeline above -- weight ring two deep,
+// activation stage one deep through buffer loads, clamped (never conditional) loads so the waits stay counted, in-block split-K
+// with an LDS reduction, fixed summation order -- specialised to what this regime needs: 4-bit weights, no glue, no cross-block
+// split (N/64 >= 256 blocks fill the chip), the regular pipeline only.  Replaces nothing upstream beyond what skinny_kernel does
+// (TorchLinear._forward_eager, torch.py:326-347).
+// ------------------------------------------------------------------------------------------------
+template <int GPC, int NT>
+struct WideStage {
+    u4_t w[NT];
+    uint32_t meta[NT * GPC];
+};
+
+template <int ACT, int SCL, int MT, int GPC, bool HALFQ, int NT>
+__global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int QUADS = HALFQ ? 4 * MT - 2 : 4 * MT;          // 4-row groups loaded per chunk (rows beyond them: never stored)
+    constexpr int NR = MT * NT * 4;                               // accumulator registers per lane
+    constexpr int kSlotA = 16 * MT * kRowsPitch * 16;
+    constexpr int kSlot = kSlotA > NR * 256 ? kSlotA : NR * 256;  // bytes per wave: activation slot, later its reduction rows
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = blockDim.x >> 6;
+    const int c = lane & 15, rq = lane >> 4;
+    const int tile0 = blockIdx.x * NT;
+    const int c_end = p.chunks;
+    const DequantConsts dk = make_dequant_consts<4>();
+
+    f4_t acc[MT * NT];
+#pragma unroll
+    for (int i = 0; i < MT * NT; ++i) acc[i] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    const char* wbase = reinterpret_cast<const char*>(p.qw) + (size_t)tile0 * p.chunks * 1024;
+    const char* mbase = reinterpret_cast<const char*>(p.meta) + (size_t)tile0 * p.G * 64;
+    const size_t wstride = (size_t)p.chunks * 1024, mstride = (size_t)p.G * 64;      // next column tile
+    const uint32_t lane16 = (uint32_t)lane * 16u, c4 = (uint32_t)c * 4u;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.M * p.K * 2, 0x00020000);
+    const uint32_t voff = (uint32_t)rq * (uint32_t)p.K * 2u + (uint32_t)c * 16u;
+    const uint32_t quad_stride = (uint32_t)p.K * 8u;
+    u4_t* aslot = reinterpret_cast<u4_t*>(reinterpret_cast<char*>(lds) + wave * kSlot);
+
+    WideStage<GPC, NT> st[2];
+    u4_t xa[QUADS];
+    auto load_w = [&](WideStage<GPC, NT>& s, int chunk) __attribute__((always_inline)) {
+        const int ck = chunk < c_end ? chunk : c_end - 1;       // padding chunks of the last ring round re-fetch the last real one
+        const char* src = wbase + (size_t)ck * 1024;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) s.w[t] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(src + t * wstride + lane16));
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < GPC; ++j) {
+                const int g = GPC == 1 ? (ck >> p.cpg_shift) : ((ck * 4 + j) >> p.cpg_shift);
+                s.meta[t * GPC + j] = *reinterpret_cast<const uint32_t*>(mbase + t * mstride + ((size_t)g << 6) + c4);
+            }
+    };
+    auto load_a = [&](int chunk) __attribute__((always_inline)) {
+        const int ck = chunk < c_end ? chunk : c_end - 1;
+#pragma unroll
+        for (int i = 0; i < QUADS; ++i) xa[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, (uint32_t)ck * 256u + (uint32_t)i * quad_stride, 0);
+    };
+    auto park = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < QUADS; ++i) aslot[(4 * i + rq) * kRowsPitch + c] = xa[i];
+    };
+    auto multiply = [&](const WideStage<GPC, NT>& s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (MT >= 4) {
+                // 64 rows: the fragments are re-read per column tile (two LDS reads instead of one) rather than held in 16 registers
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const ColConst cc = expand_meta<4, SCL>(s.meta[t * GPC + (GPC == 4 ? j : 0)]);
+                    const u4_t b = dequant_word4<ACT, SCL>(s.w[t][j], cc, dk);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt * NT + t] = mfma16<ACT>(aslot[(16 * mt + c) * kRowsPitch + 4 * j + rq], b, acc[mt * NT + t]);
+                }
+            } else {
+                u4_t av[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[mt] = aslot[(16 * mt + c) * kRowsPitch + 4 * j + rq];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const ColConst cc = expand_meta<4, SCL>(s.meta[t * GPC + (GPC == 4 ? j : 0)]);
+                    const u4_t b = dequant_word4<ACT, SCL>(s.w[t][j], cc, dk);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt * NT + t] = mfma16<ACT>(av[mt], b, acc[mt * NT + t]);
+                }
+            }
+        }
+    };
+
+    int cur = wave;
+    load_a(cur);                       // (waited for first)
+    load_w(st[0], cur);
+    load_w(st[1], cur + W);
+    for (int it = 2; it < p.n_mine; it += 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            park();
+            load_a(cur + W);
+            multiply(st[d]);
+            load_w(st[d], cur + 2 * W);
+            cur += W;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        if (cur < c_end) {             // (only the last ring round can hold padding chunks: wave-uniform skip)
+            park();
+            if (d == 0) load_a(cur + W);
+            multiply(st[d]);
+        }
+        cur += W;
+    }
+
+    // ---- in-block split-K reduction through LDS, then the reference's rounding chain (fixed summation order) ----
+    __syncthreads();                   // the activation slots alias the reduction rows
+    float(*red)[NR][64] = reinterpret_cast<float(*)[NR][64]>(lds);
+#pragma unroll
+    for (int r = 0; r < MT * NT; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][r * 4 + i][lane] = acc[r][i];
+    __syncthreads();
+    for (int r = wave; r < NR; r += W) {
+        float v = 0.f;
+        for (int w = 0; w < W; ++w) v += red[w][r][lane];
+        const int a = r >> 2, i = r & 3, mt = a / NT, t = a - mt * NT;
+        const int m = 16 * mt + 4 * rq + i, n = (tile0 + t) * kTileN + c;
+        if (m < p.M && n < p.N) {
+            if (p.out_f32) {
+                reinterpret_cast<float*>(p.out)[(size_t)m * p.N + n] = v;
+            } else {
+                float y = round_through<ACT>(v);
+                if (p.bias != nullptr) y = y + load16_as_f32<ACT>(p.bias, (size_t)n);
+                reinterpret_cast<uint16_t*>(p.out)[(size_t)m * p.N + n] = f32_to_16<ACT>(y);
+            }
+        }
+    }
+}
+
+// Column tiles per block: 4 where N / 64 >= 256 blocks still fill the chip (N >= 16384), else 2 (N >= 8192).  5..32 rows only: at
+// 33..64 rows (measured with two tiles per block, profiles/r03_wide_layers.txt) the MFMA-tiled kernel is faster (28.7 vs 39.0 us on
+// 4096x28672 at M = 48) and four tiles would not fit 256 VGPRs beside 64 accumulator + 64 activation registers.
+constexpr int kWideMaxWaves = 8;    // (512-thread bound for every instantiation)
+constexpr int kWideMaxM = 32;
+
+template <int ACT, int SCL, int MT, bool HALFQ, int kWideNT>
+static int launch_wide_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
+    const dim3 grid(ceil_div(p.N, kTileN) / kWideNT), block(64 * pl.waves);
+    constexpr int NR = MT * kWideNT * 4;
+    constexpr int kSlotA = 16 * MT * kRowsPitch * 16;
+    constexpr int kSlot = kSlotA > NR * 256 ? kSlotA : NR * 256;
+    const size_t lds_bytes = (size_t)pl.waves * kSlot;
+    if (pl.gpc == 1) {
+        hipLaunchKernelGGL((skinny_wide_kernel<ACT, SCL, MT, 1, HALFQ, kWideNT>), grid, block, lds_bytes, stream, p);
+    } else {
+        hipLaunchKernelGGL((skinny_wide_kernel<ACT, SCL, MT, 4, HALFQ, kWideNT>), grid, block, lds_bytes, stream, p);
+    }
+    return check_hip(hipGetLastError(), "skinny_wide_kernel launch");
+}
+
+template <int ACT, int SCL, int NT>
+static int launch_wide_nt(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
+    if (pl.mt == 1) return p.M <= 8 ? launch_wide_gpc<ACT, SCL, 1, true, NT>(p, pl, stream) : launch_wide_gpc<ACT, SCL, 1, false, NT>(p, pl, stream);
+    if (pl.mt == 2) return p.M <= 24 ? launch_wide_gpc<ACT, SCL, 2, true, NT>(p, pl, stream) : launch_wide_gpc<ACT, SCL, 2, false, NT>(p, pl, stream);
+    set_error("skinny_wide_kernel: at most %d rows", kWideMaxM);
+    return -22;
+}
+template <int ACT, int SCL>
+static int launch_wide(const SkinnyParams& p, const SkinnyPlan& pl, hipStream_t stream) {
+    return pl.nt == 4 ? launch_wide_nt<ACT, SCL, 4>(p, pl, stream) : launch_wide_nt<ACT, SCL, 2>(p, pl, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1028,7 +1209,7 @@ static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStre
     }
 }
 
-SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm, int bits) {
+SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm, int bits, bool allow_wide) {
     static const bool allow_depth2 = [] { const char* v = getenv("GPTQHIP_NO_DEPTH2"); return !(v && *v && *v != '0'); }();
     static const bool allow_pad = [] { const char* v = getenv("GPTQHIP_NO_PAD"); return !(v && *v && *v != '0'); }();   // A/B switch
     SkinnyPlan pl;
@@ -1142,6 +1323,31 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
                                       : (group_size == 32 || group_size == 64))
                      ? 1
                      : 0;
+    // wide layers at 5..64 rows (skinny_wide_kernel: four column tiles per block share one staging of the activation tile).  Needs
+    // the regular pipeline with a two-deep weight ring, 4-bit weights, whole groups of four tiles and enough of them to fill the chip
+    // without a cross-block split; the caller says whether its epilogue is the plain one (allow_wide: gptqhip_gemm yes, decode op no)
+    static const bool wide_off = [] { const char* v = getenv("GPTQHIP_NO_WIDE"); return v && *v && *v != '0'; }();   // A/B switch
+    const int kWideNT = (tiles % 4 == 0 && tiles / 4 >= 256) ? 4 : 2;
+    if (allow_wide && !wide_off && bits == 4 && M >= 5 && M <= kWideMaxM && !in_kernel_perm && tiles % kWideNT == 0 &&
+        tiles / kWideNT >= 256 && force_split <= 1 && K % kChunkK == 0 &&
+        (pl.gpc == 1 ? (group_size >= K || ((group_size / kChunkK) & (group_size / kChunkK - 1)) == 0) : (group_size == 32 || group_size == 64))) {
+        const int cap = force_waves > 0 && force_waves < kWideMaxWaves ? force_waves : kWideMaxWaves;
+        int best = 0;
+        for (int w = cap; w >= 4 && best == 0; --w) {
+            const int virt = ceil_div(pl.chunks, w * 2) * w * 2;
+            if ((virt - pl.chunks) * 8 <= pl.chunks) best = w;      // whole ring rounds, at most 1/8 padding chunks
+        }
+        if (best > 0) {
+            pl.nt = kWideNT;
+            pl.waves = best;
+            pl.depth = 2;
+            pl.splits = 1;
+            pl.chunks_per_split = pl.chunks;
+            pl.slab_floats = 0;
+            pl.rounds = ceil_div(pl.chunks, best * 2);
+            pl.regular = 1;
+        }
+    }
     return pl;
 }
 
@@ -1188,6 +1394,17 @@ int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* co
     p.stats_out = a.stats_out;
     p.out_glue = a.out_glue;
     p.stats_n = a.stats_n;
+    if (pl.nt > 1) {
+        if (a.bits != 4 || a.in_glue != kGlueNone || a.out_glue != kOutNone || a.residual != nullptr || a.stats_out != nullptr || a.perm != nullptr) {
+            set_error("skinny_wide_kernel: planned for a call it cannot serve (glue / permutation / 8-bit)");
+            return -22;
+        }
+        if (a.group_size % kChunkK != 0) p.cpg_shift = a.group_size == 64 ? 1 : 0;      // K-steps (32 rows) per group, log2
+        if (a.act_dtype == kFP16 && a.scale_dtype == kFP16) return launch_wide<kFP16, kFP16>(p, pl, stream);
+        if (a.act_dtype == kBF16 && a.scale_dtype == kFP16) return launch_wide<kBF16, kFP16>(p, pl, stream);
+        if (a.act_dtype == kFP16 && a.scale_dtype == kBF16) return launch_wide<kFP16, kBF16>(p, pl, stream);
+        return launch_wide<kBF16, kBF16>(p, pl, stream);
+    }
 #define GPTQHIP_DISPATCH(B, A_, S_) return launch_skinny_mt<B, A_, S_>(p, pl, stream)
     if (a.bits == 4) {
         if (a.act_dtype == kFP16 && a.scale_dtype == kFP16) GPTQHIP_DISPATCH(4, kFP16, kFP16);

@@ -26,7 +26,13 @@
 
 #include <utility>
 
+#ifndef GPTQHIP_TILED_D64   // pipeline stages of the 64-row-tile instantiations (dev A/B builds override it)
+#define GPTQHIP_TILED_D64 3
+#endif
+
 namespace gptqhip {
+
+constexpr int kTiledD64 = GPTQHIP_TILED_D64;
 
 struct TiledParams {
     const void* x;
@@ -159,23 +165,21 @@ __device__ __forceinline__ void lds_wait(u4_t (&frag)[N]) {
 }
 
 // s_waitcnt vmcnt(stages * OPS + (plus_stores ? S : 0)) for block-uniform run-time arguments, stages in [0, MAXS]
-// (the immediate must be a constant)
+// (the immediate must be a constant: one compare per possible stage count, unrolled at compile time)
 template <int OPS, int S, int MAXS>
 __device__ __forceinline__ void vm_wait(int stages, bool plus_stores) {
-    static_assert(MAXS <= 1, "at most 3 pipeline stages");
+    static_assert(MAXS >= 0 && MAXS <= 4, "at most 6 pipeline stages");
     static_assert(MAXS * OPS + S <= 63, "vmcnt is a 6-bit field");
+    if constexpr (MAXS >= 1) {
+        if (stages < MAXS) {
+            vm_wait<OPS, S, MAXS - 1>(stages, plus_stores);
+            return;
+        }
+    }
     if (plus_stores) {
-        if (MAXS >= 1 && stages >= 1) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXS * OPS + S) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
-        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXS * OPS + S) : "memory");
     } else {
-        if (MAXS >= 1 && stages >= 1) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXS * OPS) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXS * OPS) : "memory");
     }
 }
 
@@ -522,7 +526,12 @@ inline int launch_tiled_out(const TiledParams& p, int bm, hipStream_t stream) {
         }
     }
     if (bm == 64) {  // M <= 64: half the MFMA work and staging of a 128-row tile
-        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 64, 8, BITS == 4 ? 3 : 2, OUTF>), grid, dim3(512), 0, stream, p);
+        // 3 stages.  Round 3 tried 5 (four 16 KiB weight chunks in flight per CU instead of two, on the theory that a block with so
+        // little MFMA work per chunk is bound by its bytes in flight: 2.3 TB/s on gate_up at M = 32) -- measured 5-8 % SLOWER on every
+        // shape from M = 17 to 256 (profiles/r03_tiled_stages_64row.txt): the small-M floor of this kernel is not a latency-hiding
+        // problem.  The waits are generalised to any depth (vm_wait) and the depth is one macro, so the experiment is one -D away.
+        constexpr int D64 = BITS == 4 ? kTiledD64 : 2;
+        hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 64, 8, D64, OUTF>), grid, dim3(512), 0, stream, p);
         return check_hip(hipGetLastError(), "tiled_kernel launch");
     }
     if (bm != 128) {

@@ -16,6 +16,7 @@ returns False.  A peer that never arrives poisons the output with NaN and sets t
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -40,6 +41,7 @@ class OneShotAllReduce:
         with torch.cuda.device(device):
             _lib.check(lib.gptqhip_comm_alloc(nbytes, ctypes.byref(own), handle), "gptqhip_comm_alloc")
         self._own = own.value
+        self._timeout_ms = int(os.environ.get("GPTQHIP_COMM_TIMEOUT_MS", "0") or 0) or 10000
         handles = [None] * self.world
         if self.world > 1:
             dist.all_gather_object(handles, handle.raw, group=group)
@@ -128,9 +130,20 @@ class OneShotAllReduce:
         n = int(n or self.n_max)
         n -= n % 16
         ok = True
+
+        def healthy() -> bool:
+            torch.cuda.synchronize(dev)
+            st = ctypes.c_uint32(0)
+            _lib.check(_lib.load().gptqhip_comm_status(self._own, ctypes.byref(st)), "gptqhip_comm_status")
+            return st.value == 0
+
         try:
+            # short peer-wait bound while testing: a link that does not deliver must cost seconds, not calls x 10 s
+            self.set_timeout_ms(1500)
             with torch.cuda.device(dev):
                 for it in range(calls):
+                    if not ok:
+                        break
                     g = torch.Generator(device=dev)
                     g.manual_seed(7919 * it + self.rank)
                     part = torch.randn(n, device=dev, generator=g) * 3.0
@@ -143,8 +156,9 @@ class OneShotAllReduce:
                         want = want + p
                     want = (res.float() + want.to(torch.float16).float()).to(torch.float16)
                     got = self(part, out_dtype=torch.float16, residual=res)
-                    torch.cuda.synchronize(dev)
-                    ok = ok and bool(torch.equal(got, want))
+                    ok = ok and healthy() and bool(torch.equal(got, want))
+                    if not ok:
+                        break
                     xl = torch.randn(512, device=dev, generator=g).to(torch.float16)
                     idx = torch.randperm(512 * self.world, device=dev, generator=gr)[:640].to(torch.int32)
                     full = torch.cat(self._gather(xl))
@@ -159,7 +173,10 @@ class OneShotAllReduce:
                 bad = torch.zeros((), dtype=torch.int64, device=dev)
                 part = torch.empty(n, device=dev)
                 out = torch.empty(n, device=dev, dtype=torch.float16)
-                for t in range(burst):
+                for t in range(burst if ok else 0):
+                    if t % 16 == 15 and not healthy():       # (a timed-out peer wait: stop launching, every further call would wait again)
+                        ok = False
+                        break
                     torch.add(base, float(t % 64), out=part)
                     self(part, out_dtype=torch.float16, out=out)
                     want = bases[0] + float(t % 64)
@@ -171,6 +188,10 @@ class OneShotAllReduce:
             self.check_status()
         except Exception:  # noqa: BLE001 -- a failing self test must not take the caller down: it answers False
             ok = False
+        try:
+            self.set_timeout_ms(self._timeout_ms)
+        except Exception:  # noqa: BLE001
+            ok = False
         if self.world > 1:
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
             if dist.get_backend(self.group) != "gloo":
@@ -178,6 +199,11 @@ class OneShotAllReduce:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
             ok = bool(int(flag.item()) == 1)
         return ok
+
+    def set_timeout_ms(self, ms: int) -> None:
+        """Bound of this rank's peer waits from now on (host write into the buffer header: call between launches)."""
+        torch.cuda.synchronize(self.device)
+        _lib.check(_lib.load().gptqhip_comm_set_timeout(self._own, int(ms)), "gptqhip_comm_set_timeout")
 
     def check_status(self) -> None:
         st = ctypes.c_uint32(0)

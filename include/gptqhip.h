@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 12
+#define GPTQHIP_ABI_VERSION 13
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -248,6 +248,8 @@ int gptqhip_rmsnorm_gather(const void* h, const void* weight, const int32_t* per
  *   gptqhip_comm_open(handle, &ptr) / gptqhip_comm_close(ptr)   map / unmap a PEER's buffer in this process
  *   gptqhip_comm_free(ptr)             free the buffer this rank allocated
  *   gptqhip_comm_status(own_buf, &st)  host read of the "a bounded wait gave up" word (0 = healthy)
+ *   gptqhip_comm_set_timeout(own_buf, ms)  bound of this rank's peer waits (host write, between launches; default 10 s or
+ *                                      GPTQHIP_COMM_TIMEOUT_MS at alloc time) -- the self-test runs with a short one
  *   gptqhip_allreduce_oneshot(partial[n] fp32, peer_bufs[world] (HOST array of device pointers, own buffer at [rank]), rank, world,
  *                             n (% 4 == 0), n_max (as allocated), bias|NULL, residual|NULL, out[n] act dtype,
  *                             stats_out[ceil(n/16)]|NULL (per-16 sums of out^2: the next decode op's RMSNorm statistic), act_dtype, stream)
@@ -271,6 +273,7 @@ int gptqhip_comm_open(const unsigned char* handle, void** dev_ptr);
 int gptqhip_comm_close(void* dev_ptr);
 int gptqhip_comm_free(void* dev_ptr);
 int gptqhip_comm_status(void* own_buf, uint32_t* status_out);
+int gptqhip_comm_set_timeout(void* own_buf, unsigned int timeout_ms);
 int gptqhip_allreduce_oneshot(const float* partial, void* const* peer_bufs, int rank, int world, int n, int n_max,
                               const void* bias, const void* residual, void* out, float* stats_out, int act_dtype,
                               gptqhip_stream_t stream);

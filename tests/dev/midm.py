@@ -2,8 +2,12 @@
 rotating weight copies (a single-kernel graph replay has a ~10 us floor that would swamp the kernels)."""
 import sys, torch
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from gptqmodel_amd import _lib
+if os.environ.get("GPTQHIP_LIB"):      # dev A/B builds (tests/dev/ablate/*.so)
+    _lib.LIB_PATH = os.environ["GPTQHIP_LIB"]
 from gptqmodel_amd import ops
 dev = "cuda"; gs = 128
+KERNS = tuple(int(v) for v in os.environ.get("MIDM_KERNELS", "1,2").split(","))
 def gtime(fn, n_launch, reps=5):
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
@@ -17,7 +21,8 @@ def gtime(fn, n_launch, reps=5):
         e1.record(s); s.synchronize()
     return e0.elapsed_time(e1) * 1e3 / (reps * n_launch)
 Ms = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024]
-for (K, N) in [(4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096)]:
+SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ["MIDM_SHAPES"].split(",")] if os.environ.get("MIDM_SHAPES") else [(4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096)]
+for (K, N) in SHAPES:
     copies = max(4, min(32, (600 << 20) // (K * N // 2)))
     sets = []
     for _ in range(copies):
@@ -29,7 +34,7 @@ for (K, N) in [(4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096)]:
         x = (torch.randn(M, K, device=dev) * 0.5).half()
         out = torch.empty((M, N), dtype=torch.float16, device=dev)
         res = []
-        for kern in (1, 2):
+        for kern in KERNS:
             if kern == 2 and M < 5: continue
             if kern == 1 and M > 256: continue
             ops.set_tuning(0, kern, 0)

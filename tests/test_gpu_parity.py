@@ -143,6 +143,14 @@ SHAPES = [
     (2048, 2048, 64, 40),
     (1056, 256, 32, 50),     # ... off the regular pipeline (K % 128 != 0): the no-ring fallback of those instantiations
     (4096, 4096, 128, 33),
+    (4096, 16384, 128, 5),   # wide layers (N >= 16384) at 5..64 rows: skinny_wide_kernel, four (two) column tiles per block
+    (4096, 16384, 128, 16),
+    (4096, 16384, 128, 24),
+    (4096, 16384, 128, 32),
+    (2048, 16384, 64, 13),
+    (4096, 8192, 128, 27),   # ... two column tiles per block (8192 <= N < 16384)
+    (8192, 10240, 128, 8),
+    (11008, 16384, 128, 9),  # ... with a padded last ring round
     (64, 32, 32, 4),         # the reference's own unit-test shape (K < one 128-row chunk, N = 2 tiles)
     (96, 8, 32, 1),          # ragged everywhere: K % 128 != 0, N < one tile
 ]
