@@ -366,7 +366,13 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
         set_error("gptqhip_decode_linear: M=%d outside 1..16, or M > 1 with perm / SiLU*mul input glue", M);
         return GPTQHIP_EINVAL;
     }
-    const SkinnyPlan pl = plan_skinny(M, op->K, op->N, op->group_size, g_force_split, g_force_waves, op->perm != nullptr);
+    // wide layers at 5..16 rows: the decode kernel's wide form serves the RMSNorm-in / paired-SiLU-out ops (gate_up); residual /
+    // statistics epilogues and the SiLU*mul input glue stay with the one-tile kernel
+    const bool wide_ok = M >= 5 && !op->perm && !op->residual && !op->stats_out && op->bits == 4 && op->group_size % kChunkK == 0 &&
+                         (op->in_glue == GPTQHIP_GLUE_RMSNORM || (op->in_glue == GPTQHIP_GLUE_NONE && op->out_glue == GPTQHIP_OUT_NONE)) &&
+                         (op->out_glue == GPTQHIP_OUT_NONE || op->out_glue == GPTQHIP_OUT_SILU_MUL_PAIRED ||
+                          (op->out_glue == GPTQHIP_OUT_PARTIAL_F32 && op->in_glue == GPTQHIP_GLUE_NONE));
+    const SkinnyPlan pl = plan_skinny(M, op->K, op->N, op->group_size, g_force_split, g_force_waves, op->perm != nullptr, op->bits, wide_ok);
     if (op->perm && !(pl.depth == 4 && (size_t)op->K * 2 <= kInKernelPermMaxRowBytes)) {
         set_error("gptqhip_decode_linear: K=%d is outside the in-kernel act-order variant (gather x and pass perm = NULL)", op->K);
         return GPTQHIP_EINVAL;

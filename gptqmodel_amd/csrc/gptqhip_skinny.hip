@@ -989,8 +989,13 @@ struct WideStage {
     uint32_t meta[NT * GPC];
 };
 
-template <int ACT, int SCL, int MT, int GPC, bool HALFQ, int NT>
+// GLUE (decode op on 5..16 rows, MT == 1 only): kGlueRmsNorm applies HF's RMSNorm to the rows while they are parked (per-row 1/rms
+// from the producer's per-tile statistics or an in-kernel reduction, like skinny_kernel); the epilogue then also serves
+// GPTQHIP_OUT_SILU_MUL_PAIRED (interleaved gate|up tiles).  Residual / stats_out epilogues stay with the one-tile kernel: the layers
+// that use them (o_proj, down_proj) are not wide.
+template <int ACT, int SCL, int MT, int GPC, bool HALFQ, int NT, int GLUE = 0>
 __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyParams p) {
+    static_assert(GLUE == 0 || MT == 1, "the decode op takes at most 16 rows");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int QUADS = HALFQ ? 4 * MT - 2 : 4 * MT;          // 4-row groups loaded per chunk (rows beyond them: never stored)
     constexpr int NR = MT * NT * 4;                               // accumulator registers per lane
@@ -1019,6 +1024,30 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyParams p) {
 
     WideStage<GPC, NT> st[2];
     u4_t xa[QUADS];
+    u4_t xnw = {0u, 0u, 0u, 0u};       // GLUE: the chunk's norm-weight segment of this lane's 16-byte column piece
+    GlueInv ginv;
+    float* scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + W * kSlot);   // GLUE: 16 x 1/rms
+    float sv[GLUE != 0 ? 4 : 1][8];
+    if constexpr (GLUE == kGlueRmsNorm) {
+        // wave w (< 4) owns the statistics of rows w, w + 4, w + 8, w + 12: the producer's per-tile sums of squares are requested in
+        // FRONT of the weight ring (eight clamped loads per lane and row)
+        if (p.stats_in != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave + 4 * r;
+                if (wave < 4 && row < p.M) {
+                    const float* srow = p.stats_in + (size_t)row * p.stats_n;
+                    const int last = p.stats_n - 1;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int idx = lane + 64 * i;
+                        sv[r][i] = srow[idx < last ? idx : last];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     auto load_w = [&](WideStage<GPC, NT>& s, int chunk) __attribute__((always_inline)) {
         const int ck = chunk < c_end ? chunk : c_end - 1;       // padding chunks of the last ring round re-fetch the last real one
         const char* src = wbase + (size_t)ck * 1024;
@@ -1036,10 +1065,21 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyParams p) {
         const int ck = chunk < c_end ? chunk : c_end - 1;
 #pragma unroll
         for (int i = 0; i < QUADS; ++i) xa[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, voff, (uint32_t)ck * 256u + (uint32_t)i * quad_stride, 0);
+        if constexpr (GLUE == kGlueRmsNorm)
+            xnw = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (size_t)ck * 256 + c * 16);
     };
     auto park = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < QUADS; ++i) aslot[(4 * i + rq) * kRowsPitch + c] = xa[i];
+        for (int i = 0; i < QUADS; ++i) {
+            if constexpr (GLUE == kGlueRmsNorm) {
+                u4_t g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = glue_pair<ACT>(xa[i][j], xnw[j], ginv.v[i], GLUE);
+                aslot[(4 * i + rq) * kRowsPitch + c] = g;
+            } else {
+                aslot[(4 * i + rq) * kRowsPitch + c] = xa[i];
+            }
+        }
     };
     auto multiply = [&](const WideStage<GPC, NT>& s) __attribute__((always_inline)) {
 #pragma unroll
@@ -1073,6 +1113,46 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyParams p) {
     load_a(cur);                       // (waited for first)
     load_w(st[0], cur);
     load_w(st[1], cur + W);
+    if constexpr (GLUE == kGlueRmsNorm) {
+        if (p.stats_in != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave + 4 * r;
+                if (wave < 4 && row < p.M) {
+                    float ssum = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ssum += (lane + 64 * i < p.stats_n) ? sv[r][i] : 0.f;
+#pragma unroll
+                    for (int mk = 32; mk >= 1; mk >>= 1) ssum += __shfl_xor(ssum, mk, 64);
+                    if (lane == 0) scratch[row] = rsqrtf(ssum / (float)p.K + p.eps);
+                }
+            }
+        } else {   // no producer statistics (the step's first op): a wave-local reduction of the row, fixed order
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave + 4 * r;
+                if (wave < 4 && row < p.M) {
+                    const u4_t* hs = reinterpret_cast<const u4_t*>(p.x) + (size_t)row * (p.K / 8);
+                    float ss = 0.f;
+                    for (int idx = lane; idx < p.K / 8; idx += 64) {
+                        const u4_t h = hs[idx];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float a = bits16_to_f32<ACT>((uint16_t)(h[j] & 0xffffu)), b = bits16_to_f32<ACT>((uint16_t)(h[j] >> 16));
+                            ss = __builtin_fmaf(a, a, ss);
+                            ss = __builtin_fmaf(b, b, ss);
+                        }
+                    }
+#pragma unroll
+                    for (int mk = 32; mk >= 1; mk >>= 1) ss += __shfl_xor(ss, mk, 64);
+                    if (lane == 0) scratch[row] = rsqrtf(ss / (float)p.K + p.eps);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < QUADS; ++i) ginv.v[i] = scratch[4 * i + rq < p.M ? 4 * i + rq : 0];
+    }
     for (int it = 2; it < p.n_mine; it += 2) {
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
@@ -1106,7 +1186,17 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyParams p) {
         for (int w = 0; w < W; ++w) v += red[w][r][lane];
         const int a = r >> 2, i = r & 3, mt = a / NT, t = a - mt * NT;
         const int m = 16 * mt + 4 * rq + i, n = (tile0 + t) * kTileN + c;
-        if (m < p.M && n < p.N) {
+        const bool live = m < p.M && n < p.N;
+        if (GLUE != 0 && p.out_glue == kOutSiluMul) {
+            // interleaved gate|up tile (fuse_gate_up_interleaved): lanes c < 8 hold gate columns, c >= 8 the matching up columns of
+            // the SAME row (the reducer wave runs one (row tile, column tile, register) for all its lanes: the shuffle is legal)
+            float y = round_through<ACT>(v);
+            if (p.bias != nullptr && live) y = round_through<ACT>(y + load16_as_f32<ACT>(p.bias, (size_t)n));
+            const float up = __shfl_down(y, 8, 64);
+            const float a = round_through<ACT>(y / (1.0f + expf(-y))) * up;
+            const int jn = (tile0 + t) * 8 + c;
+            if (live && c < 8 && jn < p.N / 2) reinterpret_cast<uint16_t*>(p.out)[(size_t)m * (p.N / 2) + jn] = f32_to_16<ACT>(a);
+        } else if (live) {
             if (p.out_f32) {
                 reinterpret_cast<float*>(p.out)[(size_t)m * p.N + n] = v;
             } else {
@@ -1130,7 +1220,13 @@ static int launch_wide_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStrea
     constexpr int NR = MT * kWideNT * 4;
     constexpr int kSlotA = 16 * MT * kRowsPitch * 16;
     constexpr int kSlot = kSlotA > NR * 256 ? kSlotA : NR * 256;
-    const size_t lds_bytes = (size_t)pl.waves * kSlot;
+    const size_t lds_bytes = (size_t)pl.waves * kSlot + 64;
+    if constexpr (MT == 1) {
+        if (p.in_glue == kGlueRmsNorm) {     // decode op on 5..16 rows (one group constant per chunk: the ABI layer checks)
+            hipLaunchKernelGGL((skinny_wide_kernel<ACT, SCL, MT, 1, HALFQ, kWideNT, kGlueRmsNorm>), grid, block, lds_bytes, stream, p);
+            return check_hip(hipGetLastError(), "skinny_wide_kernel (decode glue) launch");
+        }
+    }
     if (pl.gpc == 1) {
         hipLaunchKernelGGL((skinny_wide_kernel<ACT, SCL, MT, 1, HALFQ, kWideNT>), grid, block, lds_bytes, stream, p);
     } else {
@@ -1395,7 +1491,9 @@ int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* co
     p.out_glue = a.out_glue;
     p.stats_n = a.stats_n;
     if (pl.nt > 1) {
-        if (a.bits != 4 || a.in_glue != kGlueNone || a.out_glue != kOutNone || a.residual != nullptr || a.stats_out != nullptr || a.perm != nullptr) {
+        const bool glue_ok = a.in_glue == kGlueNone ? a.out_glue == kOutNone
+                                                    : (a.in_glue == kGlueRmsNorm && pl.mt == 1 && pl.gpc == 1 && (a.out_glue == kOutNone || a.out_glue == kOutSiluMul));
+        if (a.bits != 4 || !glue_ok || a.residual != nullptr || a.stats_out != nullptr || a.perm != nullptr || (a.out_glue == kOutSiluMul && a.out_f32)) {
             set_error("skinny_wide_kernel: planned for a call it cannot serve (glue / permutation / 8-bit)");
             return -22;
         }

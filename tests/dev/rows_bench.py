@@ -1,4 +1,4 @@
-"""dev: decode op with full glue at M = 1..4 rows, Llama-3-8B layer shapes (us per launch, 24 distinct-weight layers per graph)."""
+"""dev: decode op with full glue at M = 1..16 rows (argv[1]: comma-separated row counts), Llama-3-8B layer shapes (us per launch, 24 distinct-weight layers per graph)."""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
@@ -11,7 +11,7 @@ NL = 24
 stream = torch.cuda.Stream()
 SHAPES = [("qkv", 4096, 6144, True, False, False), ("o", 4096, 4096, False, True, False),
           ("gate_up", 4096, 28672, True, False, True), ("down", 14336, 4096, False, True, False)]
-for M in (1, 2, 4, 6, 8):
+for M in ([int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else (1, 2, 4, 6, 8)):
     tot = 0.0
     line = [f"M={M}"]
     for name, K, N, rms, res, paired in SHAPES:

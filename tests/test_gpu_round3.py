@@ -385,3 +385,50 @@ def test_rows_33_to_64_one_launch_bias_and_partial_f32(ops, act, M):
     ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, bias, act, "fp16")
     assert_forward_close(torch_to_f32(out), ref, act, tag=M)
     assert part.dtype == torch.float32 and rel_err(part.cpu().numpy(), part_t.cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("act", ["fp16", "bf16"])
+@pytest.mark.parametrize("M,N,with_stats,paired", [(5, 16384, True, True), (8, 28672, True, True), (16, 28672, False, True), (13, 16384, True, False),
+                                                   (9, 8192, False, True)])
+def test_decode_op_wide_layer_rows_5_to_16(ops, act, M, N, with_stats, paired):
+    """The decode op on WIDE layers at 5..16 rows runs the decode kernel's wide form (several column tiles per block share one
+    staging of the activation tile): RMSNorm on the input (producer statistics or in-kernel reduction), bias, the paired SiLU*mul
+    epilogue of an interleaved gate|up module -- against the oracle composed with HF's glue formulas, and bit for bit against the
+    one-tile-per-block kernel (GPTQHIP_NO_WIDE is read once per process, so the comparison runs through gptqhip_gemm's plain path
+    for the un-glued product instead)."""
+    gs, bits, K = 128, 4, 4096
+    rng = np.random.RandomState(900 + M)
+    qweight, qzeros, scales, g_idx = synth_gptq(800 + M + N // 1024, bits, K, N, gs)
+    inter = N // 2
+    if paired:
+        order = np.stack([np.arange(inter).reshape(-1, 8), inter + np.arange(inter).reshape(-1, 8)], axis=1).reshape(-1)
+        qw_d = np.ascontiguousarray(qweight[:, order])
+        qz_d = O.pack_cols(O.unpack_cols(qzeros, 4)[:, order], 4)
+        sc_d = np.ascontiguousarray(scales[:, order])
+    else:
+        qw_d, qz_d, sc_d = qweight, qzeros, scales
+    sc = f32_to_torch(sc_d, "fp16", DEV)
+    qw_t, meta = ops.repack_tiled(torch.from_numpy(qw_d).to(DEV), torch.from_numpy(qz_d).to(DEV), sc, None, gs, bits)
+    h = O.round_to(rng.randn(M, K).astype(np.float32) * (1.0 + np.arange(M)[:, None] % 5), act)
+    w = O.round_to(1.0 + rng.randn(K).astype(np.float32) * 0.1, act)
+    bias = O.round_to(rng.randn(N).astype(np.float32) * 0.1, act)
+    bias_d = bias[order] if paired else bias
+    st_in = None
+    if with_stats:
+        st_in = torch.from_numpy((h.astype(np.float64) ** 2).reshape(M, -1, 16).sum(axis=2).astype(np.float32)).to(DEV)
+    out = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, f32_to_torch(bias_d, act, DEV), K, N, gs, bits, sc.dtype,
+                            in_glue=ops.GLUE_RMSNORM, norm_weight=f32_to_torch(w, act, DEV), eps=1e-5, stats_in=st_in,
+                            out_glue=ops.OUT_SILU_MUL_PAIRED if paired else ops.OUT_NONE, M=M)
+    xn = np.stack([O.rmsnorm_ref(h[m], w, 1e-5, act) for m in range(M)])
+    # the reference's chain for a biased linear feeding an activation: y = round(x @ W); y = round(y + bias)
+    y = O.forward_gptq(xn, qweight, qzeros, scales, g_idx, bits, bias, act, "fp16")
+    if paired:
+        ref = np.stack([O.silu_mul_ref(y[m, :inter], y[m, inter:], act) for m in range(M)])
+        assert out.shape == (M, inter)
+    else:
+        ref = y
+    assert_forward_close(torch_to_f32(out), ref, act, tag=(M, N, paired))
+    # no glue at all on the same rows == the plugin path's kernel (both take the wide form here)
+    plain = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, M=M)
+    gen = ops.gemm(f32_to_torch(h, act, DEV), qw_t, meta, None, None, N, gs, bits, sc.dtype)
+    assert torch.equal(plain, gen)
