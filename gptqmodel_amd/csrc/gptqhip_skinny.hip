@@ -983,6 +983,13 @@ __global__ __launch_bounds__(LB) void skinny_kernel(SkinnyParams p) {
 // split (N/64 >= 256 blocks fill the chip), the regular pipeline only.  Replaces nothing upstream beyond what skinny_kernel does
 // (TorchLinear._forward_eager, torch.py:326-347).
 // ------------------------------------------------------------------------------------------------
+// 4 waves per SIMD (<= 128 VGPRs: two blocks per CU) wherever that does not push registers to scratch (ISA audit): not with
+// per-K-step group constants, not for the bf16 / bf16 glue variant on 9..16 rows, not for 17..32 rows
+template <int ACT, int SCL, int MT, int GPC, bool HALFQ, int GLUE>
+__host__ __device__ constexpr int wide_waves_per_simd() {
+    return (MT == 1 && GPC == 1 && !(GLUE != 0 && ACT == kBF16 && SCL == kBF16 && !HALFQ)) ? 4 : 2;
+}
+
 template <int GPC, int NT>
 struct WideStage {
     u4_t w[NT];
@@ -993,8 +1000,11 @@ struct WideStage {
 // from the producer's per-tile statistics or an in-kernel reduction, like skinny_kernel); the epilogue then also serves
 // GPTQHIP_OUT_SILU_MUL_PAIRED (interleaved gate|up tiles).  Residual / stats_out epilogues stay with the one-tile kernel: the layers
 // that use them (o_proj, down_proj) are not wide.
+// Up to 16 rows (MT == 1) two 8-wave blocks share a CU (LDS: 2 x 35 KiB) as long as a wave stays within 128 VGPRs: the glue variant
+// came out at 129-131 and ran ONE block per CU (gate_up with glue 23.5 us vs 16.7 without) -- hence the waves-per-SIMD hint.
 template <int ACT, int SCL, int MT, int GPC, bool HALFQ, int NT, int GLUE = 0>
-__global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyParams p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(wide_waves_per_simd<ACT, SCL, MT, GPC, HALFQ, GLUE>())))
+void skinny_wide_kernel(SkinnyParams p) {
     static_assert(GLUE == 0 || MT == 1, "the decode op takes at most 16 rows");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int QUADS = HALFQ ? 4 * MT - 2 : 4 * MT;          // 4-row groups loaded per chunk (rows beyond them: never stored)
@@ -1423,9 +1433,10 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     // the regular pipeline with a two-deep weight ring, 4-bit weights, whole groups of four tiles and enough of them to fill the chip
     // without a cross-block split; the caller says whether its epilogue is the plain one (allow_wide: gptqhip_gemm yes, decode op no)
     static const bool wide_off = [] { const char* v = getenv("GPTQHIP_NO_WIDE"); return v && *v && *v != '0'; }();   // A/B switch
-    const int kWideNT = (tiles % 4 == 0 && tiles / 4 >= 256) ? 4 : 2;
+    static const int wide_min_blocks = [] { const char* v = getenv("GPTQHIP_WIDE_MIN_BLOCKS"); return (v && *v) ? atoi(v) : 192; }();   // A/B switch; 192: measured, profiles/r03_wide_layers.txt
+    const int kWideNT = (tiles % 4 == 0 && tiles / 4 >= wide_min_blocks) ? 4 : 2;
     if (allow_wide && !wide_off && bits == 4 && M >= 5 && M <= kWideMaxM && !in_kernel_perm && tiles % kWideNT == 0 &&
-        tiles / kWideNT >= 256 && force_split <= 1 && K % kChunkK == 0 &&
+        tiles / kWideNT >= wide_min_blocks && force_split <= 1 && K % kChunkK == 0 &&
         (pl.gpc == 1 ? (group_size >= K || ((group_size / kChunkK) & (group_size / kChunkK - 1)) == 0) : (group_size == 32 || group_size == 64))) {
         const int cap = force_waves > 0 && force_waves < kWideMaxWaves ? force_waves : kWideMaxWaves;
         int best = 0;
