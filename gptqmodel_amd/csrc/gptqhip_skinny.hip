@@ -1435,7 +1435,8 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     static const bool wide_off = [] { const char* v = getenv("GPTQHIP_NO_WIDE"); return v && *v && *v != '0'; }();   // A/B switch
     static const int wide_min_blocks = [] { const char* v = getenv("GPTQHIP_WIDE_MIN_BLOCKS"); return (v && *v) ? atoi(v) : 192; }();   // A/B switch; 192: measured, profiles/r03_wide_layers.txt
     const int kWideNT = (tiles % 4 == 0 && tiles / 4 >= wide_min_blocks) ? 4 : 2;
-    if (allow_wide && !wide_off && bits == 4 && M >= 5 && M <= kWideMaxM && !in_kernel_perm && tiles % kWideNT == 0 &&
+    static const int wide_min_m = [] { const char* v = getenv("GPTQHIP_WIDE_MIN_M"); return (v && *v) ? atoi(v) : 5; }();   // A/B switch
+    if (allow_wide && !wide_off && bits == 4 && M >= wide_min_m && M <= kWideMaxM && !in_kernel_perm && tiles % kWideNT == 0 &&
         tiles / kWideNT >= wide_min_blocks && force_split <= 1 && K % kChunkK == 0 &&
         (pl.gpc == 1 ? (group_size >= K || ((group_size / kChunkK) & (group_size / kChunkK - 1)) == 0) : (group_size == 32 || group_size == 64))) {
         const int cap = force_waves > 0 && force_waves < kWideMaxWaves ? force_waves : kWideMaxWaves;
