@@ -252,3 +252,33 @@ def test_hf_contract_check_rejects_older_calling_conventions():
     assert "past_key_values" in hf_llama._hf_contract(OldLayer())
     dense, quant = _build(False, False, torch.float16)
     assert hf_llama._hf_contract(dense.model.layers[0]) is None
+
+
+def test_mistral_fast_paths_hand_the_sliding_window_to_the_attention_interface():
+    """MistralAttention has no `sliding_window` attribute: HF's own forward reads it from the config and passes it to the attention
+    interface as a keyword (modeling_mistral.py).  The decode-op fast path and the prefill path must do the same -- with
+    flash-attention the window is NOT encoded in the mask.  A recording attention function registered through
+    transformers' AttentionInterface sees what every path hands over."""
+    from transformers import AttentionInterface
+    from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+    dense, quant = _build(False, "layers", torch.float16, "mistral")
+    assert not hasattr(quant.model.layers[0].self_attn, "sliding_window")
+    seen = []
+    sdpa = ALL_ATTENTION_FUNCTIONS["sdpa"]
+
+    def capture(module, q, k, v, mask, **kw):
+        seen.append((q.shape[-2], kw.get("sliding_window", "MISSING")))
+        return sdpa(module, q, k, v, mask, **kw)
+
+    AttentionInterface.register("gptqhip_capture_sw", capture)
+    for m in (dense, quant):
+        m.set_attn_implementation("gptqhip_capture_sw")
+    ids = torch.randint(0, 2048, (1, 20), device="cuda")
+    with torch.no_grad():
+        for model in (dense, quant):
+            seen.clear()
+            o = model(input_ids=ids, use_cache=True)                       # 20 tokens: HF's layer / the prefill path
+            model(input_ids=ids[:, :1], past_key_values=o.past_key_values, use_cache=True)   # 1 token: HF's layer / the decode ops
+            assert [w for _, w in seen] == [64] * 4 and [n for n, _ in seen] == [20, 20, 1, 1], seen
+    assert all(L._gptqhip_fused["state"] is not None and L._gptqhip_fused["prefill"].get("dtype") == torch.float16
+               for L in quant.model.layers), "the fast paths must have run"
