@@ -432,3 +432,30 @@ def test_decode_op_wide_layer_rows_5_to_16(ops, act, M, N, with_stats, paired):
     plain = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, M=M)
     gen = ops.gemm(f32_to_torch(h, act, DEV), qw_t, meta, None, None, N, gs, bits, sc.dtype)
     assert torch.equal(plain, gen)
+
+
+@pytest.mark.parametrize("act,sdt", [("fp16", "fp16"), ("bf16", "bf16"), ("fp16", "bf16")])
+@pytest.mark.parametrize("M,N", [(7, 16384), (32, 12288), (16, 6144)])
+def test_wide_form_partial_f32_and_scale_dtypes(ops, act, sdt, M, N):
+    """skinny_wide_kernel on the instantiations the shape table above does not reach: bf16 scales, the unrounded fp32 partial sums
+    (tensor-parallel row shards of a wide layer) against the prefill kernel's, and the 4-tile / 2-tile forms (N = 16384 / 12288 ->
+    four tiles per block, 6144 -> two)."""
+    K, gs = 4096, 128
+    qweight, qzeros, scales, g_idx = synth_gptq(1200 + M + N // 512, 4, K, N, gs, scale_dtype=sdt)
+    rng = np.random.RandomState(M + N)
+    x = O.round_to(rng.randn(M, K).astype(np.float32) * 0.5, act)
+    bias = O.round_to(rng.randn(N).astype(np.float32) * 0.1, act)
+    sc = f32_to_torch(scales, sdt, DEV)
+    qw_t, meta = ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV), sc, None, gs, 4)
+    xt = f32_to_torch(x, act, DEV)
+    out = ops.gemm(xt, qw_t, meta, f32_to_torch(bias, act, DEV), None, N, gs, 4, sc.dtype)
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, bias, act, sdt)
+    assert_forward_close(torch_to_f32(out), ref, act, tag=(M, N, act, sdt))
+    try:
+        ops.set_tuning(0, 1, 0)
+        part = ops.gemm(xt, qw_t, meta, None, None, N, gs, 4, sc.dtype, partial_f32=True)
+        ops.set_tuning(0, 2, 0)
+        part_t = ops.gemm(xt, qw_t, meta, None, None, N, gs, 4, sc.dtype, partial_f32=True)
+    finally:
+        ops.set_tuning(0, 0, 0)
+    assert part.dtype == torch.float32 and rel_err(part.cpu().numpy(), part_t.cpu().numpy()) <= 1e-5
