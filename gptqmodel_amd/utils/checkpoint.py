@@ -150,6 +150,12 @@ def load_quantized_checkpoint(model: nn.Module, ckpt_dir: str, device="cuda", ba
                 seen.add(key)
     quant_owned = [k for k in targets if any(k.startswith(n + ".") for n in names)]
     missing = [k for k in quant_owned if k not in seen and not k.endswith((".meta", ".perm"))]
+    for k in [k for k in missing if k.endswith(".g_idx")]:
+        # checkpoints written without act-order sometimes omit g_idx: the trivial mapping row k -> group k // group_size
+        mod = model.get_submodule(k[: -len(".g_idx")])
+        with torch.no_grad():
+            targets[k].copy_((torch.arange(targets[k].numel(), device=targets[k].device) // mod.group_size).to(targets[k].dtype))
+        missing.remove(k)
     if missing:
         raise ValueError(f"the checkpoint lacks tensors of quantised modules: {missing[:8]}")
     if fmt == FORMAT.GPTQ:
