@@ -985,8 +985,10 @@ __global__ __launch_bounds__(LB) void skinny_kernel(SkinnyParams p) {
 // ------------------------------------------------------------------------------------------------
 // 4 waves per SIMD (<= 128 VGPRs: two blocks per CU) wherever that does not push registers to scratch (ISA audit): not with
 // per-K-step group constants, not for the bf16 / bf16 glue variant on 9..16 rows, not for 17..32 rows
-template <int ACT, int SCL, int MT, int GPC, bool HALFQ, int GLUE>
+template <int ACT, int SCL, int MT, int GPC, bool HALFQ, int GLUE, int NT = 4>
 __host__ __device__ constexpr int wide_waves_per_simd() {
+    // (17..32 rows: two tiles per block fit 128 VGPRs too, but two such blocks per CU measured equal to one four-tile block:
+    // profiles/r03_wide_layers.txt)
     return (MT == 1 && GPC == 1 && !(GLUE != 0 && ACT == kBF16 && SCL == kBF16 && !HALFQ)) ? 4 : 2;
 }
 
@@ -1003,7 +1005,7 @@ struct WideStage {
 // Up to 16 rows (MT == 1) two 8-wave blocks share a CU (LDS: 2 x 35 KiB) as long as a wave stays within 128 VGPRs: the glue variant
 // came out at 129-131 and ran ONE block per CU (gate_up with glue 23.5 us vs 16.7 without) -- hence the waves-per-SIMD hint.
 template <int ACT, int SCL, int MT, int GPC, bool HALFQ, int NT, int GLUE = 0>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(wide_waves_per_simd<ACT, SCL, MT, GPC, HALFQ, GLUE>())))
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(wide_waves_per_simd<ACT, SCL, MT, GPC, HALFQ, GLUE, NT>())))
 void skinny_wide_kernel(SkinnyParams p) {
     static_assert(GLUE == 0 || MT == 1, "the decode op takes at most 16 rows");
     extern __shared__ __attribute__((aligned(16))) float lds[];
