@@ -213,12 +213,22 @@ def _has_hooks(*mods) -> bool:
     return any(m._forward_pre_hooks or any(not _is_hf_capture_hook(h) for h in m._forward_hooks.values()) for m in mods)
 
 
+_COLLECTOR = [False]   # transformers' active-output collector (utils/output_capturing.py), resolved on first use; None: not available
+
+
 def _capture_keys(module):
     """Output kinds transformers is recording during this call ("hidden_states", "attentions", ...): the keys of its active
     collector; when that machinery is not importable (other releases), every kind a recorder hook on `module` could serve."""
+    if _COLLECTOR[0] is False:
+        try:
+            from transformers.utils.output_capturing import _active_collector
+            _COLLECTOR[0] = _active_collector
+        except Exception:  # noqa: BLE001
+            _COLLECTOR[0] = None
+    if _COLLECTOR[0] is None:
+        return ("hidden_states", "attentions") if module._forward_hooks else ()
     try:
-        from transformers.utils.output_capturing import _active_collector
-        col = _active_collector.get()
+        col = _COLLECTOR[0].get()
         return () if col is None else tuple(col.keys())
     except Exception:  # noqa: BLE001
         return ("hidden_states", "attentions") if module._forward_hooks else ()
