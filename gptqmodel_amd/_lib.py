@@ -17,7 +17,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libgptqhip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # every symbol include/gptqhip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -33,6 +33,7 @@ SIGNATURES = {
     "gptqhip_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_decode_linear": (_i, [_vp, _vp]),
     "gptqhip_decode_supported": (_i, [_i, _i, _i, _i, _i]),
+    "gptqhip_plan_describe": (_i, [_i, _i, _i, _i, _i, _i, _c.c_char_p, _i]),
     "gptqhip_decode_linear_seq": (_i, [_vp, _i, _vp]),
     "gptqhip_comm_bytes": (_sz, [_i, _i]),
     "gptqhip_comm_alloc": (_i, [_sz, _c.POINTER(_vp), _c.c_char_p]),

@@ -99,6 +99,16 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
     return L;
 }
 
+// Kernel family of one gptqhip_gemm call (the measured crossover; the comments at its use in gptqhip_gemm give the numbers)
+static bool gemm_uses_tiled(int M, int K, int N, int group_size, int bits) {
+    bool wide = N >= 8192 && M > 16;
+    if (wide && M <= 32 && K < 8192 && N < 65536 && g_force_kernel == 0 &&
+        plan_skinny(M, K, N, group_size, g_force_split, g_force_waves, false, bits, true).nt > 1)
+        wide = false;
+    const int skinny_max = (bits == 4 && K < 8192 && N < 8192) ? kSkinnyMaxRows4 : kSkinnyMaxM;
+    return (g_force_kernel == 2) || (g_force_kernel == 0 && (M > skinny_max || wide));
+}
+
 }  // namespace gptqhip
 
 using namespace gptqhip;
@@ -261,12 +271,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     // 17..32 rows too when K < 8192 and N < 65536 (4096x28672 at M=32 32.4 -> 24.4 us vs 27.3 us tiled, 4096x8192 11.9 -> 8.7 vs 13.0;
     // but 8192x10240 22.6 vs 20.8 tiled, 4096x128256 91.9 vs 80.7); above that the tiled kernel (4096x28672 at M=48: 28.7 vs 39.0 us).
     // profiles/r03_wide_layers.txt
-    bool wide = N >= 8192 && M > 16;
-    if (wide && M <= 32 && K < 8192 && N < 65536 && g_force_kernel == 0 &&
-        plan_skinny(M, K, N, group_size, g_force_split, g_force_waves, false, bits, true).nt > 1)
-        wide = false;
-    const int skinny_max = (bits == 4 && K < 8192 && N < 8192) ? kSkinnyMaxRows4 : kSkinnyMaxM;
-    const bool use_tiled = (g_force_kernel == 2) || (g_force_kernel == 0 && (M > skinny_max || wide));
+    const bool use_tiled = gemm_uses_tiled(M, K, N, group_size, bits);
     // rows per decode-kernel launch: 32, or 64 with 4-bit weights (one launch, the weights are streamed once)
     const int rows_per_launch = bits == 4 ? kSkinnyMaxRows4 : kSkinnyMaxM;
     if (use_tiled) {
@@ -311,6 +316,35 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         rc = launch_skinny(a, pl, slabs, counters, stream);
         if (rc) return rc;
     }
+    return GPTQHIP_OK;
+}
+
+int gptqhip_plan_describe(int M, int K, int N, int group_size, int bits, int has_perm, char* buf, int buf_len) {
+    if (!buf || buf_len <= 0) {
+        set_error("gptqhip_plan_describe: no buffer");
+        return GPTQHIP_EINVAL;
+    }
+    int rc = validate_common("gptqhip_plan_describe", K, N, group_size, bits);
+    if (rc) return rc;
+    if (M <= 0) {
+        set_error("gptqhip_plan_describe: M=%d", M);
+        return GPTQHIP_EINVAL;
+    }
+    if (gemm_uses_tiled(M, K, N, group_size, bits)) {
+        const TiledPlan tp = plan_tiled(M, K, N, group_size, bits, g_force_waves, g_force_split);
+        snprintf(buf, (size_t)buf_len, "tiled bm=%d splits=%d tail_cols=%d gather=%d", tp.bm, tp.splits, tp.tail_cols, has_perm ? 1 : 0);
+        return GPTQHIP_OK;
+    }
+    const int rows = bits == 4 ? kSkinnyMaxRows4 : kSkinnyMaxM;
+    const int mc = M < rows ? M : rows;
+    bool fused_perm = false;
+    if (has_perm && M == 1) {
+        const SkinnyPlan pl1 = plan_skinny(1, K, N, group_size, g_force_split, g_force_waves, true);
+        fused_perm = pl1.regular && pl1.gpc == 1 && pl1.depth == 4 && (size_t)K * 2 <= kInKernelPermMaxRowBytes;
+    }
+    const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves, fused_perm, bits, true);
+    snprintf(buf, (size_t)buf_len, "skinny launches=%d mt=%d nt=%d waves=%d depth=%d regular=%d splits=%d gather=%d", ceil_div(M, rows), pl.mt,
+             pl.nt, pl.waves, pl.depth, pl.regular, pl.splits, has_perm && !fused_perm ? 1 : 0);
     return GPTQHIP_OK;
 }
 

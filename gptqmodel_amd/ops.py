@@ -410,6 +410,14 @@ def rmsnorm_gather(h: torch.Tensor, weight: torch.Tensor, eps: float, perm: Opti
     return out
 
 
+def plan_describe(M: int, K: int, N: int, group_size: int, bits: int = 4, has_perm: bool = False) -> str:
+    """Kernel family + launch geometry gptqhip_gemm would pick for this call (host logic; needs no GPU)."""
+    import ctypes
+    buf = ctypes.create_string_buffer(256)
+    _lib.check(_lib.load().gptqhip_plan_describe(M, K, N, group_size, bits, 1 if has_perm else 0, buf, 256), "gptqhip_plan_describe")
+    return buf.value.decode()
+
+
 def set_tuning(force_split_k: int = 0, force_kernel: int = 0, force_waves: int = 0) -> None:
     _need_cache.clear()  # forced plans change the workspace layout
     _lib.check(_lib.load().gptqhip_set_tuning(force_split_k, force_kernel, force_waves), "gptqhip_set_tuning")

@@ -81,6 +81,38 @@ def test_decode_op_shape_predicate_is_host_logic(lib):
     assert lib.gptqhip_decode_supported(4096, 4096, 128, 0, 17) == 0 and lib.gptqhip_decode_supported(4096, 4096, 128, 1, 2) == 0
 
 
+def test_kernel_family_crossover_is_host_logic(lib):
+    """gptqhip_plan_describe = the planner's decisions without a GPU: the measured crossover between the decode kernel (one / several
+    row tiles, one / several column tiles per block) and the MFMA-tiled prefill kernel (profiles/r03_mid_m_sweep.txt,
+    r03_wide_layers.txt).  Pinned here so that a planner edit that silently re-routes a regime shows up on the CPU."""
+    def d(M, K, N, gs=128, bits=4, perm=0):
+        buf = ctypes.create_string_buffer(256)
+        assert lib.gptqhip_plan_describe(M, K, N, gs, bits, perm, buf, 256) == 0, lib.gptqhip_last_error()
+        return dict(kv.split("=") for kv in buf.value.decode().split()[1:]) | {"family": buf.value.decode().split()[0]}
+    # batch-1 decode: one row tile, one column tile, counted-wait pipeline
+    for K, N in ((4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096), (8192, 57344)):
+        p = d(1, K, N)
+        assert p["family"] == "skinny" and p["mt"] == "1" and p["nt"] == "1" and p["regular"] == "1" and p["launches"] == "1"
+    # 17..64 rows on narrow layers: ONE launch, two / four row tiles, 8 waves (512-thread instantiations)
+    assert d(32, 4096, 4096) | {} == d(32, 4096, 4096) and d(32, 4096, 4096)["mt"] == "2" and d(32, 4096, 4096)["waves"] == "8"
+    p = d(64, 4096, 4096)
+    assert p["family"] == "skinny" and p["mt"] == "4" and p["launches"] == "1" and p["splits"] == "1"
+    assert d(65, 4096, 4096)["family"] == "tiled" and d(48, 4096, 4096, bits=8)["family"] == "tiled"
+    assert d(32, 14336, 4096)["family"] == "skinny" and d(40, 14336, 4096)["family"] == "tiled"      # long K: tiled above 32 rows
+    # wide layers: the wide form (4 / 2 column tiles per block) from 5 rows, up to 16 rows everywhere, up to 32 where measured ahead
+    assert d(4, 4096, 28672)["nt"] == "1" and d(5, 4096, 28672)["nt"] == "4" and d(16, 4096, 28672)["nt"] == "4"
+    assert d(32, 4096, 28672)["family"] == "skinny" and d(32, 4096, 28672)["nt"] == "4" and d(33, 4096, 28672)["family"] == "tiled"
+    assert d(16, 4096, 6144)["nt"] == "2" and d(16, 4096, 8192)["nt"] == "2" and d(16, 4096, 4096)["nt"] == "1"
+    assert d(16, 4096, 128256)["nt"] == "4" and d(32, 4096, 128256)["family"] == "tiled"               # lm_head: tiled from 17 rows
+    assert d(16, 8192, 10240)["family"] == "skinny" and d(24, 8192, 10240)["family"] == "tiled"       # K >= 8192: tiled from 17 rows
+    # prefill: 256- / 128- / 64-row tiles
+    assert d(8192, 4096, 4096)["bm"] == "256" and d(128, 4096, 4096)["bm"] == "64"
+    # act-order: in-kernel permutation at one row, a gather pass otherwise
+    assert d(1, 4096, 4096, perm=1)["gather"] == "0" and d(1, 4096, 4096, perm=1)["depth"] == "4"
+    assert d(8, 4096, 4096, perm=1)["gather"] == "1" and d(2048, 4096, 4096, perm=1)["gather"] == "1"
+    assert lib.gptqhip_plan_describe(0, 4096, 4096, 128, 4, 0, ctypes.create_string_buffer(8), 8) == -22
+
+
 def test_comm_buffer_sizes_and_collective_argument_checks(lib):
     """The one-shot collectives' host logic: buffer size = header + 2 x 8 all-reduce slots + 2 x 8 all-gather slots, argument
     validation before anything touches a GPU."""
