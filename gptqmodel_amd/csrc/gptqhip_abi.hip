@@ -103,7 +103,7 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
 static bool gemm_uses_tiled(int M, int K, int N, int group_size, int bits) {
     bool wide = N >= 8192 && M > 16;
     if (wide && M <= 32 && K < 8192 && N < 65536 && g_force_kernel == 0 &&
-        plan_skinny(M, K, N, group_size, g_force_split, g_force_waves, false, bits, true).nt > 1)
+        plan_skinny(M, K, N, group_size, g_force_split, g_force_waves, false, bits, 1).nt > 1)
         wide = false;
     const int skinny_max = (bits == 4 && K < 8192 && N < 8192) ? kSkinnyMaxRows4 : kSkinnyMaxM;
     return (g_force_kernel == 2) || (g_force_kernel == 0 && (M > skinny_max || wide));
@@ -312,7 +312,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         a.x = reinterpret_cast<const char*>(xin) + (size_t)m0 * K * 2;
         a.out = reinterpret_cast<char*>(out) + (size_t)m0 * N * (partial_f32 ? 4 : 2);
         a.M = mc;
-        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves, fused_perm, bits, true);
+        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves, fused_perm, bits, 1);
         rc = launch_skinny(a, pl, slabs, counters, stream);
         if (rc) return rc;
     }
@@ -342,7 +342,7 @@ int gptqhip_plan_describe(int M, int K, int N, int group_size, int bits, int has
         const SkinnyPlan pl1 = plan_skinny(1, K, N, group_size, g_force_split, g_force_waves, true);
         fused_perm = pl1.regular && pl1.gpc == 1 && pl1.depth == 4 && (size_t)K * 2 <= kInKernelPermMaxRowBytes;
     }
-    const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves, fused_perm, bits, true);
+    const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves, fused_perm, bits, 1);
     snprintf(buf, (size_t)buf_len, "skinny launches=%d mt=%d nt=%d waves=%d depth=%d regular=%d splits=%d gather=%d", ceil_div(M, rows), pl.mt,
              pl.nt, pl.waves, pl.depth, pl.regular, pl.splits, has_perm && !fused_perm ? 1 : 0);
     return GPTQHIP_OK;
@@ -402,11 +402,12 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
     }
     // wide layers at 5..16 rows: the decode kernel's wide form serves the RMSNorm-in / paired-SiLU-out ops (gate_up); residual /
     // statistics epilogues and the SiLU*mul input glue stay with the one-tile kernel
-    const bool wide_ok = M >= 5 && !op->perm && !op->residual && !op->stats_out && op->bits == 4 && op->group_size % kChunkK == 0 &&
+    const bool wide_ok = M >= 2 && !op->perm && !op->residual && !op->stats_out && op->bits == 4 && op->group_size % kChunkK == 0 &&
                          (op->in_glue == GPTQHIP_GLUE_RMSNORM || (op->in_glue == GPTQHIP_GLUE_NONE && op->out_glue == GPTQHIP_OUT_NONE)) &&
                          (op->out_glue == GPTQHIP_OUT_NONE || op->out_glue == GPTQHIP_OUT_SILU_MUL_PAIRED ||
                           (op->out_glue == GPTQHIP_OUT_PARTIAL_F32 && op->in_glue == GPTQHIP_GLUE_NONE));
-    const SkinnyPlan pl = plan_skinny(M, op->K, op->N, op->group_size, g_force_split, g_force_waves, op->perm != nullptr, op->bits, wide_ok);
+    const SkinnyPlan pl = plan_skinny(M, op->K, op->N, op->group_size, g_force_split, g_force_waves, op->perm != nullptr, op->bits,
+                                      !wide_ok ? 0 : (op->in_glue == GPTQHIP_GLUE_RMSNORM ? 2 : 1));
     if (op->perm && !(pl.depth == 4 && (size_t)op->K * 2 <= kInKernelPermMaxRowBytes)) {
         set_error("gptqhip_decode_linear: K=%d is outside the in-kernel act-order variant (gather x and pass perm = NULL)", op->K);
         return GPTQHIP_EINVAL;

@@ -58,7 +58,7 @@ int check_hip(hipError_t e, const char* what);
 
 // in_kernel_perm: the plan is for the batch-1 act-order variant (AM_ROW1P), which only exists with the 4-deep ring
 SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm = false, int bits = 4,
-                       bool allow_wide = false);
+                       int allow_wide = 0);   // 0: one column tile per block; 1: wide form from 5 rows; 2: decode op with glue (from 2 rows)
 int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* counters, hipStream_t stream);
 
 TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_variant, int force_split);

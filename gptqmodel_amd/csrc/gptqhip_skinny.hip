@@ -1317,7 +1317,7 @@ static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStre
     }
 }
 
-SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm, int bits, bool allow_wide) {
+SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm, int bits, int allow_wide) {
     static const bool allow_depth2 = [] { const char* v = getenv("GPTQHIP_NO_DEPTH2"); return !(v && *v && *v != '0'); }();
     static const bool allow_pad = [] { const char* v = getenv("GPTQHIP_NO_PAD"); return !(v && *v && *v != '0'); }();   // A/B switch
     SkinnyPlan pl;
@@ -1437,7 +1437,10 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     static const bool wide_off = [] { const char* v = getenv("GPTQHIP_NO_WIDE"); return v && *v && *v != '0'; }();   // A/B switch
     static const int wide_min_blocks = [] { const char* v = getenv("GPTQHIP_WIDE_MIN_BLOCKS"); return (v && *v) ? atoi(v) : 192; }();   // A/B switch; 192: measured, profiles/r03_wide_layers.txt
     const int kWideNT = (tiles % 4 == 0 && tiles / 4 >= wide_min_blocks) ? 4 : 2;
-    static const int wide_min_m = [] { const char* v = getenv("GPTQHIP_WIDE_MIN_M"); return (v && *v) ? atoi(v) : 5; }();   // A/B switch
+    // from 5 rows; the decode op WITH glue (allow_wide == 2) on four-tile layers from 2 rows (gate_up with RMSNorm + paired SiLU at
+    // 2 / 4 rows: 18.8 -> 17.8 / 20.2 -> 18.3 us; the plain product and two-tile layers lose below 5: profiles/r03_wide_layers.txt)
+    static const int wide_min_m_env = [] { const char* v = getenv("GPTQHIP_WIDE_MIN_M"); return (v && *v) ? atoi(v) : 0; }();   // A/B switch
+    const int wide_min_m = wide_min_m_env > 0 ? wide_min_m_env : ((allow_wide == 2 && kWideNT == 4) ? 2 : 5);
     if (allow_wide && !wide_off && bits == 4 && M >= wide_min_m && M <= kWideMaxM && !in_kernel_perm && tiles % kWideNT == 0 &&
         tiles / kWideNT >= wide_min_blocks && force_split <= 1 && K % kChunkK == 0 &&
         (pl.gpc == 1 ? (group_size >= K || ((group_size / kChunkK) & (group_size / kChunkK - 1)) == 0) : (group_size == 32 || group_size == 64))) {

@@ -389,9 +389,9 @@ def test_rows_33_to_64_one_launch_bias_and_partial_f32(ops, act, M):
 
 @pytest.mark.parametrize("act", ["fp16", "bf16"])
 @pytest.mark.parametrize("M,N,with_stats,paired", [(5, 16384, True, True), (8, 28672, True, True), (16, 28672, False, True), (13, 16384, True, False),
-                                                   (9, 8192, False, True)])
-def test_decode_op_wide_layer_rows_5_to_16(ops, act, M, N, with_stats, paired):
-    """The decode op on WIDE layers at 5..16 rows runs the decode kernel's wide form (several column tiles per block share one
+                                                   (9, 8192, False, True), (2, 28672, True, True), (4, 16384, False, True), (3, 16384, True, False)])
+def test_decode_op_wide_layer_rows_2_to_16(ops, act, M, N, with_stats, paired):
+    """The decode op on WIDE layers at 5..16 rows (with glue on four-tile layers: from 2 rows) runs the decode kernel's wide form (several column tiles per block share one
     staging of the activation tile): RMSNorm on the input (producer statistics or in-kernel reduction), bias, the paired SiLU*mul
     epilogue of an interleaved gate|up module -- against the oracle composed with HF's glue formulas, and bit for bit against the
     one-tile-per-block kernel (GPTQHIP_NO_WIDE is read once per process, so the comparison runs through gptqhip_gemm's plain path
@@ -428,7 +428,7 @@ def test_decode_op_wide_layer_rows_5_to_16(ops, act, M, N, with_stats, paired):
     else:
         ref = y
     assert_forward_close(torch_to_f32(out), ref, act, tag=(M, N, paired))
-    # no glue at all on the same rows == the plugin path's kernel (both take the wide form here)
+    # no glue at all on the same rows == the plugin path's kernel (from 5 rows both take the wide form; below, the one-tile kernel)
     plain = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, M=M)
     gen = ops.gemm(f32_to_torch(h, act, DEV), qw_t, meta, None, None, N, gs, bits, sc.dtype)
     assert torch.equal(plain, gen)
