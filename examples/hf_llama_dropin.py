@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--new-tokens", type=int, default=64)
     ap.add_argument("--no-fuse", action="store_true")
-    ap.add_argument("--batch", type=int, default=1, help="sequences decoded together (<= 4 stay on the decode-op fast path)")
+    ap.add_argument("--batch", type=int, default=1, help="sequences decoded together (<= 16 stay on the decode-op fast path)")
     ap.add_argument("--siblings-only", action="store_true", help="fuse q/k/v and gate/up only (no decode-op layer fast path)")
     ap.add_argument("--quant-lm-head", action="store_true", help="also quantise lm_head (qcfg.lm_head upstream, loader.py:1376)")
     ap.add_argument("--desc-act", action="store_true", help="act-order checkpoint: g_idx = a random permutation per input tensor "
