@@ -41,6 +41,15 @@ __host__ __device__ constexpr int skinny_launch_bound() {
 }
 static int skinny_max_waves(int bits, int mt) { (void)bits; return mt >= 2 ? 8 : 16; }
 
+// Occupancy hint: none.  (Round 3 measured one: the bf16 batch-1 instantiations with the 4-deep ring need 82-84 VGPRs = 5 waves per SIMD
+// where fp16 needs 67 = 7, so a Llama-3-8B gate_up -- 7 four-wave blocks per CU -- runs in two rounds.  amdgpu_waves_per_eu(6) brings
+// them to 78-80 VGPRs without scratch, (7) spills 20 registers; with (6) the bf16 chain got SLOWER, 771 vs 808 tokens/s against 886 / 898
+// fp16 on the same boxes: the squeezed schedule costs more than the sixth wave brings.)
+template <int BITS, int ACT, int MT, int AM, int D>
+__host__ __device__ constexpr int skinny_min_waves_per_simd() {
+    return 1;
+}
+
 struct SkinnyParams {
     const void* x;
     const int32_t* perm;   // act-order row permutation applied to x inside the kernel (AM_ROW1P), else nullptr
@@ -527,7 +536,8 @@ __device__ __forceinline__ void finish_outputs(const SkinnyParams& p, float v, b
 // LB = 512 (<= 8 waves per block, 256-VGPR budget) instead and the planner picks <= 8 waves for them.  33..64 rows (MT == 4, round 3:
 // one launch -- the weights are read ONCE -- instead of two 32-row launches) live in the same 512-thread budget.
 template <int BITS, int ACT, int SCL, int MT, int GPC, int AM, int D, int GLUE = 0, int LB = skinny_launch_bound<BITS, MT>()>
-__global__ __launch_bounds__(LB) void skinny_kernel(SkinnyParams p) {
+__global__ __launch_bounds__(LB) __attribute__((amdgpu_waves_per_eu(skinny_min_waves_per_simd<BITS, ACT, MT, AM, D>())))
+void skinny_kernel(SkinnyParams p) {
     // ONE dynamic LDS array (16-B aligned base, no statics in front of it): per-wave activation slots during the K
     // loop, then the split-K reduction buffer red[W][MT*4][64]; the last 16 bytes hold the "last arriver" flag.
     extern __shared__ __attribute__((aligned(16))) float lds[];
