@@ -459,3 +459,30 @@ def test_wide_form_partial_f32_and_scale_dtypes(ops, act, sdt, M, N):
     finally:
         ops.set_tuning(0, 0, 0)
     assert part.dtype == torch.float32 and rel_err(part.cpu().numpy(), part_t.cpu().numpy()) <= 1e-5
+
+
+def test_small_batch_regimes_random_stress(ops):
+    """Seeded random shapes over the regimes round 3 added (5..64 rows; narrow, long-K and wide layers; group sizes 32 / 64 / 128 /
+    per-channel; fp16 / bf16; bias): whatever kernel family / tiling the planner picks (recorded in the failure message) must meet
+    the oracle within the forward gates."""
+    rng = np.random.RandomState(20260924)
+    seen = set()
+    for case in range(14):
+        M = int(rng.choice([5, 7, 12, 16, 17, 23, 31, 32, 33, 40, 48, 56, 57, 64]))
+        K = int(rng.choice([1024, 2048, 3072, 4096, 5120, 8192, 11008]))
+        N = int(rng.choice([1024, 4096, 6144, 8192, 12288, 16384, 20480, 28672]))
+        gs = int(rng.choice([32, 64, 128, 128, 128, K]))
+        if K % gs:
+            gs = 128
+        act = "fp16" if rng.rand() < 0.6 else "bf16"
+        plan = ops.plan_describe(M, K, N, gs)
+        seen.add(plan.split()[0] + " " + " ".join(p for p in plan.split() if p.startswith(("mt=", "nt=", "bm="))))
+        qweight, qzeros, scales, g_idx = synth_gptq(5000 + case, 4, K, N, gs)
+        x = O.round_to(rng.randn(M, K).astype(np.float32) * 0.5, act)
+        bias = O.round_to(rng.randn(N).astype(np.float32) * 0.1, act)
+        sc = f32_to_torch(scales, "fp16", DEV)
+        qw_t, meta = ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV), sc, None, gs, 4)
+        out = ops.gemm(f32_to_torch(x, act, DEV), qw_t, meta, f32_to_torch(bias, act, DEV), None, N, gs, 4, sc.dtype)
+        ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, bias, act, "fp16")
+        assert_forward_close(torch_to_f32(out), ref, act, tag=(M, K, N, gs, act, plan))
+    assert len(seen) >= 4, seen      # the draw must actually visit several kernel forms
