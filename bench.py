@@ -750,6 +750,11 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
         res.append(prefill_entry("C3", "GPTQ int4 g128 desc_act=True (act-order g_idx gather), M=65536 (batch 32 x 2048 ctx), "
                                  "4096x4096 (q/o_proj shape)", [a44], 65536, dtype, dev))
         del a44
+        # the same layer WITHOUT act-order in the same run: what the x-gather pass (1 GiB of HBM traffic at M = 65536) costs
+        p44 = make_gptq(4096, 4096, gs, dev, gen, dtype, desc_act=False)
+        plain = prefill_entry("C3", "", [p44], 65536, dtype, dev)
+        res[-1]["same_layer_desc_act_false"] = {"value": plain["value"], "unit": "TFLOP/s", "ms": plain["ms"]}
+        del p44
         agu = make_gptq(4096, 2 * cfg["inter"], gs, dev, gen, dtype, desc_act=True)
         res.append(prefill_entry("C3", "GPTQ int4 g128 desc_act=True, M=65536, 4096x28672 (fused gate_up)", [agu], 65536, dtype, dev,
                                  iters=2))

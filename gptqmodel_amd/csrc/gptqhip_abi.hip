@@ -355,7 +355,8 @@ int gptqhip_decode_supported(int K, int N, int group_size, int has_perm, int M) 
     if (M < 1 || M > 16 || (M > 1 && has_perm)) return 0;
     const SkinnyPlan pl = plan_skinny(M, K, N, group_size, 0, 0, has_perm != 0);
     if (has_perm && !(pl.depth == 4 && (size_t)K * 2 <= kInKernelPermMaxRowBytes)) return 0;
-    return (pl.regular && pl.gpc == 1 && pl.mt == 1) ? 1 : 0;
+    // (group_size 32 / 64 -- a group constant per K-step -- rides the same pipeline; the in-kernel permutation needs one per chunk)
+    return (pl.regular && (pl.gpc == 1 || !has_perm) && pl.mt == 1) ? 1 : 0;
 }
 
 int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) {
@@ -412,7 +413,7 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
         set_error("gptqhip_decode_linear: K=%d is outside the in-kernel act-order variant (gather x and pass perm = NULL)", op->K);
         return GPTQHIP_EINVAL;
     }
-    if (!(pl.regular && pl.gpc == 1 && pl.mt == 1)) {
+    if (!(pl.regular && (pl.gpc == 1 || !op->perm) && pl.mt == 1)) {
         set_error("gptqhip_decode_linear: K=%d group_size=%d is outside the decode op's regular pipeline (use gptqhip_gemm)",
                   op->K, op->group_size);
         return GPTQHIP_EINVAL;

@@ -291,50 +291,72 @@ int launch_dequant_tiled(const uint32_t* qweight_t, const uint32_t* meta, const 
 // kernel.
 constexpr int kGatherMaxK = 16384;  // 32 KiB of LDS per staged row
 
+// byte offsets (2 * column) of 8 consecutive permutation entries, packed two per register
+__device__ __forceinline__ u4_t pack_byte_offsets(const int32_t* __restrict__ p) {
+    const u4_t a = *reinterpret_cast<const u4_t*>(p), b = *reinterpret_cast<const u4_t*>(p + 4);
+    u4_t o;
+    o.x = (a.x << 1) | (a.y << 17);
+    o.y = (a.z << 1) | (a.w << 17);
+    o.z = (b.x << 1) | (b.y << 17);
+    o.w = (b.z << 1) | (b.w << 17);
+    return o;
+}
+__device__ __forceinline__ uint16_t lds_u16(const uint16_t* row, uint32_t byte_off) {
+    return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(row) + byte_off);
+}
+
 // R rows per pass: all R*IT 16-byte loads of a pass are issued before the first LDS write (R * K * 2 bytes in flight per
-// block instead of one row's latency per row), the permutation is read once per pass and reused for the R rows.
+// block instead of one row's latency per row).  A thread assembles the SAME output columns in every pass, so its slice of
+// the permutation lives in registers (read once per block), and the next pass's rows are requested as soon as this pass's
+// have been parked in LDS: they land under the gather phase instead of in front of it (round 3: a pass used to be
+// load -> park -> permutation load -> gather -> store, each step waiting for the one before: 2 TB/s of the ~5 a copy reaches).
 template <int R, int IT>
 __global__ __launch_bounds__(256) void gather_cols_lds_kernel(const uint16_t* __restrict__ x,
                                                               const int32_t* __restrict__ perm,
                                                               uint16_t* __restrict__ out, int M, int K) {
     extern __shared__ __attribute__((aligned(16))) uint16_t rows[];  // [R][K]
     const int k8 = K / 8;
-    for (int m0 = blockIdx.x * R; m0 < M; m0 += gridDim.x * R) {
-        u4_t stage[R][IT];
+    int piece[IT];      // this thread's 16-byte output pieces (clamped: out-of-range pieces load piece 0 and store nothing)
+    u4_t off[IT];       // byte offsets of the piece's 8 source columns inside a staged row, two per register (K <= 16384: 15 bits each)
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int i = threadIdx.x + it * 256;
+        piece[it] = i < k8 ? i : 0;
+        off[it] = pack_byte_offsets(perm + 8 * piece[it]);
+    }
+    u4_t stage[R][IT];
+    auto request = [&](int m0) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int m = m0 + r < M ? m0 + r : M - 1;
             const u4_t* src = reinterpret_cast<const u4_t*>(x + (size_t)m * K);
 #pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                const int i = threadIdx.x + it * 256;
-                if (i < k8) stage[r][it] = src[i];
-            }
+            for (int it = 0; it < IT; ++it) stage[r][it] = src[piece[it]];
         }
+    };
+    int m0 = blockIdx.x * R;
+    if (m0 < M) request(m0);
+    for (; m0 < M; m0 += gridDim.x * R) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                const int i = threadIdx.x + it * 256;
-                if (i < k8) reinterpret_cast<u4_t*>(rows + (size_t)r * K)[i] = stage[r][it];
-            }
+            for (int it = 0; it < IT; ++it)
+                if (threadIdx.x + it * 256 < k8) reinterpret_cast<u4_t*>(rows + (size_t)r * K)[piece[it]] = stage[r][it];
+        const int m_next = m0 + gridDim.x * R;
+        if (m_next < M) request(m_next);   // in flight under the gather phase
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int i = threadIdx.x + it * 256;
-            if (i < k8) {
-                const u4_t p0 = *reinterpret_cast<const u4_t*>(perm + 8 * i);
-                const u4_t p1 = *reinterpret_cast<const u4_t*>(perm + 8 * i + 4);
+            if (threadIdx.x + it * 256 < k8) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if (m0 + r < M) {
                         const uint16_t* row = rows + (size_t)r * K;
                         u4_t v;
-                        v.x = (uint32_t)row[p0.x] | ((uint32_t)row[p0.y] << 16);
-                        v.y = (uint32_t)row[p0.z] | ((uint32_t)row[p0.w] << 16);
-                        v.z = (uint32_t)row[p1.x] | ((uint32_t)row[p1.y] << 16);
-                        v.w = (uint32_t)row[p1.z] | ((uint32_t)row[p1.w] << 16);
-                        reinterpret_cast<u4_t*>(out + (size_t)(m0 + r) * K)[i] = v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            v[j] = (uint32_t)lds_u16(row, off[it][j] & 0xffffu) | ((uint32_t)lds_u16(row, off[it][j] >> 16) << 16);
+                        reinterpret_cast<u4_t*>(out + (size_t)(m0 + r) * K)[piece[it]] = v;
                     }
                 }
             }
@@ -392,37 +414,58 @@ template <int ACT, int R, int IT>
 __global__ __launch_bounds__(256) void rmsnorm_gather_kernel(const uint16_t* __restrict__ h, const uint16_t* __restrict__ weight,
                                                              const int32_t* __restrict__ perm, uint16_t* __restrict__ out, int M, int K,
                                                              float eps) {
-    extern __shared__ __attribute__((aligned(16))) uint16_t rows[];  // [R][K] normalised rows, then [K] the norm weight
+    extern __shared__ __attribute__((aligned(16))) uint16_t rows[];  // [R][K] normalised rows
     __shared__ float red[4][R];
-    uint16_t* wl = rows + (size_t)R * K;
     const int k8 = K / 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < k8; i += 256) reinterpret_cast<u4_t*>(wl)[i] = reinterpret_cast<const u4_t*>(weight)[i];
-    for (int m0 = blockIdx.x * R; m0 < M; m0 += gridDim.x * R) {
-        u4_t stage[R][IT];
+    // a thread writes the same output columns in every pass: their source columns (as byte offsets into a staged row, two per
+    // register) and norm weights (raw 16-bit pairs) stay in registers
+    int piece[IT];
+    u4_t off[IT], wv[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int i = threadIdx.x + it * 256;
+        piece[it] = i < k8 ? i : 0;
+        if (perm != nullptr) {
+            const int32_t* pp = perm + 8 * piece[it];
+            off[it] = pack_byte_offsets(pp);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[it][j] = (uint32_t)weight[pp[2 * j]] | ((uint32_t)weight[pp[2 * j + 1]] << 16);
+        } else {
+            wv[it] = reinterpret_cast<const u4_t*>(weight)[piece[it]];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) off[it][j] = (uint32_t)(16 * piece[it] + 4 * j) | ((uint32_t)(16 * piece[it] + 4 * j + 2) << 16);
+        }
+    }
+    u4_t stage[R][IT];
+    auto request = [&](int m0) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int m = m0 + r < M ? m0 + r : M - 1;
-            const u4_t* src = reinterpret_cast<const u4_t*>(h + (size_t)m * K);
+            const u4_t* s = reinterpret_cast<const u4_t*>(h + (size_t)m * K);
 #pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                const int i = threadIdx.x + it * 256;
-                stage[r][it] = i < k8 ? src[i] : u4_t{0u, 0u, 0u, 0u};
-            }
+            for (int it = 0; it < IT; ++it) stage[r][it] = s[piece[it]];
         }
+    };
+    int m0 = blockIdx.x * R;
+    if (m0 < M) request(m0);
+    for (; m0 < M; m0 += gridDim.x * R) {
         // statistics: fp32 sum of squares per row, fixed order (thread pieces, shuffle tree, four waves)
         float ss[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float a = 0.f;
 #pragma unroll
-            for (int it = 0; it < IT; ++it)
+            for (int it = 0; it < IT; ++it) {
+                if (threadIdx.x + it * 256 < k8) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float lo = bits16_to_f32<ACT>((uint16_t)(stage[r][it][j] & 0xffffu)), hi = bits16_to_f32<ACT>((uint16_t)(stage[r][it][j] >> 16));
-                    a = __builtin_fmaf(lo, lo, a);
-                    a = __builtin_fmaf(hi, hi, a);
+                    for (int j = 0; j < 4; ++j) {
+                        const float lo = bits16_to_f32<ACT>((uint16_t)(stage[r][it][j] & 0xffffu)), hi = bits16_to_f32<ACT>((uint16_t)(stage[r][it][j] >> 16));
+                        a = __builtin_fmaf(lo, lo, a);
+                        a = __builtin_fmaf(hi, hi, a);
+                    }
                 }
+            }
 #pragma unroll
             for (int mk = 32; mk >= 1; mk >>= 1) a += __shfl_xor(a, mk, 64);
             ss[r] = a;
@@ -437,36 +480,23 @@ __global__ __launch_bounds__(256) void rmsnorm_gather_kernel(const uint16_t* __r
             const float inv = rsqrtf((red[0][r] + red[1][r] + red[2][r] + red[3][r]) / (float)K + eps);
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                const int i = threadIdx.x + it * 256;
-                if (i < k8) {
+                if (threadIdx.x + it * 256 < k8) {
                     u4_t v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float lo = bits16_to_f32<ACT>((uint16_t)(stage[r][it][j] & 0xffffu)), hi = bits16_to_f32<ACT>((uint16_t)(stage[r][it][j] >> 16));
                         v[j] = (uint32_t)f32_to_16<ACT>(lo * inv) | ((uint32_t)f32_to_16<ACT>(hi * inv) << 16);
                     }
-                    reinterpret_cast<u4_t*>(rows + (size_t)r * K)[i] = v;
+                    reinterpret_cast<u4_t*>(rows + (size_t)r * K)[piece[it]] = v;
                 }
             }
         }
+        const int m_next = m0 + gridDim.x * R;
+        if (m_next < M) request(m_next);   // the next pass's rows land under the gather phase
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int i = threadIdx.x + it * 256;
-            if (i < k8) {
-                int src[8];
-                if (perm != nullptr) {
-                    const u4_t p0 = *reinterpret_cast<const u4_t*>(perm + 8 * i);
-                    const u4_t p1 = *reinterpret_cast<const u4_t*>(perm + 8 * i + 4);
-                    src[0] = p0.x; src[1] = p0.y; src[2] = p0.z; src[3] = p0.w;
-                    src[4] = p1.x; src[5] = p1.y; src[6] = p1.z; src[7] = p1.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) src[e] = 8 * i + e;
-                }
-                float w8[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) w8[e] = bits16_to_f32<ACT>(wl[src[e]]);
+            if (threadIdx.x + it * 256 < k8) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if (m0 + r < M) {
@@ -474,16 +504,16 @@ __global__ __launch_bounds__(256) void rmsnorm_gather_kernel(const uint16_t* __r
                         u4_t v;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float a = w8[2 * j] * bits16_to_f32<ACT>(row[src[2 * j]]);
-                            const float b = w8[2 * j + 1] * bits16_to_f32<ACT>(row[src[2 * j + 1]]);
+                            const float a = bits16_to_f32<ACT>((uint16_t)(wv[it][j] & 0xffffu)) * bits16_to_f32<ACT>(lds_u16(row, off[it][j] & 0xffffu));
+                            const float b = bits16_to_f32<ACT>((uint16_t)(wv[it][j] >> 16)) * bits16_to_f32<ACT>(lds_u16(row, off[it][j] >> 16));
                             v[j] = (uint32_t)f32_to_16<ACT>(a) | ((uint32_t)f32_to_16<ACT>(b) << 16);
                         }
-                        reinterpret_cast<u4_t*>(out + (size_t)(m0 + r) * K)[i] = v;
+                        reinterpret_cast<u4_t*>(out + (size_t)(m0 + r) * K)[piece[it]] = v;
                     }
                 }
             }
         }
-        __syncthreads();
+        __syncthreads();   // (also orders this pass's reads of red[] / rows[] before the next pass's writes)
     }
 }
 
@@ -496,7 +526,7 @@ int launch_rmsnorm_gather(const void* h, const void* weight, const int32_t* perm
     const int r = K <= 8192 ? 4 : 2;      // rows per pass
     const int passes = ceil_div(M, r);
     const dim3 grid(passes < 2048 ? passes : 2048);
-    const size_t lds = (size_t)(r + 1) * K * 2;
+    const size_t lds = (size_t)r * K * 2;
 #define GPTQHIP_RMSG(A_, R_, IT_)                                                                                       \
     do {                                                                                                                  \
         auto kern = rmsnorm_gather_kernel<A_, R_, IT_>;                                                                   \

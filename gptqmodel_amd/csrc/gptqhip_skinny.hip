@@ -1284,11 +1284,23 @@ static int launch_skinny_gpc(const SkinnyParams& p, const SkinnyPlan& pl, hipStr
     const size_t lds_bytes = (size_t)pl.waves * kSlot + 16 + (AM == AM_ROW1P ? (size_t)p.K * 2 + 80 : 64);
     if constexpr ((AM == AM_ROW1 && MT == 1 && (D == 4 || D == 2)) || (AM == AM_ROW1P && MT == 1 && D == 4) || (AM == AM_ROW4 && MT == 1 && D == 4) ||
                   (is_rows<AM>() && MT == 1 && D == 2)) {
-        if (p.in_glue != kGlueNone) {  // decode op with input glue: regular single-group-per-chunk plans only (ABI checks)
+        if (p.in_glue != kGlueNone) {  // decode op with input glue: regular plans only (ABI checks)
+            if (pl.gpc != 1 && AM == AM_ROW1P) {
+                set_error("skinny_kernel: the in-kernel act-order variant needs group_size %% 128 == 0");
+                return -22;
+            }
             if (p.in_glue == kGlueRmsNorm) {
-                hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueRmsNorm>), grid, block, lds_bytes, stream, p);
+                if (pl.gpc == 1) {
+                    hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueRmsNorm>), grid, block, lds_bytes, stream, p);
+                } else if constexpr (AM != AM_ROW1P) {   // group_size 32 / 64: a group constant per K-step
+                    hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 4, AM, D, kGlueRmsNorm>), grid, block, lds_bytes, stream, p);
+                }
             } else if constexpr (AM != AM_ROW4 && !is_rows<AM>()) {
-                hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueSiluMul>), grid, block, lds_bytes, stream, p);
+                if (pl.gpc == 1) {
+                    hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 1, AM, D, kGlueSiluMul>), grid, block, lds_bytes, stream, p);
+                } else if constexpr (AM != AM_ROW1P) {
+                    hipLaunchKernelGGL((skinny_kernel<BITS, ACT, SCL, MT, 4, AM, D, kGlueSiluMul>), grid, block, lds_bytes, stream, p);
+                }
             } else {
                 set_error("decode op: SiLU*mul INPUT glue exists for one row only (use the paired gate_up epilogue)");
                 return -22;   // GPTQHIP_EINVAL (the ABI layer rejects this combination before it gets here)

@@ -370,6 +370,24 @@ def make_hip_classes(ns, module_name: str):
                 out = out.to(in_dtype)
             return out.reshape(out_shape)
 
+        def forward_pregathered(self, x: torch.Tensor) -> torch.Tensor:
+            """Same contract as HipGptqLinear.forward_pregathered.  AWQ has no act-order permutation, so this is forward()
+            minus the adapter hook; it exists so that the prefill path of utils.hf_llama (ops.rmsnorm_gather feeding the
+            GEMM directly) serves AWQ models as well."""
+            if not self._ready:
+                raise RuntimeError("HipAwqLinear.forward_pregathered called before post_init()")
+            if self.adapter:
+                raise NotImplementedError("forward_pregathered: adapters are applied by forward()")
+            from gptqmodel_amd import ops
+            out_shape = x.shape[:-1] + (self.out_features,)
+            x2, in_dtype = flatten_input(x, self.in_features)
+            meta, bias = self._runtime(x2.dtype)
+            out = ops.gemm(x2, self.qweight, meta, bias, None, self.out_features, self.group_size, self.bits, x2.dtype,
+                           exact_bf16=self.EXACT_BF16_DECODE)
+            if out.dtype != in_dtype:
+                out = out.to(in_dtype)
+            return out.reshape(out_shape)
+
         def forward_partial(self, x: torch.Tensor) -> torch.Tensor:
             """float32 [.., N] unrounded accumulators without bias (row-parallel tensor-parallel shards all-reduce these
             before the single final rounding, gptqmodel_amd/utils/tp.py) -- same contract as HipGptqLinear."""

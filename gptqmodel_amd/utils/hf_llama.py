@@ -48,7 +48,10 @@ from .model import (FusedSiblingView, _FusedGroup, fold_act_order_into_producers
 
 
 def _is_quant(m) -> bool:
-    return isinstance(m, BaseQuantLinear) and getattr(m, "adapter", None) is None
+    # the fast paths call the kernels directly (not module.forward): modules whose forward does more than the GEMM -- an adapter,
+    # an online Hadamard rotation of the input (qlinear/__init__.py:134-135) -- keep HF's own layer code
+    return (isinstance(m, BaseQuantLinear) and getattr(m, "adapter", None) is None
+            and not getattr(m, "online_full_had", False) and not getattr(m, "online_partial_had", False))
 
 
 MAX_ROWS = 16   # tokens per call on the fast path (gptqhip_decode_op.M): a few sequences at q_len 1, or speculative tokens of one
@@ -416,8 +419,8 @@ def fuse_llama_decoder_layers(model: nn.Module, allow_unknown: bool = False) -> 
                                 "sliding_window": type(attn).__name__ != "LlamaAttention" and (
                                     hasattr(attn, "sliding_window") or hasattr(attn.config, "sliding_window")),
                                 "qk_norm": qk_norm, "interfaces": ALL_ATTENTION_FUNCTIONS,
-                                # prefill path (ops.rmsnorm_gather + forward_pregathered): GPTQ modules only (AWQ has no
-                                # forward_pregathered: no act-order there) and hidden sizes the norm kernel stages in LDS
+                                # prefill path (ops.rmsnorm_gather + forward_pregathered; GPTQ and AWQ modules both have
+                                # it) for hidden sizes the norm kernel stages in LDS
                                 # (GPTQHIP_HF_PREFILL=0: A/B switch, keeps HF's own layer code for prefill)
                                 "prefill": ({} if hasattr(qkv, "forward_pregathered") and hasattr(gu, "forward_pregathered")
                                             and in_f % 8 == 0 and in_f <= 16384 and os.environ.get("GPTQHIP_HF_PREFILL", "1") != "0"

@@ -139,8 +139,9 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight_t, const uint32_t* meta,
  *            row itself (first op of a step, whose input comes from outside the chain)
  * The glue is applied to each ring stage's activation pair on its way into the MFMA A fragment (RMSNorm statistics are
  * reduced once per block while the first weight loads are in flight).  Stream-ordered like every other entry point.
- * Supported: shapes on the decode kernel's regular pipeline (K % 128 == 0, group_size = 128 * 2^n, a wave count dividing
- * K / 128 evenly -- every Llama-3 8B / 70B shape, also tensor-parallel shards), bits 4 | 8, no act-order permutation;
+ * Supported: shapes on the decode kernel's regular pipeline (K % 128 == 0, group_size = 128 * 2^n or 32 | 64, a wave count
+ * dividing K / 128 evenly -- every Llama-3 8B / 70B shape, also tensor-parallel shards), bits 4 | 8; an act-order permutation
+ * (`perm`, applied to the glued row inside the kernel) for M = 1 and group_size % 128 == 0 only;
  * gptqhip_decode_supported() tells, anything else returns GPTQHIP_EINVAL -- use gptqhip_gemm (+ separate glue) there.
  * workspace: as gptqhip_gemm (gptqhip_workspace_bytes(1, K, N, ...)); only narrow layers (cross-block split-K) touch it.
  * The glue replaces no reference interface: it mirrors what the reference's caller (HF LlamaDecoderLayer) does between

@@ -61,12 +61,16 @@ def test_size_helpers(lib):
 def test_decode_op_shape_predicate_is_host_logic(lib):
     """gptqhip_decode_supported is the planner's predicate (no GPU): every layer shape of the BASELINE models, and the common
     checkpoint shapes whose K / 128 has no waves x ring-depth factorisation (padded last ring round), are on the decode op's
-    pipeline; sub-128 groups and ragged K are not (they take gptqhip_gemm's general path)."""
+    pipeline; ragged K is not (it takes gptqhip_gemm's general path)."""
     yes = [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096), (8192, 10240), (8192, 8192), (8192, 57344), (28672, 8192),
            (11008, 4096), (4096, 22016), (18944, 3584), (3584, 37888), (5120, 27648), (13824, 5120), (1536, 8960), (8960, 1536)]
     for K, N in yes:
         assert lib.gptqhip_decode_supported(K, N, 128, 0, 1) == 1, (K, N)
-    assert lib.gptqhip_decode_supported(4096, 4096, 64, 0, 1) == 0      # four constants per 128-row chunk: general kernel
+    # group_size 32 / 64 (a constant per 32-row K-step): on the pipeline since round 3, without the in-kernel permutation
+    for gs in (32, 64):
+        assert all(lib.gptqhip_decode_supported(K, N, gs, 0, M) == 1 for K, N in yes[:4] for M in (1, 4, 16)), gs
+        assert lib.gptqhip_decode_supported(4096, 4096, gs, 1, 1) == 0
+    assert lib.gptqhip_decode_supported(4096, 4096, 16, 0, 1) == 0      # not a supported group size at all
     assert lib.gptqhip_decode_supported(4000, 4096, 32, 0, 1) == 0      # K % 128 != 0
     assert lib.gptqhip_decode_supported(4096, 4096, 4096, 0, 1) == 1    # one group for the whole K (group_size = -1 checkpoints)
     assert lib.gptqhip_decode_supported(14336, 4096, 14336, 0, 1) == 1

@@ -141,16 +141,14 @@ def test_decode_op_act_order_in_kernel_perm_with_glue(ops, act):
         ops.decode_linear(torch.zeros(K, dtype=TDT[act], device=DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, perm=perm)
 
 
-@pytest.mark.parametrize("M", [2, 3, 4, 5, 7, 8, 9, 12, 13, 16])
-@pytest.mark.parametrize("act", ["fp16", "bf16"])
-def test_decode_op_rows_2_to_16(ops, M, act):
-    """The decode op on up to sixteen rows (a few sequences, or speculative tokens of one): per-row RMSNorm statistics (from the
-    producer and reduced in the kernel), per-row residual + stats_out, the paired SiLU*mul epilogue, bias, cross-block split-K
-    and a padded plan -- each against the oracle composed with HF's glue formulas, row by row."""
-    gs, bits = 128, 4
+_ROWS_SHAPES = ((4096, 6144, True, False), (4096, 4096, False, False), (4096, 512, True, False), (11008, 1024, False, False),
+                (4096, 2048, True, True))
+
+
+def _check_decode_rows(ops, M, act, gs, shapes=_ROWS_SHAPES):
+    bits = 4
     rng = np.random.RandomState(31 + M)
-    for K, N, with_stats, paired in ((4096, 6144, True, False), (4096, 4096, False, False), (4096, 512, True, False),
-                                     (11008, 1024, False, False), (4096, 2048, True, True)):
+    for K, N, with_stats, paired in shapes:
         qweight, qzeros, scales, g_idx = synth_gptq(700 + K // 128 + N // 16, bits, K, N, gs)
         if paired:   # interleave gate|up columns in blocks of 8 (what fuse_gate_up_interleaved stores)
             inter = N // 2
@@ -175,7 +173,7 @@ def test_decode_op_rows_2_to_16(ops, M, act):
         if paired:
             out = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, in_glue=ops.GLUE_RMSNORM,
                                     norm_weight=f32_to_torch(w, act, DEV), eps=1e-5, stats_in=st_in,
-                                    out_glue=ops.OUT_SILU_MUL_PAIRED, M=M)
+                                    out_glue=ops.OUT_SILU_MUL_PAIRED, M=M).reshape(M, -1)
             ref = np.stack([O.silu_mul_ref(y[m, :inter], y[m, inter:], act) for m in range(M)])
             assert out.shape == (M, inter)
             assert_forward_close(torch_to_f32(out), ref, act, tag=(K, N, M, "paired"))
@@ -183,7 +181,7 @@ def test_decode_op_rows_2_to_16(ops, M, act):
             st_out = torch.zeros((M, -(-N // 16)), dtype=torch.float32, device=DEV)
             out = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, f32_to_torch(bias, act, DEV), K, N, gs, bits, sc.dtype,
                                     in_glue=ops.GLUE_RMSNORM, norm_weight=f32_to_torch(w, act, DEV), eps=1e-5,
-                                    residual=f32_to_torch(res, act, DEV), stats_in=st_in, stats_out=st_out, M=M)
+                                    residual=f32_to_torch(res, act, DEV), stats_in=st_in, stats_out=st_out, M=M).reshape(M, -1)
             ref = O.residual_add_ref(res, y, act)
             got = torch_to_f32(out)
             assert_forward_close(got, ref, act, tag=(K, N, M, with_stats))
@@ -191,9 +189,32 @@ def test_decode_op_rows_2_to_16(ops, M, act):
             # no glue at all == the plugin path's kernel on the same rows
             plain = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, M=M)
             gen = ops.gemm(f32_to_torch(h, act, DEV), qw_t, meta, None, None, N, gs, bits, sc.dtype)
-            assert torch.equal(plain, gen)
+            assert torch.equal(plain.reshape(M, -1), gen)
+    return qw_t, meta, sc
+
+
+@pytest.mark.parametrize("M", [2, 3, 4, 5, 7, 8, 9, 12, 13, 16])
+@pytest.mark.parametrize("act", ["fp16", "bf16"])
+def test_decode_op_rows_2_to_16(ops, M, act):
+    """The decode op on up to sixteen rows (a few sequences, or speculative tokens of one): per-row RMSNorm statistics (from the
+    producer and reduced in the kernel), per-row residual + stats_out, the paired SiLU*mul epilogue, bias, cross-block split-K
+    and a padded plan -- each against the oracle composed with HF's glue formulas, row by row."""
+    qw_t, meta, sc = _check_decode_rows(ops, M, act, 128)
     with pytest.raises(RuntimeError, match="1..16"):
-        ops.decode_linear(torch.zeros((17, 4096), dtype=TDT[act], device=DEV), qw_t, meta, None, 4096, 2048, gs, bits, sc.dtype, M=17)
+        ops.decode_linear(torch.zeros((17, 4096), dtype=TDT[act], device=DEV), qw_t, meta, None, 4096, 2048, 128, 4, sc.dtype, M=17)
+
+
+@pytest.mark.parametrize("gs", [32, 64])
+@pytest.mark.parametrize("M", [1, 3, 8, 16])
+@pytest.mark.parametrize("act", ["fp16", "bf16"])
+def test_decode_op_with_glue_group_size_32_64(ops, M, act, gs):
+    """group_size 32 / 64 (a group constant per 32-row K-step instead of one per 128-row chunk) through the decode op with all of
+    its glue: same oracle composition as the 128-group test (round 3: the glue variants used to exist for group_size % 128 == 0 only,
+    so a 32g / 64g checkpoint fell back to per-module launches + torch glue)."""
+    assert ops.decode_supported(4096, 6144, gs, False, M)
+    assert not ops.decode_supported(4096, 6144, gs, True, 1)      # the in-kernel permutation needs one group constant per chunk
+    _check_decode_rows(ops, M, act, gs, shapes=((4096, 6144, True, False), (4096, 4096, False, False), (4096, 2048, True, True),
+                                                 (11008, 1024, False, False)))
 
 
 def test_decode_op_rejects_unsupported_shapes(ops):

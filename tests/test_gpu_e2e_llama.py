@@ -35,7 +35,7 @@ def _get(model, name):
     return mod
 
 
-def _build(desc_act: bool, fuse, dtype, family="llama"):
+def _build(desc_act: bool, fuse, dtype, family="llama", gs=128):
     from transformers import LlamaConfig, LlamaForCausalLM
     from gptqmodel_amd import ops
     from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
@@ -70,7 +70,7 @@ def _build(desc_act: bool, fuse, dtype, family="llama"):
     quant = copy.deepcopy(dense)
     names = [n for n, m in dense.named_modules() if isinstance(m, nn.Linear) and ".layers." in n]
     assert len(names) == 14
-    gs, bits = 128, 4
+    bits = 4
     make_quant(quant, names, bits=bits, group_size=gs, desc_act=desc_act, sym=False, backend=BACKEND.AUTO,
                format=FORMAT.GPTQ, dtype=dtype)
     for name in names:
@@ -183,6 +183,29 @@ def test_llama_decoder_layers_on_decode_ops_match_dense(desc_act, dtype, family)
     assert out.shape == (1, 14)
 
 
+def test_llama_decoder_layers_group_size_32_take_the_decode_ops():
+    """A 32g checkpoint (a group constant per K-step) on the fused decoder layers: prefill path + decode ops, as for 128g."""
+    dense, quant = _build(False, "layers", torch.float16, gs=32)
+    torch.manual_seed(17)
+    ids = torch.randint(0, 2048, (1, 20), device="cuda")
+    with torch.no_grad():
+        o_d, o_q = dense(input_ids=ids, use_cache=True), quant(input_ids=ids, use_cache=True)
+        assert rel_err(o_q.logits.float().cpu().numpy(), o_d.logits.float().cpu().numpy()) < 2e-2
+        pk_d, pk_q = o_d.past_key_values, o_q.past_key_values
+        tok = o_d.logits[:, -1].argmax(-1, keepdim=True)
+        for _ in range(4):
+            s_d = dense(input_ids=tok, past_key_values=pk_d, use_cache=True)
+            s_q = quant(input_ids=tok, past_key_values=pk_q, use_cache=True)
+            assert rel_err(s_q.logits.float().cpu().numpy(), s_d.logits.float().cpu().numpy()) < 2e-2
+            pk_d, pk_q = s_d.past_key_values, s_q.past_key_values
+            tok = s_d.logits[:, -1].argmax(-1, keepdim=True)
+        ids6 = torch.randint(0, 2048, (2, 3), device="cuda")
+        assert rel_err(quant(input_ids=ids6).logits.float().cpu().numpy(), dense(input_ids=ids6).logits.float().cpu().numpy()) < 2e-2
+    states = [L._gptqhip_fused["state"] for L in quant.model.layers]
+    assert all(st is not None and 1 in st.ops and 6 in st.ops for st in states)
+    assert not any(L._gptqhip_fused["disabled"] for L in quant.model.layers)
+
+
 def test_llama_generate_runs_on_quantised_model():
     dense, quant = _build(False, True, torch.float16)
     ids = torch.randint(0, 2048, (1, 8), device="cuda")
@@ -282,3 +305,61 @@ def test_mistral_fast_paths_hand_the_sliding_window_to_the_attention_interface()
             assert [w for _, w in seen] == [64] * 4 and [n for n, _ in seen] == [20, 20, 1, 1], seen
     assert all(L._gptqhip_fused["state"] is not None and L._gptqhip_fused["prefill"].get("dtype") == torch.float16
                for L in quant.model.layers), "the fast paths must have run"
+
+
+def test_awq_llama_decoder_layers_prefill_and_decode_match_dense():
+    """An AWQ (gemm format) model through the same two fast paths: the prefill path (ops.rmsnorm_gather feeding
+    HipAwqLinear.forward_pregathered) and the decode ops, against the dense model holding the AWQ-dequantised weights
+    (packing_utils.py:106-121: (code - zero) * scale, rounded once)."""
+    import numpy as np
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from oracle import gptq_oracle as O
+    from gptqmodel_amd.nn_modules.qlinear.hip_awq import HipAwqLinear
+    from gptqmodel_amd.utils.backend import BACKEND
+    from gptqmodel_amd.utils.const import FORMAT, METHOD
+    from gptqmodel_amd.utils.hf_llama import fuse_llama_decoder_layers
+    from gptqmodel_amd.utils.model import gptqmodel_post_init, make_quant
+
+    torch.manual_seed(5)
+    dtype, gs = torch.float16, 128
+    dense = LlamaForCausalLM(LlamaConfig(num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2, vocab_size=2048,
+                                         max_position_embeddings=128, tie_word_embeddings=False, hidden_size=2048,
+                                         intermediate_size=5632)).to(dtype).cuda().eval()
+    quant = copy.deepcopy(dense)
+    names = [n for n, m in dense.named_modules() if isinstance(m, nn.Linear) and ".layers." in n]
+    make_quant(quant, names, bits=4, group_size=gs, desc_act=False, sym=False, backend=BACKEND.AUTO, format=FORMAT.GEMM,
+               quant_method=METHOD.AWQ, dtype=dtype)
+    for name in names:
+        lin, qm = _get(dense, name), _get(quant, name)
+        assert isinstance(qm, HipAwqLinear)
+        scales, zeros = _rtn(lin.weight.data, gs, 4)                                   # [N, G]
+        n, k = lin.weight.shape
+        w = lin.weight.data.float().reshape(n, k // gs, gs)
+        codes = torch.clamp(torch.round(w / scales[:, :, None]) + zeros[:, :, None], 0, 15).reshape(n, k)
+        qm.qweight.data = torch.from_numpy(O.pack_awq_cols(codes.T.contiguous().cpu().numpy().astype(np.uint8))).cuda()
+        qm.qzeros.data = torch.from_numpy(O.pack_awq_cols(zeros.T.contiguous().cpu().numpy().astype(np.uint8))).cuda()
+        qm.scales.data = scales.T.contiguous().to(dtype).cuda()
+        deq = ((codes.reshape(n, k // gs, gs) - zeros[:, :, None]) * scales[:, :, None].half().float()).reshape(n, k)
+        lin.weight.data.copy_(deq.to(dtype))
+    quant = quant.cuda()
+    fused, skipped = fuse_llama_decoder_layers(quant)
+    assert len(fused) == 2 and not skipped, skipped
+    gptqmodel_post_init(quant)
+    tol = 2e-2
+    ids = torch.randint(0, 2048, (1, 20), device="cuda")
+    with torch.no_grad():
+        o_d, o_q = dense(input_ids=ids, use_cache=True), quant(input_ids=ids, use_cache=True)
+        assert rel_err(o_q.logits.float().cpu().numpy(), o_d.logits.float().cpu().numpy()) < tol
+        assert all(L._gptqhip_fused["prefill"].get("dtype") == dtype for L in quant.model.layers)    # the prefill path ran
+        pk_d, pk_q = o_d.past_key_values, o_q.past_key_values
+        tok = o_d.logits[:, -1].argmax(-1, keepdim=True)
+        for _ in range(4):
+            s_d = dense(input_ids=tok, past_key_values=pk_d, use_cache=True)
+            s_q = quant(input_ids=tok, past_key_values=pk_q, use_cache=True)
+            assert rel_err(s_q.logits.float().cpu().numpy(), s_d.logits.float().cpu().numpy()) < tol
+            pk_d, pk_q = s_d.past_key_values, s_q.past_key_values
+            tok = s_d.logits[:, -1].argmax(-1, keepdim=True)
+        ids8 = torch.randint(0, 2048, (2, 4), device="cuda")
+        assert rel_err(quant(input_ids=ids8).logits.float().cpu().numpy(), dense(input_ids=ids8).logits.float().cpu().numpy()) < tol
+    states = [L._gptqhip_fused["state"] for L in quant.model.layers]
+    assert all(st is not None and 1 in st.ops and 8 in st.ops for st in states)
