@@ -9,31 +9,44 @@ int launch_tiled_w4(const TiledParams& p, int act_dtype, int scale_dtype, int gp
 }
 
 // Sum the split-K slabs in a fixed order (deterministic), then the reference's rounding chain.  One thread per 4
-// consecutive columns (16-byte slab loads).
-template <int ACT>
+// consecutive columns (16-byte slab loads).  SP > 0: the split count is a compile-time constant and all slab loads (and the
+// bias) are requested before the first addition; SP == 0: any split count, eight loads in flight.  The additions stay in slab
+// order either way.  The kernel takes 4.5-4.8 us for 2..8 slabs of a 128 x 4096 output whatever the load order (measured both
+// ways, profiles/r03_midm_trace.txt): it is bound by reading slabs that the producing blocks on OTHER XCDs wrote (the L2s are
+// per XCD and written back at the kernel boundary), i.e. 17 MB through the memory side at ~4 TB/s, not by latency.
+template <int ACT, int SP>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, const void* __restrict__ bias,
                                                             void* __restrict__ out, int M, int N, int ldo, int splits, int out_f32) {
     const size_t quads = (size_t)M * N / 4;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= quads) return;
     const size_t stride = (size_t)M * N;
-    // loads four slabs ahead (independent 16-byte loads in flight), additions stay in slab order
     const float* src = slabs + 4 * i;
-    f4_t s = *reinterpret_cast<const f4_t*>(src);
-    int sp = 1;
-    for (; sp + 4 <= splits; sp += 4) {
-        const f4_t a = *reinterpret_cast<const f4_t*>(src + (size_t)sp * stride);
-        const f4_t b = *reinterpret_cast<const f4_t*>(src + (size_t)(sp + 1) * stride);
-        const f4_t c = *reinterpret_cast<const f4_t*>(src + (size_t)(sp + 2) * stride);
-        const f4_t d = *reinterpret_cast<const f4_t*>(src + (size_t)(sp + 3) * stride);
-        s += a;
-        s += b;
-        s += c;
-        s += d;
+    const int row = (int)((4 * i) / (size_t)N);
+    const int n = (int)(4 * i - (size_t)row * N);
+    const size_t o = (size_t)row * (size_t)ldo + n;  // N % 4 == 0: the quad stays inside one row
+    u2_t bq = {0u, 0u};
+    if (bias != nullptr && !out_f32) bq = *reinterpret_cast<const u2_t*>(reinterpret_cast<const uint16_t*>(bias) + n);
+    f4_t s;
+    if constexpr (SP > 0) {
+        f4_t v[SP];
+#pragma unroll
+        for (int sp = 0; sp < SP; ++sp) v[sp] = *reinterpret_cast<const f4_t*>(src + (size_t)sp * stride);
+        s = v[0];
+#pragma unroll
+        for (int sp = 1; sp < SP; ++sp) s += v[sp];
+    } else {
+        s = *reinterpret_cast<const f4_t*>(src);
+        int sp = 1;
+        for (; sp + 8 <= splits; sp += 8) {
+            f4_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f4_t*>(src + (size_t)(sp + j) * stride);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; sp < splits; ++sp) s += *reinterpret_cast<const f4_t*>(src + (size_t)sp * stride);
     }
-    for (; sp < splits; ++sp) s += *reinterpret_cast<const f4_t*>(src + (size_t)sp * stride);
-    const int n = (int)((4 * i) % N);
-    const size_t o = (4 * i) / N * (size_t)ldo + n;  // N % 4 == 0: the quad stays inside one row
     if (out_f32) {
         *reinterpret_cast<f4_t*>(reinterpret_cast<float*>(out) + o) = s;
         return;
@@ -42,7 +55,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float y = round_through<ACT>(s[j]);
-        if (bias != nullptr) y = y + load16_as_f32<ACT>(bias, (size_t)n + j);
+        if (bias != nullptr) y = y + bits16_to_f32<ACT>((uint16_t)((j < 2 ? bq.x : bq.y) >> (16 * (j & 1))));
         r[j] = f32_to_16<ACT>(y);
     }
     u2_t ov;
@@ -149,11 +162,26 @@ int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, hipStream
     if (rc_main != 0 || pl.splits <= 1) return rc_main;
     const size_t quads = (size_t)a.M * a.N / 4;
     const dim3 grid((unsigned)((quads + 255) / 256));
-    if (a.act_dtype == kFP16) {
-        hipLaunchKernelGGL(splitk_reduce_kernel<kFP16>, grid, dim3(256), 0, stream, slabs, a.bias, a.out, a.M, a.N, p.ldo, pl.splits, a.out_f32);
-    } else {
-        hipLaunchKernelGGL(splitk_reduce_kernel<kBF16>, grid, dim3(256), 0, stream, slabs, a.bias, a.out, a.M, a.N, p.ldo, pl.splits, a.out_f32);
+#define GPTQHIP_REDUCE(SP_)                                                                                                          \
+    do {                                                                                                                              \
+        if (a.act_dtype == kFP16)                                                                                                     \
+            hipLaunchKernelGGL((splitk_reduce_kernel<kFP16, SP_>), grid, dim3(256), 0, stream, slabs, a.bias, a.out, a.M, a.N, p.ldo, \
+                               pl.splits, a.out_f32);                                                                                 \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((splitk_reduce_kernel<kBF16, SP_>), grid, dim3(256), 0, stream, slabs, a.bias, a.out, a.M, a.N, p.ldo, \
+                               pl.splits, a.out_f32);                                                                                 \
+    } while (0)
+    switch (pl.splits) {
+        case 2: GPTQHIP_REDUCE(2); break;
+        case 3: GPTQHIP_REDUCE(3); break;
+        case 4: GPTQHIP_REDUCE(4); break;
+        case 5: GPTQHIP_REDUCE(5); break;
+        case 6: GPTQHIP_REDUCE(6); break;
+        case 7: GPTQHIP_REDUCE(7); break;
+        case 8: GPTQHIP_REDUCE(8); break;
+        default: GPTQHIP_REDUCE(0); break;
     }
+#undef GPTQHIP_REDUCE
     return check_hip(hipGetLastError(), "splitk_reduce_kernel launch");
 }
 

@@ -306,6 +306,11 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         constexpr int PF = BM == 128 ? 8 : 4;  // measured: deeper spills at BM=256, helps at BM=128; 64-row tiles: MT = 4
         constexpr int NG = 4 * MT / PF;        // fragment groups per chunk
         constexpr int NPIECE = BM * 16 / NT;
+#ifdef GPTQHIP_TILED_INTERLEAVE
+        constexpr int kInterleaveValu = GPTQHIP_TILED_INTERLEAVE;   // dev A/B builds
+#else
+        constexpr int kInterleaveValu = BM == 64 ? 4 : 0;
+#endif
         static_assert(NPIECE <= NG, "one DMA piece per fragment group");
         u4_t abuf[2][PF];
 
@@ -347,7 +352,11 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
                 }
             }
             lds_wait<(g + 1 < NG) ? PF : 0, PF>(abuf[g & 1]);
-            __builtin_amdgcn_s_setprio(1);
+            // 64-row tiles: the next K-step's dequant VALU (26 per 8 MFMAs there) is interleaved with this group's MFMAs instead of
+            // running as one block in front of them (s_setprio is a scheduling boundary for hipcc, so such a group goes without it).
+            // Measured (round 3, profiles/r03_tiled_ablation.txt): 4096x28672 at M=128 45 -> 41 us; no gain on 128- / 256-row tiles.
+            constexpr bool kInterleaved = kInterleaveValu > 0 && (g * PF) % MT == 0 && (j < 3 || kNext);
+            if constexpr (!kInterleaved) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int mt = (g * PF + i) % MT;
@@ -360,7 +369,13 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
                     }
                 }
             }
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr (kInterleaved) {
+                static_for<PF * TPW>([&](auto) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA ...
+                    __builtin_amdgcn_sched_group_barrier(0x002, kInterleaveValu, 0);   // ... then up to kInterleaveValu VALU
+                });
+            }
+            if constexpr (!kInterleaved) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (last_of_step && (j < 3 || kNext)) {
 #pragma unroll
