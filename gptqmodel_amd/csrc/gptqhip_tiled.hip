@@ -64,6 +64,33 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *reinterpret_cast<u2_t*>(reinterpret_cast<uint16_t*>(out) + o) = ov;
 }
 
+// Launch model of the prefill kernel for grids of at most one round of 256-row tiles, microseconds (main kernel + split-K reduce):
+//   main = a + b f + r cps (c + d f)      f = share of the 256 CUs with a block, cps = 128-row chunks per block, r = rounds of the
+//                                          persistent tile loop (a partial last round counts 0.75 + 0.25 rem/256: it clocks higher)
+//   reduce = max(4.6, 1.5 + slab bytes / 6.2 TB/s)
+// a..d per tile height, least squares over 926 timed (shape, M, tile height, split) points on one MI355X (tests/dev/tiled_plan_check.py,
+// tiled_model_check.py; 10 layer shapes of Llama-2/3 7B..70B, M = 96..2048): mean error 3 %, 90th percentile 6 %.  It only has to RANK
+// the candidates; measured against the round-2 rules on the same box it wins 5-32 % on 50 of 160 points and loses > 4 % on 3.
+static double tiled_cost_us(int M, int K, int N, int bm, int s) {
+    static const double kCoef[3][4] = {{0.524, 6.140, 0.971, 0.139}, {2.563, 6.964, 1.254, 0.473}, {8.431, 4.717, 1.899, 1.208}};
+    const double* co = kCoef[bm == 64 ? 0 : bm == 128 ? 1 : 2];
+    const int chunks = ceil_div(K, kChunkK), cps = ceil_div(chunks, s), s_eff = ceil_div(chunks, cps);
+    const long tiles = (long)ceil_div(N, kTiledBN) * ceil_div(M, bm), blocks = tiles * s_eff;
+    double r, f;
+    if (s_eff == 1) {
+        const long full = tiles / 256, rem = tiles % 256;
+        r = (double)full + (rem ? 0.75 + 0.25 * (double)rem / 256.0 : 0.0);
+        f = full >= 1 ? 1.0 : (double)rem / 256.0;
+    } else {
+        r = blocks <= 256 ? 1.0 : (double)blocks / 256.0;
+        f = blocks <= 256 ? (double)blocks / 256.0 : 1.0;
+    }
+    const double main_us = co[0] + co[1] * f + r * cps * (co[2] + co[3] * f);
+    const double slab_mb = (double)s_eff * M * N * 4.0 / 1e6;
+    const double reduce_us = s_eff > 1 ? (slab_mb / 6.2 + 1.5 > 4.6 ? slab_mb / 6.2 + 1.5 : 4.6) : 0.0;
+    return main_us + reduce_us;
+}
+
 TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_variant, int force_split) {
     TiledPlan pl;
     pl.gpc = (group_size % kChunkK == 0) ? 1 : 4;
@@ -120,6 +147,27 @@ TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_va
         if (s < 1) s = 1;
     }
     if (force_split > 0) s = force_split < chunks ? force_split : chunks;
+    if (force_variant == 0 && force_split == 0 && blocks256 <= cus) {
+        // at most ONE round of 256-row tiles (serving batches, short prefills, K-heavy layers): tile height and split factor together
+        // from the measured launch model below instead of the two rules above -- those picked 128-row tiles + 5 splits where 64-row
+        // tiles + 3 are 15-20 % faster (4096x6144 at M=160..320), never combined 256-row tiles with split-K (14336x4096 at M=1280:
+        // 174 -> 137 us, 8192x10240 at M=448: 101 -> 89) and kept 64-row tiles on very wide layers (8192x57344 at M<=128: 148 -> 113 us).
+        double best = 1e30;
+        for (int bm : {64, 128, 256}) {
+            if (bm == 64 && M > 1024) continue;
+            const long tiles = (long)nbx * ceil_div(M, bm);
+            for (int sc = 1; sc <= 16; ++sc) {
+                if (sc > 1 && (sc > chunks / 4 || tiles * sc > cus || (size_t)sc * M * N > ((size_t)16 << 20))) break;
+                const double t = tiled_cost_us(M, K, N, bm, sc);
+                if (t < best) {
+                    best = t;
+                    pl.bm = bm;
+                    s = sc;
+                }
+            }
+        }
+        pl.tail_cols = 0;
+    }
     pl.chunks_per_split = ceil_div(chunks, s);
     pl.splits = ceil_div(chunks, pl.chunks_per_split);
     pl.slab_floats = pl.splits > 1 ? (size_t)pl.splits * M * N : 0;

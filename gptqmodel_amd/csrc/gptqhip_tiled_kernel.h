@@ -27,7 +27,7 @@
 #include <utility>
 
 #ifndef GPTQHIP_TILED_D64   // pipeline stages of the 64-row-tile instantiations (dev A/B builds override it)
-#define GPTQHIP_TILED_D64 3
+#define GPTQHIP_TILED_D64 2
 #endif
 
 namespace gptqhip {
@@ -541,10 +541,12 @@ inline int launch_tiled_out(const TiledParams& p, int bm, hipStream_t stream) {
         }
     }
     if (bm == 64) {  // M <= 64: half the MFMA work and staging of a 128-row tile
-        // 3 stages.  Round 3 tried 5 (four 16 KiB weight chunks in flight per CU instead of two, on the theory that a block with so
-        // little MFMA work per chunk is bound by its bytes in flight: 2.3 TB/s on gate_up at M = 32) -- measured 5-8 % SLOWER on every
-        // shape from M = 17 to 256 (profiles/r03_tiled_stages_64row.txt): the small-M floor of this kernel is not a latency-hiding
-        // problem.  The waits are generalised to any depth (vm_wait) and the depth is one macro, so the experiment is one -D away.
+        // 2 stages.  Same-box A/B of 2 / 3 / 4 / 5 stages (round 3, profiles/r03_tiled_stages_64row.txt): the 64-row tile only runs where
+        // blocks are short (split-K: 4..14 chunks each) or the grid is one round of a wide layer, and there every extra stage is a
+        // longer prologue burst that never pays back -- 4096^2 at M=128 15.5 / 16.6 / 17.6 / 17.9 us, 14336x4096 27.2 / 28.2 / 28.5 / 28.9,
+        // gate_up at M=128 equal (40.7 / 40.6 / 41.4 / 43.0).  (Five stages were tried first on the theory that a block with so little
+        // MFMA work per chunk is bound by its bytes in flight: it is not.)  The waits are generalised to any depth (vm_wait) and the
+        // depth is one macro, so the experiment is one -D away.
         constexpr int D64 = BITS == 4 ? kTiledD64 : 2;
         hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 64, 8, D64, OUTF>), grid, dim3(512), 0, stream, p);
         return check_hip(hipGetLastError(), "tiled_kernel launch");
@@ -556,7 +558,10 @@ inline int launch_tiled_out(const TiledParams& p, int bm, hipStream_t stream) {
     // (a 4-wave x 4-tile variant with two independent blocks per CU was measured 25-30 % slower: 660 vs 950 TF)
     // 3 stages in flight (measured on 128-row tiles, M=2048 4096^2: 951 / 1061 / 984 TF for 2 / 3 / 4 stages -- the
     // fourth only lengthens the start-up burst); the 8-bit register stages are twice as large: 2 stages there
-    hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 128, 8, BITS == 4 ? 3 : 2, OUTF>), grid, dim3(512), 0, stream, p);
+#ifndef GPTQHIP_TILED_D128
+#define GPTQHIP_TILED_D128 3
+#endif
+    hipLaunchKernelGGL((tiled_kernel<BITS, ACT, SCL, GPC, 128, 8, BITS == 4 ? GPTQHIP_TILED_D128 : 2, OUTF>), grid, dim3(512), 0, stream, p);
     return check_hip(hipGetLastError(), "tiled_kernel launch");
 }
 

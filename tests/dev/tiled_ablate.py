@@ -15,6 +15,8 @@ from gptqmodel_amd import ops  # noqa: E402
 dev = "cuda"
 CASES = [(8192, 4096, 4096, 0, 0), (2048, 4096, 4096, 0, 0), (128, 4096, 28672, 0, 0), (128, 4096, 4096, 3, 1), (128, 4096, 4096, 0, 0),
          (512, 4096, 28672, 0, 0), (65536, 4096, 4096, 0, 0)]
+if os.environ.get("ABLATE_CASES") == "midm2":     # 128-row tiles with and without split-K
+    CASES = [(M, K, N, 0, 0) for (K, N) in ((4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096)) for M in (384, 512, 1024, 2048)]
 if os.environ.get("ABLATE_CASES") == "midm":      # planner's choice at serving-batch sizes (same-box A/B of two builds: r3_call_ab.sh)
     CASES = [(M, K, N, 0, 0) for (K, N) in ((4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096)) for M in (96, 128, 192, 256)]
 out = [os.path.basename(os.environ.get("GPTQHIP_LIB", "shipped"))[:28].ljust(28)]
