@@ -743,6 +743,15 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
     lins = [L0.qkv, L0.o, L0.gate_up, L0.down]
     pre = prefill_entry("_prefill_headline", "one Llama-3-8B decoder layer's quantised linears (4 launches) at M=8192 tokens",
                         lins, 8192, dtype, dev, iters=5, kernel="gptqhip::tiled_kernel<BITS=4,...,BM=256,D=2>")
+    # serving-batch sizes (the backend's weakest regime): one decoder layer's four linears at M = 128 and 512 rows
+    for m_mid in (128, 512):
+        e = prefill_entry("C2", f"one Llama-3-8B decoder layer's quantised linears (4 launches) at M={m_mid} rows (batched decode / chunked "
+                          "prefill: prefill kernel with split-K on the narrow layers)", lins, m_mid, dtype, dev, iters=20)
+        e["tokens_per_s_linear_stack_equiv"] = m_mid / (e["ms"] * cfg["layers"] * 1e-3)
+        # at these sizes the op is neither purely HBM- nor MFMA-bound: both fractions are given
+        bytes_layer = sum(algorithmic_bytes(m_mid, lin.in_features, lin.out_features, gs) for lin in lins)
+        e["roofline"]["hbm_frac"] = bytes_layer / (e["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        res.append(e)
     # C3: act-order prefill, batch 32 x 2048 ctx = 65536 tokens
     torch.cuda.empty_cache()
     try:

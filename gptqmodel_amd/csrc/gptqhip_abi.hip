@@ -102,10 +102,15 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
 // Kernel family of one gptqhip_gemm call (the measured crossover; the comments at its use in gptqhip_gemm give the numbers)
 static bool gemm_uses_tiled(int M, int K, int N, int group_size, int bits) {
     bool wide = N >= 8192 && M > 16;
-    if (wide && M <= 32 && K < 8192 && N < 65536 && g_force_kernel == 0 &&
-        plan_skinny(M, K, N, group_size, g_force_split, g_force_waves, false, bits, 1).nt > 1)
-        wide = false;
-    const int skinny_max = (bits == 4 && K < 8192 && N < 8192) ? kSkinnyMaxRows4 : kSkinnyMaxM;
+    if (wide && M <= 32 && N < 65536 && g_force_kernel == 0) {
+        // 17..32 rows on a wide layer: the decode kernel's wide form where it is plannable and either K is short or its blocks fit ONE
+        // round of the chip (8192x8192: 256 blocks, 13.0-13.5 us vs 16.4-17.4 tiled; 8192x10240: 320 blocks, 19.1-22.3 vs 18.9-19.9)
+        const int nt = plan_skinny(M, K, N, group_size, g_force_split, g_force_waves, false, bits, 1).nt;
+        if (nt > 1 && (K < 8192 || ceil_div(ceil_div(N, kTileN), nt) <= 256)) wide = false;
+    }
+    // 33..64 rows in one launch of the decode kernel: 4-bit, short K, narrow layers (4096^2: 8.8-10.7 us vs 12.2-14.8 tiled; at
+    // N = 6144 the prefill kernel is level or ahead since its round-3 retuning: 13.7-17.6 vs 15.2-18.0 us; profiles/r03_mid_m_sweep.txt)
+    const int skinny_max = (bits == 4 && K < 8192 && N < 6144) ? kSkinnyMaxRows4 : kSkinnyMaxM;
     return (g_force_kernel == 2) || (g_force_kernel == 0 && (M > skinny_max || wide));
 }
 
@@ -262,14 +267,14 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     a.exact_bf16 = (flags & GPTQHIP_GEMM_EXACT_BF16) ? 1 : 0;
 
     // measured crossover (profiles/r03_mid_m_sweep.txt, round 3: split-ring pipeline for 17..64 rows, 33..64 rows in one launch with
-    // 4-bit weights): the decode kernel leads up to 64 rows on layers with K < 8192 and N < 8192 (4096^2 at M=64 10.7 us vs 15.8 us
-    // tiled; 4096x6144 18.1 vs 18.4), up to 32 rows on long-K layers (14336x4096: 18.4 vs 18.1 us at M=32, 24.6 vs 19.2 at M=40), and
+    // 4-bit weights): the decode kernel leads up to 64 rows on layers with K < 8192 and N < 6144 (4096^2 at M=64 10.7 us vs 14.8 us
+    // tiled; at N = 6144 the retuned prefill kernel is level or ahead: 17.6 vs 18.0), up to 32 rows on long-K layers (14336x4096: 18.4 vs 18.1 us at M=32, 24.6 vs 19.2 at M=40), and
     // up to 16 rows on wide layers (N >= 8192, e.g. fused gate_up: 28.4 vs 25.6 us at M=24) where every 16-column block of the decode
     // kernel re-stages the whole activation tile.  Everything above goes to the MFMA-tiled kernel (64-row tiles, split-K).
     // wide layers (N >= 8192): up to 16 rows the decode kernel (its wide-layer form where plannable: several column tiles per block
     // share one staging of the activation tile -- 4096x28672 at M=16 23.7 -> 16.7 us, 8192x57344 80.5 -> 53.2, lm_head 87.4 -> 55.6);
-    // 17..32 rows too when K < 8192 and N < 65536 (4096x28672 at M=32 32.4 -> 24.4 us vs 27.3 us tiled, 4096x8192 11.9 -> 8.7 vs 13.0;
-    // but 8192x10240 22.6 vs 20.8 tiled, 4096x128256 91.9 vs 80.7); above that the tiled kernel (4096x28672 at M=48: 28.7 vs 39.0 us).
+    // 17..32 rows too when N < 65536 and K < 8192 or the blocks fit one round (4096x28672 at M=32 32.4 -> 24.4 us vs 27.3 us tiled,
+    // 4096x8192 11.9 -> 8.7 vs 13.0, 8192x8192 13.5 vs 17.4; but 8192x10240 22.3 vs 19.9 tiled, 4096x128256 91.9 vs 80.7); above that the tiled kernel (4096x28672 at M=48: 28.7 vs 39.0 us).
     // profiles/r03_wide_layers.txt
     const bool use_tiled = gemm_uses_tiled(M, K, N, group_size, bits);
     // rows per decode-kernel launch: 32, or 64 with 4-bit weights (one launch, the weights are streamed once)

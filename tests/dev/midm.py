@@ -7,7 +7,7 @@ if os.environ.get("GPTQHIP_LIB"):      # dev A/B builds (tests/dev/ablate/*.so)
     _lib.LIB_PATH = os.environ["GPTQHIP_LIB"]
 from gptqmodel_amd import ops
 dev = "cuda"; gs = 128
-KERNS = tuple(int(v) for v in os.environ.get("MIDM_KERNELS", "1,2").split(","))
+KERNS = tuple(int(v) for v in os.environ.get("MIDM_KERNELS", "1,2").split(","))   # 1 decode kernel, 2 prefill kernel, 0 gptqhip_gemm's own choice
 def gtime(fn, n_launch, reps=5):
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
@@ -41,7 +41,7 @@ for (K, N) in SHAPES:
             def fn():
                 for qw_t, meta in sets: ops.gemm(x, qw_t, meta, None, None, N, gs, 4, torch.float16, out=out)
             us = gtime(fn, len(sets))
-            res.append(f"{'skinny' if kern == 1 else 'tiled'} {us:.1f}us {2*M*K*N/us/1e6:.0f}TF")
+            res.append(f"{ {0: 'auto', 1: 'skinny', 2: 'tiled'}[kern] } {us:.1f}us {2*M*K*N/us/1e6:.0f}TF" + (f" [{ops.plan_describe(M, K, N, gs).split(' ')[0]}]" if kern == 0 else ""))
         ops.set_tuning(0, 0, 0)
         print(f"K={K} N={N} M={M}: " + " | ".join(res), flush=True)
     del sets

@@ -108,7 +108,13 @@ def test_kernel_family_crossover_is_host_logic(lib):
     assert d(32, 4096, 28672)["family"] == "skinny" and d(32, 4096, 28672)["nt"] == "4" and d(33, 4096, 28672)["family"] == "tiled"
     assert d(16, 4096, 6144)["nt"] == "2" and d(16, 4096, 8192)["nt"] == "2" and d(16, 4096, 4096)["nt"] == "1"
     assert d(16, 4096, 128256)["nt"] == "4" and d(32, 4096, 128256)["family"] == "tiled"               # lm_head: tiled from 17 rows
-    assert d(16, 8192, 10240)["family"] == "skinny" and d(24, 8192, 10240)["family"] == "tiled"       # K >= 8192: tiled from 17 rows
+    assert d(16, 8192, 10240)["family"] == "skinny" and d(24, 8192, 10240)["family"] == "tiled"       # K >= 8192: tiled from 17 rows ...
+    assert d(24, 8192, 8192)["family"] == "skinny" and d(24, 8192, 8192)["nt"] == "2"                   # ... unless the wide form fits one round
+    assert d(48, 4096, 6144)["family"] == "tiled" and d(32, 4096, 6144)["family"] == "skinny"          # 33..64 rows in one launch: N < 6144 only
+    # mid M: tile height and split factor come from the launch model together (profiles/r03_tiled_planner.txt)
+    assert d(160, 4096, 6144)["bm"] == "64" and d(160, 4096, 6144)["splits"] == "3"
+    assert d(1280, 14336, 4096)["bm"] == "256" and d(1280, 14336, 4096)["splits"] == "3"
+    assert d(96, 8192, 57344)["bm"] == "128" and d(96, 8192, 57344)["splits"] == "1"
     # prefill: 256- / 128- / 64-row tiles
     assert d(8192, 4096, 4096)["bm"] == "256" and d(128, 4096, 4096)["bm"] == "64"
     # act-order: in-kernel permutation at one row, a gather pass otherwise

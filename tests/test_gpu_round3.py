@@ -461,6 +461,22 @@ def test_wide_form_partial_f32_and_scale_dtypes(ops, act, sdt, M, N):
     assert part.dtype == torch.float32 and rel_err(part.cpu().numpy(), part_t.cpu().numpy()) <= 1e-5
 
 
+def test_wide_form_long_k_layer_whose_blocks_fit_one_round(ops):
+    """17..32 rows on a K = 8192 layer: the wide decode form is chosen when its blocks fit one round of the chip (8192 x 8192: 256 blocks
+    of two tiles), the prefill kernel otherwise (8192 x 10240) -- both against the oracle."""
+    K, gs, M = 8192, 128, 24
+    for N, family in ((8192, "skinny"), (10240, "tiled")):
+        assert ops.plan_describe(M, K, N, gs).startswith(family)
+        qweight, qzeros, scales, g_idx = synth_gptq(1500 + N // 1024, 4, K, N, gs)
+        rng = np.random.RandomState(N)
+        x = O.round_to(rng.randn(M, K).astype(np.float32) * 0.5, "fp16")
+        sc = f32_to_torch(scales, "fp16", DEV)
+        qw_t, meta = ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV), sc, None, gs, 4)
+        out = ops.gemm(f32_to_torch(x, "fp16", DEV), qw_t, meta, None, None, N, gs, 4, sc.dtype)
+        ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, None, "fp16", "fp16")
+        assert_forward_close(torch_to_f32(out), ref, "fp16", tag=(M, K, N, family))
+
+
 def test_small_batch_regimes_random_stress(ops):
     """Seeded random shapes over the regimes round 3 added (5..64 rows; narrow, long-K and wide layers; group sizes 32 / 64 / 128 /
     per-channel; fp16 / bf16; bias): whatever kernel family / tiling the planner picks (recorded in the failure message) must meet
