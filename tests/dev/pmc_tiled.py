@@ -1,7 +1,13 @@
-import sys, torch
-sys.path.insert(0, "/root/repo")
-from gptqmodel_amd import ops
-M, K, N = 8192, 4096, 4096
+"""dev (run under rocprofv3 --pmc ...): a few launches of the prefill kernel.  argv: M K N (default 8192 4096 4096)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from gptqmodel_amd import ops  # noqa: E402
+
+M, K, N = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (8192, 4096, 4096)
 dev = "cuda"
 qw = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=dev)
 qz = torch.randint(-2**31, 2**31 - 1, (K // 128, N // 8), dtype=torch.int32, device=dev)
@@ -9,5 +15,7 @@ sc = (torch.rand((K // 128, N), device=dev) * 0.01 + 0.005).half()
 qw_t, meta = ops.repack_tiled(qw, qz, sc, None, 128, 4)
 x = (torch.randn(M, K, device=dev) * 0.5).half()
 out = torch.empty((M, N), dtype=torch.float16, device=dev)
-for _ in range(5): ops.gemm(x, qw_t, meta, None, None, N, 128, 4, torch.float16, out=out)
+ops.set_tuning(0, 2, 0)
+for _ in range(6):
+    ops.gemm(x, qw_t, meta, None, None, N, 128, 4, torch.float16, out=out)
 torch.cuda.synchronize()
