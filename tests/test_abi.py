@@ -85,6 +85,30 @@ def test_decode_op_shape_predicate_is_host_logic(lib):
     assert lib.gptqhip_decode_supported(4096, 4096, 128, 0, 17) == 0 and lib.gptqhip_decode_supported(4096, 4096, 128, 1, 2) == 0
 
 
+def test_prefill_planner_invariants_over_a_grid_of_shapes(lib):
+    """plan_tiled (through gptqhip_plan_describe, forced to the prefill kernel) over a grid of M x layer shapes: whatever the launch model
+    picks must be launchable -- a tile height that exists, at least 4 chunks of K per split block, at most 64 MiB of fp32 slabs, one round
+    of blocks when K is split -- and gptqhip_workspace_bytes must cover the slabs."""
+    assert lib.gptqhip_set_tuning(0, 2, 0) == 0
+    try:
+        for K, N in ((4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096), (8192, 10240), (28672, 8192), (8192, 57344), (1024, 512),
+                     (4096, 128256), (11008, 4096), (2048, 2048)):
+            for M in (17, 33, 64, 65, 100, 128, 200, 256, 384, 512, 777, 1024, 1536, 2048, 4096, 9000, 65536):
+                buf = ctypes.create_string_buffer(256)
+                assert lib.gptqhip_plan_describe(M, K, N, 128, 4, 0, buf, 256) == 0
+                words = buf.value.decode().split()
+                assert words[0] == "tiled", (M, K, N, words)
+                pl = dict(kv.split("=") for kv in words[1:])
+                bm, s, tail = int(pl["bm"]), int(pl["splits"]), int(pl["tail_cols"])
+                chunks, nbx = -(-K // 128), -(-N // 256)
+                assert bm in (64, 128, 256) and 1 <= s <= max(1, chunks // 4) and 0 <= tail < nbx, (M, K, N, pl)
+                if s > 1:
+                    assert s * M * N * 4 <= 64 << 20 and nbx * -(-M // bm) * s <= 256 and tail == 0, (M, K, N, pl)
+                    assert lib.gptqhip_workspace_bytes(M, K, N, 128, 4, 0) >= s * M * N * 4, (M, K, N, pl)
+    finally:
+        assert lib.gptqhip_set_tuning(0, 0, 0) == 0
+
+
 def test_kernel_family_crossover_is_host_logic(lib):
     """gptqhip_plan_describe = the planner's decisions without a GPU: the measured crossover between the decode kernel (one / several
     row tiles, one / several column tiles per block) and the MFMA-tiled prefill kernel (profiles/r03_mid_m_sweep.txt,
