@@ -74,7 +74,9 @@ int gptqhip_device_info(int device, int* cu_count, size_t* hbm_bytes, char* arch
  * arrival counters + act-order gather buffer).  Precedent: ExllamaV2 per-device ScratchSpace,
  * gptqmodel/utils/model.py:1304-1313.  The workspace must be zero-filled once at allocation; the
  * kernels leave it zeroed where it matters (counters).  Takes the same (group_size, bits) gptqhip_gemm will be
- * called with: both sides run the same launch planner, so the size can never disagree with the launch.  0 = bad args. */
+ * called with: both sides run the same launch planner, so the size can never disagree with the launch.  The size is NOT monotonic
+ * in M (the planner may split K at one batch size and not at a larger one): size a shared workspace by the maximum over the M values
+ * that will be used, not by the largest M.  0 = bad args. */
 size_t gptqhip_workspace_bytes(int M, int K, int N, int group_size, int bits, int has_perm);
 
 /* Sizes (in 32-bit words) of the tiled weight / meta arrays for a [K,N] layer. */
