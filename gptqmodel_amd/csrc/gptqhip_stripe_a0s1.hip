@@ -1,0 +1,4 @@
+// Stripe kernel instantiations: fp16 activations, bf16 scales (one translation unit per dtype pair so they compile in parallel).
+#define GPTQHIP_STRIPE_ACT 0
+#define GPTQHIP_STRIPE_SCL 1
+#include "gptqhip_stripe.hip"
