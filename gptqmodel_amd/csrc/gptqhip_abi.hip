@@ -80,10 +80,10 @@ struct WorkspaceLayout {
 
 // The stripe kernel (gptqhip_stripe_kernel.h) takes the batch sizes between the decode kernel's and the prefill kernel's regimes.
 // Its queue heads live at the END of the fixed counter region, its arrival tickets at the start (all restored to zero by the kernel).
-constexpr int kStripeHeadSlots = 16;
+constexpr int kStripeHeadSlots = (8 + 1) * 64;   // = kStripeHeadInts (gptqhip_stripe_kernel.h): 9 counters, 256 B apart
 static bool gemm_uses_stripe(int M, int K, int N, int group_size, int bits, int partial_f32) {
     if (partial_f32 || g_force_kernel == 1 || g_force_kernel == 2) return false;
-    const StripePlan sp = plan_stripe(M, K, N, group_size, bits, g_force_kernel == 3 ? g_force_waves : 0);
+    const StripePlan sp = plan_stripe(M, K, N, group_size, bits, g_force_kernel == 3 ? g_force_waves : 0, g_force_kernel == 3 ? g_force_split : 0);
     if (!sp.ok || (size_t)sp.vstripes * sizeof(int) > kCounterBytes - kStripeHeadSlots * sizeof(int)) return false;
     if (g_force_kernel == 3) return true;
     return stripe_preferred(M, K, N, bits);
@@ -113,7 +113,7 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
         if (tp.slab_floats > floats) floats = tp.slab_floats;
     }
     if (gemm_uses_stripe(M, K, N, group_size, bits, 0)) {
-        const StripePlan sp = plan_stripe(M, K, N, group_size, bits, g_force_kernel == 3 ? g_force_waves : 0);
+        const StripePlan sp = plan_stripe(M, K, N, group_size, bits, g_force_kernel == 3 ? g_force_waves : 0, g_force_kernel == 3 ? g_force_split : 0);
         if (sp.slab_floats > floats) floats = sp.slab_floats;
     }
     L.slabs_bytes = align_up(floats * sizeof(float), 256);
@@ -304,7 +304,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         a.x = xin;
         a.out = out;
         a.M = M;
-        const StripePlan sp = plan_stripe(M, K, N, group_size, bits, g_force_kernel == 3 ? g_force_waves : 0);
+        const StripePlan sp = plan_stripe(M, K, N, group_size, bits, g_force_kernel == 3 ? g_force_waves : 0, g_force_kernel == 3 ? g_force_split : 0);
         int* heads = counters + kCounterBytes / sizeof(int) - kStripeHeadSlots;
         const int wt = g_force_split == 1 || env_int("GPTQHIP_STRIPE_WRITE_THROUGH") == 1 ? 1 : 0;
         return launch_stripe(a, sp, slabs, heads, counters, wt, stream);
@@ -369,7 +369,7 @@ int gptqhip_plan_describe(int M, int K, int N, int group_size, int bits, int has
         return GPTQHIP_EINVAL;
     }
     if (gemm_uses_stripe(M, K, N, group_size, bits, 0)) {
-        const StripePlan sp = plan_stripe(M, K, N, group_size, bits, g_force_kernel == 3 ? g_force_waves : 0);
+        const StripePlan sp = plan_stripe(M, K, N, group_size, bits, g_force_kernel == 3 ? g_force_waves : 0, g_force_kernel == 3 ? g_force_split : 0);
         int maxc = 0;
         rc = stripe_selfcheck(sp, &maxc);
         if (rc) return GPTQHIP_EINVAL;

@@ -77,7 +77,7 @@ int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* co
 TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_variant, int force_split);
 int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, hipStream_t stream);
 
-StripePlan plan_stripe(int M, int K, int N, int group_size, int bits, int force_kg);
+StripePlan plan_stripe(int M, int K, int N, int group_size, int bits, int force_kg, int force_items = 0);
 int launch_stripe(const GemmArgs& a, const StripePlan& pl, float* slabs, int* heads, int* tickets, int write_through, hipStream_t stream);
 int stripe_selfcheck(const StripePlan& pl, int* max_contrib);
 

@@ -3,6 +3,8 @@
 // gptqhip_stripe.hip without them builds the shared host code + the fp16/fp16 kernels).
 #include "gptqhip_stripe_kernel.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -63,15 +65,20 @@ int launch_stripe_a1_s1(const StripeParams& p, int gpc, int mt, int kg, hipStrea
 // reads short; wide layers have more stripes than items anyway and take KG = 1 (128-column stripes: half the activation traffic
 // per column, each of the 8 waves a full chunk per stage).  Rows beyond one panel (128 / 256) become further row panels = further
 // virtual stripes of the same columns (their weights come from the L2 the second time).
-StripePlan plan_stripe(int M, int K, int N, int group_size, int bits, int force_kg) {
+StripePlan plan_stripe(int M, int K, int N, int group_size, int bits, int force_kg, int force_items) {
     StripePlan pl;
     pl.ok = 0;
     if (bits != 4 || M < 1 || K % kChunkK != 0 || group_size % 32 != 0) return pl;
     const int chunks = K / kChunkK;
+    // (tuning: force_kg = kg + 10 * max row tiles per panel, e.g. 41 = 64-row panels on 128-column stripes)
+    const int force_mt = force_kg / 10;
+    force_kg %= 10;
     int kg = N >= 8192 ? 1 : 2;
     if (force_kg == 1 || force_kg == 2) kg = force_kg;
     if (chunks % kg != 0) kg = 1;
-    const int max_mt = kg == 2 ? 8 : 16, step_mt = kg == 2 ? 2 : 4;
+    int max_mt = kg == 2 ? 8 : 16;
+    const int step_mt = kg == 2 ? 2 : 4;
+    if (force_mt >= step_mt && force_mt <= max_mt && force_mt % step_mt == 0) max_mt = force_mt;
     const int panels = ceil_div(M, max_mt * 16);
     const int rows = ceil_div(M, panels);                    // rows per panel, balanced
     const int mt = ceil_div(ceil_div(rows, 16), step_mt) * step_mt;
@@ -85,6 +92,7 @@ StripePlan plan_stripe(int M, int K, int N, int group_size, int bits, int force_
     pl.sps = chunks / kg;
     pl.nq = kStripeQueues;
     pl.items = kStripeItemsPerQueue;
+    if (force_items >= 2 && force_items <= kStripeItemsPerQueue) pl.items = force_items;   // (tuning: fewer, longer items)
     pl.slab_floats = (size_t)pl.nq * pl.items * 2 * (size_t)(mt * 16 * bn);
     if (pl.slab_floats * 4 >= ((size_t)1 << 31)) return pl;
     // 32-bit partition arithmetic in the kernel (stripe_item_start / stripe_item_of / stripe_queue_range)
@@ -136,6 +144,13 @@ int launch_stripe(const GemmArgs& a, const StripePlan& pl, float* slabs, int* he
     p.slabs = slabs;
     p.heads = heads;
     p.tickets = tickets;
+    p.stamps = nullptr;
+#ifdef GPTQHIP_STRIPE_STAMPS
+    {
+        const char* e = getenv("GPTQHIP_STRIPE_STAMP_PTR");   // dev builds: device buffer of [grid][16] uint64, address in hex
+        if (e && *e) p.stamps = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 16));
+    }
+#endif
     if (a.act_dtype == kFP16 && a.scale_dtype == kFP16) return launch_stripe_a0_s0(p, pl.gpc, pl.mt, pl.kg, stream);
     if (a.act_dtype == kBF16 && a.scale_dtype == kFP16) return launch_stripe_a1_s0(p, pl.gpc, pl.mt, pl.kg, stream);
     if (a.act_dtype == kFP16 && a.scale_dtype == kBF16) return launch_stripe_a0_s1(p, pl.gpc, pl.mt, pl.kg, stream);

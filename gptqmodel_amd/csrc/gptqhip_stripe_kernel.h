@@ -1,29 +1,31 @@
-// Serving-batch / chunked-prefill / speculative-decoding regime (about 33..512 rows): the "stripe" kernel.
+// The "stripe" kernel: a stream-K decomposition with the split-K reduction INSIDE the launch, for batches of roughly 33..512 rows.
+// OPT-IN (GPTQHIP_FORCE_KERNEL=3 / gptqhip_set_tuning(.., 3, ..)): parity-tested like the other kernels, but gptqhip_gemm does not
+// route to it -- measured on MI355X it lands within +-10 % of the prefill kernel's 64-row tiles + reduce launch on every shape of the
+// reference's TFLOPS benchmark (scripts/benchmark_marlin_a100.py:35-44: M = 64..192 on 4096x11008 / 11008x4096 / 4096x4096) and
+// ahead of it on none by more than 3 % (profiles/r04_stripe_midm.txt).  DESIGN.md 4.4 has the per-phase timeline and why: the regime
+// is bound by the L2 -> LDS path and by dependent round trips, not by the dequant VALU this decomposition saves.
 //
 // Same contraction and rounding chain as the other two kernels (reference: TorchLinear._forward_eager,
-// gptqmodel/nn_modules/qlinear/torch.py:326-347, dequant :700-717); this is the regime the reference's own TFLOPS benchmark
-// measures (scripts/benchmark_marlin_a100.py:35-44: M = 64..192 on 4096x11008 / 11008x4096 / 4096x4096).  Neither of the other
-// kernels fits it: the decode kernel re-stages the whole activation tile in every 16-column block, the prefill kernel's 64-row
-// tiles dequantise every packed word M/64 times, and its split-K costs a 64 KB fp32 slab per block through HBM plus a
-// second launch (7 us fixed per block + a 4.8 us reduce kernel on 4096^2 at M=128).
+// gptqmodel/nn_modules/qlinear/torch.py:326-347, dequant :700-717).
 //
-// Decomposition (DESIGN.md 4.4):
-//   * a block (8 waves) owns ALL rows (up to MT*16, MT <= 16) of a column STRIPE (BN = 64 or 128 columns) over a contiguous K
-//     range: every packed word is fetched and dequantised ONCE per launch (in registers, straight into MFMA B fragments, like
-//     the prefill kernel), the activation tile is the shared operand (LDS-DMA in full 256-byte rows, XOR-swizzled).
+// Decomposition:
+//   * a block (8 waves) owns ALL rows of a row panel (up to MT*16, MT <= 16) of a column STRIPE (BN = 64 or 128 columns) over a
+//     contiguous K range: every packed word is fetched and dequantised ONCE per panel (in registers, straight into MFMA B fragments,
+//     like the prefill kernel); the activation tile is the shared operand (LDS-DMA in full 256-byte rows, XOR-swizzled).
 //       KG = 2: waves = 4 column tiles x 2 K-groups; a pipeline stage is TWO 128-row chunks (one per K-group), BN = 64
-//       KG = 1: waves = 8 column tiles; a stage is one chunk, BN = 128 (wide layers: half the activation traffic per column)
-//   * work = the linearised (stripe, step) space, cut into equal contiguous ITEMS (stream-K): an item may end in the middle of
-//     a stripe and continue at the start of the next one, so every block gets the same number of steps whatever N and K are.
-//   * stripes are dealt to the 8 XCDs in contiguous runs and each XCD's items sit in that XCD's QUEUE; a block reads its XCC id
-//     from the hardware register and pulls items from the queue of the XCD it actually runs on.  All contributors of a stripe
-//     therefore share one L2 BY CONSTRUCTION -- not by assuming block b runs on XCD b % 8 -- whatever the dispatcher does
-//     (a queue nobody served is drained by the last block to leave the launch, whole stripes at a time, no cross-block sums).
-//   * split-K reduction inside the launch: contributors publish their fp32 fragment slabs (fragment-major, 1 KiB per wave
-//     store), `s_waitcnt vmcnt(0)`, ticket; the last arriver sums all slabs in ITEM order (deterministic, independent of the
-//     arrival order) with L1-bypassing loads and runs the reference's rounding epilogue.  No slab leaves the XCD's L2 on its
-//     way to the reducer, there is no second launch.  (`write_through` = 1 publishes with sc1 stores instead: the
-//     placement-independent form of cdna_hip_programming.md Guideline 16, kept as a switch for A/B and triage.)
+//       KG = 1: waves = 8 column tiles; a stage is one chunk, BN = 128
+//   * work = the linearised (stripe, step) space of an XCD's stripes, cut into equal contiguous ITEMS (stream-K): an item may end in
+//     the middle of a stripe and continue at the start of the next one, so every block gets the same number of steps whatever N, K.
+//   * stripes are dealt to the 8 XCDs in contiguous runs; each XCD's items form a QUEUE = a 32-bit claim mask.  A block reads its
+//     XCC id from the hardware register and claims items of the XCD it actually runs on (one atomic OR, speculatively: the first
+//     item's loads start before the claim returns).  All contributors of a stripe therefore share one L2 BY CONSTRUCTION -- not by
+//     assuming block b runs on XCD b % 8 -- whatever the dispatcher does; a queue nobody served is drained by the last block to
+//     leave the launch, whole stripes at a time.
+//   * split-K reduction inside the launch: contributors publish their fp32 fragment slabs (fragment-major, 1 KiB per wave store),
+//     `s_waitcnt vmcnt(0)`, ticket; the last arriver sums all slabs in ITEM order (deterministic, independent of the arrival order)
+//     with L1-bypassing loads and runs the reference's rounding epilogue.  No slab leaves the XCD's L2 on its way to the reducer
+//     and there is no second launch.  (`write_through` = 1 publishes with sc1 stores instead: the placement-independent form of
+//     cdna_hip_programming.md Guideline 16; bit-identical results, same speed -- kept as a switch.)
 #pragma once
 #include "gptqhip_tiled_kernel.h"
 
@@ -31,7 +33,9 @@ namespace gptqhip {
 
 constexpr int kStripeQueues = 8;        // XCDs of an MI355X
 constexpr int kStripeGrid = 256;        // one block per CU
-constexpr int kStripeItemsPerQueue = 32;
+constexpr int kStripeItemsPerQueue = 32;   // a queue is a 32-bit claim mask
+constexpr int kStripeHeadStride = 64;   // ints between queue heads: 256 B, so the 8 XCDs' dequeues do not serialise on one line / channel
+constexpr int kStripeHeadInts = (kStripeQueues + 1) * kStripeHeadStride;
 
 struct StripeParams {
     TiledParams t;      // x, qw, meta, bias, out, M, K, N, G, group_size, ldo, chunks, tiles, cpg_shift
@@ -41,9 +45,21 @@ struct StripeParams {
     int nq, items;      // queues, items per queue
     int write_through;  // publish slabs with sc1 stores
     float* slabs;       // [nq][items][2][MT*16*BN] fp32 fragment slabs
-    int* heads;         // [nq] queue heads, [nq] exit counter                 (all zero between launches)
+    int* heads;         // [nq + 1][kStripeHeadStride]: queue heads, then the exit counter   (all zero between launches)
     int* tickets;       // [vstripes] arrival counters                        (all zero between launches)
+    unsigned long long* stamps;   // dev builds (-DGPTQHIP_STRIPE_STAMPS): [grid][16] phase stamps of each block's FIRST segment
 };
+
+#ifdef GPTQHIP_STRIPE_STAMPS
+#define STRIPE_STAMP(i)                                                                                          \
+    do {                                                                                                          \
+        if (p.stamps && tid == 0 && !stamped) p.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define STRIPE_STAMP(i) \
+    do {                \
+    } while (0)
+#endif
 
 // ---- the partition arithmetic, shared by the kernel, the planner and the CPU self-check ------------------------------
 struct StripeGeom {
@@ -64,6 +80,7 @@ __host__ __device__ inline int stripe_item_of(int x, int U, int P) {
 
 // items of a queue with U steps: the planned count, but never more than there are steps (no empty items: the contributors of a
 // stripe are then exactly the items stripe_item_of(first step) .. stripe_item_of(last step))
+// (at most 32: a queue is a 32-bit claim mask)
 __host__ __device__ inline int stripe_items_of_queue(int items, int U) { return U < items ? U : items; }
 
 __device__ __forceinline__ int stripe_xcc_id() {
@@ -94,6 +111,13 @@ __global__ __launch_bounds__(512) void stripe_kernel(StripeParams p) {
 
     const TiledParams& tp = p.t;
     const int tid = threadIdx.x;
+#ifdef GPTQHIP_STRIPE_STAMPS
+    bool stamped = false;
+    if (p.stamps && tid == 0) {
+        p.stamps[(size_t)blockIdx.x * 16 + 0] = __builtin_amdgcn_s_memrealtime();
+        p.stamps[(size_t)blockIdx.x * 16 + 15] = (unsigned long long)stripe_xcc_id();
+    }
+#endif
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = KG == 1 ? 0 : wave / CT;
@@ -113,14 +137,22 @@ __global__ __launch_bounds__(512) void stripe_kernel(StripeParams p) {
     // (hardware returns zeros, no memory traffic), so all vmcnt waits are the same compile-time count on every path.
     struct Seg {
         int tile;      // this wave's 16-column weight tile (clamped for a ragged last stripe)
-        int u1;        // one past the segment's last step
+        int u0, n;     // the segment: steps [u0, u0 + n) of the stripe
         const char* abase;
         int arows;     // valid rows of the panel
     };
+    // logical step i (0 .. n-1) -> the chunk this wave's K-group works on
+    // (walking the steps of a segment in a per-stripe rotated order -- so that blocks sharing a K range read different column slices
+    // at any moment -- was measured: no gain at K = 4096, 25 % slower at K = 11008; blocks in lockstep share their L2 misses.)
+    auto chunk_of = [&](const Seg& g, int i, bool valid) __attribute__((always_inline)) { return (g.u0 + (valid ? i : 0)) * KG + kg; };
+    // (Also measured and dropped: warming the L2 ahead of the LDS-DMA with one dword load per 128-byte line, requested in bulk for the
+    // next 8 steps.  A stage holds 64 KiB of the 160 KiB of LDS, so only one stage of activations is in flight while another is
+    // multiplied and every stage waits a miss latency; but a 64-lane dword load costs the texture addresser as much as a 1 KiB DMA
+    // piece, and the extra 9 instructions per stage -- even through a zero-length descriptor -- took the step from 1.3 to 2.3 us.)
     auto issue = [&](auto sc, const Seg& g, int step) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
-        const bool valid = step < g.u1;
-        const int chunk = (valid ? step : g.u1 - 1) * KG + kg;
+        const bool valid = step < g.n;
+        const int chunk = chunk_of(g, step, valid);
         const __amdgpu_buffer_rsrc_t ars =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g.abase), 0, valid ? g.arows * tp.K * 2 : 0, 0x00020000);
         const int rl = ct * 4 + rq;
@@ -142,8 +174,8 @@ __global__ __launch_bounds__(512) void stripe_kernel(StripeParams p) {
     // the same, spread over a stage: weights right after the first fragment reads, DMA pieces PPG per read group
     auto issue_b = [&](auto sc, const Seg& g, int step) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
-        const bool valid = step < g.u1;
-        const int chunk = (valid ? step : g.u1 - 1) * KG + kg;
+        const bool valid = step < g.n;
+        const int chunk = chunk_of(g, step, valid);
         const __amdgpu_buffer_rsrc_t brs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(tp.qw), 0, valid ? (int)qw_bytes : 0, 0x00020000);
         bst[s].w[0][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, bsrc.l16, (uint32_t)(g.tile * tp.chunks + chunk) * 1024u, 0);
@@ -178,13 +210,14 @@ __global__ __launch_bounds__(512) void stripe_kernel(StripeParams p) {
             lds_read_b128<(i % MT) * 4096>(abuf[0][i], aaddr[i / MT]);
         });
         const int nstep = step + D - 1;
-        const bool nvalid = nstep < g.u1;
-        const int nchunk = (nvalid ? nstep : g.u1 - 1) * KG + kg;
+        const bool nvalid = nstep < g.n;
+        const int nchunk = chunk_of(g, nstep, nvalid);
         const __amdgpu_buffer_rsrc_t ars =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(g.abase), 0, nvalid ? g.arows * tp.K * 2 : 0, 0x00020000);
         const int rl = ct * 4 + rq;
         const uint32_t voff = (uint32_t)(rl * tp.K * 2 + ((c ^ (rl & 15)) << 4));
-        issue_b(std::integral_constant<int, si>{}, g, nstep);
+        // (the first stage of a segment issues nothing: the prologue has put D stages in flight, one per buffer)
+        if constexpr (!kFirst) issue_b(std::integral_constant<int, si>{}, g, nstep);
         __builtin_amdgcn_sched_barrier(0);
         static_for<NG>([&](auto gc) {
             constexpr int gi = decltype(gc)::value;
@@ -197,7 +230,7 @@ __global__ __launch_bounds__(512) void stripe_kernel(StripeParams p) {
             __builtin_amdgcn_sched_barrier(0);
             static_for<PPG>([&](auto pc) {
                 constexpr int I = gi * PPG + decltype(pc)::value;
-                if constexpr (I < NPIECE) {
+                if constexpr (I < NPIECE && !kFirst) {
                     typedef __attribute__((address_space(3))) void* lptr_t;
                     char* dst = lds + si * STAGE + kg * SUB + (I * CT + ct) * 4 * 256;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lptr_t)dst, 16, voff,
@@ -232,12 +265,22 @@ __global__ __launch_bounds__(512) void stripe_kernel(StripeParams p) {
     };
 
     // ---- the accumulators of one segment: steps [u0, u1) of one virtual stripe
-    auto run_segment = [&](const Seg& g, int u0) __attribute__((always_inline)) {
-        const int nsteps = g.u1 - u0;
-        static_for<D - 1>([&](auto dc) { issue(dc, g, u0 + decltype(dc)::value); });
-        vm_wait<OPS, 0, D - 2>(D - 2, false);
-        dequant_step(bst[0], 0, bnow);
+    auto run_segment = [&](const Seg& g) __attribute__((always_inline)) {
+        const int nsteps = g.n;
+        constexpr int u0 = 0;   // (logical step indices from here on)
+        // Prologue.  A segment of at least D steps starts with ALL D buffers in flight (its first stage then issues nothing): at
+        // 64 KiB per stage only two stages fit the LDS, every stage of a short segment waits a full cold-miss latency (1.3 us against
+        // 0.45 us of MFMA work, profiles/r04_stripe_stamps.txt), and this takes one of those latencies off each segment.
         int i = 0;
+        if (nsteps >= D) {
+            static_for<D>([&](auto dc) { issue(dc, g, u0 + decltype(dc)::value); });
+            vm_wait<OPS, 0, D - 1>(D - 1, false);
+        } else {
+            static_for<D - 1>([&](auto dc) { issue(dc, g, u0 + decltype(dc)::value); });
+            vm_wait<OPS, 0, D - 2>(D - 2, false);
+        }
+        STRIPE_STAMP(2);   // first stage's loads have landed
+        dequant_step(bst[0], 0, bnow);
         if (nsteps >= D) {
             static_for<D>([&](auto sc) {
                 stage(sc, std::integral_constant<bool, decltype(sc)::value == 0>{}, g, u0 + decltype(sc)::value);
@@ -259,6 +302,7 @@ __global__ __launch_bounds__(512) void stripe_kernel(StripeParams p) {
         // the trailing (zero-length) DMA writes must have landed before the stage buffers are reused below
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        STRIPE_STAMP(3);   // main loop done
     };
 
     // ---- in-block K-group exchange (KG = 2): wave (kg, ct) keeps row tiles [kg * MTW, (kg + 1) * MTW) and adds its partner's
@@ -321,20 +365,39 @@ __global__ __launch_bounds__(512) void stripe_kernel(StripeParams p) {
         __builtin_amdgcn_make_buffer_rsrc(p.slabs, 0, (int)((size_t)p.nq * p.items * 2 * kSlabF4 * 16), 0x00020000);
     const uint32_t slab_lane = (uint32_t)((wave * MTW * 64 + lane) * 16);
 
+    int pre = 0;             // thread 0: value returned by the claim atomic in flight (see the work loop)
+    bool spec = false;       // the current item was started BEFORE its claim was confirmed
     // ---- one segment from start to finish.  my_item < 0: the caller owns the whole stripe (no cross-block sum).
-    auto do_segment = [&](int q, int v, int ub, int ue, int my_item, int i_first, int i_last, int U, int P, int vbase_steps, bool first_seg)
-                          __attribute__((always_inline)) {
+    auto do_segment = [&](int q, int v, int ub, int ue, int my_item, int i_first, int i_last, int U, int P, int vbase_steps, bool first_seg,
+                          bool last_seg, int pre_q) __attribute__((always_inline)) -> bool {
         const int stripe = v / p.panels, panel = v - stripe * p.panels;
         const int m0 = panel * (MT * 16);
         Seg g;
         int tile = stripe * CT + ct;
         g.tile = tile < tp.tiles ? tile : tp.tiles - 1;
-        g.u1 = ue;
+        g.u0 = ub;
+        g.n = ue - ub;
         g.abase = reinterpret_cast<const char*>(tp.x) + (size_t)m0 * tp.K * 2;
         g.arows = min(tp.M - m0, MT * 16);
-        run_segment(g, ub);
+        run_segment(g);
+        if (spec) {
+            // the claim of this item was issued before its loads and has long returned: nothing has left the block yet, so a lost
+            // claim (another block of this XCD holds the item: only possible when the dispatcher did not place block b on XCD
+            // b % 8) simply drops the accumulators
+            if (tid == 0) bcast[2] = (int)(((uint32_t)pre >> my_item) & 1u);
+            __syncthreads();
+            const bool lost = bcast[2] != 0;
+            __syncthreads();
+            spec = false;
+            if (lost) return false;
+        }
+        // a fresh view of the claim mask for the next item, requested here so that its round trip runs under the exchange /
+        // publish / reduce / epilogue below instead of after them
+        if (last_seg && my_item >= 0 && tid == 0)
+            pre = __hip_atomic_fetch_or(&p.heads[pre_q * kStripeHeadStride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         f4_t mine[MTW];
         exchange(mine);
+        STRIPE_STAMP(4);   // K-group exchange done
         const int contrib = my_item < 0 ? 1 : i_last - i_first + 1;
         if (contrib > 1) {
             // publish this block's fragments: [wave][row tile][lane] float4, 1 KiB per wave store
@@ -350,12 +413,14 @@ __global__ __launch_bounds__(512) void stripe_kernel(StripeParams p) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores are in the L2 (or in memory: sc1)
             __syncthreads();
+            STRIPE_STAMP(5);   // slab published
             if (tid == 0) bcast[0] = __hip_atomic_fetch_add(&p.tickets[v], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             const int ticket = bcast[0];
+            STRIPE_STAMP(6);   // ticket drawn
             if (ticket != contrib - 1) {
-                __syncthreads();   // (bcast is reused by the next dequeue)
-                return;
+                __syncthreads();   // (bcast is reused by the next claim)
+                return true;
             }
             if (tid == 0) __hip_atomic_store(&p.tickets[v], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // every contributor's ticket precedes ours, its slab stores precede its ticket: sum the slabs in ITEM order (own slab
@@ -366,60 +431,130 @@ __global__ __launch_bounds__(512) void stripe_kernel(StripeParams p) {
                 const int started_here = stripe_item_start(ii, U, P) >= stripe_first_step;
                 return (uint32_t)(((q * p.items + ii) * 2 + (started_here ? 0 : 1)) * (kSlabF4 * 16));
             };
-            f4_t cur[MTW], nxt[MTW];
+            const int slab_bytes_all = (int)((size_t)p.nq * p.items * 2 * kSlabF4 * 16);
+            constexpr int CMAX = 4, MG = MTW < 4 ? MTW : 4;   // up to 4 contributors x 4 row tiles in flight per wave (64 registers)
+            if (contrib <= CMAX) {
+                // every slab load is requested before the first addition (one loaded L2 round trip instead of one per contributor);
+                // the slots beyond the last contributor go through a zero-length descriptor and are not added
 #pragma unroll
-            for (int m = 0; m < MTW; ++m)
-                cur[m] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(slab_rs, slab_lane + m * 1024, slab_of(i_first), 16));
-            for (int ii = i_first; ii <= i_last; ++ii) {
-                const bool more = ii < i_last;
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    p.slabs, 0, more ? (int)((size_t)p.nq * p.items * 2 * kSlabF4 * 16) : 0, 0x00020000);
-                const uint32_t so = slab_of(more ? ii + 1 : ii);
+                for (int mg = 0; mg < MTW; mg += MG) {
+                    f4_t buf[CMAX][MG];
+#pragma unroll
+                    for (int k = 0; k < CMAX; ++k) {
+                        const bool on = k < contrib;
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slabs, 0, on ? slab_bytes_all : 0, 0x00020000);
+                        const uint32_t so = slab_of(on ? i_first + k : i_first);
+#pragma unroll
+                        for (int m = 0; m < MG; ++m)
+                            buf[k][m] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, slab_lane + (mg + m) * 1024, so, 16));
+                    }
+#pragma unroll
+                    for (int m = 0; m < MG; ++m) {
+                        f4_t sum = buf[0][m];
+#pragma unroll
+                        for (int k = 1; k < CMAX; ++k)
+                            if (k < contrib) sum = sum + buf[k][m];
+                        mine[mg + m] = sum;
+                    }
+                }
+            } else {
+                f4_t cur[MTW], nxt[MTW];
 #pragma unroll
                 for (int m = 0; m < MTW; ++m)
-                    nxt[m] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, slab_lane + m * 1024, so, 16));
-                if (ii == i_first) {
+                    cur[m] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(slab_rs, slab_lane + m * 1024, slab_of(i_first), 16));
+                for (int ii = i_first; ii <= i_last; ++ii) {
+                    const bool more = ii < i_last;
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.slabs, 0, more ? slab_bytes_all : 0, 0x00020000);
+                    const uint32_t so = slab_of(more ? ii + 1 : ii);
 #pragma unroll
-                    for (int m = 0; m < MTW; ++m) mine[m] = cur[m];
-                } else {
+                    for (int m = 0; m < MTW; ++m)
+                        nxt[m] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, slab_lane + m * 1024, so, 16));
+                    if (ii == i_first) {
 #pragma unroll
-                    for (int m = 0; m < MTW; ++m) mine[m] = mine[m] + cur[m];
+                        for (int m = 0; m < MTW; ++m) mine[m] = cur[m];
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < MTW; ++m) mine[m] = mine[m] + cur[m];
+                    }
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) cur[m] = nxt[m];
                 }
-#pragma unroll
-                for (int m = 0; m < MTW; ++m) cur[m] = nxt[m];
             }
+            STRIPE_STAMP(7);   // slabs summed (last arriver only)
         }
         epilogue(mine, stripe, m0);
+        STRIPE_STAMP(8);       // output stored
+        return true;
     };
 
-    // ---- work loop.  mode 0: pull items from the queue of the XCD this block runs on, one segment per iteration (an item that
-    // crosses a stripe boundary is two or more segments).  When the queue is empty the block leaves; the LAST block to leave the
-    // launch resets the queue heads, and a queue whose head is still zero was served by nobody (no block of this launch ran on
-    // that XCD): mode 1 drains it here, whole stripes at a time, no cross-block sums.  (One call site of do_segment on purpose:
-    // the pipeline is a few thousand instructions.)
+    // ---- work loop.
+    // Queue of XCD q = a 32-bit CLAIM MASK (bit i: item i is taken).  A block claims an item with one returning atomic OR; it owns
+    // the item iff the bit was clear before.  All items of queue q are therefore processed by blocks that read XCC id q from the
+    // hardware -- the contributors of a stripe share one L2 by construction, wherever the dispatcher put them.
+    //   * first item: block b guesses item b / nq (every block a different one when block b runs on XCD b % 8, as observed) and
+    //     starts its loads IMMEDIATELY; the claim's round trip (1.7 us at kernel start, measured) runs under the first miss latency
+    //     and the main loop, and is checked before anything leaves the block.  A lost claim only costs the work done so far.
+    //   * further items (fewer blocks than items on this XCD, or a lost claim): lowest clear bit of the freshest known mask, retried
+    //     until owned or the mask is full.
+    //   * exit: the LAST block to leave the launch clears the masks; a mask that is still zero belongs to an XCD no block of this
+    //     launch ran on: mode 1 drains that queue here, whole stripes at a time, no cross-block sums.
+    // (One call site of do_segment on purpose: the pipeline is a few thousand instructions.)
     const StripeGeom geom = {p.vstripes, p.sps, p.nq, p.items};
     int q = stripe_xcc_id() % p.nq;
     int v0, nvs;
     stripe_queue_range(geom, q, v0, nvs);
     int U = nvs * p.sps;
-    const int P = stripe_items_of_queue(p.items, U);   // every item holds at least one step
-    int mode = 0, item = 0, s0 = 0, s = 0, s1 = 0, ot = 0;
+    const int P = stripe_items_of_queue(p.items, U);   // every item holds at least one step; P <= 32
+    int mode = 0, item = -1, s0 = 0, s = 0, s1 = 0, ot = 0;
+    uint32_t known = 0;   // thread 0: the claim mask as far as this block has seen it
+    if (P > 0) {
+        item = (int)((blockIdx.x / (unsigned)p.nq) % (unsigned)P);
+        if (tid == 0) pre = __hip_atomic_fetch_or(&p.heads[q * kStripeHeadStride], 1 << item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        spec = true;
+    }
+    bool have_item = P > 0;
     for (;;) {
         int v, ub, ue, my_item, i_first = 0, i_last = 0, vbase;
         bool first_seg = true;
         if (mode == 0) {
             if (s >= s1) {
-                if (tid == 0) bcast[0] = __hip_atomic_fetch_add(&p.heads[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-                item = bcast[0];
-                __syncthreads();
-                if (item >= P) {
-                    if (tid == 0) bcast[0] = __hip_atomic_fetch_add(&p.heads[p.nq], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!have_item) {
+                    // claim the lowest clear bit of the freshest mask (thread 0; `pre` holds the mask read after the last main loop,
+                    // or the mask returned by a lost speculative claim)
+                    if (tid == 0) {
+                        int got = -1;
+                        known |= (uint32_t)pre;
+                        const uint32_t full = P >= 32 ? 0xFFFFFFFFu : (1u << P) - 1u;
+                        while ((known & full) != full) {
+                            const int cand = __builtin_ctz(~known & full);
+                            const uint32_t old = __hip_atomic_fetch_or(reinterpret_cast<uint32_t*>(&p.heads[q * kStripeHeadStride]), 1u << cand,
+                                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            known |= old | (1u << cand);
+                            if (!((old >> cand) & 1u)) {
+                                got = cand;
+                                break;
+                            }
+                        }
+                        bcast[0] = got;
+                    }
+                    __syncthreads();
+                    item = bcast[0];
+                    __syncthreads();
+                }
+#ifdef GPTQHIP_STRIPE_STAMPS
+                if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + (stamped ? 9 : 1)] = __builtin_amdgcn_s_memrealtime();
+#endif
+                if (item < 0) {
+                    if (tid == 0)
+                        bcast[0] = __hip_atomic_fetch_add(&p.heads[p.nq * kStripeHeadStride], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __syncthreads();
                     const bool last_out = bcast[0] == (int)gridDim.x - 1;
                     __syncthreads();
+#ifdef GPTQHIP_STRIPE_STAMPS
+                    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+#endif
                     if (!last_out) return;
-                    if (tid <= p.nq) bcast[1 + tid] = __hip_atomic_exchange(&p.heads[tid], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid <= p.nq) bcast[1 + tid] = __hip_atomic_exchange(&p.heads[tid * kStripeHeadStride], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __syncthreads();
                     mode = 1;
                     q = -1;
@@ -427,6 +562,7 @@ __global__ __launch_bounds__(512) void stripe_kernel(StripeParams p) {
                     ot = 0;
                     continue;
                 }
+                have_item = false;
                 s0 = stripe_item_start(item, U, P);
                 s1 = stripe_item_start(item + 1, U, P);
                 s = s0;
@@ -458,7 +594,11 @@ __global__ __launch_bounds__(512) void stripe_kernel(StripeParams p) {
             U = nvs * p.sps;
             ++ot;
         }
-        do_segment(q, v, ub, ue, my_item, i_first, i_last, U, P, vbase, first_seg);
+        const bool ok = do_segment(q, v, ub, ue, my_item, i_first, i_last, U, P, vbase, first_seg, mode == 0 && s >= s1, q);
+        if (!ok) s = s1;   // lost speculative claim: forget the item
+#ifdef GPTQHIP_STRIPE_STAMPS
+        stamped = true;
+#endif
     }
 }
 

@@ -2,7 +2,9 @@
 
 TEST INFRASTRUCTURE ONLY.  Used by oracle/make_golden.py (to generate tests/golden/*) and by the
 `-m "not gpu"` tests that cross-check the oracle against the live reference when it is mounted.
-Nothing under gptqmodel_amd/ imports this, and /root/reference does not exist on the GPU box.
+Nothing under gptqmodel_amd/ imports this.  /root/reference does not exist on the GPU box: there the shim falls back to
+`oracle/_ref/` (the files this import executes, copied by oracle/make_ref_snapshot.py; git-ignored, travels with a push),
+which bench.py's cpu_baseline leg uses to time the reference's own modules.
 
 Recipe: the reference's `gptqmodel/__init__.py` eagerly imports the model zoo, which
 needs packages absent here (tokenicer, defuser, torchvision ...).  We pre-seed `sys.modules` with
@@ -13,8 +15,21 @@ import os
 import sys
 import types
 
-REF_ROOT = os.environ.get("GPTQ_REFERENCE_ROOT", "/root/reference")
+_SNAPSHOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")   # oracle/make_ref_snapshot.py (git-ignored)
+
+
+def _pick_root() -> str:
+    env = os.environ.get("GPTQ_REFERENCE_ROOT")
+    if env:
+        return env
+    if os.path.isdir("/root/reference/gptqmodel"):
+        return "/root/reference"
+    return _SNAPSHOT   # the GPU box: only the files the shim executes, for timing the reference's CPU path
+
+
+REF_ROOT = _pick_root()
 REF_PKG = os.path.join(REF_ROOT, "gptqmodel")
+REF_IS_SNAPSHOT = os.path.abspath(REF_ROOT) == os.path.abspath(_SNAPSHOT)
 _SHIM_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_shim")
 
 

@@ -1,0 +1,10 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_stripe.py -x -q 2>&1 | tail -5 > gpurun_out/r4c4_pytest.txt
+cat gpurun_out/r4c4_pytest.txt
+timeout 300 python tests/dev/stripe_stamps.py 4096x4096,4096x11008,11008x4096,8192x8192 128 > gpurun_out/r4c4_stamps.txt 2>&1
+cat gpurun_out/r4c4_stamps.txt
+MIDM_KERNELS=2,3 MIDM_SHAPES=4096x4096,4096x11008,11008x4096,4096x28672,8192x8192 timeout 600 python tests/dev/midm.py 64,128,192,256 > gpurun_out/r4c4_midm.txt 2>&1
+cat gpurun_out/r4c4_midm.txt
