@@ -201,6 +201,70 @@ def prefill_entry(name, workload, lins, m, dtype, dev, iters=3, kernel="gptqhip:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# T1: the reference's OWN dequant-GEMM TFLOPS benchmark, replayed (scripts/benchmark_marlin_a100.py:35-44 cases, :127-160 tensors,
+# :163-201 timing: warmup 30, iters 80, eager module(x) calls bracketed by synchronize, tflops = 2 M K N / t)
+# ---------------------------------------------------------------------------------------------------------------------
+T1_CASES = ([("mlp_up", m, 4096, 11008) for m in (64, 72, 80, 88, 96, 104, 112, 120, 128, 136, 144, 152, 160, 168, 176, 184, 192)]
+            + [("mlp_down", m, 11008, 4096) for m in (64, 80, 96, 112, 128, 160, 192)]
+            + [("attn", m, 4096, 4096) for m in (64, 96, 128, 192)])
+
+
+def t1_entry(dtype, dev, stream, warmup=30, iters=80, seed=1234):
+    """28 cases of the reference's Marlin benchmark through the plugin class's forward(): the reference's eager wall-clock method
+    (`tflops`) and, next to it, the same launch timed from a HIP graph (`tflops_graph`: the kernel without the Python call)."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    from gptqmodel_amd import ops as _ops
+    gs = 128
+    mods, cases = {}, []
+    for idx, (tag, m, k, n) in enumerate(T1_CASES):
+        if (k, n) not in mods:
+            g = torch.Generator(device=dev)
+            g.manual_seed(seed + len(mods))
+            lin = HipGptqLinear(bits=4, group_size=gs, sym=True, desc_act=False, in_features=k, out_features=n, bias=False,
+                                register_buffers=False)
+            lin.qweight = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=dev, generator=g)
+            lin.scales = (torch.rand((k // gs, n), device=dev, generator=g) * 0.5 + 0.5).to(dtype)
+            lin.qzeros = torch.zeros((k // gs, n // 8), dtype=torch.int32, device=dev)      # the benchmark zeroes them (:157)
+            lin.g_idx = (torch.arange(k, device=dev, dtype=torch.int32) // gs)
+            lin.bias = None
+            lin.qzero_format(format=2)
+            lin.eval()
+            lin.post_init()
+            mods[(k, n)] = lin
+        lin = mods[(k, n)]
+        gx = torch.Generator(device=dev)
+        gx.manual_seed(seed + idx)
+        x = torch.rand((m, k), device=dev, generator=gx).to(dtype)
+        with torch.inference_mode():
+            for _ in range(warmup):
+                lin(x)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                y = lin(x)
+            torch.cuda.synchronize(dev)
+            mean_ms = (time.perf_counter() - t0) * 1e3 / iters
+        with torch.no_grad():
+            ms_g, g = time_graph(lambda: [lin(x) for _ in range(8)], stream, 20, 3)
+        ms_g /= 8
+        del g
+        flops = 2.0 * m * k * n
+        by = algorithmic_bytes(m, k, n, gs)
+        cases.append({"case_id": f"{tag}_m{m}", "m": m, "in_features": k, "out_features": n, "shape": list(y.shape),
+                      "mean_ms": mean_ms, "tflops": flops / (mean_ms * 1e9), "us_graph": ms_g * 1e3, "tflops_graph": flops / (ms_g * 1e9),
+                      "kernel": _ops.plan_describe(m, k, n, gs).split(" ")[0],
+                      "roofline": {"mfma_frac": flops / (ms_g * 1e9) / MFMA_PEAK_TFLOPS, "hbm_frac": by / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS}})
+    best = max(c["tflops_graph"] for c in cases)
+    return {"config": "T1", "workload": "the reference's own dequant-GEMM TFLOPS benchmark replayed (scripts/benchmark_marlin_a100.py: 28 cases, "
+                                        "M = 64..192 on 4096x11008 / 11008x4096 / 4096x4096, int4 g128 sym, warmup 30 / iters 80, eager module(x) "
+                                        "wall clock, tflops = 2MKN/t); tflops_graph = the same launch replayed from a HIP graph",
+            "dtype": str(dtype).replace("torch.", ""), "unit": "TFLOP/s", "value": best, "value_is": "best tflops_graph over the 28 cases",
+            "warmup": warmup, "iters": iters, "cases": cases,
+            "roofline": {"bound": "mfma", "achieved": best, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": best / MFMA_PEAK_TFLOPS,
+                         "kernel": "gptqhip::tiled_kernel<BM=64> + splitk_reduce_kernel (gptqhip_gemm's choice at these sizes)"}}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle's torch-CPU port of BACKEND.TORCH (kind "port"), thread count swept
 # ---------------------------------------------------------------------------------------------------------------------
 def _cpu_tensors(k, n, gs, dtype):
@@ -222,6 +286,53 @@ def _time_cpu(fn, budget_s, max_iters):
             return el / iters * 1e3, iters
 
 
+def _reference_modules():
+    """The REAL reference classes (TorchLinear / AwqTorchLinear) through the oracle's import shim: /root/reference where it is mounted
+    (the build container), else the snapshot oracle/_ref that oracle/make_ref_snapshot.py ships with the push (the GPU box).  None
+    when neither is there: cpu_baseline then falls back to the oracle's torch port and says so (kind "port")."""
+    try:
+        from oracle.ref_import import load_reference, reference_available
+        if not reference_available():
+            return None
+        had = os.environ.get("CUDA_VISIBLE_DEVICES")
+        try:
+            return load_reference()     # (the shim hides the GPUs from the reference's import-time probes: undo that for this process)
+        finally:
+            if had is None:
+                os.environ.pop("CUDA_VISIBLE_DEVICES", None)
+            else:
+                os.environ["CUDA_VISIBLE_DEVICES"] = had
+    except Exception:  # noqa: BLE001 -- a broken snapshot must not take the benchmark down
+        return None
+
+
+def _ref_gptq_module(ref, k, n, gs, dtype, compiled=False):
+    """A reference TorchLinear holding synthetic C1-style tensors (sym, v2 zero-points), post_init()ed on the CPU.  compiled=False
+    replaces optimize() by a no-op (the reference's own trick, tests/test_torch.py:417): eager dequant + matmul."""
+    qw, qz, sc, gi = _cpu_tensors(k, n, gs, dtype)
+    lin = ref.TorchLinear(bits=4, group_size=gs, desc_act=False, sym=True, in_features=k, out_features=n, bias=False,
+                          pack_dtype=torch.int32, register_buffers=True)
+    lin.qweight, lin.qzeros, lin.scales, lin.g_idx = qw, qz, sc, gi
+    lin.qzero_format(format=2)
+    if not compiled:
+        lin.optimize = lambda *a, **kw: None
+    lin = lin.eval()
+    lin.post_init()
+    return lin
+
+
+def _ref_awq_module(ref, k, n, gs, dtype):
+    lin = ref.AwqTorchLinear(bits=4, group_size=gs, desc_act=False, sym=False, in_features=k, out_features=n, bias=False,
+                             pack_dtype=torch.int32, register_buffers=True)
+    lin.qweight = torch.randint(-2**31, 2**31 - 1, (k, n // 8), dtype=torch.int32)
+    lin.qzeros = torch.randint(-2**31, 2**31 - 1, (k // gs, n // 8), dtype=torch.int32)
+    lin.scales = (torch.rand((k // gs, n)) * 0.01 + 0.005).to(dtype)
+    lin.optimize = lambda *a, **kw: None
+    lin = lin.eval()
+    lin.post_init()
+    return lin
+
+
 def cpu_baseline(cfg, gs=128, budget_s=24.0):
     """Reference path on the host cores: upstream's CPU test runs bf16 (tests/test_q4_torch.py:27,50) and
     flags fp16 CPU matmul as slow (:52-53); both are timed.  The thread count is swept on the actual sample (one decoder
@@ -233,13 +344,27 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
     ncpu = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
     t_start = time.perf_counter()
-    mods = []
-    for _, kk, nn in layer_shapes(cfg):
-        mods.append(((torch.randn(1, kk) * 0.5).to(torch.bfloat16),) + _cpu_tensors(kk, nn, gs, torch.bfloat16))
+    ref = _reference_modules()
+    kind = "reference" if ref is not None else "port"
+
+    def gptq_fn(k, n, dtype, m):
+        """-> a callable running ONE forward of a [k, n] layer at m rows: the reference module's forward() (kind "reference"), else
+        the oracle's torch port of the same op sequence (kind "port")."""
+        x = (torch.randn(m, k) * 0.5).to(dtype)
+        if ref is not None:
+            lin = _ref_gptq_module(ref, k, n, gs, dtype)
+
+            def run():
+                with torch.inference_mode():
+                    return lin(x)
+            return run
+        t = _cpu_tensors(k, n, gs, dtype)
+        return lambda: torch_cpu_forward_gptq(x, *t, 4)
+    mods = [gptq_fn(kk, nn, torch.bfloat16, 1) for _, kk, nn in layer_shapes(cfg)]
 
     def one_pass():
-        for x, qw, qz, sc, gi in mods:
-            torch_cpu_forward_gptq(x, qw, qz, sc, gi, 4)
+        for f in mods:
+            f()
     sweep = sorted({c for c in (8, 16, 32, 64, 128) if c <= ncpu})
     per_thread = {}
     for th in sweep:   # one decoder layer per thread count (after a warm-up pass), the workload the tokens/s is extrapolated from
@@ -261,8 +386,7 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
                 # M=2048 per call; upstream flags it too, tests/test_q4_torch.py:52-53): not part of a bounded leg
                 c1[f"{tag}_m{m}"] = None
                 continue
-            x = (torch.randn(m, k) * 0.5).to(dt)
-            ms, _ = _time_cpu(lambda: torch_cpu_forward_gptq(x, *t, 4), budget_s * 0.05, 4)
+            ms, _ = _time_cpu(gptq_fn(k, n, dt, m), budget_s * 0.05, 4)
             c1[f"{tag}_m{m}"] = round(ms, 3)
     # per-shape C1-style timings (each linear of the model on its own, warm, M=1, bf16): the model-level figure they add up to is
     # the trustworthy CPU number -- the 7-linear layer pass above streams 218 M codes through the caches per pass and reads ~2x
@@ -272,11 +396,8 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
         key = f"{kk}x{nn}"
         if key in per_shape:
             continue
-        t = _cpu_tensors(kk, nn, gs, torch.bfloat16)
-        x = (torch.randn(1, kk) * 0.5).to(torch.bfloat16)
-        ms, _ = _time_cpu(lambda: torch_cpu_forward_gptq(x, *t, 4), budget_s * 0.04, 3)
+        ms, _ = _time_cpu(gptq_fn(kk, nn, torch.bfloat16, 1), budget_s * 0.04, 3)
         per_shape[key] = round(ms, 3)
-        del t
     model_ms = cfg["layers"] * sum(per_shape[f"{kk}x{nn}"] for _, kk, nn in layer_shapes(cfg))
     # C4: the AWQ reference path (AwqTorchLinear.forward op sequence, torch_awq.py:157-195 + dequantize_gemm) on a 4096x4096 layer
     from oracle.gptq_oracle import torch_cpu_forward_awq
@@ -284,13 +405,20 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
     qw = torch.randint(-2**31, 2**31 - 1, (k, n // 8), dtype=torch.int32)
     qz = torch.randint(-2**31, 2**31 - 1, (k // gs, n // 8), dtype=torch.int32)
     sc = (torch.rand((k // gs, n)) * 0.01 + 0.005).to(torch.bfloat16)
+    awq_ref = _ref_awq_module(ref, k, n, gs, torch.bfloat16) if ref is not None else None
     for m in (1, 32):
         x = (torch.randn(m, k) * 0.5).to(torch.bfloat16)
-        ms, _ = _time_cpu(lambda: torch_cpu_forward_awq(x, qw, qz, sc, gs), budget_s * 0.05, 4)
+        if awq_ref is not None:
+            def run_awq():
+                with torch.inference_mode():
+                    return awq_ref(x)
+            ms, _ = _time_cpu(run_awq, budget_s * 0.05, 4)
+        else:
+            ms, _ = _time_cpu(lambda: torch_cpu_forward_awq(x, qw, qz, sc, gs), budget_s * 0.05, 4)
         c4[f"bf16_m{m}"] = round(ms, 3)
-    del qw, qz, sc
+    del qw, qz, sc, awq_ref
     torch.set_num_threads(default_threads)
-    c1["bf16_m1_compiled_dequant"], compiled_note = _cpu_compiled_c1(best, gs)
+    c1["bf16_m1_compiled_dequant"], compiled_note = _cpu_compiled_c1(best, gs, use_reference=ref is not None)
     cpu_model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -298,7 +426,11 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
     except OSError:
         pass
     return {
-        "value": 1e3 / (per_layer * cfg["layers"]), "unit": "tokens/s", "cores": best, "kind": "port",
+        "value": 1e3 / (per_layer * cfg["layers"]), "unit": "tokens/s", "cores": best, "kind": kind,
+        "kind_note": ("the reference's own TorchLinear.forward / AwqTorchLinear.forward (gptqmodel/nn_modules/qlinear/torch.py:302, "
+                      "torch_awq.py:157) imported through oracle/ref_import.py" if kind == "reference" else
+                      "oracle/gptq_oracle.py torch port of BACKEND.TORCH (pinned bit for bit to the reference's outputs): no reference "
+                      "tree or oracle/_ref snapshot on this box"),
         "cpu_model": cpu_model, "torch": torch.__version__,
         "measured": ["ms_per_layer (one decoder layer's 7 linears, M=1)", "threads_swept", "c1_ms", "c4_awq_ms", "per_shape_ms"],
         "extrapolated": ["value = 1000 / (ms_per_layer x layers)", "model_tokens_per_s_from_per_shape = 1000 / (layers x sum of per_shape_ms)"],
@@ -310,8 +442,10 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
                  "x layers) includes the cache thrash of streaming 7 layers' codes per pass and reads ~2x lower",
         "c1_compiled_note": compiled_note,
         "sample": f"1 of {cfg['layers']} decoder layers (7 linears, M=1, bf16 like upstream's CPU test), {iters} passes, "
-                  f"extrapolated x{cfg['layers']}; torch CPU port of BACKEND.TORCH (oracle/gptq_oracle.py), not the reference "
-                  f"module itself; host os.cpu_count()={ncpu}",
+                  f"extrapolated x{cfg['layers']}; "
+                  + ("the REFERENCE's TorchLinear modules, eager (optimize() replaced by a no-op like tests/test_torch.py:417)" if kind == "reference"
+                     else "torch CPU port of BACKEND.TORCH (oracle/gptq_oracle.py), not the reference module itself")
+                  + f"; host os.cpu_count()={ncpu}",
         "ms_per_layer": per_layer, "threads_swept": per_thread, "threads_swept_unit": "ms per decoder layer (7 linears, M=1, bf16)",
         "best_threads": best,
         "c1_ms": c1, "c1_workload": "single QuantLinear 4096x4096 int4 g128 sym=True, eager dequant + matmul, best_threads "
@@ -320,10 +454,29 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
     }
 
 
-def _cpu_compiled_c1(threads, gs, limit_s=150):
-    """C1 (4096x4096, bf16, M=1) with the dequant under torch.compile like upstream's post_init: (ms | None, note)."""
+def _cpu_compiled_c1(threads, gs, limit_s=150, use_reference=False):
+    """C1 (4096x4096, bf16, M=1) with the dequant under torch.compile like upstream's post_init: (ms | None, note).  With the
+    reference available it is the reference's OWN post_init() (TorchLinear.optimize, torch.py:215-216,259) that compiles."""
     import subprocess
-    code = f"""
+    if use_reference:
+        code = f"""
+import sys, time, torch
+sys.path.insert(0, {ROOT!r})
+import bench as B
+torch.set_num_threads({threads})
+torch.manual_seed(1234)
+ref = B._reference_modules()
+t0 = time.perf_counter()
+lin = B._ref_gptq_module(ref, 4096, 4096, {gs}, torch.bfloat16, compiled=True)
+x = (torch.randn(1, 4096) * 0.5).to(torch.bfloat16)
+with torch.inference_mode():
+    lin(x)
+    comp = time.perf_counter() - t0
+    ms, _ = B._time_cpu(lambda: lin(x), 2.0, 4)
+print("RESULT", ms, comp)
+"""
+    else:
+        code = f"""
 import sys, time, torch
 sys.path.insert(0, {ROOT!r})
 import bench as B
@@ -752,6 +905,11 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
         bytes_layer = sum(algorithmic_bytes(m_mid, lin.in_features, lin.out_features, gs) for lin in lins)
         e["roofline"]["hbm_frac"] = bytes_layer / (e["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         res.append(e)
+    # T1: the reference's own TFLOPS benchmark (M = 64..192), case by case
+    try:
+        res.append(t1_entry(dtype, dev, stream))
+    except Exception as e:  # noqa: BLE001
+        res.append({"config": "T1", "error": str(e)[:300]})
     # C3: act-order prefill, batch 32 x 2048 ctx = 65536 tokens
     torch.cuda.empty_cache()
     try:

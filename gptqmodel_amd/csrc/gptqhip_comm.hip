@@ -222,6 +222,13 @@ __global__ __launch_bounds__(256) void allgather_select_kernel(const uint16_t* _
     const char* slots = peers.base[rank] + gather_off + (size_t)par * kCommMaxWorld * gslot_bytes;
     for (int j = tid; j < n_out; j += 256) {
         const int src = index != nullptr ? index[j] : j;
+        // an index outside the concatenation would read another slot region or past the buffer: poison the element and raise the
+        // sticky status word (status bit 2), like a lost peer -- never a silent wrong value
+        if ((unsigned)src >= (unsigned)(n_local * world)) {
+            out[j] = (uint16_t)nan_bits;
+            atomicOr(&mine->status, 2u);
+            continue;
+        }
         const int r = src / n_local, off = src - r * n_local;
         uint16_t* q = reinterpret_cast<uint16_t*>(const_cast<char*>(slots) + (size_t)r * gslot_bytes) + off;
         const uint16_t v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -1325,7 +1325,7 @@ static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStre
     if (pl.mt == 1 && p.M == 1 && p.perm != nullptr) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1P, 4>(p, pl, stream);
     if (pl.mt == 1 && p.M == 1 && pl.depth == 2) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1, 2>(p, pl, stream);
     if (pl.mt == 1 && p.M == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW1, 4>(p, pl, stream);
-    if (pl.mt == 1 && p.M <= 4) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW4, 4>(p, pl, stream);
+    if (pl.mt == 1 && p.M <= 4 && pl.depth == 4) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROW4, 4>(p, pl, stream);
     if (pl.mt == 1 && p.M <= 8) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROWSH, 2>(p, pl, stream);
     if (pl.mt == 1) return launch_skinny_gpc<BITS, ACT, SCL, 1, AM_ROWS, 2>(p, pl, stream);
     if (pl.mt == 2 && p.M <= 24) return launch_skinny_gpc<BITS, ACT, SCL, 2, AM_ROWSH, 2>(p, pl, stream);
@@ -1368,7 +1368,11 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
         // once they have landed -- narrow layers like o_proj are latency-, not stream-bound)
         const int force_s = force_split > 0 ? (force_split < pl.chunks ? force_split : pl.chunks) : 0;
         const int depth_hi = pl.depth;                                        // the kernel variants: D = 4 up to 4 rows, else 2
-        const int depth_lo = (M == 1 && allow_depth2 && !in_kernel_perm) ? 2 : pl.depth;
+        // 2..4 rows on a SHORT K (fewer than 16 chunks, e.g. the o_proj row shard of Llama-3-70B at TP = 8: K = 1024): no wave count
+        // gives whole rounds of the 4-deep ring, so those rows may ride the 2-deep pipeline of the 5..8-row variant (round 4: before,
+        // the shape fell off the regular pipeline and gptqhip_decode_supported said no -- found by tests/test_gpu_tp8_shapes.py)
+        const bool short_k_rows = M >= 2 && M <= 4 && pl.chunks < 16 && !in_kernel_perm;
+        const int depth_lo = ((M == 1 && allow_depth2 && !in_kernel_perm) || short_k_rows) ? 2 : pl.depth;
         // pass 0: exact plans (every wave's chunks are whole ring rounds); pass 1: plans whose LAST round carries padding chunks
         // (clamped loads, skipped compute -- see Cursor) for chunk counts with awkward factors (Llama-2 down_proj: 86 = 2 * 43,
         // Qwen2-7B: 148 = 4 * 37), accepted up to 1/8 of wasted loads, least waste first
@@ -1386,7 +1390,9 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
                     const int nsp = ceil_div(pl.chunks, cps);
                     const int virt = ceil_div(cps, w * depth) * w * depth * nsp;
                     const int waste = virt - pl.chunks;
-                    if (pass == 0 ? waste != 0 : waste * 8 > pl.chunks) continue;
+                    // (a SHORT K -- fewer than 16 chunks, e.g. the 512-row o_proj shard of an 8B model at TP = 8 -- cannot fill whole
+                    // rounds of four or more waves: there any padding is accepted, it is at most one round of L2-hit loads)
+                    if (pass == 0 ? waste != 0 : (waste * 8 > pl.chunks && (pl.chunks >= 16 || in_kernel_perm))) continue;
                     // pass 1 trades wasted loads against the distance from the wave target: one wave off ~ 1 % of extra loads
                     const float score = (float)waste / (float)pl.chunks + 0.01f * (float)abs(w - target);
                     bool better;
@@ -1448,7 +1454,8 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
     pl.slab_floats = pl.splits > 1 ? (size_t)pl.splits * M * N : 0;
     pl.rounds = ceil_div(pl.chunks_per_split, pl.waves * pl.depth);
     const int virt_chunks = pl.rounds * pl.waves * pl.depth * pl.splits;   // incl. the padding of every block's last ring round
-    pl.regular = (allow_pad ? (virt_chunks - pl.chunks) * 8 <= pl.chunks : virt_chunks == pl.chunks) && K % kChunkK == 0 &&
+    pl.regular = (allow_pad ? ((virt_chunks - pl.chunks) * 8 <= pl.chunks || (pl.chunks < 16 && pl.mt == 1 && pl.splits == 1 && !in_kernel_perm)) : virt_chunks == pl.chunks) &&
+                         K % kChunkK == 0 &&
                          (pl.gpc == 1 ? (group_size >= K || ((group_size / kChunkK) & (group_size / kChunkK - 1)) == 0)
                                       : (group_size == 32 || group_size == 64))
                      ? 1

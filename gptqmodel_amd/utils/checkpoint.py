@@ -16,6 +16,7 @@ is.  safetensors shards + `model.safetensors.index.json` (`weight_map`: tensor n
 from __future__ import annotations
 
 import json
+import logging
 import os
 from typing import Dict, Iterable, List, Optional
 
@@ -32,6 +33,9 @@ _SYNONYMS = {"w_bit": "bits", "wbits": "bits", "q_group_size": "group_size", "ve
 _SYNONYMS_NEGATED = {"zero_point": "sym"}
 SAFETENSORS_INDEX = "model.safetensors.index.json"
 SAFETENSORS_SINGLE = "model.safetensors"
+
+
+log = logging.getLogger("gptqmodel_amd")
 
 
 def normalize_quantize_config(raw: Dict) -> Dict:
@@ -62,8 +66,9 @@ def normalize_quantize_config(raw: Dict) -> Dict:
         "lm_head": bool(cfg.get("lm_head", False)),
         "meta": cfg.get("meta") or {},
     }
-    if out["bits"] not in (2, 3, 4, 8):
-        raise ValueError(f"quantize_config: bits={out['bits']}")
+    if out["bits"] not in (4, 8):
+        # (the reference also packs 2 / 3 bits; the HIP modules -- and this reader / writer -- cover 4 and 8, SUPPORTS_BITS)
+        raise ValueError(f"quantize_config: bits={out['bits']} is outside this backend (4 or 8)")
     if out["group_size"] != -1 and out["group_size"] <= 0:
         raise ValueError(f"quantize_config: group_size={out['group_size']}")
     return out
@@ -96,6 +101,23 @@ def _shard_map(ckpt_dir: str) -> Dict[str, str]:
         raise ValueError(f"no {SAFETENSORS_INDEX} / {SAFETENSORS_SINGLE} in {ckpt_dir}")
     with safe_open(single, framework="pt") as f:
         return {k: SAFETENSORS_SINGLE for k in f.keys()}
+
+
+def _written_by_v2_aware_quantizer(cfg: Dict) -> bool:
+    """meta.quantizer names `gptqmodel:<version >= 0.9.0>` (quantization/config.py:2786-2792, MIN_VERSION_WITH_V2)."""
+    vals = (cfg.get("meta") or {}).get("quantizer") or []
+    if not isinstance(vals, list):
+        vals = [vals]
+    for val in vals:
+        parts = str(val).split(":")
+        if len(parts) >= 2 and parts[0].lower() in ("gptqmodel", "gptqmodel_amd"):
+            digits = []
+            for tok in parts[1].split("."):
+                num = "".join(ch for ch in tok if ch.isdigit())
+                digits.append(int(num) if num else 0)
+            if parts[0].lower() == "gptqmodel_amd" or tuple(digits[:3] + [0] * (3 - len(digits[:3]))) >= (0, 9, 0):
+                return True
+    return False
 
 
 def quantized_module_names(weight_map: Iterable[str]) -> List[str]:
@@ -138,9 +160,13 @@ def load_quantized_checkpoint(model: nn.Module, ckpt_dir: str, device="cuda", ba
             for key in keys:
                 t = f.get_tensor(key)
                 if key not in targets:
-                    if key.endswith(".g_idx") or key.endswith(".bias"):
-                        # optional tensors of a quant module that this module instance does not register (e.g. no bias)
-                        raise ValueError(f"checkpoint tensor `{key}` has no counterpart in the model")
+                    # extra keys the reference tolerates too (it loads through accelerate's non-strict load_checkpoint_in_model,
+                    # models/loader.py:1646): AutoGPTQ-era files carry an all-zero `.bias` for every quantised Linear even when the
+                    # model's Linear has bias=False, older ones a `rotary_emb.inv_freq` buffer.  Anything else is an error.
+                    owner = key.rsplit(".", 1)[0]
+                    if key.endswith(".rotary_emb.inv_freq") or (key.endswith(".bias") and owner in names and not bool(t.any())):
+                        log.warning("load_quantized_checkpoint: ignoring checkpoint tensor `%s` (no counterpart in the model)", key)
+                        continue
                     raise ValueError(f"unexpected checkpoint tensor `{key}`")
                 dst = targets[key]
                 if tuple(dst.shape) != tuple(t.shape):
@@ -158,6 +184,21 @@ def load_quantized_checkpoint(model: nn.Module, ckpt_dir: str, device="cuda", ba
         missing.remove(k)
     if missing:
         raise ValueError(f"the checkpoint lacks tensors of quantised modules: {missing[:8]}")
+    # every OTHER parameter / persistent buffer must have been loaded as well (norms, embeddings, an untied lm_head): a silently
+    # random-initialised tensor is worse than an error.  Tied parameters count as loaded when any alias was.
+    persistent = set(model.state_dict().keys())
+    by_storage: Dict[int, List[str]] = {}
+    for k, t in targets.items():
+        by_storage.setdefault(t.data_ptr(), []).append(k)
+    unloaded = [k for k in targets if k in persistent and k not in seen and k not in quant_owned
+                and not any(a in seen for a in by_storage[targets[k].data_ptr()])]
+    if unloaded:
+        raise ValueError(f"the checkpoint lacks model tensors: {unloaded[:8]}")
+    if fmt == FORMAT.GPTQ and not cfg["sym"] and not _written_by_v2_aware_quantizer(cfg):
+        # v1 files of asymmetric models from producers older than the v2-aware code base store zero-points this conversion would
+        # shift by one: the reference refuses them (models/loader.py:1658-1663), so does this loader
+        raise ValueError("loading a sym=False `format: gptq` (v1) checkpoint needs meta.quantizer = gptqmodel:>=0.9.0 "
+                         "(models/loader.py:1658-1663)")
     if fmt == FORMAT.GPTQ:
         # on-disk v1 (zero - 1) -> runtime v2, for every kernel that asks for it (loader.py:1658-1675)
         convert_gptq_v1_to_v2_format(model, bits=cfg["bits"])
@@ -212,6 +253,10 @@ def save_quantized_checkpoint(model: nn.Module, ckpt_dir: str, quantize_config: 
             size = 0
         shards[-1][key] = state[key]
         size += nbytes
+    # a directory that already holds a save must not keep stale shards / a stale index (the reader prefers the index)
+    for old in os.listdir(ckpt_dir):
+        if old == SAFETENSORS_INDEX or old == SAFETENSORS_SINGLE or (old.startswith("model-") and old.endswith(".safetensors")):
+            os.remove(os.path.join(ckpt_dir, old))
     files, weight_map = [], {}
     for i, sh in enumerate(shards):
         fname = SAFETENSORS_SINGLE if len(shards) == 1 else f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors"

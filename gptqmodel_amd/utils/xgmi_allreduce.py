@@ -137,39 +137,58 @@ class OneShotAllReduce:
             _lib.check(_lib.load().gptqhip_comm_status(self._own, ctypes.byref(st)), "gptqhip_comm_status")
             return st.value == 0
 
+        def agree(local_ok: bool) -> bool:
+            """MIN over the ranks: every rank leaves the test loop in the same iteration (a rank that saw a failure must not skip
+            process-group collectives its healthy peers are still going to enter -- mismatched collectives hang)."""
+            if self.world == 1:
+                return local_ok
+            flag = torch.tensor([1 if local_ok else 0], dtype=torch.int32)
+            if dist.get_backend(self.group) != "gloo":
+                flag = flag.to(dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            return bool(int(flag.item()) == 1)
+
+        # The process-group collectives (all_gather / all_reduce) run in the SAME order on every rank whatever any rank observes:
+        # failures -- a wrong result, a timed-out peer wait, an exception -- are only recorded, and the ranks agree on them once per
+        # iteration.  (A one-directional link fault or a time-out on one rank only is the normal failure shape.)
         try:
             # short peer-wait bound while testing: a link that does not deliver must cost seconds, not calls x 10 s
             self.set_timeout_ms(1500)
-            with torch.cuda.device(dev):
-                for it in range(calls):
-                    if not ok:
-                        break
-                    g = torch.Generator(device=dev)
-                    g.manual_seed(7919 * it + self.rank)
-                    part = torch.randn(n, device=dev, generator=g) * 3.0
-                    gr = torch.Generator(device=dev)
-                    gr.manual_seed(104729 + it)
-                    res = torch.randn(n, device=dev, generator=gr).to(torch.float16)
-                    parts = self._gather(part)
+        except Exception:  # noqa: BLE001
+            ok = False
+        with torch.cuda.device(dev):
+            for it in range(calls):
+                g = torch.Generator(device=dev)
+                g.manual_seed(7919 * it + self.rank)
+                part = torch.randn(n, device=dev, generator=g) * 3.0
+                gr = torch.Generator(device=dev)
+                gr.manual_seed(104729 + it)
+                res = torch.randn(n, device=dev, generator=gr).to(torch.float16)
+                xl = torch.randn(512, device=dev, generator=g).to(torch.float16)
+                idx = torch.randperm(512 * self.world, device=dev, generator=gr)[:640].to(torch.int32)
+                parts = self._gather(part)                  # process-group collectives: unconditional
+                full = torch.cat(self._gather(xl))
+                try:
                     want = parts[0].clone()
                     for p in parts[1:]:
                         want = want + p
                     want = (res.float() + want.to(torch.float16).float()).to(torch.float16)
                     got = self(part, out_dtype=torch.float16, residual=res)
-                    ok = ok and healthy() and bool(torch.equal(got, want))
-                    if not ok:
-                        break
-                    xl = torch.randn(512, device=dev, generator=g).to(torch.float16)
-                    idx = torch.randperm(512 * self.world, device=dev, generator=gr)[:640].to(torch.int32)
-                    full = torch.cat(self._gather(xl))
+                    it_ok = healthy() and bool(torch.equal(got, want))
                     sel = self.gather_select(xl, idx)
                     torch.cuda.synchronize(dev)
-                    ok = ok and bool(torch.equal(sel, full[idx.long()]))
-                # burst: payload of epoch t = base_r + t (exact in fp32 for these magnitudes); mismatches counted on the device
-                g = torch.Generator(device=dev)
-                g.manual_seed(31337 + self.rank)
-                base = torch.randn(n, device=dev, generator=g).to(torch.float16).float()   # 11 significant bits: base + t is exact
-                bases = self._gather(base)
+                    it_ok = it_ok and healthy() and bool(torch.equal(sel, full[idx.long()]))
+                except Exception:  # noqa: BLE001 -- a failing self test must not take the caller down: it answers False
+                    it_ok = False
+                ok = agree(ok and it_ok)
+                if not ok:
+                    break
+            # burst: payload of epoch t = base_r + t (exact in fp32 for these magnitudes); mismatches counted on the device
+            g = torch.Generator(device=dev)
+            g.manual_seed(31337 + self.rank)
+            base = torch.randn(n, device=dev, generator=g).to(torch.float16).float()   # 11 significant bits: base + t is exact
+            bases = self._gather(base)                       # unconditional, like the final agreement below
+            try:
                 bad = torch.zeros((), dtype=torch.int64, device=dev)
                 part = torch.empty(n, device=dev)
                 out = torch.empty(n, device=dev, dtype=torch.float16)
@@ -185,19 +204,14 @@ class OneShotAllReduce:
                     bad += (out != want.to(torch.float16)).sum()
                 torch.cuda.synchronize(dev)
                 ok = ok and int(bad.item()) == 0
-            self.check_status()
-        except Exception:  # noqa: BLE001 -- a failing self test must not take the caller down: it answers False
-            ok = False
+                self.check_status()
+            except Exception:  # noqa: BLE001
+                ok = False
         try:
             self.set_timeout_ms(self._timeout_ms)
         except Exception:  # noqa: BLE001
             ok = False
-        if self.world > 1:
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
-            if dist.get_backend(self.group) != "gloo":
-                flag = flag.to(dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-            ok = bool(int(flag.item()) == 1)
+        ok = agree(ok)
         return ok
 
     def set_timeout_ms(self, ms: int) -> None:
@@ -208,6 +222,8 @@ class OneShotAllReduce:
     def check_status(self) -> None:
         st = ctypes.c_uint32(0)
         _lib.check(_lib.load().gptqhip_comm_status(self._own, ctypes.byref(st)), "gptqhip_comm_status")
+        if st.value & 2:
+            raise RuntimeError("OneShotAllReduce.gather_select: an index outside [0, n_local * world) was poisoned with NaN")
         if st.value != 0:
             raise RuntimeError("OneShotAllReduce: a bounded wait for a peer timed out; results are invalid")
 

@@ -250,7 +250,9 @@ int gptqhip_rmsnorm_gather(const void* h, const void* weight, const int32_t* per
  *   gptqhip_comm_alloc(bytes, &ptr, handle[64])   uncached (fine-grained) device memory, zero-filled, + its IPC handle
  *   gptqhip_comm_open(handle, &ptr) / gptqhip_comm_close(ptr)   map / unmap a PEER's buffer in this process
  *   gptqhip_comm_free(ptr)             free the buffer this rank allocated
- *   gptqhip_comm_status(own_buf, &st)  host read of the "a bounded wait gave up" word (0 = healthy)
+ *   gptqhip_comm_status(own_buf, &st)  host read of the sticky status word (0 = healthy; bit 0: a bounded wait for a peer gave up,
+ *                                      bit 1: gptqhip_allgather_select met an index outside [0, n_local * world) -- in both cases
+ *                                      the affected outputs were poisoned with NaN)
  *   gptqhip_comm_set_timeout(own_buf, ms)  bound of this rank's peer waits (host write, between launches; default 10 s or
  *                                      GPTQHIP_COMM_TIMEOUT_MS at alloc time) -- the self-test runs with a short one
  *   gptqhip_allreduce_oneshot(partial[n] fp32, peer_bufs[world] (HOST array of device pointers, own buffer at [rank]), rank, world,

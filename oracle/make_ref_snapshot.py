@@ -30,7 +30,20 @@ def make_snapshot(verbose: bool = True) -> int:
         f"sys.path.insert(0, {ROOT!r})\n"
         f"os.environ['GPTQ_REFERENCE_ROOT'] = {LIVE!r}\n"
         "from oracle.ref_import import load_reference\n"
-        "load_reference()\n"
+        "ref = load_reference()\n"
+        # exercise what the CPU baseline runs, so that lazily imported modules (e.g. the rotation hook imported inside forward())
+        # are recorded too
+        "import torch\n"
+        "lin = ref.TorchLinear(bits=4, group_size=128, desc_act=False, sym=True, in_features=256, out_features=256, bias=False,\n"
+        "                      pack_dtype=torch.int32, register_buffers=True)\n"
+        "lin.optimize = lambda *a, **k: None\n"
+        "lin = lin.eval(); lin.post_init()\n"
+        "lin(torch.zeros(1, 256, dtype=torch.bfloat16)); lin.dequantize_weight()\n"
+        "awq = ref.AwqTorchLinear(bits=4, group_size=128, desc_act=False, sym=False, in_features=256, out_features=256, bias=False,\n"
+        "                         pack_dtype=torch.int32, register_buffers=True)\n"
+        "awq.optimize = lambda *a, **k: None\n"
+        "awq = awq.eval(); awq.post_init()\n"
+        "awq(torch.zeros(1, 256, dtype=torch.bfloat16))\n"
         f"root = {LIVE!r} + os.sep\n"
         "for m in list(sys.modules.values()):\n"
         "    f = getattr(m, '__file__', None)\n"

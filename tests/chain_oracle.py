@@ -8,8 +8,19 @@ import torch
 from oracle import gptq_oracle as O
 
 
+_DEQ_CACHE = {}
+
+
 def deq(t, bits=4):
-    return O.dequant_gptq(t["qweight"], t["qzeros"], t["scales"], t["g_idx"], bits)
+    """Dequantised weights of one checkpoint-tensor dict, cached per dict object (a chain is evaluated for several inputs)."""
+    key = id(t)
+    hit = _DEQ_CACHE.get(key)
+    if hit is None or hit[0] is not t:
+        if len(_DEQ_CACHE) > 256:
+            _DEQ_CACHE.clear()
+        hit = (t, O.dequant_gptq(t["qweight"], t["qzeros"], t["scales"], t["g_idx"], bits))
+        _DEQ_CACHE[key] = hit
+    return hit[1]
 
 
 def oracle_chain(x, layers, act, eps):

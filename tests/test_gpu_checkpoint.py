@@ -64,6 +64,54 @@ def test_on_disk_gptq_checkpoint_round_trip(tmp_path, desc_act, fuse):
     # greedy decoding of a random-init model is sensitive to 1-ulp logit differences: require the first generated tokens to agree
     assert torch.equal(out[:, :10], ref[:, :10])
 
+    # extra keys the reference's non-strict load tolerates: an all-zero `.bias` of a quantised Linear created without
+    # bias (AutoGPTQ-era files) and a `rotary_emb.inv_freq` buffer are skipped; a NON-zero stray bias or a missing norm weight is an error
+    from safetensors.torch import load_file, save_file
+    with open(os.path.join(ckpt, "model.safetensors.index.json")) as f:
+        idx0 = json.load(f)
+    shard = idx0["weight_map"][name + ".qweight"]
+    tensors = load_file(os.path.join(ckpt, shard))
+    tensors[name + ".bias"] = torch.zeros(quant.config.hidden_size, dtype=torch.float16)
+    tensors["model.layers.0.self_attn.rotary_emb.inv_freq"] = torch.ones(8)
+    save_file(tensors, os.path.join(ckpt, shard), metadata={"format": "pt"})
+    idx1 = json.loads(json.dumps(idx0))
+    idx1["weight_map"][name + ".bias"] = shard
+    idx1["weight_map"]["model.layers.0.self_attn.rotary_emb.inv_freq"] = shard
+    with open(os.path.join(ckpt, "model.safetensors.index.json"), "w") as f:
+        json.dump(idx1, f)
+    tolerant = load_quantized_checkpoint(LlamaForCausalLM(LlamaConfig.from_pretrained(ckpt)).to(torch.float16), ckpt, device="cuda",
+                                         fuse_decoder_layers=fuse)
+    with torch.no_grad():
+        assert torch.equal(tolerant(input_ids=ids).logits, got)
+    tensors[name + ".bias"] = torch.ones(quant.config.hidden_size, dtype=torch.float16)
+    save_file(tensors, os.path.join(ckpt, shard), metadata={"format": "pt"})
+    with pytest.raises(ValueError, match="unexpected checkpoint tensor"):
+        load_quantized_checkpoint(LlamaForCausalLM(LlamaConfig.from_pretrained(ckpt)).to(torch.float16), ckpt, device="cuda")
+    tensors.pop(name + ".bias")
+    tensors.pop("model.layers.0.self_attn.rotary_emb.inv_freq")
+    save_file(tensors, os.path.join(ckpt, shard), metadata={"format": "pt"})
+    idx2 = json.loads(json.dumps(idx0))
+    idx2["weight_map"].pop("model.norm.weight")
+    with open(os.path.join(ckpt, "model.safetensors.index.json"), "w") as f:
+        json.dump(idx2, f)
+    with pytest.raises(ValueError, match="lacks model tensors"):
+        load_quantized_checkpoint(LlamaForCausalLM(LlamaConfig.from_pretrained(ckpt)).to(torch.float16), ckpt, device="cuda")
+    with open(os.path.join(ckpt, "model.safetensors.index.json"), "w") as f:
+        json.dump(idx0, f)
+    # an asymmetric v1 checkpoint from a producer older than the v2-aware code base is refused (models/loader.py:1658-1663)
+    with open(os.path.join(ckpt, "quantize_config.json")) as f:
+        qc = json.load(f)
+    with open(os.path.join(ckpt, "quantize_config.json"), "w") as f:
+        json.dump(dict(qc, meta={"quantizer": ["auto_gptq:0.7.1"]}), f)
+    with pytest.raises(ValueError, match="sym=False"):
+        load_quantized_checkpoint(LlamaForCausalLM(LlamaConfig.from_pretrained(ckpt)).to(torch.float16), ckpt, device="cuda")
+    with open(os.path.join(ckpt, "quantize_config.json"), "w") as f:
+        json.dump(qc, f)
+    # a single-shard save into the same directory leaves no stale index / shards behind
+    save_quantized_checkpoint(quant, ckpt, qcfg, max_shard_bytes=1 << 40)
+    assert sorted(fn for fn in os.listdir(ckpt) if fn.endswith(".safetensors") or fn.endswith(".index.json")) == ["model.safetensors"]
+    save_quantized_checkpoint(quant, ckpt, qcfg, max_shard_bytes=(6 << 20) if fuse else (1 << 20))
+
     # a truncated checkpoint (one shard's tensors missing from the index) is an error, not a half-loaded model
     with open(os.path.join(ckpt, "model.safetensors.index.json")) as f:
         idx = json.load(f)

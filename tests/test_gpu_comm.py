@@ -103,14 +103,16 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_oneshot_allreduce_two_processes_one_gpu():
-    world = 2
-    port = 29700 + (os.getpid() % 2000)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_oneshot_allreduce_processes_sharing_one_gpu(world):
+    """world = 4 / 8 exercise what only an 8-GPU node would otherwise reach first: 8 flags per block, 7 peer mappings, every
+    `tid < world` lane, the rank-ordered sum over 8 slots."""
+    port = 29700 + (os.getpid() % 2000) + 7 * world
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    assert dict(ret) == {r: True for r in range(world)}
 
 
 def _tp_chain_worker(rank, world, port, ret):
@@ -186,13 +188,15 @@ def _tp_chain_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_tp_decode_chain_two_processes_one_gpu():
-    world = 2
-    port = 31700 + (os.getpid() % 2000)
+@pytest.mark.parametrize("world", [2, 8])
+def test_tp_decode_chain_processes_sharing_one_gpu(world):
+    """Llama-3-8B-shaped layers at TP = 2 and TP = 8 (shards 512 + 128 + 128 query / key / value columns, 1792 MLP columns,
+    o_proj K = 512, down_proj K = 1792 = 14 x 128)."""
+    port = 31700 + (os.getpid() % 2000) + 7 * world
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     mp.spawn(_tp_chain_worker, args=(world, port, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    assert dict(ret) == {r: True for r in range(world)}
 
 
 def test_oneshot_allreduce_world1_is_the_rounding_chain():
@@ -207,4 +211,12 @@ def test_oneshot_allreduce_world1_is_the_rounding_chain():
     with pytest.raises(RuntimeError, match="elements"):
         comm(torch.zeros(8192, device=dev))
     comm.check_status()
+    # gather + select with an index outside the concatenation: that element is NaN and the status word says so
+    xl = torch.randn(512, device=dev).half()
+    idx = torch.tensor([0, 511, 512, -1, 7], dtype=torch.int32, device=dev)
+    sel = comm.gather_select(xl, idx)
+    torch.cuda.synchronize()
+    assert torch.equal(sel[[0, 1, 4]], xl[[0, 511, 7]]) and bool(torch.isnan(sel[[2, 3]]).all())
+    with pytest.raises(RuntimeError, match="index outside"):
+        comm.check_status()
     comm.close()

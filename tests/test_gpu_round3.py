@@ -248,13 +248,14 @@ def _stress_worker(rank, world, port, ret, epochs):
         dist.destroy_process_group()
 
 
-def test_oneshot_collectives_stress_1e5_epochs_two_processes_one_gpu():
-    world = 2
-    port = 33100 + (os.getpid() % 2000)
+@pytest.mark.parametrize("world,epochs", [(2, 100000), (4, 10000), (8, 10000)])
+def test_oneshot_collectives_stress_processes_sharing_one_gpu(world, epochs):
+    """10^5 epochs on two ranks, 10^4 on four and eight (world = 8 has to have run before an 8-GPU node does)."""
+    port = 33100 + (os.getpid() % 2000) + 7 * world
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    mp.spawn(_stress_worker, args=(world, port, ret, int(os.environ.get("GPTQHIP_STRESS_EPOCHS", "100000"))), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    mp.spawn(_stress_worker, args=(world, port, ret, int(os.environ.get("GPTQHIP_STRESS_EPOCHS", str(epochs)))), nprocs=world, join=True)
+    assert dict(ret) == {r: True for r in range(world)}
 
 
 def _lost_peer_worker(rank, world, port, ret):
@@ -266,8 +267,9 @@ def _lost_peer_worker(rank, world, port, ret):
         part = torch.ones(4096, device=dev)
         ok = torch.equal(comm(part, out_dtype=torch.float16).cpu(), torch.full((4096,), float(world), dtype=torch.float16))
         dist.barrier()
-        if rank == 0:
-            # rank 1 never makes this call: the wait gives up after 300 ms, the output is poisoned and the status word set
+        if rank != world - 1:
+            # the LAST rank never makes this call: every other rank's wait gives up after 300 ms, its output is poisoned and its
+            # status word set
             stats = torch.zeros(4096 // 16, device=dev)
             out = comm(part, out_dtype=torch.float16, stats_out=stats)
             torch.cuda.synchronize()
@@ -285,13 +287,13 @@ def _lost_peer_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_oneshot_allreduce_lost_peer_poisons_output():
-    world = 2
-    port = 35100 + (os.getpid() % 2000)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_oneshot_allreduce_lost_peer_poisons_output(world):
+    port = 35100 + (os.getpid() % 2000) + 7 * world
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     mp.spawn(_lost_peer_worker, args=(world, port, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    assert dict(ret) == {r: True for r in range(world)}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -302,7 +304,9 @@ def _tp_oracle_worker(rank, world, port, ret, desc_act):
     try:
         from gptqmodel_amd.utils.decode_chain import TPDecodeStep
         from gptqmodel_amd.utils.xgmi_allreduce import OneShotAllReduce
-        hidden, inter, q_dim, kv_dim, gs = 2048, 4096, 2048, 512, 128
+        # (at TP = 8 the q|k|v shard must keep >= 48 column tiles and the act-order column shards >= 16 chunks of K, else the decode op
+        # would want a cross-block split-K next to the in-kernel permutation: 32 query heads x 128 like a real 8-way sharded model)
+        hidden, inter, q_dim, kv_dim, gs = (2048, 4096, 2048, 512, 128) if world <= 4 else (2048, 4096, 4096, 1024, 128)
         layers, shards = _build_layers(world, 2, hidden, inter, q_dim, kv_dim, gs, desc_act, seed=5)
         dl = _decode_layers(shards[rank], layers, gs, torch.float16, desc_act)
         if desc_act:
@@ -312,14 +316,16 @@ def _tp_oracle_worker(rank, world, port, ret, desc_act):
         step = TPDecodeStep(dl, hidden, q_dim // world, torch.float16, comm)
         ok = True
         errs = []
-        for i in range(3):
-            x = O.round_to(np.random.RandomState(90 + i).randn(hidden).astype(np.float32) * 0.5, "fp16")
+        xs = [O.round_to(np.random.RandomState(90 + i).randn(hidden).astype(np.float32) * 0.5, "fp16") for i in range(3)]
+        # the oracle composition is the same on every rank: rank 0 evaluates it, the others receive it
+        refs = [[_oracle_chain(x, layers, "fp16", 1e-5) for x in xs]] if rank == 0 else [None]
+        dist.broadcast_object_list(refs, src=0)
+        for i, x in enumerate(xs):
             step.x_in.copy_(f32_to_torch(x, "fp16", dev))
             got = step.run().clone()
             torch.cuda.synchronize()
             step.check()
-            ref = _oracle_chain(x, layers, "fp16", 1e-5)
-            e = rel_err(torch_to_f32(got), ref)
+            e = rel_err(torch_to_f32(got), refs[0][i])
             errs.append(e)
             ok = ok and bool(torch.isfinite(got).all()) and e <= CHAIN_TOL
             both = [torch.empty(hidden, dtype=torch.float16) for _ in range(world)]
@@ -347,13 +353,12 @@ def _tp_oracle_worker(rank, world, port, ret, desc_act):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("desc_act", [False, True])
-def test_tp2_chain_two_layers_vs_oracle_composition(desc_act):
+@pytest.mark.parametrize("world,desc_act", [(2, False), (2, True), (4, True), (8, True)])
+def test_tp_chain_two_layers_vs_oracle_composition(world, desc_act):
     """TPDecodeStep on two ranks (two processes, one GPU, real IPC mappings): column shards with the in-kernel act-order
     permutation, down_proj's permutation folded into gate / up's column ownership, o_proj behind the one-shot all-gather + select,
     fp32 partial sums reduced in rank order -- against the ORACLE composition of the same shards."""
-    world = 2
-    port = 37100 + (os.getpid() % 2000) + (500 if desc_act else 0)
+    port = 37100 + (os.getpid() % 2000) + (500 if desc_act else 0) + 7 * world
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     mp.spawn(_tp_oracle_worker, args=(world, port, ret, desc_act), nprocs=world, join=True)
