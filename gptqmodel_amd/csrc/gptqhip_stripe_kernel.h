@@ -186,9 +186,11 @@ __global__ __launch_bounds__(512) void stripe_kernel(StripeParams p) {
     };
 
     u4_t bnow, bnext;
+    // (the group constants are expanded once per chunk, at its K-step 0, like in the prefill kernel)
+    ColConst ccs;
     auto dequant_step = [&](const BStage<4, GPC, 1>& bs, int j, u4_t& b) __attribute__((always_inline)) {
-        const ColConst cc = expand_meta<4, SCL>(bs.meta[0][GPC == 4 ? j : 0]);
-        b = dequant_word4<ACT, SCL>(bs.w[0][0][j], cc, dk);
+        if (GPC == 4 || j == 0) ccs = expand_meta<4, SCL>(bs.meta[0][GPC == 4 ? j : 0]);
+        b = dequant_word4<ACT, SCL>(bs.w[0][0][j], ccs, dk);
     };
 
     // One stage: barrier (the stage's sub-tiles have landed -- every wave waited for its own pieces -- and everybody is done

@@ -93,13 +93,23 @@ __device__ __forceinline__ void load_b(BStage<BITS, GPC, TPW>& st, const TiledPa
         int tile = tile0 + t;
         tile = tile < p.tiles ? tile : p.tiles - 1;  // ragged N: clamp (those columns are never stored)
         const uint32_t soff = (uint32_t)(tile * p.chunks + chunk) * (uint32_t)(WPC * 1024);
+#if defined(GPTQHIP_ABLATE_BLOAD)   // dev timing build (tests/dev/r4_pmc_tiled.sh; WRONG results): no weight loads at all
+#pragma unroll
+        for (int h = 0; h < WPC; ++h) st.w[t][h] = u4_t{soff, bs.l16, soff ^ bs.l16, soff + bs.l16};
+#else
 #pragma unroll
         for (int h = 0; h < WPC; ++h) st.w[t][h] = __builtin_amdgcn_raw_buffer_load_b128(bs.qw, bs.l16, soff + h * 1024, 0);
+#endif
         const uint32_t mrow = (uint32_t)(tile * p.G);
+#if defined(GPTQHIP_ABLATE_BLOAD) || defined(GPTQHIP_ABLATE_META)   // dev timing build: the group constants without their loads
+#pragma unroll
+        for (int j = 0; j < GPC; ++j) st.meta[t][j] = 0xE4082000u + mrow;
+#else
 #pragma unroll
         for (int j = 0; j < GPC; ++j)
             st.meta[t][j] = __builtin_amdgcn_raw_buffer_load_b32(bs.meta, bs.c4,
                                                                  (mrow + (uint32_t)tiled_group_of(p, chunk * kChunkK + j * (kChunkK / GPC))) * 64u, 0);
+#endif
     }
 }
 
@@ -246,7 +256,13 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     // chunks i+1 .. i+D-1 are in flight while chunk i is multiplied.  One chunk of a 128-row tile is only ~1000
     // matrix-pipe cycles per wave -- shorter than a loaded HBM round trip -- so D = 3 there; 256-row tiles (2 x 64 KiB
     // of LDS) keep D = 2.
+#if defined(GPTQHIP_ABLATE_BLOAD)
+    constexpr int OPS = BM * 16 / NT;
+#elif defined(GPTQHIP_ABLATE_META)
+    constexpr int OPS = BM * 16 / NT + TPW * (BITS == 4 ? 1 : 2);
+#else
     constexpr int OPS = BM * 16 / NT + TPW * ((BITS == 4 ? 1 : 2) + GPC);  // VMEM instructions per stage and wave
+#endif
     constexpr int NST = OUTF ? BM / 8 : BM / 16;  // 16-byte store instructions per wave and tile in the epilogue
     // Every issue is UNCONDITIONAL (a chunk index past the end is clamped and re-fetches the last chunk into a stage
     // nobody reads): the instruction stream between any load and its use is then the same on every path, which is what
@@ -265,10 +281,29 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     // K-step's MFMAs of the current one, so that after the barrier the matrix pipe restarts after one LDS round trip
     // instead of after a VMEM issue burst + a dequant pass (all 8 waves leave the barrier together: nobody covers).
     u4_t bnow[TPW], bnext[TPW];
+    // The per-(group, column) constants are expanded from the meta word ONCE per chunk (K-step 0) and kept for its other three
+    // K-steps.  (Round 4: the stage's sched_barrier fences kept hipcc from sharing the expansion between the K-steps, so it ran four
+    // times per chunk and tile -- ~9 of the ~22 VALU a K-step of one tile costs; the PMC pass that looked for the "B-load cost"
+    // found VALU / SALU issue slots, not memory: profiles/r04_pmc_tiled_vmem.jsonl.)
+    // (Not on 256-row tiles with bf16 scales or the fp32 epilogue: the kept constants -- four or five registers per tile there -- do not
+    // fit beside the 128 accumulators and come back as scratch traffic; those instantiations keep the per-K-step expansion.)
+    constexpr bool kHoistMeta = GPC == 1 && !(BM == 256 && (SCL == kBF16 || OUTF == 1));
+    ColConst ccs[TPW];
     auto dequant_step = [&](const BStage<BITS, GPC, TPW>& bs, int j, u4_t (&b)[TPW]) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            const ColConst cc = expand_meta<BITS, SCL>(bs.meta[t][GPC == 4 ? j : 0]);
+#ifdef GPTQHIP_TILED_NO_HOIST      // dev A/B build: the round-3 form everywhere
+            constexpr bool kHoist = false;
+#else
+            constexpr bool kHoist = kHoistMeta;
+#endif
+            ColConst cnow;
+            if constexpr (kHoist) {
+                if (j == 0) ccs[t] = expand_meta<BITS, SCL>(bs.meta[t][0]);
+            } else {
+                cnow = expand_meta<BITS, SCL>(bs.meta[t][GPC == 4 ? j : 0]);
+            }
+            const ColConst& cc = kHoist ? ccs[t] : cnow;
             if constexpr (BITS == 4) {
                 b[t] = dequant_word4<ACT, SCL>(bs.w[t][0][j], cc, dk);
             } else {
@@ -303,7 +338,9 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         constexpr bool kIssue = kind != 2;
         constexpr bool kNext = !(kind == 2 && pos == D - 2);  // loads of a next chunk exist (clamped past the end)
         constexpr int sn = (s + 1) % D, si = (s + D - 1) % D;
-        constexpr int PF = BM == 128 ? 8 : 4;  // measured: deeper spills at BM=256, helps at BM=128; 64-row tiles: MT = 4
+        constexpr int PF = BM == 128 ? 8 : 4;  // measured: deeper spills at BM=256, helps at BM=128; 64-row tiles: MT = 4.  (Round 4: reading the
+        // fragments two at a time on the 256-row 8-bit / per-K-step-constant instantiations, to free the registers they spill, made hipcc
+        // spill MORE -- 60-132 bytes instead of 20-72 -- and was dropped.)
         constexpr int NG = 4 * MT / PF;        // fragment groups per chunk
         constexpr int NPIECE = BM * 16 / NT;
 #ifdef GPTQHIP_TILED_INTERLEAVE

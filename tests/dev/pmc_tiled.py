@@ -5,6 +5,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from gptqmodel_amd import _lib  # noqa: E402
+if os.environ.get("GPTQHIP_LIB"):      # dev A/B builds (tests/dev/ablate/*.so)
+    _lib.LIB_PATH = os.environ["GPTQHIP_LIB"]
 from gptqmodel_amd import ops  # noqa: E402
 
 M, K, N = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (8192, 4096, 4096)
