@@ -93,7 +93,7 @@ __device__ __forceinline__ void load_b(BStage<BITS, GPC, TPW>& st, const TiledPa
         int tile = tile0 + t;
         tile = tile < p.tiles ? tile : p.tiles - 1;  // ragged N: clamp (those columns are never stored)
         const uint32_t soff = (uint32_t)(tile * p.chunks + chunk) * (uint32_t)(WPC * 1024);
-#if defined(GPTQHIP_ABLATE_BLOAD)   // dev timing build (tests/dev/r4_pmc_tiled.sh; WRONG results): no weight loads at all
+#if defined(GPTQHIP_ABLATE_BLOAD)   // dev timing build (tests/dev/tiled_ablate_build.sh; WRONG results): no weight loads at all
 #pragma unroll
         for (int h = 0; h < WPC; ++h) st.w[t][h] = u4_t{soff, bs.l16, soff ^ bs.l16, soff + bs.l16};
 #else

@@ -1,6 +1,6 @@
-"""Turn gpurun_out/r02_* (written by collect_profiles_r02.sh on the GPU box) into the committed profiles/r02_* summaries."""
+"""Turn gpurun_out/r04_* (written by collect_profiles_r04.sh on the GPU box) into the committed profiles/r04_* summaries."""
 import collections, csv, json, os, re, shutil, sys
-tag = "r02"
+tag = "r04"
 src, dst = "gpurun_out/", "profiles/"
 os.makedirs(dst, exist_ok=True)
 rows = list(csv.reader(open(f"{src}{tag}_stats/bench_kernel_stats.csv")))
@@ -16,7 +16,7 @@ kt = list(csv.DictReader(open(f"{src}{tag}_stats/bench_kernel_trace.csv")))
 agg = collections.defaultdict(list)
 for r in kt:
     if "skinny_kernel" in r["Kernel_Name"]:
-        glue = re.search(r"skinny_kernel<([^>]*)>", r["Kernel_Name"]).group(1).split(",")[-1].strip()
+        glue = re.search(r"skinny_kernel<([^>]*)>", r["Kernel_Name"]).group(1).split(",")[-2].strip()
         agg[(int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]), glue)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 names = {(6144 // 16, "1"): "qkv (RMSNorm in)", (4096 // 16, "0"): "o / down (residual + stats out)", (28672 // 16, "1"): "gate_up (RMSNorm in, SiLU*mul out)"}
 per = []
@@ -36,7 +36,7 @@ def pmc(d, name):
     return sum(vals) / len(vals) if vals else None
 fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
 summ = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-configs "
-                   "(kernel table and bench line from the SAME run); separate --pmc passes with --no-graph (tests/dev/collect_profiles_r02.sh)",
+                   "(kernel table and bench line from the SAME run); separate --pmc passes with --no-graph (tests/dev/collect_profiles_r04.sh)",
         "kernel": "gptqhip::skinny_kernel<...,GLUE> (batch-1 decode op)", "launches": len(allv),
         "avg_kernel_us_rocprof": sum(allv) / len(allv) / 1e3,
         "bench_line_same_run": {k: bench_prof[k] for k in ("value", "ms_per_step")} | {"avg_launch_us": bench_prof["roofline"]["avg_launch_us"],
@@ -57,7 +57,9 @@ if sq.get("SQ_INSTS_VALU") and summ["avg_kernel_us_rocprof"]:
                        "valu_share_of_avg_launch": sq["SQ_INSTS_VALU"] / 1024 * 4 / 2400 / summ["avg_kernel_us_rocprof"],
                        "note": "averaged over the four launch shapes of a layer; on gate_up alone the loop issues 66 VALU per 1 KiB chunk = 6.3 us of its 14.7"}
 json.dump(summ, open(f"{dst}{tag}_pmc_summary.json", "w"), indent=1)
-for f in ("bench.json", "bench_bf16.json", "bench_modules.json", "decode_ops.txt", "eager_overhead.txt", "e2e_llama8b.txt", "configs.txt", "torch_gpu_baseline.txt"):
+for f in ("bench.json", "bench_bf16.json", "bench_modules.json", "decode_ops.txt", "eager_overhead.txt", "e2e_llama8b.txt", "configs.txt", "torch_gpu_baseline.txt",
+          "gemm_tflops.txt", "gemm_tflops_bf16.txt", "gemm_tflops_bf16_bf16scales.txt", "e2e_llama8b_actorder.txt", "e2e_llama8b_actorder_hfprefill.txt",
+          "e2e_llama8b_hfprefill.txt", "mid_m_sweep.txt"):
     if os.path.exists(f"{src}{tag}_{f}"): shutil.copy(f"{src}{tag}_{f}", f"{dst}{tag}_{f}")
 print(json.dumps({k: summ[k] for k in ("avg_kernel_us_rocprof", "bench_line_same_run", "traffic_over_algorithmic")}, indent=1))
 for p in per: print(p)
