@@ -71,9 +71,10 @@ def cat_cols(ts):
             "scales": np.concatenate([t["scales"] for t in ts], axis=1), "g_idx": ts[0]["g_idx"], "bias": None}
 
 
-def build_layers(world, n_layers, hidden, inter, q_dim, kv_dim, gs, desc_act, seed=0):
+def build_layers(world, n_layers, hidden, inter, q_dim, kv_dim, gs, desc_act, seed=0, only_ranks=None):
     """Full-model checkpoint tensors + their TP shards.  Returns (oracle layer list, per-rank shard tensors [rank][layer]); every
-    oracle layer also carries the un-sharded tensors under "full"."""
+    oracle layer also carries the un-sharded tensors under "full".  only_ranks: build the shards of these ranks only (the others are
+    None) -- a worker process of an 8-rank test needs its own shard, only the rank that evaluates the oracle needs them all."""
     from gptqmodel_amd.utils import tp
     rng = np.random.RandomState(1000 + seed)
     layers, shards = [], [[] for _ in range(world)]
@@ -91,6 +92,10 @@ def build_layers(world, n_layers, hidden, inter, q_dim, kv_dim, gs, desc_act, se
         w_post = O.round_to(1.0 + 0.1 * rng.randn(hidden).astype(np.float32), "fp16")
         ranks = []
         for r in range(world):
+            if only_ranks is not None and r not in only_ranks:
+                ranks.append(None)
+                shards[r].append(None)
+                continue
             tt = {k: to_torch(v) for k, v in full.items()}
             sh = {n: to_np(tp.shard_gptq_column(tt[n], r, world, 4)) for n in ("q", "k", "v")}
             o_t = tp.shard_gptq_row(tt["o"], r, world, 4, gs, act_order="global_sort" if desc_act else "reject")

@@ -2,5 +2,5 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests/ -x -q -m gpu --durations=25 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo\|Terminating process" | tail -45 > gpurun_out/r4_full_pytest.txt
+timeout 2400 python -m pytest tests/ -q -m gpu --maxfail=8 --durations=12 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo\|Terminating process" | tail -45 > gpurun_out/r4_full_pytest.txt
 cat gpurun_out/r4_full_pytest.txt

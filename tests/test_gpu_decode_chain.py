@@ -218,11 +218,20 @@ def test_decode_op_with_glue_group_size_32_64(ops, M, act, gs):
 
 
 def test_decode_op_rejects_unsupported_shapes(ops):
-    qweight, qzeros, scales, _ = synth_gptq(1, 4, 256, 64, 64)
-    qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, 64, 4)
-    assert not ops.decode_supported(256, 64, 64)
+    # K not a multiple of the 128-row chunk: not on the decode op's pipeline (gptqhip_gemm's general path takes it)
+    qweight, qzeros, scales, _ = synth_gptq(1, 4, 160, 64, 32)
+    qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, 32, 4)
+    assert not ops.decode_supported(160, 64, 32)
     with pytest.raises(RuntimeError, match="outside the decode op's regular pipeline"):
-        ops.decode_linear(torch.zeros(256, dtype=torch.float16, device=DEV), qw_t, meta, None, 256, 64, 64, 4, sc.dtype)
+        ops.decode_linear(torch.zeros(160, dtype=torch.float16, device=DEV), qw_t, meta, None, 160, 64, 32, 4, sc.dtype)
+    # a tiny layer (K = 256: two chunks, four column tiles, a group constant per K-step) IS on it since round 4 (short-K plans: the
+    # only ring round is mostly padding) -- and right
+    qweight, qzeros, scales, g_idx = synth_gptq(1, 4, 256, 64, 64)
+    qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, 64, 4)
+    assert ops.decode_supported(256, 64, 64)
+    x = O.round_to(np.random.RandomState(4).randn(256).astype(np.float32) * 0.5, "fp16")
+    y = ops.decode_linear(f32_to_torch(x, "fp16", DEV), qw_t, meta, None, 256, 64, 64, 4, sc.dtype)
+    assert_forward_close(torch_to_f32(y)[None], O.forward_gptq(x[None], qweight, qzeros, scales, g_idx, 4, None, "fp16", "fp16"), "fp16")
     with pytest.raises(RuntimeError, match="norm_weight"):
         ops.decode_linear(torch.zeros(256, dtype=torch.float16, device=DEV), qw_t, meta, None, 256, 64, 64, 4, sc.dtype,
                           in_glue=ops.GLUE_RMSNORM)

@@ -307,7 +307,9 @@ def _tp_oracle_worker(rank, world, port, ret, desc_act):
         # (at TP = 8 the q|k|v shard must keep >= 48 column tiles and the act-order column shards >= 16 chunks of K, else the decode op
         # would want a cross-block split-K next to the in-kernel permutation: 32 query heads x 128 like a real 8-way sharded model)
         hidden, inter, q_dim, kv_dim, gs = (2048, 4096, 2048, 512, 128) if world <= 4 else (2048, 4096, 4096, 1024, 128)
-        layers, shards = _build_layers(world, 2, hidden, inter, q_dim, kv_dim, gs, desc_act, seed=5)
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))      # the ranks share the host's cores
+        layers, shards = _build_layers(world, 2, hidden, inter, q_dim, kv_dim, gs, desc_act, seed=5,
+                                       only_ranks=None if rank == 0 else {rank})
         dl = _decode_layers(shards[rank], layers, gs, torch.float16, desc_act)
         if desc_act:
             assert all(L.o_input_index is not None and L.qkv.perm is not None and L.gate_up.perm is not None and L.down.perm is None
