@@ -26,7 +26,7 @@ static thread_local int t_force_waves = 0;
 
 // process-wide DEFAULTS from the environment, read once and immutable afterwards (triage switches, like the env flags
 // the reference steers its kernels with, torch.py:172-190):
-//   GPTQHIP_FORCE_KERNEL=1|2  always the decode (skinny) / prefill (tiled) kernel;  GPTQHIP_FORCE_SPLIT_K=n;
+//   GPTQHIP_FORCE_KERNEL=1|2|3  always the decode (skinny) / prefill (tiled) / opt-in stripe kernel;  GPTQHIP_FORCE_SPLIT_K=n;
 //   GPTQHIP_FORCE_VARIANT=n   decode: waves per block; prefill: 1/2/3 = 256/128/64-row tiles
 struct EnvTuning {
     int split, kernel, waves;
@@ -306,7 +306,8 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         a.M = M;
         const StripePlan sp = plan_stripe(M, K, N, group_size, bits, g_force_kernel == 3 ? g_force_waves : 0, g_force_kernel == 3 ? g_force_split : 0);
         int* heads = counters + kCounterBytes / sizeof(int) - kStripeHeadSlots;
-        const int wt = g_force_split == 1 || env_int("GPTQHIP_STRIPE_WRITE_THROUGH") == 1 ? 1 : 0;
+        static const int env_wt = env_int("GPTQHIP_STRIPE_WRITE_THROUGH");
+        const int wt = g_force_split == 1 || env_wt == 1 ? 1 : 0;
         return launch_stripe(a, sp, slabs, heads, counters, wt, stream);
     }
     const bool use_tiled = gemm_uses_tiled(M, K, N, group_size, bits);
