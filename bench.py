@@ -506,8 +506,8 @@ print("RESULT", ms, comp)
         return None, f"torch.compile leg unavailable: {e}"
 
 
-def live_pmc(dtype_flag, limit_s=170):
-    """--live-pmc: HBM bytes per decode launch measured NOW on this box: two separate `rocprofv3 --kernel-trace --pmc <counter>`
+def live_pmc(dtype_flag, limit_s=100):
+    """HBM bytes per decode launch measured NOW on this box (the default; --no-live-pmc skips it): two separate `rocprofv3 --kernel-trace --pmc <counter>`
     passes (MI355X_MICROARCH.md: counters in their own run, no other trace domains) over a 3-step eager run of this same script,
     FETCH_SIZE doubled (the guide's gfx950 correction for wide coalesced reads) + WRITE_SIZE.  (bytes | None, source string)."""
     import csv
@@ -522,7 +522,7 @@ def live_pmc(dtype_flag, limit_s=170):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         td = tempfile.mkdtemp(prefix="gptqhip_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", td, "-o", "bench", "--", sys.executable,
-               os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-configs", "--no-graph", "--dtype", dtype_flag]
+               os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-configs", "--no-graph", "--no-live-pmc", "--dtype", dtype_flag]
         try:
             pr = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp", start_new_session=True,
                                   env=dict(os.environ, TMPDIR="/tmp"))
@@ -617,9 +617,10 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end HF Llama-3-8B-shaped decode leg (`e2e` key)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--tp-steps", type=int, default=30, help="timed steps of the C5 tp=N entry appended when N > 1")
-    ap.add_argument("--live-pmc", action="store_true",
-                    help="measure roofline.traffic live (two short rocprofv3 --pmc passes of this script, ~1-2 min) instead of reading "
-                         "the committed profiles/*_pmc_summary.json")
+    ap.add_argument("--live-pmc", action="store_true", help="(default since round 4; kept so that old command lines still parse)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure roofline.traffic live (two short rocprofv3 --pmc passes of this script, ~20-40 s) and read the "
+                         "committed profiles/*_pmc_summary.json instead")
     ap.add_argument("--handshake-only", action="store_true",
                     help="launch / rendezvous check only: spawn the ranks, all-reduce ones, print {n_gpus, ranks_seen}; needs no GPU "
                          "(gloo when CUDA is unavailable) -- tests/test_host_logic.py uses it to prove --gpus is honoured")
@@ -758,7 +759,7 @@ def main():
 
     if rank == 0:
         traffic, traffic_source = (None, "")
-        if args.live_pmc and world == 1:
+        if not args.no_live_pmc and world == 1 and not os.environ.get("GPTQHIP_BENCH_SHARE_GPU"):
             traffic, traffic_source = live_pmc(args.dtype)
         if traffic is None:
             note = traffic_source

@@ -546,6 +546,21 @@ int gptqhip_repack_awq(const int32_t* qweight_awq, const int32_t* qzeros_awq, in
                              reinterpret_cast<hipStream_t>(stream));
 }
 
+int gptqhip_widen_codes(const int32_t* qweight, const int32_t* qzeros, int32_t* qweight_out, int32_t* qzeros_out, int K, int N, int G,
+                        int bits, int planar, gptqhip_stream_t stream) {
+    if (!qweight || !qzeros || !qweight_out || !qzeros_out) {
+        set_error("gptqhip_widen_codes: null tensor pointer");
+        return GPTQHIP_EINVAL;
+    }
+    if (bits < 2 || bits > 8 || K <= 0 || N <= 0 || G <= 0 || K % 32 != 0 || N % 32 != 0 || (planar != 0 && planar != 1) ||
+        ((bits == 5 || bits == 6 || bits == 7) && !planar)) {
+        set_error("gptqhip_widen_codes: bad args K=%d N=%d G=%d bits=%d planar=%d (bits 2..8, K and N multiples of 32, 5 / 6 / 7 bits "
+                  "exist only planar)", K, N, G, bits, planar);
+        return GPTQHIP_EINVAL;
+    }
+    return launch_widen_codes(qweight, qzeros, qweight_out, qzeros_out, K, N, G, bits, planar, reinterpret_cast<hipStream_t>(stream));
+}
+
 int gptqhip_dequant_tiled(const uint32_t* qweight_t, const uint32_t* meta, const int32_t* perm, void* out, int K,
                           int N, int group_size, int bits, int scale_dtype, int out_dtype, gptqhip_stream_t stream) {
     if (!qweight_t || !meta || !out) {

@@ -104,6 +104,85 @@ int launch_repack_awq(const int32_t* qw_awq, const int32_t* qz_awq, int32_t* qw_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Other bit widths (the reference's generic dequantize_weight, gptqmodel/nn_modules/qlinear/__init__.py:947-999):
+// a checkpoint with 2-, 3-, 5-, 6- or 7-bit codes is brought to the continuous 4-bit (bits <= 4) or 8-bit layout the kernels read.
+// The codes and zero-points keep their VALUES, only the field width grows, so W = scale * (code - zero) -- hence every result -- is
+// unchanged.  Source layouts: continuous fields of `bits` bits in the little-endian bit stream of each group of 32 codes (2 / 4 / 8
+// bits never straddle a word; 3 bits do, at codes 10 and 21: the reference special-cases exactly those, :982-991), or PLANAR
+// (utils/planar_packing.py:7-24; always for 5 / 6 / 7 bits): per 32 codes `bits` words, low plane first, a plane of width w holding
+// codes [i*32/w, (i+1)*32/w) of the group in its word i at shifts w*j.  One thread per OUTPUT word; reads and writes are coalesced
+// along N for qweight (N-major words) and along the packed columns for qzeros.
+// ---------------------------------------------------------------------------------------------
+struct WidenSrc {
+    int bits, planar;
+};
+// code `i` (0..31) of a group whose `bits` words are word(0) .. word(bits-1)
+template <class F>
+__device__ __forceinline__ uint32_t widen_extract(const WidenSrc& s, int i, F&& word) {
+    if (!s.planar) {
+        const int pos = s.bits * i, w = pos >> 5, sh = pos & 31;
+        uint32_t v = word(w) >> sh;
+        if (sh + s.bits > 32) v |= word(w + 1) << (32 - sh);
+        return v & ((1u << s.bits) - 1u);
+    }
+    // planes: (width, offset) low to high -- 2: (2,0); 3: (2,0)(1,2); 4: (4,0); 5: (4,0)(1,4); 6: (4,0)(2,4); 7: (4,0)(2,4)(1,6); 8: (8,0)
+    uint32_t v = 0;
+    int row = 0, off = 0, left = s.bits;
+    while (left > 0) {
+        const int width = left >= 8 ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1));
+        const int pf = 32 / width;
+        v |= ((word(row + i / pf) >> (width * (i % pf))) & ((1u << width) - 1u)) << off;
+        row += width;
+        off += width;
+        left -= width;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void widen_qweight_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int K, int N,
+                                                            WidenSrc ws, int wide) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;                 // output word row: rows pf_out * r .. + pf_out - 1
+    if (n >= N) return;
+    const int pf_out = 32 / wide;
+    uint32_t w = 0;
+    for (int j = 0; j < pf_out; ++j) {
+        const int k = r * pf_out + j;
+        const int grp = k >> 5, i = k & 31;
+        const uint32_t code = widen_extract(ws, i, [&](int t) { return (uint32_t)src[(size_t)(grp * ws.bits + t) * N + n]; });
+        w |= code << (wide * j);
+    }
+    dst[(size_t)r * N + n] = (int32_t)w;
+}
+
+__global__ __launch_bounds__(256) void widen_qzeros_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int G, int N,
+                                                           WidenSrc ws, int wide) {
+    const int pf_out = 32 / wide;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;   // output word column: columns pf_out * c ..
+    const int g = blockIdx.y;
+    if (c >= N / pf_out) return;
+    const size_t src_cols = (size_t)N * ws.bits / 32;
+    uint32_t w = 0;
+    for (int j = 0; j < pf_out; ++j) {
+        const int n = c * pf_out + j;
+        const int grp = n >> 5, i = n & 31;
+        const uint32_t z = widen_extract(ws, i, [&](int t) { return (uint32_t)src[(size_t)g * src_cols + (size_t)grp * ws.bits + t]; });
+        w |= z << (wide * j);
+    }
+    dst[(size_t)g * (N / pf_out) + c] = (int32_t)w;
+}
+
+int launch_widen_codes(const int32_t* qweight, const int32_t* qzeros, int32_t* qweight_out, int32_t* qzeros_out, int K, int N, int G,
+                       int bits, int planar, hipStream_t stream) {
+    const int wide = bits <= 4 ? 4 : 8;
+    const WidenSrc ws = {bits, planar};
+    hipLaunchKernelGGL(widen_qweight_kernel, dim3((N + 255) / 256, K * wide / 32), dim3(256), 0, stream, qweight, qweight_out, K, N, ws, wide);
+    const int zc = N * wide / 32;
+    hipLaunchKernelGGL(widen_qzeros_kernel, dim3((zc + 255) / 256, G), dim3(256), 0, stream, qzeros, qzeros_out, G, N, ws, wide);
+    return check_hip(hipGetLastError(), "widen_codes launch");
+}
+
+// ---------------------------------------------------------------------------------------------
 // canonical GPTQ layout (+ optional act-order row permutation) -> tile-major layout + meta constants.
 // One thread per output word.  With perm, sorted row k' is checkpoint row perm[k'] (stable argsort of
 // g_idx), so rows of one group become contiguous -- same role as ExllamaV2 make_sequential

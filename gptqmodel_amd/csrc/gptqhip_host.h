@@ -87,6 +87,8 @@ int launch_dequant_tiled(const uint32_t* qweight_t, const uint32_t* meta, const 
                          int group_size, int bits, int scale_dtype, int out_dtype, hipStream_t stream);
 int launch_repack_awq(const int32_t* qw_awq, const int32_t* qz_awq, int32_t* qw_out, int32_t* qz_out, int K, int N,
                       int G, hipStream_t stream);
+int launch_widen_codes(const int32_t* qweight, const int32_t* qzeros, int32_t* qweight_out, int32_t* qzeros_out, int K, int N, int G,
+                       int bits, int planar, hipStream_t stream);
 int launch_repack_tiled(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* perm,
                         uint32_t* qweight_t, uint32_t* meta, int K, int N, int group_size, int bits,
                         hipStream_t stream);

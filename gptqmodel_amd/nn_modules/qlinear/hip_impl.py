@@ -28,10 +28,8 @@ def _fmt_value(fmt) -> Optional[str]:
 def _convert_v1_to_v2_inplace(module) -> None:
     """The loader's v1 -> v2 qzeros conversion for one module (reference utils/model.py:814-831): checkpoints in
     FORMAT.GPTQ store zero-1; add 1 to every packed field with int32 wraparound."""
-    add = {4: 0x11111111, 8: 0x01010101}[module.bits]
-    if add >= 2 ** 31:
-        add -= 2 ** 32
-    module.qzeros.data += add
+    from gptqmodel_amd.utils.model import shift_v1_qzeros
+    module.qzeros.data = shift_v1_qzeros(module.qzeros.data, module.bits, planar=bool(getattr(module, "planar", False)))
     module.qzero_format(format=2)
 
 
@@ -48,7 +46,10 @@ def make_hip_classes(ns, module_name: str):
         SUPPORTS_BACKENDS = [BACKEND.GPTQ_HIP]
         SUPPORTS_METHODS = [METHOD.GPTQ]
         SUPPORTS_FORMATS = {FORMAT.GPTQ: 120, FORMAT.GPTQ_V2: 120}
-        SUPPORTS_BITS = [4, 8]
+        # 4 and 8 bits are the kernels' native field widths; 2 / 3 bits are widened to 4-bit fields and 5 / 6 / 7 (planar) to 8-bit fields
+        # at post_init (gptqhip_widen_codes: same codes, same zero-points, same results -- the generic dequantize_weight of the
+        # reference, qlinear/__init__.py:947-999), at the price of the wider copy's HBM bytes
+        SUPPORTS_BITS = [2, 3, 4, 5, 6, 7, 8]
         SUPPORTS_GROUP_SIZE = [-1, 32, 64, 128, 256, 512, 1024]
         SUPPORTS_DESC_ACT = [True, False]
         SUPPORTS_SYM = [True, False]
@@ -84,6 +85,14 @@ def make_hip_classes(ns, module_name: str):
             self._scale_dtype = torch.float16
             self._ready = False
             self._bias_cache = None
+            # field width of the layout the kernels read (== bits for 4 / 8); 5 / 6 / 7 bits only exist in the planar layout, 3 bits
+            # are planar under FORMAT.GPTQ_P only (qlinear/__init__.py:766-773; the reference's base class sets `planar` itself)
+            self.kernel_bits = 4 if bits <= 4 else 8
+            if not hasattr(self, "planar"):
+                self.planar = bits in (5, 6, 7) or (_fmt_value(format) == "gptq_p" and bits == 3)
+            if (bits == 3 or self.planar) and (in_features % 32 != 0 or out_features % 32 != 0):
+                raise NotImplementedError(f"{bits}-bit (planar: {self.planar}) packing needs in / out features divisible by 32 "
+                                          f"(qlinear/__init__.py:780-786): got {in_features} x {out_features}")
 
         @classmethod
         def validate_once(cls):
@@ -113,8 +122,11 @@ def make_hip_classes(ns, module_name: str):
                 perm = act_order_permutation(self.g_idx, self.group_size, groups)
             elif self.g_idx is not None and self.g_idx.numel() not in (0, self.in_features):
                 raise NotImplementedError("stacked g_idx (num_itr > 1, torch.py:327) is not supported by the HIP kernel")
-            qw_t, meta = ops.repack_tiled(self.qweight.data, self.qzeros.data, self.scales.data, perm, self.group_size,
-                                          self.bits)
+            qw, qz = self.qweight.data, self.qzeros.data
+            if self.bits not in (4, 8):
+                qw, qz, wide = ops.widen_codes(qw, qz, self.bits, planar=bool(self.planar))
+                assert wide == self.kernel_bits
+            qw_t, meta = ops.repack_tiled(qw, qz, self.scales.data, perm, self.group_size, self.kernel_bits)
             self.qweight.data = qw_t  # tiled words; the checkpoint-layout copy is released
             self._set_derived("meta", meta)
             self._set_derived("perm", perm)
@@ -161,7 +173,7 @@ def make_hip_classes(ns, module_name: str):
             out_shape = x.shape[:-1] + (self.out_features,)
             x2, in_dtype = flatten_input(self._apply_rotation_to_input(x), self.in_features)
             out = ops.gemm(x2, self.qweight, self.meta, self._bias_for(x2.dtype, x2.device), self.perm,
-                           self.out_features, self.group_size, self.bits, self._scale_dtype,
+                           self.out_features, self.group_size, self.kernel_bits, self._scale_dtype,
                            exact_bf16=self.EXACT_BF16_DECODE)
             if self.adapter:
                 out = self.adapter.apply(x=x2, out=out)  # torch.py:344-345
@@ -181,7 +193,7 @@ def make_hip_classes(ns, module_name: str):
             out_shape = x.shape[:-1] + (self.out_features,)
             x2, in_dtype = flatten_input(x, self.in_features)
             out = ops.gemm(x2, self.qweight, self.meta, self._bias_for(x2.dtype, x2.device), None, self.out_features,
-                           self.group_size, self.bits, self._scale_dtype, exact_bf16=self.EXACT_BF16_DECODE)
+                           self.group_size, self.kernel_bits, self._scale_dtype, exact_bf16=self.EXACT_BF16_DECODE)
             if out.dtype != in_dtype:
                 out = out.to(in_dtype)
             return out.reshape(out_shape)
@@ -192,6 +204,9 @@ def make_hip_classes(ns, module_name: str):
             signature and bit-exact output as PackableQuantLinear.pack_block (qlinear/__init__.py:1036-1323):
             scales / zeros arrive as [out, G]."""
             from gptqmodel_amd import ops
+            if self.bits not in (4, 8):
+                # NotImplementedError = "try the next candidate" (utils/model.py:703-707): the reference's own packer serves these widths
+                raise NotImplementedError(f"HipGptqLinear.pack_block packs 4- and 8-bit codes only (got bits={self.bits})")
             dev = linear.weight.device if linear.weight.is_cuda else torch.device("cuda", torch.cuda.current_device())
             w = linear.weight.detach().to(dev)
             sc = scales.T.contiguous().to(dev)
@@ -217,7 +232,7 @@ def make_hip_classes(ns, module_name: str):
                 raise RuntimeError("HipGptqLinear.forward_partial called before post_init()")
             from gptqmodel_amd import ops
             x2, _ = flatten_input(x, self.in_features)
-            out = ops.gemm(x2, self.qweight, self.meta, None, self.perm, self.out_features, self.group_size, self.bits,
+            out = ops.gemm(x2, self.qweight, self.meta, None, self.perm, self.out_features, self.group_size, self.kernel_bits,
                            self._scale_dtype, partial_f32=True)
             return out.reshape(x.shape[:-1] + (self.out_features,))
 
@@ -227,9 +242,12 @@ def make_hip_classes(ns, module_name: str):
                 raise NotImplementedError("num_itr > 1 is not supported")
             from gptqmodel_amd import ops
             if not self._ready:  # still in checkpoint layout
-                return ops.dequant(self.qweight, self.qzeros, self.scales, self.g_idx, self.group_size, self.bits)
+                qw, qz = self.qweight, self.qzeros
+                if self.bits not in (4, 8):
+                    qw, qz, _ = ops.widen_codes(qw, qz, self.bits, planar=bool(self.planar))
+                return ops.dequant(qw, qz, self.scales, self.g_idx, self.group_size, self.kernel_bits)
             return ops.dequant_tiled(self.qweight, self.meta, self.perm, self.in_features, self.out_features,
-                                     self.group_size, self.bits, self._scale_dtype)
+                                     self.group_size, self.kernel_bits, self._scale_dtype)
 
     class HipQuantEmbeddings(HipGptqLinear):
         """Quantised embedding table on the HIP backend: the mirror of TorchQuantEmbeddings
@@ -273,7 +291,7 @@ def make_hip_classes(ns, module_name: str):
                 raise RuntimeError("HipQuantEmbeddings.forward called before post_init()")
             from gptqmodel_amd import ops
             return ops.embedding(input_ids, self.qweight, self.meta, self._inv_perm, self.in_features,
-                                 self.out_features, self.group_size, self.bits, self._scale_dtype)
+                                 self.out_features, self.group_size, self.kernel_bits, self._scale_dtype)
 
     class HipAwqLinear(AWQuantLinear):
         """BACKEND.AWQ_HIP: MI355X fused dequant-matmul QuantLinear for AWQ (FORMAT.GEMM) checkpoints.  Drop-in for

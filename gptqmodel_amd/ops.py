@@ -289,6 +289,31 @@ def dequant_tiled(qweight_t, meta, perm, K: int, N: int, group_size: int, bits: 
     return out
 
 
+PLANAR_ONLY_BITS = (5, 6, 7)
+
+
+def kernel_bits(bits: int) -> int:
+    """Field width of the layout the kernels read for a checkpoint of `bits`-bit codes (gptqhip_widen_codes)."""
+    return 4 if bits <= 4 else 8
+
+
+def widen_codes(qweight: torch.Tensor, qzeros: torch.Tensor, bits: int, planar: Optional[bool] = None):
+    """(qweight, qzeros) of a 2 / 3 / 5 / 6 / 7-bit checkpoint -> the same codes in the continuous 4- or 8-bit layout + that width."""
+    lib = _lib.load()
+    _require_cuda(qweight, qzeros)
+    if planar is None:
+        planar = bits in PLANAR_ONLY_BITS
+    K, N, G = qweight.shape[0] * 32 // bits, qweight.shape[1], qzeros.shape[0]
+    wide = kernel_bits(bits)
+    qw = torch.empty((K * wide // 32, N), dtype=torch.int32, device=qweight.device)
+    qz = torch.empty((G, N * wide // 32), dtype=torch.int32, device=qweight.device)
+    with torch.cuda.device(qweight.device):
+        rc = lib.gptqhip_widen_codes(_ptr(qweight.contiguous()), _ptr(qzeros.contiguous()), _ptr(qw), _ptr(qz), K, N, G, bits,
+                                     1 if planar else 0, _stream(qweight.device))
+    _lib.check(rc, "gptqhip_widen_codes")
+    return qw, qz, wide
+
+
 def repack_awq(qweight_awq: torch.Tensor, qzeros_awq: torch.Tensor):
     lib = _lib.load()
     _require_cuda(qweight_awq, qzeros_awq)

@@ -66,9 +66,10 @@ def normalize_quantize_config(raw: Dict) -> Dict:
         "lm_head": bool(cfg.get("lm_head", False)),
         "meta": cfg.get("meta") or {},
     }
-    if out["bits"] not in (4, 8):
-        # (the reference also packs 2 / 3 bits; the HIP modules -- and this reader / writer -- cover 4 and 8, SUPPORTS_BITS)
-        raise ValueError(f"quantize_config: bits={out['bits']} is outside this backend (4 or 8)")
+    ok_bits = (4,) if method == "awq" else (2, 3, 4, 5, 6, 7, 8)
+    if out["bits"] not in ok_bits:
+        # HipGptqLinear.SUPPORTS_BITS (2 / 3 / 5 / 6 / 7 are widened to the 4- / 8-bit kernel layout at post_init); AWQ is 4-bit
+        raise ValueError(f"quantize_config: bits={out['bits']} is outside this backend ({method}: {ok_bits})")
     if out["group_size"] != -1 and out["group_size"] <= 0:
         raise ValueError(f"quantize_config: group_size={out['group_size']}")
     return out
@@ -210,16 +211,11 @@ def load_quantized_checkpoint(model: nn.Module, ckpt_dir: str, device="cuda", ba
     return model
 
 
-def _v2_to_v1_qzeros(qzeros: torch.Tensor, bits: int) -> torch.Tensor:
-    """Runtime (v2) zero-points -> on-disk `format: gptq` (v1, zero - 1 per field): the inverse of utils/model.py:814-818 /
-    the reference writer's convert_gptq_v2_to_v1_format.  Fields wrap modulo 2^bits like the reference's integer subtraction."""
-    pf = 32 // bits
-    mask = (1 << bits) - 1
-    sh = torch.arange(0, 32, bits, dtype=torch.int64, device=qzeros.device)
-    z = (qzeros.to(torch.int64).unsqueeze(-1) >> sh) & mask
-    w = (((z - 1) & mask) << sh).sum(dim=-1) & 0xFFFFFFFF
-    assert z.shape[-1] == pf
-    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+def _v2_to_v1_qzeros(qzeros: torch.Tensor, bits: int, planar=None) -> torch.Tensor:
+    """Runtime (v2) zero-points -> on-disk `format: gptq` (v1, zero - 1): the reference writer's
+    convert_gptq_v2_to_v1_format_module (utils/model.py:900-943), the exact inverse of the loader's conversion."""
+    from .model import unshift_v2_qzeros
+    return unshift_v2_qzeros(qzeros, bits, planar)
 
 
 def save_quantized_checkpoint(model: nn.Module, ckpt_dir: str, quantize_config: Dict, max_shard_bytes: int = 1 << 30) -> List[str]:
@@ -232,17 +228,18 @@ def save_quantized_checkpoint(model: nn.Module, ckpt_dir: str, quantize_config: 
     cfg = normalize_quantize_config(quantize_config)
     os.makedirs(ckpt_dir, exist_ok=True)
     state = {}
-    v1_owners = set()
+    v1_owners, planar_of = set(), {}
     for name, mod in model.named_modules():
         if isinstance(mod, BaseQuantLinear):
             if getattr(mod, "_ready", False):
                 raise RuntimeError(f"`{name}` is already post_init()ed: save from the checkpoint-layout model")
             if cfg["format"] == "gptq" and hasattr(mod, "qzero_format") and mod.qzero_format() == 2:
                 v1_owners.add(name)
+                planar_of[name] = bool(getattr(mod, "planar", False))
     for key, t in model.state_dict().items():
         t = t.detach()
         if key.endswith(".qzeros") and key[: -len(".qzeros")] in v1_owners:
-            t = _v2_to_v1_qzeros(t, cfg["bits"])
+            t = _v2_to_v1_qzeros(t, cfg["bits"], planar_of[key[: -len(".qzeros")]])
         state[key] = t.to("cpu").contiguous()
     shards: List[Dict[str, torch.Tensor]] = [{}]
     size = 0

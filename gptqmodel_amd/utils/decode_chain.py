@@ -84,7 +84,7 @@ class DecodeStep:
         need = 0
         for L in self.layers:
             for lin in (L.qkv, L.o, L.gate_up, L.down):
-                need = max(need, ops.workspace_bytes(1, lin.in_features, lin.out_features, lin.group_size, lin.bits, False))
+                need = max(need, ops.workspace_bytes(1, lin.in_features, lin.out_features, lin.group_size, getattr(lin, "kernel_bits", lin.bits), False))
         self.workspace = torch.zeros(max(need, 1 << 20), dtype=torch.uint8, device=dev)
         h_in, st_in = self.x_in, None     # the step's input comes from outside the chain: no producer statistics
         for li, L in enumerate(self.layers):
@@ -107,7 +107,7 @@ class DecodeStep:
                 if not ops.decode_supported(K, N, lin.group_size, perm is not None):
                     raise NotImplementedError(f"decode chain: layer shape K={K} N={N} group_size={lin.group_size} unsupported")
                 self._keep.extend([qw, meta, bias, nw, perm])
-                self.ops.append(ops.make_decode_op(x, qw, meta, bias, out, K, N, lin.group_size, lin.bits, sdt, in_glue=glue,
+                self.ops.append(ops.make_decode_op(x, qw, meta, bias, out, K, N, lin.group_size, getattr(lin, "kernel_bits", lin.bits), sdt, in_glue=glue,
                                                    norm_weight=nw, eps=eps, residual=res, workspace=self.workspace,
                                                    out_glue=oglue, stats_in=s_in, stats_out=s_out, perm=perm, exact=exact))
             h_in, st_in = h2, st2
@@ -162,7 +162,7 @@ class TPDecodeStep:
         need = 0
         for L in self.layers:
             for lin in (L.qkv, L.o, L.gate_up, L.down):
-                need = max(need, ops.workspace_bytes(1, lin.in_features, lin.out_features, lin.group_size, lin.bits, False))
+                need = max(need, ops.workspace_bytes(1, lin.in_features, lin.out_features, lin.group_size, getattr(lin, "kernel_bits", lin.bits), False))
         self.workspace = torch.zeros(max(need, 1 << 20), dtype=torch.uint8, device=dev)
         self._keep, self.steps = [], []   # steps: ("op", struct) | ("ar", residual, bias, out, stats_out) | ("ag", x_local, index, out)
         self.o_in = None                  # act-order o_proj shards: the gathered + selected attention-output features
@@ -178,7 +178,7 @@ class TPDecodeStep:
             if not ops.decode_supported(K, N, lin.group_size, perm is not None):
                 raise NotImplementedError(f"decode chain: shard shape K={K} N={N} group_size={lin.group_size} unsupported")
             self._keep.extend([qw, meta, bias, nw, perm])
-            self.steps.append(("op", ops.make_decode_op(x, qw, meta, bias, out, K, N, lin.group_size, lin.bits, sdt, in_glue=glue,
+            self.steps.append(("op", ops.make_decode_op(x, qw, meta, bias, out, K, N, lin.group_size, getattr(lin, "kernel_bits", lin.bits), sdt, in_glue=glue,
                                                         norm_weight=nw, eps=eps, workspace=self.workspace, out_glue=oglue,
                                                         stats_in=s_in, perm=perm)))
 

@@ -103,7 +103,7 @@ class _LayerDecodeState:
             from .decode_chain import _lin_tensors
             qw, meta, bias, sdt, perm = _lin_tensors(lin, dtype)
             self._keep.extend([qw, meta, bias, perm])
-            return ops.make_decode_op(x, qw, meta, bias, out, lin.in_features, lin.out_features, lin.group_size, lin.bits, sdt,
+            return ops.make_decode_op(x, qw, meta, bias, out, lin.in_features, lin.out_features, lin.group_size, getattr(lin, "kernel_bits", lin.bits), sdt,
                                       workspace=ws, perm=perm, M=M, **kw)
 
         # qkv / o come in two flavours: chained to the previous layer's h2 (+ its statistics), or fed from x_in (first layer, or
@@ -350,7 +350,7 @@ def fuse_llama_decoder_layers(model: nn.Module, allow_unknown: bool = False) -> 
             need = 1 << 20
             for L in fused:
                 for lin in (L.self_attn.fused_q_proj_k_proj_v_proj.fused, L.self_attn.o_proj, L.mlp.fused_gate_up.fused, L.mlp.down_proj):
-                    need = max(need, ops.workspace_bytes(1, lin.in_features, lin.out_features, lin.group_size, lin.bits, False))
+                    need = max(need, ops.workspace_bytes(1, lin.in_features, lin.out_features, lin.group_size, getattr(lin, "kernel_bits", lin.bits), False))
             ws_holder["t"] = torch.zeros(need, dtype=torch.uint8, device=fused[0].self_attn.o_proj.qweight.device)
         return ws_holder["t"]
 

@@ -15,14 +15,94 @@ from .importer import select_quant_linear
 _V1_TO_V2_ADD = {4: 0x11111111, 8: 0x01010101}
 
 
-def convert_gptq_v1_to_v2_format_module(module: BaseQuantLinear, bits: int, pack_dtype: torch.dtype = torch.int32):
-    """v1 checkpoints store zero-1; add 1 to every packed field with int32 wraparound (utils/model.py:814-831)."""
-    if pack_dtype != torch.int32 or bits not in _V1_TO_V2_ADD:
-        raise NotImplementedError(f"v1->v2 conversion supports int32 words with 4/8 bits, got {pack_dtype}/{bits}")
-    add = _V1_TO_V2_ADD[bits]
+_PLANES = {2: ((2, 0),), 3: ((2, 0), (1, 2)), 4: ((4, 0),), 5: ((4, 0), (1, 4)), 6: ((4, 0), (2, 4)), 7: ((4, 0), (2, 4), (1, 6)), 8: ((8, 0),)}
+
+
+def _zero_fields(qzeros: torch.Tensor, bits: int, planar: bool) -> torch.Tensor:
+    """qzeros int32 [G, N*bits/32] -> int64 [G, N] zero-points, continuous `bits`-bit fields of each 32-column group's bit stream or
+    the planar layout (utils/planar_packing.py:7-24)."""
+    g, cols = qzeros.shape
+    w = (qzeros.to(torch.int64) & 0xFFFFFFFF).reshape(g, cols // bits, bits)
+    out = torch.zeros((g, cols // bits, 32), dtype=torch.int64, device=qzeros.device)
+    if planar:
+        row = 0
+        for width, offset in _PLANES[bits]:
+            pf = 32 // width
+            sh = torch.arange(pf, dtype=torch.int64, device=qzeros.device) * width
+            codes = (w[:, :, row:row + width, None] >> sh) & ((1 << width) - 1)
+            out |= codes.reshape(g, cols // bits, 32) << offset
+            row += width
+    else:
+        for i in range(32):
+            pos = bits * i
+            wi, sh = pos // 32, pos % 32
+            v = w[:, :, wi] >> sh
+            if sh + bits > 32:
+                v = v | (w[:, :, wi + 1] << (32 - sh))
+            out[:, :, i] = v & ((1 << bits) - 1)
+    return out.reshape(g, -1)
+
+
+def _pack_zero_fields(z: torch.Tensor, bits: int, planar: bool) -> torch.Tensor:
+    g, n = z.shape
+    c = z.to(torch.int64).reshape(g, n // 32, 32)
+    out = torch.zeros((g, n // 32, bits), dtype=torch.int64, device=z.device)
+    if planar:
+        row = 0
+        for width, offset in _PLANES[bits]:
+            pf = 32 // width
+            plane = ((c >> offset) & ((1 << width) - 1)).reshape(g, n // 32, width, pf)
+            sh = torch.arange(pf, dtype=torch.int64, device=z.device) * width
+            out[:, :, row:row + width] = (plane << sh).sum(dim=-1)
+            row += width
+    else:
+        for i in range(32):
+            pos = bits * i
+            wi, sh = pos // 32, pos % 32
+            out[:, :, wi] |= (c[:, :, i] << sh) & 0xFFFFFFFF
+            if sh + bits > 32:
+                out[:, :, wi + 1] |= c[:, :, i] >> (32 - sh)
+    out = out.reshape(g, -1) & 0xFFFFFFFF
+    return torch.where(out >= 2 ** 31, out - 2 ** 32, out).to(torch.int32)
+
+
+def unshift_v2_qzeros(qzeros: torch.Tensor, bits: int, planar=None) -> torch.Tensor:
+    """Runtime (v2) zero-points -> the on-disk `format: gptq` ones (v1, zero - 1 in every field, modulo 2^bits): the inverse of
+    shift_v1_qzeros, what the reference's writer applies (convert_gptq_v2_to_v1_format_module, utils/model.py:900-943): a word subtract for
+    2 / 4 / 8 bits, the decoded values shifted by one for 3 / 5 / 6 / 7 bits and the planar layouts."""
+    if bits not in _PLANES:
+        raise NotImplementedError(f"v2->v1 conversion: bits={bits}")
+    planar = bits in (5, 6, 7) if planar is None else bool(planar)
+    if bits in (2, 4, 8) and not planar:          # the reference's word subtract (:910-931), the exact inverse of the word add
+        sub = {2: 0x55555555, 4: 0x11111111, 8: 0x01010101}[bits]
+        return qzeros - (sub - 2 ** 32 if sub >= 2 ** 31 else sub)
+    z = (_zero_fields(qzeros, bits, planar) - 1) & ((1 << bits) - 1)
+    return _pack_zero_fields(z, bits, planar)
+
+
+def shift_v1_qzeros(qzeros: torch.Tensor, bits: int, planar=None) -> torch.Tensor:
+    """v1 -> v2 zero-points for every bit width the reference converts (utils/model.py:750-844): 2 / 4 / 8 bits add one to every packed
+    field with int32 wraparound (the word add of :756-831); 3 / 5 / 6 / 7 bits and every planar layout have fields that straddle words
+    or planes, so the DECODED values are shifted by one modulo 2^bits and re-encoded (:767-775, :834-839)."""
+    planar = bits in (5, 6, 7) if planar is None else bool(planar)
+    if bits in (3, 5, 6, 7) or planar:
+        if bits not in _PLANES:
+            raise NotImplementedError(f"v1->v2 conversion: bits={bits}")
+        z = (_zero_fields(qzeros, bits, planar) + 1) & ((1 << bits) - 1)
+        return _pack_zero_fields(z, bits, planar)
+    add = {2: 0x55555555, 4: 0x11111111, 8: 0x01010101}.get(bits)
+    if add is None:
+        raise NotImplementedError(f"v1->v2 conversion: bits={bits}")
     if add >= 2 ** 31:
         add -= 2 ** 32
-    module.qzeros.data += add  # int32 tensor add wraps like the reference's `+= 0b0001...`
+    return qzeros + add  # int32 tensor add wraps like the reference's `+= 0b0001...`
+
+
+def convert_gptq_v1_to_v2_format_module(module: BaseQuantLinear, bits: int, pack_dtype: torch.dtype = torch.int32):
+    """v1 checkpoints store zero-1; the loader turns them into v2 zero-points before post_init (utils/model.py:750-844)."""
+    if pack_dtype != torch.int32:
+        raise NotImplementedError(f"v1->v2 conversion supports int32 words, got {pack_dtype}")
+    module.qzeros.data = shift_v1_qzeros(module.qzeros.data, bits, planar=bool(getattr(module, "planar", False)))
     module.qzero_format(format=2)
     return module
 
@@ -205,6 +285,9 @@ def fuse_quant_linears(mods: List[BaseQuantLinear]) -> BaseQuantLinear:
     post_init().  Raises NotImplementedError when the siblings cannot share one kernel launch (different
     quantisation parameters, or act-order with different permutations)."""
     m0 = mods[0]
+    if m0.bits not in (4, 8):
+        # (the column concatenation works on whole packed words: 4- and 8-bit fields; the widened bit widths keep separate launches)
+        raise NotImplementedError(f"sibling fusion packs 4- and 8-bit columns only (bits={m0.bits}); not fusing")
     for m in mods[1:]:
         same = (type(m) is type(m0) and m.bits == m0.bits and m.group_size == m0.group_size
                 and m.in_features == m0.in_features and m.sym == m0.sym and m.desc_act == m0.desc_act
@@ -259,6 +342,8 @@ def fuse_gate_up_interleaved(gate: BaseQuantLinear, up: BaseQuantLinear) -> Base
     for m in (gate, up):
         if getattr(m, "_ready", False):
             raise RuntimeError("fuse_gate_up_interleaved must be called before post_init()")
+    if gate.bits not in (4, 8):
+        raise NotImplementedError(f"gate/up interleaving packs 4- and 8-bit columns only (bits={gate.bits}); not fusing")
     same = (type(gate) is type(up) and gate.bits == up.bits and gate.group_size == up.group_size and gate.sym == up.sym
             and gate.in_features == up.in_features and gate.out_features == up.out_features and gate.desc_act == up.desc_act
             and gate.scales.dtype == up.scales.dtype and (gate.bias is None) == (up.bias is None))
@@ -344,6 +429,8 @@ def fold_act_order_into_producers(consumer: BaseQuantLinear, producers: List[Bas
     integer codes move.  GPTQ checkpoint-layout modules BEFORE post_init(); returns False (nothing changed) when the consumer
     has no act-order permutation or the modules do not fit (producer out_features != consumer in_features, adapters, AWQ)."""
     g = getattr(consumer, "g_idx", None)
+    if consumer.bits not in (4, 8):
+        return False        # (rows are re-packed in 4- / 8-bit fields here; the other widths keep their gather)
     if g is None or g.numel() != consumer.in_features or getattr(consumer, "_ready", False):
         return False
     if any(getattr(p, "_ready", False) or p.out_features != consumer.in_features or getattr(p, "adapter", None) is not None

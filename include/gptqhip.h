@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 14
+#define GPTQHIP_ABI_VERSION 15
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -195,6 +195,16 @@ int gptqhip_dequant(const int32_t* qweight, const int32_t* qzeros, const void* s
 int gptqhip_dequant_tiled(const uint32_t* qweight_t, const uint32_t* meta, const int32_t* perm, void* out,
                           int K, int N, int group_size, int bits, int scale_dtype, int out_dtype,
                           gptqhip_stream_t stream);
+
+/* post_init helper for the OTHER bit widths of the reference's generic dequantize_weight (gptqmodel/nn_modules/qlinear/__init__.py:947-999:
+ * continuous 2- and 3-bit words -- the 3-bit codes 10 and 21 of every 32 straddle a word, :982-991 -- and the planar 3 / 5 / 6 / 7-bit
+ * layout of gptqmodel/utils/planar_packing.py:7-24): qweight int32 [K*bits/32, N] / qzeros int32 [G, N*bits/32] -> the same codes and
+ * zero-points in the continuous 4-bit (bits <= 4) or 8-bit layout every other entry point reads (qweight_out [K*wide/32, N], qzeros_out
+ * [G, N*wide/32], wide = bits <= 4 ? 4 : 8).  Values are unchanged, so W = scale * (code - zero) is too; the wider copy costs HBM bytes
+ * (3 bits stored as 4: +33 %), not correctness.  K % 32 == 0, N % 32 == 0; planar = 1 for 5 / 6 / 7 bits (they exist only planar) and for
+ * FORMAT.GPTQ_P checkpoints of the other widths. */
+int gptqhip_widen_codes(const int32_t* qweight, const int32_t* qzeros, int32_t* qweight_out, int32_t* qzeros_out,
+                        int K, int N, int G, int bits, int planar, gptqhip_stream_t stream);
 
 /* post_init helper: AWQ GEMM layout (qweight [K,N/8], qzeros [G,N/8], nibble i <-> column 8c+[0,2,4,6,1,3,5,7][i])
  * -> checkpoint-canonical layout.  Semantics of unpack_reorder_pack (packing_utils.py:90-103); zero-points kept as-is. */

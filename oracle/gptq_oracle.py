@@ -97,7 +97,115 @@ def unpack_cols(qzeros: np.ndarray, bits: int) -> np.ndarray:
     return z.reshape(w.shape[0], w.shape[1] * pf).astype(np.uint8)
 
 
-def convert_v1_to_v2_qzeros(qzeros: np.ndarray, bits: int) -> np.ndarray:
+# ---- the other bit widths of the generic dequantize_weight (qlinear/__init__.py:947-999) -------------------
+# continuous 3-bit: 32 codes in three int32 words, code i at bit 3 i of the 96-bit little-endian group -- the reference special-cases
+# the two codes that straddle a word boundary (i = 10: bits 30-31 of word 0 + bit 0 of word 1; i = 21: bit 31 of word 1 + bits 0-1 of
+# word 2; qlinear/__init__.py:982-991).  Planar ("split-plane", utils/planar_packing.py:7-24; always for 5 / 6 / 7 bits): per 32 codes
+# `bits` words, first the low plane's words, then the higher planes; inside a plane of width w, word i holds codes [i*32/w, (i+1)*32/w)
+# at shifts w*j.
+PLANES = {2: ((2, 0),), 3: ((2, 0), (1, 2)), 4: ((4, 0),), 5: ((4, 0), (1, 4)), 6: ((4, 0), (2, 4)), 7: ((4, 0), (2, 4), (1, 6)), 8: ((8, 0),)}
+PLANAR_ONLY_BITS = (5, 6, 7)
+
+
+def is_planar(bits: int, planar=None) -> bool:
+    """5 / 6 / 7 bits only exist planar; 3 bits are planar only under FORMAT.GPTQ_P (qlinear/__init__.py:766-773)."""
+    return bits in PLANAR_ONLY_BITS if planar is None else bool(planar)
+
+
+def _unpack_groups(words: np.ndarray, bits: int, planar: bool) -> np.ndarray:
+    """words uint32 [blocks, bits, cols] (the `bits` words of every group of 32 codes) -> codes uint32 [blocks, 32, cols]."""
+    blocks, _, cols = words.shape
+    out = np.zeros((blocks, 32, cols), dtype=np.uint32)
+    if planar:
+        row = 0
+        for width, offset in PLANES[bits]:
+            pf = 32 // width
+            sh = (np.arange(pf, dtype=np.uint32) * width)[None, None, :, None]
+            codes = (words[:, row:row + width, None, :] >> sh) & np.uint32((1 << width) - 1)      # [blocks, width, pf, cols]
+            out |= codes.reshape(blocks, 32, cols) << np.uint32(offset)
+            row += width
+        return out
+    stream = words.astype(np.uint64)
+    for i in range(32):
+        pos = bits * i
+        w, sh = pos // 32, pos % 32
+        v = stream[:, w] >> np.uint64(sh)
+        if sh + bits > 32:
+            v = v | (stream[:, w + 1] << np.uint64(32 - sh))
+        out[:, i] = (v & np.uint64((1 << bits) - 1)).astype(np.uint32)
+    return out
+
+
+def unpack_rows_any(qweight: np.ndarray, bits: int, planar=None) -> np.ndarray:
+    """qweight int32 [K*bits/32, N] -> codes uint8 [K, N] for every bit width the reference's generic path reads."""
+    if bits in (2, 4, 8) and not is_planar(bits, planar):
+        return unpack_rows(qweight, bits)
+    w = np.ascontiguousarray(qweight).view(np.uint32)
+    assert w.shape[0] % bits == 0
+    return _unpack_groups(w.reshape(w.shape[0] // bits, bits, w.shape[1]), bits, is_planar(bits, planar)).reshape(-1, w.shape[1]).astype(np.uint8)
+
+
+def unpack_cols_any(qzeros: np.ndarray, bits: int, planar=None) -> np.ndarray:
+    """qzeros int32 [G, N*bits/32] -> zero-points uint8 [G, N] (the column-packed twin of unpack_rows_any)."""
+    if bits in (2, 4, 8) and not is_planar(bits, planar):
+        return unpack_cols(qzeros, bits)
+    return unpack_rows_any(np.ascontiguousarray(np.ascontiguousarray(qzeros).T), bits, planar).T.copy()
+
+
+def _pack_groups(codes: np.ndarray, bits: int, planar: bool) -> np.ndarray:
+    """codes [blocks, 32, cols] -> words uint32 [blocks, bits, cols] (inverse of _unpack_groups; test-tensor synthesis only)."""
+    blocks, _, cols = codes.shape
+    c = codes.astype(np.uint64)
+    out = np.zeros((blocks, bits, cols), dtype=np.uint64)
+    if planar:
+        row = 0
+        for width, offset in PLANES[bits]:
+            pf = 32 // width
+            plane = ((c >> np.uint64(offset)) & np.uint64((1 << width) - 1)).reshape(blocks, width, pf, cols)
+            sh = (np.arange(pf, dtype=np.uint64) * np.uint64(width))[None, None, :, None]
+            out[:, row:row + width] = np.bitwise_or.reduce(plane << sh, axis=2)
+            row += width
+    else:
+        for i in range(32):
+            pos = bits * i
+            w, sh = pos // 32, pos % 32
+            out[:, w] |= (c[:, i] << np.uint64(sh)) & np.uint64(0xFFFFFFFF)
+            if sh + bits > 32:
+                out[:, w + 1] |= c[:, i] >> np.uint64(32 - sh)
+    return (out & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+
+
+def pack_rows_any(codes: np.ndarray, bits: int, planar=None) -> np.ndarray:
+    if bits in (2, 4, 8) and not is_planar(bits, planar):
+        return pack_rows(codes, bits)
+    k, n = codes.shape
+    assert k % 32 == 0
+    return _pack_groups(codes.reshape(k // 32, 32, n), bits, is_planar(bits, planar)).reshape(-1, n).view(np.int32)
+
+
+def pack_cols_any(zeros: np.ndarray, bits: int, planar=None) -> np.ndarray:
+    if bits in (2, 4, 8) and not is_planar(bits, planar):
+        return pack_cols(zeros, bits)
+    return np.ascontiguousarray(pack_rows_any(np.ascontiguousarray(zeros.T), bits, planar).T)
+
+
+def widen_codes(qweight: np.ndarray, qzeros: np.ndarray, bits: int, planar=None):
+    """Checkpoint tensors of any bit width -> the SAME codes and zero-points in the continuous 4-bit (bits <= 4) or 8-bit layout the
+    HIP kernels read: W = scale * (code - zero) is unchanged, only the field width grows.  (The layout model of gptqhip_widen_codes.)"""
+    wide = 4 if bits <= 4 else 8
+    return pack_rows(unpack_rows_any(qweight, bits, planar), wide), pack_cols(unpack_cols_any(qzeros, bits, planar), wide), wide
+
+
+def convert_v1_to_v2_qzeros(qzeros: np.ndarray, bits: int, planar=None) -> np.ndarray:
+    if bits in (3, 5, 6, 7) or is_planar(bits, planar):
+        # fields that straddle words or planes: shift the DECODED values by one, modulo 2^bits, and re-encode
+        # (utils/model.py:767-775,834-839 -> model_dequant._shift_gptq_qzeros)
+        z = (unpack_cols_any(qzeros, bits, planar).astype(np.uint32) + 1) & ((1 << bits) - 1)
+        return pack_cols_any(z.astype(np.uint8), bits, planar)
+    return _convert_v1_to_v2_words(qzeros, bits)
+
+
+def _convert_v1_to_v2_words(qzeros: np.ndarray, bits: int) -> np.ndarray:
     """GPTQ v1 checkpoints store zero-1; the loader adds 0x11111111 (4-bit) / 0x01010101 (8-bit) per
     int32 word with wraparound.  utils/model.py:814-831."""
     add = {2: 0x55555555, 4: 0x11111111, 8: 0x01010101}[bits]
@@ -118,8 +226,8 @@ def dequant_gptq(qweight, qzeros, scales_f32, g_idx, bits: int, scale_dtype: str
     W = scales[g_idx] * (code - zeros[g_idx])   torch.py:716-717  == qlinear/__init__.py:1001-1003.
     (code - zero) is an int8/int16 subtraction (exact), the product of an fp16|bf16 scale and an integer
     |.|<=255 is exact in fp32, so rounding the fp32 product once reproduces torch's fp16/bf16 multiply."""
-    codes = unpack_rows(qweight, bits).astype(np.int32)
-    zeros = unpack_cols(qzeros, bits).astype(np.int32)
+    codes = unpack_rows_any(qweight, bits).astype(np.int32)
+    zeros = unpack_cols_any(qzeros, bits).astype(np.int32)
     scales_f32 = np.asarray(scales_f32, dtype=np.float32)
     g = normalize_g_idx(g_idx, scales_f32.shape[0])
     w = scales_f32[g] * (codes - zeros[g]).astype(np.float32)

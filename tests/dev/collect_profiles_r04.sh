@@ -6,10 +6,10 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # (1) the bench number and the per-kernel table from the SAME run
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r04_stats -o bench -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-configs > $O/r04_stats_bench.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r04_stats -o bench -- python $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-configs --no-live-pmc > $O/r04_stats_bench.log 2>&1
 # (2) HBM traffic: separate --pmc passes (no trace domains besides --kernel-trace), eager launches so every dispatch is counted
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/r04_pmc_fetch -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-graph > $O/r04_pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/r04_pmc_write -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-graph > $O/r04_pmc_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/r04_pmc_fetch -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-graph --no-live-pmc > $O/r04_pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/r04_pmc_write -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --no-graph --no-live-pmc > $O/r04_pmc_write.log 2>&1
 for d in r04_pmc_fetch r04_pmc_write; do python $R/tests/dev/pmc_agg.py $O/$d > /dev/null 2>&1; done
 find $O/r04_stats $O/r04_pmc_fetch $O/r04_pmc_write -type f -size +12M -delete 2>/dev/null
 cd $R

@@ -26,7 +26,7 @@ def declared_symbols():
 def test_header_declares_the_expected_entry_points():
     syms = declared_symbols()
     for must in ("gptqhip_gemm", "gptqhip_repack_tiled", "gptqhip_repack_awq", "gptqhip_dequant",
-                 "gptqhip_dequant_tiled", "gptqhip_workspace_bytes", "gptqhip_last_error", "gptqhip_device_info"):
+                 "gptqhip_dequant_tiled", "gptqhip_widen_codes", "gptqhip_workspace_bytes", "gptqhip_last_error", "gptqhip_device_info"):
         assert must in syms
 
 

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from conftest import load_golden
+from conftest import golden_files, load_golden
 from helpers import assert_forward_close, bits_to_f32, bits_to_torch, f32_to_torch, rel_err, synth_gptq, torch_to_bits, torch_to_f32
 from oracle import gptq_oracle as O
 
@@ -389,3 +389,61 @@ def test_awq_forward_partial_matches_unrounded_product():
     ref = bits_to_f32(g["x"], "fp16").astype(np.float64) @ w
     assert rel_err(part.cpu().numpy(), ref.astype(np.float32)) <= 1e-5
     assert torch.equal(part.to(torch.float16), lin(x))  # one rounding of the same accumulators
+
+
+OTHER_BITS_GOLDEN = [n for n in golden_files("ref_gptq_w") if n[len("ref_gptq_w")] in "23567"]
+
+
+@pytest.mark.parametrize("name", OTHER_BITS_GOLDEN)
+def test_other_bit_widths_through_the_plugin_class(name):
+    """2- / 3-bit (continuous) and 5- / 6- / 7-bit (planar) checkpoints through HipGptqLinear -- post_init widens the
+    codes to the 4- / 8-bit kernel layout (same values), dequantize_weight() is BIT-EXACT with the reference's generic
+    dequantize_weight (gptqmodel/nn_modules/qlinear/__init__.py:977-1100) before and after post_init, forward() is inside the
+    reference's tolerances, a v1 checkpoint (zero-1 on disk) converts to the same tensors, AUTO selection picks the class."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    from gptqmodel_amd.utils.backend import BACKEND
+    from gptqmodel_amd.utils.const import DEVICE, FORMAT, METHOD
+    from gptqmodel_amd.utils.importer import select_quant_linear
+    from gptqmodel_amd.utils.model import convert_gptq_v1_to_v2_format_module
+    g = load_golden(name)
+    bits, act, sdt, gs = int(g["bits"]), str(g["act"]), str(g["scale_dtype"]), int(g["group_size"])
+    K, N = g["g_idx"].shape[0], g["scales"].shape[1]
+    desc = not np.array_equal(g["g_idx"], np.arange(K) // gs)
+    cls = select_quant_linear(bits=bits, group_size=gs, desc_act=desc, sym=False, device=DEVICE.ROCM, backend=BACKEND.AUTO,
+                              format=FORMAT.GPTQ_V2, quant_method=METHOD.GPTQ)
+    assert cls is HipGptqLinear
+
+    def module(qzeros, fmt):
+        lin = cls(bits=bits, group_size=gs, sym=False, desc_act=desc, in_features=K, out_features=N, bias=False)
+        assert tuple(lin.qweight.shape) == g["qweight"].shape and tuple(lin.qzeros.shape) == g["qzeros"].shape
+        assert lin.kernel_bits == (4 if bits <= 4 else 8) and lin.planar == (bits in (5, 6, 7))
+        lin.qweight, lin.qzeros = torch.from_numpy(g["qweight"]), torch.from_numpy(qzeros)
+        lin.scales, lin.g_idx = bits_to_torch(g["scales"], sdt), torch.from_numpy(g["g_idx"])
+        lin.qzero_format(format=fmt)
+        return lin.to(DEV).eval()
+
+    lin = module(g["qzeros"], 2)
+    assert np.array_equal(torch_to_bits(lin.dequantize_weight()), g["w_ref"].reshape(K, N))     # checkpoint layout
+    lin.post_init()
+    assert (lin.perm is not None) == desc
+    assert np.array_equal(torch_to_bits(lin.dequantize_weight()), g["w_ref"].reshape(K, N))     # kernel layout, act-order undone
+    out = lin(bits_to_torch(g["x"], act, DEV))
+    torch.cuda.synchronize()
+    assert_forward_close(torch_to_f32(out), bits_to_f32(g["out_ref"], act), act)
+
+    z1 = (O.unpack_cols_any(g["qzeros"], bits).astype(np.int32) - 1) & ((1 << bits) - 1)        # what a v1 quantizer wrote: zero-1
+    v1 = module(O.pack_cols_any(z1.astype(np.uint8), bits), 1)
+    convert_gptq_v1_to_v2_format_module(v1, bits=bits, pack_dtype=torch.int32)
+    assert v1.qzero_format() == 2 and np.array_equal(v1.qzeros.cpu().numpy(), g["qzeros"])
+    v1.post_init()
+    assert torch.equal(v1(bits_to_torch(g["x"], act, DEV)), out)
+
+    with pytest.raises(NotImplementedError):      # quantisation-time packing stays 4- / 8-bit
+        lin.pack_block(nn.Linear(K, N), torch.ones(N, K // gs), torch.zeros(N, K // gs, dtype=torch.int32), torch.arange(K) // gs)
+
+
+def test_three_bit_needs_multiples_of_32():
+    """3-bit packs 32 codes into three words (qlinear/__init__.py:1001-1043): in / out features must be multiples of 32."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    with pytest.raises(NotImplementedError):
+        HipGptqLinear(bits=3, group_size=128, sym=False, desc_act=False, in_features=256, out_features=72, bias=False)

@@ -34,6 +34,8 @@ def run_gptq(ops, x_f32, qweight, qzeros, scales_f32, g_idx, bits, gs, bias_f32,
     dev = DEV
     qw = torch.from_numpy(qweight).to(dev)
     qz = torch.from_numpy(qzeros).to(dev)
+    if bits not in (4, 8):     # the other bit widths are widened to 4- / 8-bit fields first (what post_init does)
+        qw, qz, bits = ops.widen_codes(qw, qz, bits)
     sc = f32_to_torch(scales_f32, sdt, dev)
     x = f32_to_torch(x_f32, act, dev)
     b = None if bias_f32 is None else f32_to_torch(bias_f32, act, dev)
@@ -71,6 +73,10 @@ def test_gptq_golden(ops, name):
     # standalone dequant is bit-exact with the reference's dequantize_weight()
     if g["w_ref"].size:
         qw, qz = torch.from_numpy(g["qweight"]).to(DEV), torch.from_numpy(g["qzeros"]).to(DEV)
+        if bits not in (4, 8):
+            wq, wz = O.widen_codes(g["qweight"], g["qzeros"], bits)[:2]
+            qw, qz, bits = ops.widen_codes(qw, qz, bits)
+            assert np.array_equal(qw.cpu().numpy(), wq) and np.array_equal(qz.cpu().numpy(), wz)     # integer relayout: bit-exact
         sc, gi = bits_to_torch(g["scales"], sdt, DEV), torch.from_numpy(g["g_idx"]).to(DEV)
         w = ops.dequant(qw, qz, sc, gi, gs, bits)
         assert np.array_equal(torch_to_bits(w), g["w_ref"].reshape(w.shape))

@@ -102,9 +102,11 @@ def test_selection_with_kernels_available(kernels_available):
     assert sel(4, 128, False, True, device=DEVICE.ROCM, multi_select=True) == [HipGptqLinear]
     assert importer.hf_select_quant_linear(4, 128, False, True, "gptq", device_map={"": "cuda:0"}) is HipGptqLinear
     with pytest.raises(NotImplementedError):      # unsupported contract under AUTO re-raises the last kernel error
-        sel(3, 128, False, True, device=DEVICE.ROCM)
+        sel(4, 48, False, True, device=DEVICE.ROCM)
     with pytest.raises(ValueError):               # explicit backend: hard error
-        sel(3, 128, False, True, device=DEVICE.ROCM, backend=BACKEND.GPTQ_HIP)
+        sel(4, 48, False, True, device=DEVICE.ROCM, backend=BACKEND.GPTQ_HIP)
+    for bits in (2, 3, 5, 6, 7):                  # the other bit widths of the reference's torch kernel
+        assert sel(bits, 128, False, True, device=DEVICE.ROCM) is HipGptqLinear
     with pytest.raises((ValueError, NotImplementedError)):   # CPU device is filtered out (SUPPORTS_DEVICES=[ROCM])
         sel(4, 128, False, True, device="cpu")
     with pytest.raises(ValueError, match="Unsupported format"):
@@ -120,12 +122,15 @@ def test_selection_with_kernels_available(kernels_available):
     (dict(bits=4, group_size=128, in_features=4096, out_features=4100), False),   # N % 8
     (dict(bits=4, group_size=128, in_features=4100, out_features=4096), False),   # K % 32
     (dict(bits=4, group_size=48, in_features=96, out_features=64), False),        # group size not listed
-    (dict(bits=2, group_size=128, in_features=4096, out_features=4096), False),
+    (dict(bits=2, group_size=128, in_features=4096, out_features=4096), True),     # widened to 4-bit fields at post_init
+    (dict(bits=3, group_size=128, in_features=4096, out_features=4096), True),
+    (dict(bits=6, group_size=64, in_features=4096, out_features=4096), True),      # planar, widened to 8-bit fields
+    (dict(bits=1, group_size=128, in_features=4096, out_features=4096), False),
     (dict(bits=4, group_size=128, in_features=4096, out_features=4096, dtype=torch.float32), False),
     (dict(bits=4, group_size=128, in_features=4096, out_features=4096, pack_dtype=torch.int16), False),
     (dict(bits=4, group_size=128, in_features=4096, out_features=4096, trainable=True), False),
     (dict(bits=4, group_size=128, in_features=4096, out_features=4096, device=DEVICE.CPU), False),
-    (dict(bits=4, group_size=128, in_features=4096, out_features=4096, dynamic={"x": {"bits": 3}}), False),
+    (dict(bits=4, group_size=128, in_features=4096, out_features=4096, dynamic={"x": {"bits": 9}}), False),
 ])
 def test_validate_contract(kernels_available, kw, ok):
     kw.setdefault("pack_dtype", torch.int32)
@@ -143,8 +148,14 @@ def test_constructor_registers_checkpoint_buffers(kernels_available):
     awq = HipAwqLinear(bits=4, group_size=128, sym=False, desc_act=False, in_features=512, out_features=256)
     assert {k: tuple(v.shape) for k, v in awq.state_dict().items()} == {
         "qweight": (512, 32), "qzeros": (4, 32), "scales": (4, 256)}
+    for bits in (2, 3, 5, 6, 7):                    # checkpoint shapes of the other bit widths (qlinear/__init__.py:595-660)
+        o = HipGptqLinear(bits=bits, group_size=128, sym=True, desc_act=False, in_features=512, out_features=256)
+        assert (tuple(o.qweight.shape), tuple(o.qzeros.shape)) == ((512 * bits // 32, 256), (4, 256 * bits // 32))
+        assert (o.kernel_bits, o.planar) == (4 if bits < 4 else 8, bits in (5, 6, 7))
     with pytest.raises(NotImplementedError):
-        HipGptqLinear(bits=3, group_size=128, sym=True, desc_act=False, in_features=512, out_features=256)
+        HipGptqLinear(bits=1, group_size=128, sym=True, desc_act=False, in_features=512, out_features=256)
+    with pytest.raises(NotImplementedError):        # 3 / 5 / 6 / 7 bits pack 32 codes into `bits` words: features in multiples of 32
+        HipGptqLinear(bits=3, group_size=128, sym=True, desc_act=False, in_features=512, out_features=264)
     with pytest.raises(RuntimeError):
         lin(torch.zeros(1, 512, dtype=torch.float16))  # forward before post_init
     with pytest.raises(RuntimeError):
@@ -503,7 +514,9 @@ def test_quantize_config_normalisation_and_v1_zero_points():
     with pytest.raises(ValueError):
         C.normalize_quantize_config({"bits": 4, "is_marlin_format": True})
     with pytest.raises(ValueError):
-        C.normalize_quantize_config({"bits": 5})
+        C.normalize_quantize_config({"bits": 9})
+    with pytest.raises(ValueError):
+        C.normalize_quantize_config({"bits": 3, "quant_method": "awq"})
     with tempfile.TemporaryDirectory() as d:
         with pytest.raises(ValueError):
             C.read_quantize_config(d)
@@ -527,10 +540,19 @@ def test_quantize_config_normalisation_and_v1_zero_points():
         ok = fields(z) != 0
         assert torch.equal(fields(back)[ok.all(dim=-1)], fields(z)[ok.all(dim=-1)])
     assert C.quantized_module_names(["a.b.qweight", "a.b.scales", "c.weight", "d.qweight"]) == ["a.b", "d"]
-    # bit widths outside the HIP modules are rejected by the reader / writer (3-bit fields do not tile an int32)
-    for bits in (2, 3):
-        with pytest.raises(ValueError):
-            C.normalize_quantize_config({"bits": bits})
+    # the other bit widths go through the decoded values (3-bit fields straddle words, 5 / 6 / 7 bits are planar: ADVICE r3)
+    import numpy as np
+    from conftest import load_golden
+    from gptqmodel_amd.utils.model import shift_v1_qzeros
+    g = load_golden("ref_v1v2_bits.npz")             # written by the reference's convert_gptq_v1_to_v2_format_module
+    for bits in (2, 3, 5, 6, 7):
+        assert C.normalize_quantize_config({"bits": bits})["bits"] == bits
+        v1, v2 = torch.from_numpy(g[f"v1_{bits}"]), torch.from_numpy(g[f"v2_{bits}"])
+        assert torch.equal(shift_v1_qzeros(v1, bits), v2)
+        assert torch.equal(C._v2_to_v1_qzeros(v2, bits), v1)
+    g = load_golden("ref_v1v2.npz")
+    for bits in (4, 8):
+        assert torch.equal(shift_v1_qzeros(torch.from_numpy(g[f"v1_{bits}"]), bits), torch.from_numpy(g[f"v2_{bits}"]))
     # the reference's guard for asymmetric v1 files (models/loader.py:1658-1663; quantization/config.py:2786-2792)
     assert C._written_by_v2_aware_quantizer({"meta": {"quantizer": ["gptqmodel:1.4.2"]}})
     assert C._written_by_v2_aware_quantizer({"meta": {"quantizer": "gptqmodel:0.9.0"}})

@@ -71,15 +71,24 @@ out["alias"] = [normalize_backend("hip", quant_method=METHOD.GPTQ).value, normal
                 normalize_backend("gptq_hip").value]
 out["hf_select"] = name(lambda: importer.hf_select_quant_linear_v2(bits=4, group_size=128, desc_act=False, sym=True, format="gptq",
                         quant_method="gptq", device_map={{"": "cuda:0"}}, backend="auto", pack=False))
-# 3-bit is outside the HIP class' contract: AUTO must fall through to an upstream kernel, explicit selection must refuse
-out["auto_3bit"] = name(lambda: importer.select_quant_linear(bits=3, group_size=128, desc_act=False, sym=True, pack_dtype=torch.int32,
-                        device=DEVICE.ROCM, backend=BACKEND.AUTO, format=FORMAT.GPTQ, quant_method=METHOD.GPTQ))
-out["explicit_3bit"] = name(lambda: importer.select_quant_linear(bits=3, group_size=128, desc_act=False, sym=True, pack_dtype=torch.int32,
-                            device=DEVICE.ROCM, backend=BACKEND.GPTQ_HIP, format=FORMAT.GPTQ, quant_method=METHOD.GPTQ))
+# group_size 16 is outside the HIP class' contract: AUTO must fall through to an upstream kernel, explicit selection must refuse
+out["auto_g16"] = name(lambda: importer.select_quant_linear(bits=4, group_size=16, desc_act=False, sym=True, pack_dtype=torch.int32,
+                       device=DEVICE.ROCM, backend=BACKEND.AUTO, format=FORMAT.GPTQ, quant_method=METHOD.GPTQ))
+out["explicit_g16"] = name(lambda: importer.select_quant_linear(bits=4, group_size=16, desc_act=False, sym=True, pack_dtype=torch.int32,
+                           device=DEVICE.ROCM, backend=BACKEND.GPTQ_HIP, format=FORMAT.GPTQ, quant_method=METHOD.GPTQ))
+# the other bit widths of the reference's torch kernel are inside it (widened to the 4- / 8-bit kernel layout at post_init)
+out["auto_bits"] = [name(lambda b=b: importer.select_quant_linear(bits=b, group_size=128, desc_act=False, sym=True, pack_dtype=torch.int32,
+                    device=DEVICE.ROCM, backend=BACKEND.AUTO, format=FORMAT.GPTQ, quant_method=METHOD.GPTQ)) for b in (2, 3, 5, 6, 7)]
 # constructing the class runs the REAL base-class __init__ + validate chain and registers the checkpoint buffers
 m = H(bits=4, group_size=128, sym=True, desc_act=False, in_features=256, out_features=64, bias=True, register_buffers=True,
       format=FORMAT.GPTQ) if {fake_device!r} else None
 if m is not None:
+    m3 = H(bits=3, group_size=128, sym=True, desc_act=False, in_features=256, out_features=64, bias=False, register_buffers=True,
+           pack_dtype=torch.int32, backend=BACKEND.GPTQ_HIP)
+    m6 = H(bits=6, group_size=128, sym=True, desc_act=False, in_features=256, out_features=64, bias=False, register_buffers=True,
+           pack_dtype=torch.int32, backend=BACKEND.GPTQ_HIP)
+    out["other_bits"] = [list(m3.qweight.shape), list(m3.qzeros.shape), m3.kernel_bits, bool(m3.planar),
+                         list(m6.qweight.shape), list(m6.qzeros.shape), m6.kernel_bits, bool(m6.planar)]
     out["buffers"] = sorted(n for n, _ in m.named_buffers())
     out["shapes"] = [list(m.qweight.shape), list(m.qzeros.shape), list(m.scales.shape), list(m.g_idx.shape)]
     out["requires_v2"] = [bool(m.REQUIRES_FORMAT_V2), m.qzero_format()]
@@ -131,8 +140,10 @@ def test_overlay_classes_are_first_class_reference_kernels(overlaid_tree):
     assert r["alias"] == ["gptq_hip", "awq_hip", "gptq_hip"]
     assert r["hf_select"] == "HipGptqLinear"
     # outside the contract: AUTO falls through, explicit refuses with the reference's ValueError
-    assert r["auto_3bit"] not in ("HipGptqLinear",) and not r["auto_3bit"].startswith("ERR")
-    assert r["explicit_3bit"].startswith("ERR:ValueError")
+    assert r["auto_g16"] not in ("HipGptqLinear",) and not r["auto_g16"].startswith("ERR")
+    assert r["explicit_g16"].startswith("ERR:ValueError")
+    assert r["auto_bits"] == ["HipGptqLinear"] * 5
+    assert r["other_bits"] == [[24, 64], [2, 6], 4, False, [48, 64], [2, 12], 8, True]
     # the REAL base class registered the checkpoint contract
     assert r["buffers"] == ["bias", "g_idx", "qweight", "qzeros", "scales"]
     assert r["shapes"] == [[32, 64], [2, 8], [2, 64], [256]]
