@@ -414,7 +414,9 @@ def test_other_bit_widths_through_the_plugin_class(name):
     assert cls is HipGptqLinear
 
     def module(qzeros, fmt):
-        lin = cls(bits=bits, group_size=gs, sym=False, desc_act=desc, in_features=K, out_features=N, bias=False)
+        lin = cls(bits=bits, group_size=gs, sym=False, desc_act=desc, in_features=K, out_features=N, bias=bool(g["bias"].size))
+        if g["bias"].size:
+            lin.bias = bits_to_torch(g["bias"], act)
         assert tuple(lin.qweight.shape) == g["qweight"].shape and tuple(lin.qzeros.shape) == g["qzeros"].shape
         assert lin.kernel_bits == (4 if bits <= 4 else 8) and lin.planar == (bits in (5, 6, 7))
         lin.qweight, lin.qzeros = torch.from_numpy(g["qweight"]), torch.from_numpy(qzeros)
@@ -431,8 +433,12 @@ def test_other_bit_widths_through_the_plugin_class(name):
     torch.cuda.synchronize()
     assert_forward_close(torch_to_f32(out), bits_to_f32(g["out_ref"], act), act)
 
-    z1 = (O.unpack_cols_any(g["qzeros"], bits).astype(np.int32) - 1) & ((1 << bits) - 1)        # what a v1 quantizer wrote: zero-1
-    v1 = module(O.pack_cols_any(z1.astype(np.uint8), bits), 1)
+    if bits == 2:      # what the reference's writer stores (utils/model.py:910-911: a WORD subtract, fields borrow from each other)
+        qz1 = (g["qzeros"].view(np.uint32) - np.uint32(0x55555555)).view(np.int32)
+    else:              # 3 / 5 / 6 / 7 bits: the decoded zero-points minus one, modulo 2^bits (:912-939)
+        z1 = (O.unpack_cols_any(g["qzeros"], bits).astype(np.int32) - 1) & ((1 << bits) - 1)
+        qz1 = O.pack_cols_any(z1.astype(np.uint8), bits)
+    v1 = module(qz1, 1)
     convert_gptq_v1_to_v2_format_module(v1, bits=bits, pack_dtype=torch.int32)
     assert v1.qzero_format() == 2 and np.array_equal(v1.qzeros.cpu().numpy(), g["qzeros"])
     v1.post_init()
