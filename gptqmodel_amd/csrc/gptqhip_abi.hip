@@ -558,6 +558,10 @@ int gptqhip_widen_codes(const int32_t* qweight, const int32_t* qzeros, int32_t* 
                   "exist only planar)", K, N, G, bits, planar);
         return GPTQHIP_EINVAL;
     }
+    if ((long long)K * (bits <= 4 ? 4 : 8) / 32 > 65535 || G > 65535) {      // one grid row per output word row / per group
+        set_error("gptqhip_widen_codes: K=%d G=%d exceed one launch (K * wide / 32 and G at most 65535)", K, G);
+        return GPTQHIP_EINVAL;
+    }
     return launch_widen_codes(qweight, qzeros, qweight_out, qzeros_out, K, N, G, bits, planar, reinterpret_cast<hipStream_t>(stream));
 }
 

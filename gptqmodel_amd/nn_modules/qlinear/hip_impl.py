@@ -88,6 +88,7 @@ def make_hip_classes(ns, module_name: str):
             # field width of the layout the kernels read (== bits for 4 / 8); 5 / 6 / 7 bits only exist in the planar layout, 3 bits
             # are planar under FORMAT.GPTQ_P only (qlinear/__init__.py:766-773; the reference's base class sets `planar` itself)
             self.kernel_bits = 4 if bits <= 4 else 8
+            self.source_bits = bits        # differs from `bits` after widen_in_place()
             if not hasattr(self, "planar"):
                 self.planar = bits in (5, 6, 7) or (_fmt_value(format) == "gptq_p" and bits == 3)
             if (bits == 3 or self.planar) and (in_features % 32 != 0 or out_features % 32 != 0):
@@ -97,6 +98,27 @@ def make_hip_classes(ns, module_name: str):
         @classmethod
         def validate_once(cls):
             return hip_validate_once()
+
+        def widen_in_place(self):
+            """Turn a 2 / 3 / 5 / 6 / 7-bit module (checkpoint layout, device tensors) into the 4- / 8-bit module that holds the SAME
+            code values: qweight / qzeros re-encoded by gptqhip_widen_codes, `bits` becomes the kernel's field width, the original
+            width stays in `source_bits`.  What post_init() does on the fly; done up front by the layer fusion (utils/hf_llama.py),
+            whose sibling concatenation / gate-up interleaving / act-order folding work on whole 4- / 8-bit words.  Such a module is no
+            longer a checkpoint of its original format: save_quantized_checkpoint refuses it."""
+            from gptqmodel_amd import ops
+            if self.bits in (4, 8) and not self.planar:
+                return self
+            if self._ready:
+                raise RuntimeError("widen_in_place must be called before post_init()")
+            if not self.qweight.is_cuda:    # (NotImplementedError: the layer fusion skips the layer, post_init widens on the device later)
+                raise NotImplementedError("HipGptqLinear.widen_in_place: buffers must be on the ROCm device (no CPU fallback)")
+            if _fmt_value(getattr(self, "format", None)) == "gptq" and self.qzero_format() == 1:
+                _convert_v1_to_v2_inplace(self)      # zero - 1 wraps modulo 2^bits: it must be undone at the ORIGINAL width
+            qw, qz, wide = ops.widen_codes(self.qweight.data, self.qzeros.data, self.bits, planar=bool(self.planar))
+            self.qweight.data, self.qzeros.data = qw, qz
+            self.source_bits, self.bits, self.kernel_bits, self.planar = self.bits, wide, wide, False
+            self.pack_factor, self.maxq = 32 // wide, 2 ** wide - 1
+            return self
 
         def post_init(self):
             """One-time device-side relayout into the MFMA-tile-major kernel layout (+ act-order row sort).  The

@@ -233,6 +233,9 @@ def save_quantized_checkpoint(model: nn.Module, ckpt_dir: str, quantize_config: 
         if isinstance(mod, BaseQuantLinear):
             if getattr(mod, "_ready", False):
                 raise RuntimeError(f"`{name}` is already post_init()ed: save from the checkpoint-layout model")
+            if getattr(mod, "source_bits", mod.bits) != mod.bits:
+                raise RuntimeError(f"`{name}` was widened from {mod.source_bits} to {mod.bits} bits (layer fusion): save from the "
+                                   f"checkpoint-layout model")
             if cfg["format"] == "gptq" and hasattr(mod, "qzero_format") and mod.qzero_format() == 2:
                 v1_owners.add(name)
                 planar_of[name] = bool(getattr(mod, "planar", False))

@@ -390,6 +390,11 @@ def fuse_llama_decoder_layers(model: nn.Module, allow_unknown: bool = False) -> 
             prev = None
             continue
         try:
+            # 2 / 3 / 5 / 6 / 7-bit modules: the same code values in the 4- / 8-bit layout first (what post_init would do anyway);
+            # everything below concatenates / interleaves / permutes whole 4- / 8-bit words
+            for lin in [getattr(attn, n) for n in names_a] + [getattr(mlp, n) for n in names_m]:
+                if hasattr(lin, "widen_in_place"):
+                    lin.widen_in_place()
             qkv = fuse_quant_linears([attn.q_proj, attn.k_proj, attn.v_proj])
             # act-order checkpoints: down_proj's input permutation moves into gate / up's column order (exact; only integer
             # codes are re-ordered), so down_proj needs no activation gather -- neither the prefill pre-pass nor the in-kernel one

@@ -35,7 +35,24 @@ def _get(model, name):
     return mod
 
 
-def _build(desc_act: bool, fuse, dtype, family="llama", gs=128):
+def _pack_other_bits(qm, lin, scales, zeros, g_idx, bits):
+    """RTN codes of a 2 / 3 / 5 / 6 / 7-bit module in the reference's checkpoint layout (continuous 2- / 3-bit words, planar 5 / 6 / 7:
+    the oracle's packers, pinned against the reference by tests/golden/ref_gptq_w*.npz); v2 zero-points."""
+    import numpy as np
+    from oracle import gptq_oracle as O
+    g = g_idx.long().to(lin.weight.device)
+    w = lin.weight.data.float().T                                   # [K, N]
+    codes = torch.clamp(torch.round(w / scales.T[g]) + zeros.T[g], 0, (1 << bits) - 1).to(torch.uint8).cpu().numpy()
+    dev = lin.weight.device
+    qm.qweight.data = torch.from_numpy(O.pack_rows_any(codes, bits)).to(dev)
+    qm.qzeros.data = torch.from_numpy(O.pack_cols_any(zeros.T.to(torch.uint8).cpu().numpy(), bits)).to(dev)
+    qm.scales.data = scales.T.contiguous().to(qm.scales.dtype).to(dev)
+    qm.g_idx.data = g_idx.to(torch.int32).to(dev)
+    qm.qzero_format(format=2)
+    assert qm.qweight.shape == (lin.in_features * bits // 32, lin.out_features)
+
+
+def _build(desc_act: bool, fuse, dtype, family="llama", gs=128, bits=4):
     from transformers import LlamaConfig, LlamaForCausalLM
     from gptqmodel_amd import ops
     from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
@@ -70,7 +87,6 @@ def _build(desc_act: bool, fuse, dtype, family="llama", gs=128):
     quant = copy.deepcopy(dense)
     names = [n for n, m in dense.named_modules() if isinstance(m, nn.Linear) and ".layers." in n]
     assert len(names) == 14
-    bits = 4
     make_quant(quant, names, bits=bits, group_size=gs, desc_act=desc_act, sym=False, backend=BACKEND.AUTO,
                format=FORMAT.GPTQ, dtype=dtype)
     for name in names:
@@ -86,8 +102,12 @@ def _build(desc_act: bool, fuse, dtype, family="llama", gs=128):
         # quantise the weight with its columns grouped by g_idx (group g = the columns whose g_idx == g)
         order = torch.argsort(g_idx.long(), stable=True).cuda()
         scales, zeros = _rtn(lin.weight.data[:, order], gs, bits)
-        qm.pack(lin, scales, zeros, g_idx)
-        w = ops.dequant(qm.qweight, qm.qzeros, qm.scales, qm.g_idx, gs, bits, dtype)       # [K, N]
+        if bits in (4, 8):
+            qm.pack(lin, scales, zeros, g_idx)
+            w = ops.dequant(qm.qweight, qm.qzeros, qm.scales, qm.g_idx, gs, bits, dtype)       # [K, N]
+        else:
+            _pack_other_bits(qm, lin, scales, zeros, g_idx, bits)
+            w = qm.dequantize_weight().to(dtype)
         lin.weight.data.copy_(w.T)
     if fuse == "layers":
         from gptqmodel_amd.utils.hf_llama import fuse_llama_decoder_layers
@@ -181,6 +201,37 @@ def test_llama_decoder_layers_on_decode_ops_match_dense(desc_act, dtype, family)
         assert 17 not in states[0].ops
         out = quant.generate(input_ids=ids[:, :8], max_new_tokens=6, do_sample=False, pad_token_id=0)
     assert out.shape == (1, 14)
+
+
+@pytest.mark.parametrize("bits,desc_act", [(3, False), (5, True)])
+def test_other_bit_widths_take_the_decode_ops(bits, desc_act):
+    """3-bit (continuous) and 5-bit (planar) checkpoints under fuse_llama_decoder_layers: the modules are widened to the 4- / 8-bit
+    layout up front (HipGptqLinear.widen_in_place: same code values), so sibling fusion, gate|up interleaving, act-order folding and
+    the 4 decode ops per layer apply unchanged; against the dense model holding the dequantised weights."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    dense, quant = _build(desc_act, "layers", torch.float16, bits=bits)
+    wide = 4 if bits < 4 else 8
+    mods = [m for m in quant.modules() if isinstance(m, HipGptqLinear)]
+    assert len(mods) == 8 and all(m.bits == wide and m.kernel_bits == wide and m._ready for m in mods)
+    assert all(L.self_attn.o_proj.source_bits == bits for L in quant.model.layers)
+    torch.manual_seed(17)
+    ids = torch.randint(0, 2048, (1, 20), device="cuda")
+    with torch.no_grad():
+        o_d = dense(input_ids=ids, use_cache=True)
+        o_q = quant(input_ids=ids, use_cache=True)
+        assert rel_err(o_q.logits.float().cpu().numpy(), o_d.logits.float().cpu().numpy()) < 2e-2
+        pk_d, pk_q = o_d.past_key_values, o_q.past_key_values
+        tok = o_d.logits[:, -1].argmax(-1, keepdim=True)
+        for _ in range(4):
+            s_d = dense(input_ids=tok, past_key_values=pk_d, use_cache=True)
+            s_q = quant(input_ids=tok, past_key_values=pk_q, use_cache=True)
+            assert rel_err(s_q.logits.float().cpu().numpy(), s_d.logits.float().cpu().numpy()) < 2e-2
+            pk_d, pk_q = s_d.past_key_values, s_q.past_key_values
+            tok = s_d.logits[:, -1].argmax(-1, keepdim=True)
+    states = [L._gptqhip_fused["state"] for L in quant.model.layers]
+    assert all(st is not None for st in states) and not any(L._gptqhip_fused["disabled"] for L in quant.model.layers)
+    if desc_act:
+        assert all(L.mlp.down_proj.perm is None for L in quant.model.layers)
 
 
 def test_llama_decoder_layers_group_size_32_take_the_decode_ops():
