@@ -16,6 +16,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "reference: needs /root/reference mounted (build container only)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The multi-process tests whose ranks all share ONE GPU (parametrised by `world`) run last, smallest world first: they depend on
+    how the GPU scheduler time-slices 2..8 (+1) processes, which the product -- one process per GPU -- never asks of it; under `-x`
+    nothing else of the suite should be hidden behind them."""
+    def world_of(item):
+        cs = getattr(item, "callspec", None)
+        if cs is None or "world" not in cs.params or item.get_closest_marker("gpu") is None:
+            return 0
+        return int(cs.params["world"])
+    items.sort(key=world_of)      # stable: everything else keeps its order
+
+
 @pytest.fixture(autouse=True)
 def _seed():
     # the reference seeds torch/random/numpy with 787 in tests/conftest.py:16-18

@@ -29,6 +29,8 @@ def _worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from helpers import shared_gpu_wait_ms
+    os.environ["GPTQHIP_COMM_TIMEOUT_MS"] = str(shared_gpu_wait_ms(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from gptqmodel_amd.utils.xgmi_allreduce import OneShotAllReduce
@@ -39,7 +41,7 @@ def _worker(rank, world, port, ret):
         ok = True
         for it, (n, dtype, use_b, use_r) in enumerate([(8192, torch.float16, False, False), (8192, torch.float16, True, True),
                                                          (4096, torch.bfloat16, True, False), (1000, torch.float16, False, True),
-                                                         (8192, torch.float16, False, True)] * 3):
+                                                         (8192, torch.float16, False, True)] * (3 if world < 8 else 1)):
             g = torch.Generator().manual_seed(1000 * it + rank)
             part = torch.randn(n, generator=g) * 3.0
             gb = torch.Generator().manual_seed(77 + it)
@@ -64,7 +66,7 @@ def _worker(rank, world, port, ret):
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr, stream=s):
                 out = comm(part_dev, out_dtype=dtype, residual=res_dev)
-            for it in range(25):
+            for it in range(25 if world < 8 else 8):
                 g = torch.Generator().manual_seed(5000 + 10 * it + rank)
                 part = torch.randn(n, generator=g)
                 res = torch.randn(n, generator=torch.Generator().manual_seed(9000 + it)).to(dtype)
@@ -121,6 +123,8 @@ def _tp_chain_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from helpers import shared_gpu_wait_ms
+    os.environ["GPTQHIP_COMM_TIMEOUT_MS"] = str(shared_gpu_wait_ms(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from test_gpu_decode_chain import _make_stack

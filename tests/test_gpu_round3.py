@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from helpers import assert_forward_close, f32_to_torch, rel_err, synth_gptq, torch_to_bits, torch_to_f32
+from helpers import assert_forward_close, f32_to_torch, rel_err, shared_gpu_wait_ms, synth_gptq, torch_to_bits, torch_to_f32
 from chain_oracle import build_layers as _build_layers, cat_cols as _cat_cols, oracle_chain as _oracle_chain
 from oracle import gptq_oracle as O
 
@@ -181,6 +181,8 @@ def _init(rank, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "GPTQHIP_COMM_TIMEOUT_MS" not in os.environ:            # (the lost-peer test sets its own, short bound)
+        os.environ["GPTQHIP_COMM_TIMEOUT_MS"] = str(shared_gpu_wait_ms(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -193,7 +195,7 @@ def _stress_worker(rank, world, port, ret, epochs):
         from gptqmodel_amd.utils.xgmi_allreduce import OneShotAllReduce
         n = 8192
         comm = OneShotAllReduce(n, dev)
-        ok = comm.self_test(calls=4, burst=256)
+        ok = comm.self_test(calls=4, burst=256, timeout_ms=shared_gpu_wait_ms(world, 1500))
         # 10^5 back-to-back epochs: a captured graph of 100 all-reduces whose payload changes EVERY epoch (base_r + a device-side
         # counter), replayed 1000 times with no host synchronisation in between; mismatches are counted on the device, bit-exactly
         bases = [torch.randn(n, generator=torch.Generator().manual_seed(500 + r)).half().float().to(dev) for r in range(world)]
@@ -259,7 +261,9 @@ def test_oneshot_collectives_stress_processes_sharing_one_gpu(world, epochs):
 
 
 def _lost_peer_worker(rank, world, port, ret):
-    os.environ["GPTQHIP_COMM_TIMEOUT_MS"] = "300"
+    # 300 ms on two ranks; 4 / 8 processes time-share the GPU (helpers.shared_gpu_wait_ms), so the call every rank DOES make needs
+    # a bound the scheduler's rotation fits in -- the lost call then costs that bound once
+    os.environ["GPTQHIP_COMM_TIMEOUT_MS"] = "300" if world < 4 else "5000"
     dev = _init(rank, world, port)
     try:
         from gptqmodel_amd.utils.xgmi_allreduce import OneShotAllReduce
@@ -268,7 +272,7 @@ def _lost_peer_worker(rank, world, port, ret):
         ok = torch.equal(comm(part, out_dtype=torch.float16).cpu(), torch.full((4096,), float(world), dtype=torch.float16))
         dist.barrier()
         if rank != world - 1:
-            # the LAST rank never makes this call: every other rank's wait gives up after 300 ms, its output is poisoned and its
+            # the LAST rank never makes this call: every other rank's wait gives up after the bound, its output is poisoned and its
             # status word set
             stats = torch.zeros(4096 // 16, device=dev)
             out = comm(part, out_dtype=torch.float16, stats_out=stats)
