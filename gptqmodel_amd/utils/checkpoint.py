@@ -228,7 +228,7 @@ def save_quantized_checkpoint(model: nn.Module, ckpt_dir: str, quantize_config: 
     cfg = normalize_quantize_config(quantize_config)
     os.makedirs(ckpt_dir, exist_ok=True)
     state = {}
-    v1_owners, planar_of = set(), {}
+    v1_owners, planar_of, bits_of = set(), {}, {}
     for name, mod in model.named_modules():
         if isinstance(mod, BaseQuantLinear):
             if getattr(mod, "_ready", False):
@@ -239,10 +239,12 @@ def save_quantized_checkpoint(model: nn.Module, ckpt_dir: str, quantize_config: 
             if cfg["format"] == "gptq" and hasattr(mod, "qzero_format") and mod.qzero_format() == 2:
                 v1_owners.add(name)
                 planar_of[name] = bool(getattr(mod, "planar", False))
+                bits_of[name] = int(mod.bits)
     for key, t in model.state_dict().items():
         t = t.detach()
         if key.endswith(".qzeros") and key[: -len(".qzeros")] in v1_owners:
-            t = _v2_to_v1_qzeros(t, cfg["bits"], planar_of[key[: -len(".qzeros")]])
+            # the MODULE's width, not the config's: `dynamic` overrides make mixed-width checkpoints (utils/model.py:908)
+            t = _v2_to_v1_qzeros(t, bits_of[key[: -len(".qzeros")]], planar_of[key[: -len(".qzeros")]])
         state[key] = t.to("cpu").contiguous()
     shards: List[Dict[str, torch.Tensor]] = [{}]
     size = 0

@@ -598,3 +598,63 @@ def test_reference_snapshot_recipe_lists_what_the_shim_executes():
             "r = load_reference(); assert REF_IS_SNAPSHOT and r.TorchLinear.__module__ == 'gptqmodel.nn_modules.qlinear.torch'\n" % (root, snap))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-800:]
+
+
+def test_qzero_offsets_like_the_reference_tests():
+    """The reference's tests/test_qzero_offsets.py restated against this package's conversions (int32 words, the only pack dtype of
+    the HIP classes): round trip (:145), scalar patterns (:189), the 3-bit canonical pack order (:203), and the module's own width
+    winning over the checkpoint-level one (:165)."""
+    import types
+    from gptqmodel_amd.utils.model import convert_gptq_v1_to_v2_format, shift_v1_qzeros, unshift_v2_qzeros
+    gen = torch.Generator().manual_seed(3)
+    for bits in (2, 3, 4, 5, 6, 7, 8):
+        z = torch.randint(-2**31, 2**31 - 1, (3, 2 * bits), dtype=torch.int32, generator=gen)
+        assert torch.equal(unshift_v2_qzeros(shift_v1_qzeros(z, bits), bits), z)
+        assert torch.equal(shift_v1_qzeros(unshift_v2_qzeros(z, bits), bits), z)
+    zero = torch.zeros((1, 1), dtype=torch.int32)
+    for bits, want in ((2, 0x55555555), (4, 0x11111111), (8, 0x01010101)):
+        assert int(shift_v1_qzeros(zero, bits).item()) & 0xFFFFFFFF == want
+    # 3 bits: thirty-two ones in the canonical continuous order (code i at bit 3 i of the 96-bit stream)
+    stream = sum(1 << (3 * i) for i in range(32))
+    want = torch.tensor([[(stream >> (32 * w)) & 0xFFFFFFFF for w in range(3)]], dtype=torch.int64)
+    got = shift_v1_qzeros(torch.zeros((1, 3), dtype=torch.int32), 3).to(torch.int64) & 0xFFFFFFFF
+    assert torch.equal(got, want)
+    # a 4-bit module inside a checkpoint whose config says 3 bits is converted at ITS width
+    mod = HipGptqLinear.__new__(HipGptqLinear)
+    torch.nn.Module.__init__(mod)
+    mod.bits, mod.planar, mod.REQUIRES_FORMAT_V2 = 4, False, True
+    mod.register_buffer("qzeros", torch.zeros((1, 1), dtype=torch.int32))
+    fmt = {"v": 1}
+    mod.qzero_format = types.MethodType(lambda self, format=None: fmt.__setitem__("v", format) or format if format is not None else fmt["v"], mod)
+    convert_gptq_v1_to_v2_format(torch.nn.Sequential(mod), bits=3)
+    assert int(mod.qzeros.item()) == 0x11111111 and mod.qzero_format() == 2
+
+
+def test_save_writes_each_module_at_its_own_width(kernels_available, tmp_path):
+    """A mixed-width model (`dynamic` overrides): `format: gptq` stores zero - 1 at the MODULE's bit width, whatever the
+    checkpoint-level `bits` says (the reference writer reads module.bits first, utils/model.py:908); a widened module is refused."""
+    pytest.importorskip("safetensors")
+    from safetensors.torch import load_file
+    from gptqmodel_amd.utils.checkpoint import save_quantized_checkpoint
+    from gptqmodel_amd.utils.model import shift_v1_qzeros
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = HipGptqLinear(bits=4, group_size=128, sym=False, desc_act=False, in_features=256, out_features=64)
+            self.b = HipGptqLinear(bits=3, group_size=128, sym=False, desc_act=False, in_features=256, out_features=64)
+
+    net = Net()
+    gen = torch.Generator().manual_seed(1)
+    for m in (net.a, net.b):
+        m.qzeros.data = torch.randint(-2**31, 2**31 - 1, tuple(m.qzeros.shape), dtype=torch.int32, generator=gen)
+        m.qzero_format(format=2)
+    save_quantized_checkpoint(net, str(tmp_path), {"bits": 4, "group_size": 128, "sym": False, "checkpoint_format": "gptq",
+                                                   "dynamic": {"+:b": {"bits": 3}}})
+    disk = load_file(str(tmp_path / "model.safetensors"))
+    assert torch.equal(shift_v1_qzeros(disk["a.qzeros"], 4), net.a.qzeros) and torch.equal(shift_v1_qzeros(disk["b.qzeros"], 3), net.b.qzeros)
+    assert not torch.equal(disk["b.qzeros"], net.b.qzeros)
+    net.b.source_bits = 3
+    net.b.bits = 4                     # what widen_in_place() leaves behind
+    with pytest.raises(RuntimeError, match="widened"):
+        save_quantized_checkpoint(net, str(tmp_path), {"bits": 4, "group_size": 128, "sym": False, "checkpoint_format": "gptq"})
