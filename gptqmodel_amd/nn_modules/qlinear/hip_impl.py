@@ -45,7 +45,8 @@ def make_hip_classes(ns, module_name: str):
         beats every kernel upstream lists for ROCm."""
         SUPPORTS_BACKENDS = [BACKEND.GPTQ_HIP]
         SUPPORTS_METHODS = [METHOD.GPTQ]
-        SUPPORTS_FORMATS = {FORMAT.GPTQ: 120, FORMAT.GPTQ_V2: 120}
+        SUPPORTS_FORMATS = ({FORMAT.GPTQ: 120, FORMAT.GPTQ_V2: 120, FORMAT.GPTQ_P: 120} if hasattr(FORMAT, "GPTQ_P")
+                            else {FORMAT.GPTQ: 120, FORMAT.GPTQ_V2: 120})
         # 4 and 8 bits are the kernels' native field widths; 2 / 3 bits are widened to 4-bit fields and 5 / 6 / 7 (planar) to 8-bit fields
         # at post_init (gptqhip_widen_codes: same codes, same zero-points, same results -- the generic dequantize_weight of the
         # reference, qlinear/__init__.py:947-999, SURVEY 8 row a8), at the price of the wider copy's HBM bytes

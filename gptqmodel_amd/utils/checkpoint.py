@@ -137,9 +137,9 @@ def load_quantized_checkpoint(model: nn.Module, ckpt_dir: str, device="cuda", ba
     cfg = read_quantize_config(ckpt_dir)
     if cfg["method"] not in ("gptq", "awq"):
         raise NotImplementedError(f"quant method `{cfg['method']}` is outside this backend (GPTQ / AWQ only)")
-    fmt = {"gptq": FORMAT.GPTQ, "gptq_v2": FORMAT.GPTQ_V2, "gemm": FORMAT.GEMM}.get(cfg["format"])
+    fmt = {"gptq": FORMAT.GPTQ, "gptq_v2": FORMAT.GPTQ_V2, "gptq_p": FORMAT.GPTQ_P, "gemm": FORMAT.GEMM}.get(cfg["format"])
     if fmt is None:
-        raise NotImplementedError(f"checkpoint format `{cfg['format']}` is outside this backend (gptq, gptq_v2, AWQ gemm)")
+        raise NotImplementedError(f"checkpoint format `{cfg['format']}` is outside this backend (gptq, gptq_v2, gptq_p, AWQ gemm)")
     method = METHOD.GPTQ if cfg["method"] == "gptq" else METHOD.AWQ
     weight_map = _shard_map(ckpt_dir)
     names = quantized_module_names(weight_map)
@@ -149,6 +149,13 @@ def load_quantized_checkpoint(model: nn.Module, ckpt_dir: str, device="cuda", ba
         dtype = next((p.dtype for p in model.parameters() if p.dtype in (torch.float16, torch.bfloat16)), torch.float16)
     make_quant(model, names, bits=cfg["bits"], group_size=cfg["group_size"], desc_act=cfg["desc_act"], sym=cfg["sym"],
                backend=backend, format=fmt, quant_method=method, dynamic=cfg["dynamic"], dtype=dtype)
+    # continuous and split-plane 3-bit words are not interchangeable, and a module is planar only if its constructor saw
+    # `format=gptq_p`: fail loudly if a construction site dropped the format (the reference's check, utils/model.py:1316-1333)
+    from ..nn_modules.qlinear import BaseQuantLinear
+    for name, mod in model.named_modules():
+        if isinstance(mod, BaseQuantLinear) and mod.bits == 3 and bool(getattr(mod, "planar", False)) != (fmt == FORMAT.GPTQ_P):
+            raise ValueError(f"`{name}`: 3-bit module constructed with planar={bool(getattr(mod, 'planar', False))} but the "
+                             f"checkpoint format is `{cfg['format']}`")
     model.to(device)
     targets = dict(model.named_parameters())
     targets.update(dict(model.named_buffers()))

@@ -35,6 +35,7 @@ class PLATFORM(str, Enum):
 class FORMAT(str, Enum):
     GPTQ = "gptq"        # v1 on disk: qzeros hold zero-1
     GPTQ_V2 = "gptq_v2"  # qzeros hold zero
+    GPTQ_P = "gptq_p"    # planar (split-plane) words, qzeros hold zero: what 5 / 6 / 7-bit checkpoints declare, optional for 3 bits
     GEMM = "gemm"        # AWQ GEMM layout
 
 

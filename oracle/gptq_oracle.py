@@ -221,13 +221,13 @@ def normalize_g_idx(g_idx: np.ndarray, groups: int) -> np.ndarray:
     return g
 
 
-def dequant_gptq(qweight, qzeros, scales_f32, g_idx, bits: int, scale_dtype: str = FP16) -> np.ndarray:
+def dequant_gptq(qweight, qzeros, scales_f32, g_idx, bits: int, scale_dtype: str = FP16, planar=None) -> np.ndarray:
     """[K,N] weights as float32 holding values exactly representable in `scale_dtype`.
     W = scales[g_idx] * (code - zeros[g_idx])   torch.py:716-717  == qlinear/__init__.py:1001-1003.
     (code - zero) is an int8/int16 subtraction (exact), the product of an fp16|bf16 scale and an integer
     |.|<=255 is exact in fp32, so rounding the fp32 product once reproduces torch's fp16/bf16 multiply."""
-    codes = unpack_rows_any(qweight, bits).astype(np.int32)
-    zeros = unpack_cols_any(qzeros, bits).astype(np.int32)
+    codes = unpack_rows_any(qweight, bits, planar).astype(np.int32)      # planar: FORMAT.GPTQ_P (3 bits; 5 / 6 / 7 always are)
+    zeros = unpack_cols_any(qzeros, bits, planar).astype(np.int32)
     scales_f32 = np.asarray(scales_f32, dtype=np.float32)
     g = normalize_g_idx(g_idx, scales_f32.shape[0])
     w = scales_f32[g] * (codes - zeros[g]).astype(np.float32)
@@ -244,9 +244,9 @@ def matmul_round(x_f32: np.ndarray, w_f32: np.ndarray, bias_f32, act_dtype: str)
 
 
 def forward_gptq(x_f32, qweight, qzeros, scales_f32, g_idx, bits: int, bias_f32=None,
-                 act_dtype: str = FP16, scale_dtype: str = FP16) -> np.ndarray:
+                 act_dtype: str = FP16, scale_dtype: str = FP16, planar=None) -> np.ndarray:
     """TorchLinear._forward_eager (torch.py:326-347): dequantize, cast weights to x.dtype, matmul, bias."""
-    w = dequant_gptq(qweight, qzeros, scales_f32, g_idx, bits, scale_dtype)
+    w = dequant_gptq(qweight, qzeros, scales_f32, g_idx, bits, scale_dtype, planar)
     if act_dtype != scale_dtype:
         w = round_to(w, act_dtype)  # torch.py:331-335  weights.to(dtype=x.dtype)
     x2 = np.asarray(x_f32, np.float32).reshape(-1, x_f32.shape[-1])

@@ -48,3 +48,8 @@ def golden_files(prefix):
 
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name))
+
+
+def golden_planar(g):
+    """True for a FORMAT.GPTQ_P fixture (3-bit split-plane words), None otherwise (the bit width's own layout: 5 / 6 / 7 always planar)."""
+    return True if "planar" in g.files and int(g["planar"]) else None

@@ -123,7 +123,7 @@ def test_on_disk_gptq_checkpoint_round_trip(tmp_path, desc_act, fuse):
         load_quantized_checkpoint(LlamaForCausalLM(LlamaConfig.from_pretrained(ckpt)).to(torch.float16), ckpt, device="cuda")
 
 
-@pytest.mark.parametrize("bits,fmt", [(3, "gptq"), (6, "gptq"), (2, "gptq_v2")])
+@pytest.mark.parametrize("bits,fmt", [(3, "gptq"), (6, "gptq"), (2, "gptq_v2"), (5, "gptq_p"), (3, "gptq_p")])
 def test_other_bit_widths_directory_round_trip(tmp_path, bits, fmt):
     """A 2- / 3- / 6-bit directory: modules in the checkpoint layout -> save (`format: gptq` stores the reference
     writer's v1 zero-points, utils/model.py:900-943) -> load into a fresh skeleton (make_quant picks HipGptqLinear, v1 -> v2 through the
@@ -134,8 +134,10 @@ def test_other_bit_widths_directory_round_trip(tmp_path, bits, fmt):
     from oracle import gptq_oracle as O
     from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
     from gptqmodel_amd.utils.checkpoint import load_quantized_checkpoint, save_quantized_checkpoint
+    from gptqmodel_amd.utils.const import FORMAT
     K, H, gs = 256, 512, 64
     rng = np.random.RandomState(bits)
+    planar = True if (fmt == "gptq_p" and bits == 3) else None      # split-plane 3-bit words exist under gptq_p only
 
     class Net(nn.Module):
         def __init__(self):
@@ -151,26 +153,28 @@ def test_other_bit_widths_directory_round_trip(tmp_path, bits, fmt):
         codes = rng.randint(0, 1 << bits, size=(k, n)).astype(np.uint8)
         zeros = rng.randint(1, 1 << bits, size=(k // gs, n)).astype(np.uint8)
         scales = O.round_to(rng.rand(k // gs, n).astype(np.float32) * 0.02 + 0.005, "fp16")
-        return O.pack_rows_any(codes, bits), O.pack_cols_any(zeros, bits), scales, (np.arange(k) // gs).astype(np.int32)
+        return O.pack_rows_any(codes, bits, planar), O.pack_cols_any(zeros, bits, planar), scales, (np.arange(k) // gs).astype(np.int32)
 
     src = Net().half()
     want = {}
     for name, (k, n) in (("up", (K, H)), ("down", (H, K))):
         qw, qz, sc, gi = tensors(k, n)
-        lin = HipGptqLinear(bits=bits, group_size=gs, sym=False, desc_act=False, in_features=k, out_features=n, bias=False)
+        lin = HipGptqLinear(bits=bits, group_size=gs, sym=False, desc_act=False, in_features=k, out_features=n, bias=False,
+                            format=FORMAT(fmt))
+        assert bool(lin.planar) == (bits in (5, 6, 7) or bool(planar))
         lin.qweight, lin.qzeros, lin.scales, lin.g_idx = (torch.from_numpy(qw), torch.from_numpy(qz), torch.from_numpy(sc).half(),
                                                           torch.from_numpy(gi))
         lin.qzero_format(format=2)
         setattr(src, name, lin)
-        want[name] = (qz, O.dequant_gptq(qw, qz, sc, gi, bits))
+        want[name] = (qz, O.dequant_gptq(qw, qz, sc, gi, bits, planar=planar))
     ckpt = str(tmp_path / "ckpt")
     qcfg = {"bits": bits, "group_size": gs, "desc_act": False, "sym": False, "quant_method": "gptq", "checkpoint_format": fmt,
             "meta": {"quantizer": ["gptqmodel:5.0.0"]}}
     save_quantized_checkpoint(src, ckpt, qcfg)
     from safetensors.torch import load_file
     disk = load_file(os.path.join(ckpt, "model.safetensors"))
-    z_disk = O.unpack_cols_any(disk["up.qzeros"].numpy(), bits).astype(np.int32)
-    z_live = O.unpack_cols_any(want["up"][0], bits).astype(np.int32)
+    z_disk = O.unpack_cols_any(disk["up.qzeros"].numpy(), bits, planar).astype(np.int32)
+    z_live = O.unpack_cols_any(want["up"][0], bits, planar).astype(np.int32)
     assert np.array_equal(z_disk, (z_live - 1) & ((1 << bits) - 1) if fmt == "gptq" else z_live)
 
     torch.manual_seed(7)

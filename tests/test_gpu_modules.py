@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from conftest import golden_files, load_golden
+from conftest import golden_files, golden_planar, load_golden
 from helpers import assert_forward_close, bits_to_f32, bits_to_torch, f32_to_torch, rel_err, synth_gptq, torch_to_bits, torch_to_f32
 from oracle import gptq_oracle as O
 
@@ -409,16 +409,21 @@ def test_other_bit_widths_through_the_plugin_class(name):
     bits, act, sdt, gs = int(g["bits"]), str(g["act"]), str(g["scale_dtype"]), int(g["group_size"])
     K, N = g["g_idx"].shape[0], g["scales"].shape[1]
     desc = not np.array_equal(g["g_idx"], np.arange(K) // gs)
+    # FORMAT.GPTQ_P: what the reference's config declares for 5 / 6 / 7-bit checkpoints (quantization/config.py:2660-2676) and for
+    # split-plane 3-bit ones; the zero-points are stored as they are (no v1 shift)
+    planar3 = bool(golden_planar(g))
+    ckpt_format = FORMAT.GPTQ_P if (planar3 or bits in (5, 6, 7)) else FORMAT.GPTQ_V2
     cls = select_quant_linear(bits=bits, group_size=gs, desc_act=desc, sym=False, device=DEVICE.ROCM, backend=BACKEND.AUTO,
-                              format=FORMAT.GPTQ_V2, quant_method=METHOD.GPTQ)
+                              format=ckpt_format, quant_method=METHOD.GPTQ)
     assert cls is HipGptqLinear
 
     def module(qzeros, fmt):
-        lin = cls(bits=bits, group_size=gs, sym=False, desc_act=desc, in_features=K, out_features=N, bias=bool(g["bias"].size))
+        lin = cls(bits=bits, group_size=gs, sym=False, desc_act=desc, in_features=K, out_features=N, bias=bool(g["bias"].size),
+                  format=FORMAT.GPTQ if fmt == 1 else ckpt_format)
         if g["bias"].size:
             lin.bias = bits_to_torch(g["bias"], act)
         assert tuple(lin.qweight.shape) == g["qweight"].shape and tuple(lin.qzeros.shape) == g["qzeros"].shape
-        assert lin.kernel_bits == (4 if bits <= 4 else 8) and lin.planar == (bits in (5, 6, 7))
+        assert lin.kernel_bits == (4 if bits <= 4 else 8) and lin.planar == (bits in (5, 6, 7) or (planar3 and fmt == 2))
         lin.qweight, lin.qzeros = torch.from_numpy(g["qweight"]), torch.from_numpy(qzeros)
         lin.scales, lin.g_idx = bits_to_torch(g["scales"], sdt), torch.from_numpy(g["g_idx"])
         lin.qzero_format(format=fmt)
@@ -433,6 +438,8 @@ def test_other_bit_widths_through_the_plugin_class(name):
     torch.cuda.synchronize()
     assert_forward_close(torch_to_f32(out), bits_to_f32(g["out_ref"], act), act)
 
+    if planar3:        # (a v1 file is FORMAT.GPTQ = continuous 3-bit words: nothing to convert in a gptq_p checkpoint)
+        return
     if bits == 2:      # what the reference's writer stores (utils/model.py:910-911: a WORD subtract, fields borrow from each other)
         qz1 = (g["qzeros"].view(np.uint32) - np.uint32(0x55555555)).view(np.int32)
     else:              # 3 / 5 / 6 / 7 bits: the decoded zero-points minus one, modulo 2^bits (:912-939)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_files, load_golden
+from conftest import golden_files, golden_planar, load_golden
 from helpers import (assert_forward_close, bits_to_f32, bits_to_torch, f32_to_torch, rel_err, synth_gptq, torch_to_bits, torch_to_f32)
 from oracle import gptq_oracle as O
 
@@ -29,13 +29,13 @@ def tol(act):
     return 1e-3 if act == "fp16" else 8e-3
 
 
-def run_gptq(ops, x_f32, qweight, qzeros, scales_f32, g_idx, bits, gs, bias_f32, act, sdt):
+def run_gptq(ops, x_f32, qweight, qzeros, scales_f32, g_idx, bits, gs, bias_f32, act, sdt, planar=None):
     """HIP forward for GPTQ tensors incl. the act-order relayout done in post_init."""
     dev = DEV
     qw = torch.from_numpy(qweight).to(dev)
     qz = torch.from_numpy(qzeros).to(dev)
     if bits not in (4, 8):     # the other bit widths are widened to 4- / 8-bit fields first (what post_init does)
-        qw, qz, bits = ops.widen_codes(qw, qz, bits)
+        qw, qz, bits = ops.widen_codes(qw, qz, bits, planar)
     sc = f32_to_torch(scales_f32, sdt, dev)
     x = f32_to_torch(x_f32, act, dev)
     b = None if bias_f32 is None else f32_to_torch(bias_f32, act, dev)
@@ -67,15 +67,16 @@ def test_gptq_golden(ops, name):
     scales = bits_to_f32(g["scales"], sdt)
     bias = bits_to_f32(g["bias"], act) if g["bias"].size else None
     x = bits_to_f32(g["x"], act)
-    out = run_gptq(ops, x, g["qweight"], g["qzeros"], scales, g["g_idx"], bits, gs, bias, act, sdt)
+    planar = golden_planar(g)
+    out = run_gptq(ops, x, g["qweight"], g["qzeros"], scales, g["g_idx"], bits, gs, bias, act, sdt, planar=planar)
     ref = bits_to_f32(g["out_ref"], act)
     assert_forward_close(torch_to_f32(out), ref, act)
     # standalone dequant is bit-exact with the reference's dequantize_weight()
     if g["w_ref"].size:
         qw, qz = torch.from_numpy(g["qweight"]).to(DEV), torch.from_numpy(g["qzeros"]).to(DEV)
         if bits not in (4, 8):
-            wq, wz = O.widen_codes(g["qweight"], g["qzeros"], bits)[:2]
-            qw, qz, bits = ops.widen_codes(qw, qz, bits)
+            wq, wz = O.widen_codes(g["qweight"], g["qzeros"], bits, planar)[:2]
+            qw, qz, bits = ops.widen_codes(qw, qz, bits, planar)
             assert np.array_equal(qw.cpu().numpy(), wq) and np.array_equal(qz.cpu().numpy(), wz)     # integer relayout: bit-exact
         sc, gi = bits_to_torch(g["scales"], sdt, DEV), torch.from_numpy(g["g_idx"]).to(DEV)
         w = ops.dequant(qw, qz, sc, gi, gs, bits)

@@ -107,6 +107,15 @@ def test_selection_with_kernels_available(kernels_available):
         sel(4, 48, False, True, device=DEVICE.ROCM, backend=BACKEND.GPTQ_HIP)
     for bits in (2, 3, 5, 6, 7):                  # the other bit widths of the reference's torch kernel
         assert sel(bits, 128, False, True, device=DEVICE.ROCM) is HipGptqLinear
+        # FORMAT.GPTQ_P (split-plane words): what the reference's config declares for 5 / 6 / 7 bits (config.py:2660-2676)
+        assert sel(bits, 128, False, True, device=DEVICE.ROCM, format=FORMAT.GPTQ_P) is HipGptqLinear
+    assert importer.hf_select_quant_linear(5, 128, False, True, "gptq_p", device_map={"": "cuda:0"}) is HipGptqLinear
+    # planar routing like the reference's constructor (qlinear/__init__.py:766-773): 5 / 6 / 7 always, 3 under gptq_p only,
+    # 2 / 4 / 8-bit planar words are bit-identical to the continuous ones
+    mk = lambda bits, fmt: HipGptqLinear(bits=bits, group_size=128, sym=True, desc_act=False, in_features=256, out_features=64, format=fmt,
+                                         register_buffers=False)
+    assert [mk(b, FORMAT.GPTQ_P).planar for b in (2, 3, 4, 5, 8)] == [False, True, False, True, False]
+    assert [mk(b, FORMAT.GPTQ_V2).planar for b in (3, 6)] == [False, True]
     with pytest.raises((ValueError, NotImplementedError)):   # CPU device is filtered out (SUPPORTS_DEVICES=[ROCM])
         sel(4, 128, False, True, device="cpu")
     with pytest.raises(ValueError, match="Unsupported format"):
@@ -513,6 +522,7 @@ def test_quantize_config_normalisation_and_v1_zero_points():
     assert n["dynamic"] == {"-:lm_head": {}} and n["pack_dtype"] == "int32"
     with pytest.raises(ValueError):
         C.normalize_quantize_config({"bits": 4, "is_marlin_format": True})
+    assert C.normalize_quantize_config({"bits": 5, "checkpoint_format": "gptq_p"})["format"] == "gptq_p"
     with pytest.raises(ValueError):
         C.normalize_quantize_config({"bits": 9})
     with pytest.raises(ValueError):

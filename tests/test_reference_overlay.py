@@ -83,6 +83,8 @@ out["auto_bits"] = [name(lambda b=b: importer.select_quant_linear(bits=b, group_
 m = H(bits=4, group_size=128, sym=True, desc_act=False, in_features=256, out_features=64, bias=True, register_buffers=True,
       format=FORMAT.GPTQ) if {fake_device!r} else None
 if m is not None:
+    out["auto_gptq_p"] = [name(lambda b=b: importer.select_quant_linear(bits=b, group_size=128, desc_act=False, sym=True, pack_dtype=torch.int32,
+                           device=DEVICE.ROCM, backend=BACKEND.AUTO, format=FORMAT.GPTQ_P, quant_method=METHOD.GPTQ)) for b in (3, 5)]
     m3 = H(bits=3, group_size=128, sym=True, desc_act=False, in_features=256, out_features=64, bias=False, register_buffers=True,
            pack_dtype=torch.int32, backend=BACKEND.GPTQ_HIP)
     m6 = H(bits=6, group_size=128, sym=True, desc_act=False, in_features=256, out_features=64, bias=False, register_buffers=True,
@@ -142,7 +144,7 @@ def test_overlay_classes_are_first_class_reference_kernels(overlaid_tree):
     # outside the contract: AUTO falls through, explicit refuses with the reference's ValueError
     assert r["auto_g16"] not in ("HipGptqLinear",) and not r["auto_g16"].startswith("ERR")
     assert r["explicit_g16"].startswith("ERR:ValueError")
-    assert r["auto_bits"] == ["HipGptqLinear"] * 5
+    assert r["auto_bits"] == ["HipGptqLinear"] * 5 and r["auto_gptq_p"] == ["HipGptqLinear"] * 2
     assert r["other_bits"] == [[24, 64], [2, 6], 4, False, [48, 64], [2, 12], 8, True]
     # the REAL base class registered the checkpoint contract
     assert r["buffers"] == ["bias", "g_idx", "qweight", "qzeros", "scales"]
