@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 # GPTQHIP_LIB: load another build of the library (dev A/B builds under tests/dev/ablate/; same ABI check as the product build)
 LIB_PATH = os.environ.get("GPTQHIP_LIB") or os.path.join(CSRC_DIR, "libgptqhip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 # every symbol include/gptqhip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -50,8 +50,8 @@ SIGNATURES = {
     "gptqhip_repack_awq": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "gptqhip_widen_codes": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gptqhip_embedding": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "gptqhip_pack_gptq": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "gptqhip_pack_gptq_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "gptqhip_pack_gptq": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "gptqhip_pack_gptq_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i]),
     "gptqhip_gather_cols": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "gptqhip_rmsnorm_gather": (_i, [_vp, _vp, _vp, _vp, _i, _i, _c.c_float, _i, _vp]),
     "gptqhip_set_tuning": (_i, [_i, _i, _i]),

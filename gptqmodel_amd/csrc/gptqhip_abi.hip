@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/gptqhip.h"
+#include "gptqhip_codes.h"
 #include "gptqhip_device.h"
 #include "gptqhip_host.h"
 
@@ -591,30 +592,39 @@ int gptqhip_embedding(const int64_t* ids, const uint32_t* qweight_t, const uint3
                             reinterpret_cast<hipStream_t>(stream));
 }
 
+static int pack_args_ok(const char* who, int K, int N, int G, int bits, int planar) {
+    const bool planar_only = bits == 5 || bits == 6 || bits == 7;
+    if (bits < 2 || bits > 8 || K <= 0 || N <= 0 || G <= 0 || K % 32 != 0 || N % 32 != 0 || (planar != 0 && planar != 1) ||
+        (planar_only && !planar)) {
+        set_error("%s: bad args K=%d N=%d G=%d bits=%d planar=%d (bits 2..8, K and N multiples of 32, 5 / 6 / 7 bits exist only planar)",
+                  who, K, N, G, bits, planar);
+        return 0;
+    }
+    return 1;
+}
+
 int gptqhip_pack_gptq(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
-                      int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, gptqhip_stream_t stream) {
+                      int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, int planar, gptqhip_stream_t stream) {
     if (!weight || !scales || !zeros || !g_idx || !qweight || !qzeros) {
         set_error("gptqhip_pack_gptq: null tensor pointer");
         return GPTQHIP_EINVAL;
     }
-    if ((bits != 4 && bits != 8) || K <= 0 || N <= 0 || G <= 0 || K % 32 != 0 || N % 32 != 0) {
-        set_error("gptqhip_pack_gptq: bad args K=%d N=%d G=%d bits=%d (K, N multiples of 32)", K, N, G, bits);
+    if (!pack_args_ok("gptqhip_pack_gptq", K, N, G, bits, planar)) return GPTQHIP_EINVAL;
+    if (K / 4 > 65535 || G > 65535) {       // one grid row per packed row (8-bit: K / 4) / per group
+        set_error("gptqhip_pack_gptq: K=%d G=%d exceed one launch", K, G);
         return GPTQHIP_EINVAL;
     }
-    return launch_pack_gptq(weight, scales, zeros, g_idx, qweight, qzeros, K, N, G, bits,
+    return launch_pack_gptq(weight, scales, zeros, g_idx, qweight, qzeros, K, N, G, bits, planar,
                             reinterpret_cast<hipStream_t>(stream));
 }
 
 int gptqhip_pack_gptq_host(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
-                           int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, int threads) {
+                           int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, int planar, int threads) {
     if (!weight || !scales || !zeros || !g_idx || !qweight || !qzeros) {
         set_error("gptqhip_pack_gptq_host: null pointer");
         return GPTQHIP_EINVAL;
     }
-    if ((bits != 4 && bits != 8) || K <= 0 || N <= 0 || G <= 0 || K % 32 != 0 || N % 32 != 0) {
-        set_error("gptqhip_pack_gptq_host: bad args K=%d N=%d G=%d bits=%d (K, N multiples of 32)", K, N, G, bits);
-        return GPTQHIP_EINVAL;
-    }
+    if (!pack_args_ok("gptqhip_pack_gptq_host", K, N, G, bits, planar)) return GPTQHIP_EINVAL;
     for (int k = 0; k < K; ++k) {
         const int g = g_idx[k] < 0 ? g_idx[k] + G : g_idx[k];
         if (g < 0 || g >= G) {
@@ -622,42 +632,44 @@ int gptqhip_pack_gptq_host(const float* weight, const float* scales, const int32
             return GPTQHIP_EINVAL;
         }
     }
-    const int pf = 32 / bits;
-    const int rows = K / pf;
+    if (bits == 2 || bits == 4 || bits == 8) planar = 0;      // planar words of these widths ARE the continuous ones
+    const int groups = K / 32;                                  // 32 rows -> `bits` packed rows (gptqhip_codes.h)
     const float maxq = (float)((1 << bits) - 1);
-    auto work = [&](int r0, int r1) {
-        for (int r = r0; r < r1; ++r) {
+    auto work = [&](int g0, int g1) {
+        uint32_t c[32], out[8];
+        for (int grp = g0; grp < g1; ++grp) {
             for (int n = 0; n < N; ++n) {
-                uint32_t w = 0;
-                for (int j = 0; j < pf; ++j) {
-                    const int k = r * pf + j;
+                for (int i = 0; i < 32; ++i) {
+                    const int k = grp * 32 + i;
                     const int g = g_idx[k] < 0 ? g_idx[k] + G : g_idx[k];
                     float scale = scales[(size_t)g * N + n];
                     const float offset = (float)zeros[(size_t)g * N + n] * scale;
                     if (scale == 0.0f) scale = 1e-6f;
                     float q = nearbyintf((weight[(size_t)n * K + k] + offset) / scale);
-                    q = std::max(0.0f, std::min(q, maxq));
-                    w |= ((uint32_t)(int)q) << (bits * j);
+                    c[i] = (uint32_t)(int)std::max(0.0f, std::min(q, maxq));
                 }
-                qweight[(size_t)r * N + n] = (int32_t)w;
+                gptqhip::encode_group32(c, bits, planar, out);
+                for (int t = 0; t < bits; ++t) qweight[((size_t)grp * bits + t) * N + n] = (int32_t)out[t];
             }
         }
     };
     int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
-    nt = std::max(1, std::min(nt, rows));
+    nt = std::max(1, std::min(nt, groups));
     std::vector<std::thread> pool;
-    const int per = (rows + nt - 1) / nt;
+    const int per = (groups + nt - 1) / nt;
     for (int t = 0; t < nt; ++t) {
-        const int r0 = t * per, r1 = std::min(rows, r0 + per);
-        if (r0 < r1) pool.emplace_back(work, r0, r1);
+        const int g0 = t * per, g1 = std::min(groups, g0 + per);
+        if (g0 < g1) pool.emplace_back(work, g0, g1);
     }
     for (auto& th : pool) th.join();
     const uint32_t mask = (1u << bits) - 1u;
+    const size_t zcols = (size_t)N * bits / 32;
     for (int g = 0; g < G; ++g)
-        for (int c = 0; c < N / pf; ++c) {
-            uint32_t w = 0;
-            for (int j = 0; j < pf; ++j) w |= ((uint32_t)zeros[(size_t)g * N + c * pf + j] & mask) << (bits * j);
-            qzeros[(size_t)g * (N / pf) + c] = (int32_t)w;
+        for (int cg = 0; cg < N / 32; ++cg) {
+            uint32_t c[32], out[8];
+            for (int i = 0; i < 32; ++i) c[i] = (uint32_t)zeros[(size_t)g * N + cg * 32 + i] & mask;
+            gptqhip::encode_group32(c, bits, planar, out);
+            for (int t = 0; t < bits; ++t) qzeros[(size_t)g * zcols + (size_t)cg * bits + t] = (int32_t)out[t];
         }
     return GPTQHIP_OK;
 }

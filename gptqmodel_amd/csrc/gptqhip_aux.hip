@@ -1,6 +1,7 @@
 // Auxiliary kernels around the hot path: standalone dequantisation (parity/debug + dequantize_weight()),
 // the one-time post_init relayouts (AWQ -> canonical, act-order row sort) and the activation gather.
 // All are pure HBM-bound integer/byte kernels: coalesced along N, one packed word per thread.
+#include "gptqhip_codes.h"
 #include "gptqhip_device.h"
 #include "gptqhip_host.h"
 
@@ -736,8 +737,52 @@ __global__ __launch_bounds__(256) void pack_qzeros_kernel(const int32_t* __restr
     qzeros[i] = (int32_t)w;
 }
 
+// the other bit widths / the planar layouts (gptqhip_codes.h): thread (group of 32 rows, n) quantises its 32 codes and writes the
+// group's `bits` words; thread (g, group of 32 columns) does the same for the zero-points.  Same fp32 arithmetic as above.
+__global__ __launch_bounds__(256) void pack_qweight_any_kernel(const float* __restrict__ weight, const float* __restrict__ scales,
+                                                               const int32_t* __restrict__ zeros, const int32_t* __restrict__ g_idx,
+                                                               int32_t* __restrict__ qweight, int K, int N, int G, int bits, int planar) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int grp = blockIdx.y;
+    if (n >= N) return;
+    const float maxq = (float)((1 << bits) - 1);
+    uint32_t c[32], out[8];
+    for (int i = 0; i < 32; ++i) {
+        const int k = grp * 32 + i;
+        int g = g_idx[k];
+        if (g < 0) g += G;
+        g = g < 0 ? 0 : (g >= G ? G - 1 : g);
+        float scale = scales[(size_t)g * N + n];
+        const float offset = __fmul_rn((float)zeros[(size_t)g * N + n], scale);
+        if (scale == 0.0f) scale = 1e-6f;
+        float q = rintf(__fdiv_rn(__fadd_rn(weight[(size_t)n * K + k], offset), scale));
+        c[i] = (uint32_t)(int)fmaxf(0.0f, fminf(q, maxq));
+    }
+    encode_group32(c, bits, planar, out);
+    for (int t = 0; t < bits; ++t) qweight[((size_t)grp * bits + t) * N + n] = (int32_t)out[t];
+}
+
+__global__ __launch_bounds__(256) void pack_qzeros_any_kernel(const int32_t* __restrict__ zeros, int32_t* __restrict__ qzeros, int N, int G,
+                                                              int bits, int planar) {
+    const int cg = blockIdx.x * blockDim.x + threadIdx.x;       // group of 32 columns
+    const int g = blockIdx.y;
+    if (cg >= N / 32) return;
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t c[32], out[8];
+    for (int i = 0; i < 32; ++i) c[i] = (uint32_t)zeros[(size_t)g * N + cg * 32 + i] & mask;
+    encode_group32(c, bits, planar, out);
+    for (int t = 0; t < bits; ++t) qzeros[(size_t)g * ((size_t)N * bits / 32) + (size_t)cg * bits + t] = (int32_t)out[t];
+}
+
 int launch_pack_gptq(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
-                     int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, hipStream_t stream) {
+                     int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, int planar, hipStream_t stream) {
+    if (bits == 2 || bits == 4 || bits == 8) planar = 0;    // planar words of these widths ARE the continuous ones
+    if (bits != 4 && bits != 8) {
+        hipLaunchKernelGGL(pack_qweight_any_kernel, dim3((N + 255) / 256, K / 32), dim3(256), 0, stream, weight, scales, zeros, g_idx, qweight,
+                           K, N, G, bits, planar);
+        hipLaunchKernelGGL(pack_qzeros_any_kernel, dim3((N / 32 + 255) / 256, G), dim3(256), 0, stream, zeros, qzeros, N, G, bits, planar);
+        return check_hip(hipGetLastError(), "pack_gptq launch");
+    }
     const int pf = 32 / bits;
     const dim3 grid((N + 255) / 256, K / pf);
     const size_t words = (size_t)G * (N / pf);

@@ -96,7 +96,7 @@ int launch_embedding(const int64_t* ids, const uint32_t* qw, const uint32_t* met
                      int32_t* status, int T, int K, int N, int group_size, int bits, int scale_dtype,
                      hipStream_t stream);
 int launch_pack_gptq(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
-                     int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, hipStream_t stream);
+                     int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, int planar, hipStream_t stream);
 int launch_gather_cols(const void* x, const int32_t* perm, void* out, int M, int K, hipStream_t stream);
 int launch_rmsnorm_gather(const void* h, const void* weight, const int32_t* perm, void* out, int M, int K, float eps, int act_dtype,
                           hipStream_t stream);

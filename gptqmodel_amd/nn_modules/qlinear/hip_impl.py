@@ -224,17 +224,15 @@ def make_hip_classes(ns, module_name: str):
         def pack_block(self, linear: torch.nn.Module, scales: torch.Tensor, zeros: torch.Tensor, g_idx: torch.Tensor,
                        block_in: int = 8192, workers: int = 1):
             """Quantise-and-pack a float Linear into this module's checkpoint-layout buffers ON THE DEVICE; same
-            signature and bit-exact output as PackableQuantLinear.pack_block (qlinear/__init__.py:1036-1323):
+            signature and bit-exact output as PackableQuantLinear.pack_block (qlinear/__init__.py:1036-1323) at
+            every bit width and layout of the class (continuous 2 / 3 / 4 / 8, split-plane 3 under gptq_p, planar 5 / 6 / 7):
             scales / zeros arrive as [out, G]."""
             from gptqmodel_amd import ops
-            if self.bits not in (4, 8):
-                # NotImplementedError = "try the next candidate" (utils/model.py:703-707): the reference's own packer serves these widths
-                raise NotImplementedError(f"HipGptqLinear.pack_block packs 4- and 8-bit codes only (got bits={self.bits})")
             dev = linear.weight.device if linear.weight.is_cuda else torch.device("cuda", torch.cuda.current_device())
             w = linear.weight.detach().to(dev)
             sc = scales.T.contiguous().to(dev)
             zr = zeros.T.contiguous().to(dev)
-            qweight, qzeros = ops.pack_gptq(w, sc, zr, g_idx.to(dev), self.bits)
+            qweight, qzeros = ops.pack_gptq(w, sc, zr, g_idx.to(dev), self.bits, planar=bool(self.planar))
             self.register_buffer("qweight", qweight)
             self.register_buffer("qzeros", qzeros)
             self.register_buffer("scales", sc.to(torch.float16))

@@ -350,14 +350,16 @@ def embedding(ids: torch.Tensor, qweight_t: torch.Tensor, meta: torch.Tensor, in
     return out.reshape(tuple(ids.shape) + (N,))
 
 
-def pack_gptq(weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, g_idx: torch.Tensor, bits: int):
+def pack_gptq(weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, g_idx: torch.Tensor, bits: int, planar: Optional[bool] = None):
     """Device quantise-and-pack: weight [N,K], scales [G,N], zeros [G,N], g_idx [K] -> (qweight, qzeros) in the
-    checkpoint layout, bit-exact with the reference's pack_block."""
+    checkpoint layout, bit-exact with the reference's pack_block.  bits 2..8; planar: split-plane words (default: the bit
+    width's own layout -- 5 / 6 / 7 bits are planar, 3 bits only under FORMAT.GPTQ_P)."""
     lib = _lib.load()
     _require_cuda(weight, scales, zeros, g_idx)
     N, K = weight.shape
     G = scales.shape[0]
-    pf = 32 // bits
+    if planar is None:
+        planar = bits in PLANAR_ONLY_BITS
     w = weight.to(torch.float32).contiguous()
     s = scales.to(torch.float32).contiguous()
     z = zeros.to(torch.int32).contiguous()
@@ -367,17 +369,17 @@ def pack_gptq(weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, g
     gn = torch.where(gi < 0, gi + G, gi)
     if gn.numel() and (int(gn.min()) < 0 or int(gn.max()) >= G):
         raise IndexError(f"pack_gptq: g_idx values out of range (groups={G})")
-    qweight = torch.empty((K // pf, N), dtype=torch.int32, device=weight.device)
-    qzeros = torch.empty((G, N // pf), dtype=torch.int32, device=weight.device)
+    qweight = torch.empty((K * bits // 32, N), dtype=torch.int32, device=weight.device)
+    qzeros = torch.empty((G, N * bits // 32), dtype=torch.int32, device=weight.device)
     with torch.cuda.device(weight.device):
         rc = lib.gptqhip_pack_gptq(_ptr(w), _ptr(s), _ptr(z), _ptr(gi), _ptr(qweight), _ptr(qzeros), K, N, G, bits,
-                                   _stream(weight.device))
+                                   1 if planar else 0, _stream(weight.device))
     _lib.check(rc, "gptqhip_pack_gptq")
     return qweight, qzeros
 
 
 def pack_gptq_host(weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, g_idx: torch.Tensor, bits: int,
-                   threads: int = 0):
+                   threads: int = 0, planar: Optional[bool] = None):
     """Host (CPU tensors) quantise-and-pack through the library's threaded C++ packer -- the equivalent of the
     reference's native pack_block_cpu.  Same contract as pack_gptq; needs no GPU."""
     lib = _lib.load()
@@ -386,17 +388,18 @@ def pack_gptq_host(weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tens
             raise RuntimeError("pack_gptq_host takes CPU tensors (use pack_gptq on the device)")
     N, K = weight.shape
     G = scales.shape[0]
-    pf = 32 // bits
+    if planar is None:
+        planar = bits in PLANAR_ONLY_BITS
     w = weight.to(torch.float32).contiguous()
     s = scales.to(torch.float32).contiguous()
     z = zeros.to(torch.int32).contiguous()
     gi = g_idx.to(torch.int32).contiguous()
     if gi.numel() != K:
         raise ValueError(f"g_idx length {gi.numel()} != in_features {K}")
-    qweight = torch.empty((K // pf, N), dtype=torch.int32)
-    qzeros = torch.empty((G, N // pf), dtype=torch.int32)
+    qweight = torch.empty((K * bits // 32, N), dtype=torch.int32)
+    qzeros = torch.empty((G, N * bits // 32), dtype=torch.int32)
     rc = lib.gptqhip_pack_gptq_host(_ptr(w), _ptr(s), _ptr(z), _ptr(gi), _ptr(qweight), _ptr(qzeros), K, N, G, bits,
-                                    threads)
+                                    1 if planar else 0, threads)
     _lib.check(rc, "gptqhip_pack_gptq_host")
     return qweight, qzeros
 

@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 15
+#define GPTQHIP_ABI_VERSION 16
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -225,15 +225,18 @@ int gptqhip_embedding(const int64_t* ids, const uint32_t* qweight_t, const uint3
  * int32 [G,N], g_idx int32 [K] (negative entries wrap by +G) -> checkpoint-layout qweight int32 [K*bits/32, N] and
  * qzeros int32 [G, N*bits/32].  q = clamp(rint((w + zero*scale)/scale), 0, maxq) in fp32, scale == 0 -> 1e-6:
  * bit-exact with the reference packer pack_block_cpu (gptqmodel_ext/pack_block_cpu.cpp:105-190) and
- * PackableQuantLinear.pack_block (gptqmodel/nn_modules/qlinear/__init__.py:1036-1323).  K % 32 == 0, N % 32 == 0. */
+ * PackableQuantLinear.pack_block (gptqmodel/nn_modules/qlinear/__init__.py:1036-1323).  K % 32 == 0, N % 32 == 0.
+ * bits 2..8: 2 / 4 / 8 bits tile a word; 3 bits are a continuous 96-bit stream per 32 codes (planar = 0) or split-plane words
+ * (planar = 1: FORMAT.GPTQ_P); 5 / 6 / 7 bits exist only planar (planar must be 1) -- the layouts of gptqhip_widen_codes' input,
+ * pinned by tests/golden/ref_pack_bits.npz (the reference's pack_block at every width). */
 int gptqhip_pack_gptq(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
-                      int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, gptqhip_stream_t stream);
+                      int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, int planar, gptqhip_stream_t stream);
 
 /* The same quantise-and-pack on the HOST (all pointers are CPU memory): the C++ equivalent of the reference's native
  * packer gptqmodel::pack_block_cpu (gptqmodel_ext/pack_block_cpu.cpp:17, at::parallel_for over blocks :100),
- * threaded over packed rows with `threads` std::threads (<= 0: hardware concurrency).  Needs no GPU. */
+ * threaded over groups of 32 rows with `threads` std::threads (<= 0: hardware concurrency).  Needs no GPU. */
 int gptqhip_pack_gptq_host(const float* weight, const float* scales, const int32_t* zeros, const int32_t* g_idx,
-                           int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, int threads);
+                           int32_t* qweight, int32_t* qzeros, int K, int N, int G, int bits, int planar, int threads);
 
 /* out[m, k'] = x[m, perm[k']]  (16-bit elements).  Used by gptqhip_gemm internally and exported for tests
  * (ExllamaV2 gathers A through q_perm: gptqmodel_ext/exllamav2/cuda/q_gemm_kernel_gptq.cuh:79-90). */

@@ -333,7 +333,7 @@ def pack_awq_cols(vals: np.ndarray) -> np.ndarray:
     return np.bitwise_or.reduce(v << shifts, axis=2).astype(np.uint32).view(np.int32)
 
 
-def quantize_pack_gptq(weight_f32: np.ndarray, scales_f32: np.ndarray, zeros: np.ndarray, g_idx: np.ndarray, bits: int):
+def quantize_pack_gptq(weight_f32: np.ndarray, scales_f32: np.ndarray, zeros: np.ndarray, g_idx: np.ndarray, bits: int, planar=None):
     """The reference packer's quantise-and-pack step: weight [N,K] fp32, scales [G,N] fp32, zeros [G,N] ints, g_idx [K]
     -> (qweight int32 [K*bits/32, N], qzeros int32 [G, N*bits/32]).
     q = clamp(rint((w + zero*scale) / scale), 0, maxq) in fp32, scale==0 -> 1e-6, negative g_idx wraps by +G
@@ -348,7 +348,7 @@ def quantize_pack_gptq(weight_f32: np.ndarray, scales_f32: np.ndarray, zeros: np
     sk = np.where(sk == 0.0, np.float32(1e-6), sk)
     q = np.rint(((w + off[g].T) / sk).astype(np.float32))
     q = np.clip(q, 0, (1 << bits) - 1).astype(np.uint8)    # [N, K]
-    return pack_rows(q.T.copy(), bits), pack_cols(np.asarray(zeros).astype(np.uint8), bits)
+    return pack_rows_any(q.T.copy(), bits, planar), pack_cols_any(np.asarray(zeros).astype(np.uint8), bits, planar)
 
 
 def act_order_perm(g_idx: np.ndarray) -> np.ndarray:

@@ -230,5 +230,18 @@ def test_host_packer_bit_exact_with_reference_pack_block(lib):
             qw, qz = ops.pack_gptq_host(torch.from_numpy(g[t + "_weight"]), torch.from_numpy(g[t + "_scales"]),
                                         torch.from_numpy(g[t + "_zeros"]), torch.from_numpy(g[t + "_g_idx"]), bits, threads)
             assert np.array_equal(qw.numpy(), g[t + "_qweight"]) and np.array_equal(qz.numpy(), g[t + "_qzeros"]), t
+    # the other bit widths / layouts (continuous 2 / 3, split-plane 3, planar 5 / 6 / 7, 4 / 8 under gptq_p)
+    g = load_golden("ref_pack_bits.npz")
+    tags = sorted({k.rsplit("_", 1)[0] for k in g.files if k.endswith("_qweight")})
+    assert len(tags) == 8
+    for t in tags:
+        bits, planar = int(t.split("_")[0][1:]), t.endswith("_p")
+        assert bool(int(g[t + "_planar"])) == (bits in (5, 6, 7) or (bits == 3 and planar))
+        for threads in (1, 3):
+            qw, qz = ops.pack_gptq_host(torch.from_numpy(g[t + "_weight"]), torch.from_numpy(g[t + "_scales"]),
+                                        torch.from_numpy(g[t + "_zeros"]), torch.from_numpy(g[t + "_g_idx"]), bits, threads, planar=planar)
+            assert np.array_equal(qw.numpy(), g[t + "_qweight"]) and np.array_equal(qz.numpy(), g[t + "_qzeros"]), t
     with pytest.raises(RuntimeError, match="out of range"):
         ops.pack_gptq_host(torch.zeros(32, 32), torch.ones(1, 32), torch.zeros(1, 32), torch.full((32,), 5), 4)
+    with pytest.raises(RuntimeError, match="only planar"):
+        ops.pack_gptq_host(torch.zeros(32, 32), torch.ones(1, 32), torch.zeros(1, 32), torch.zeros(32), 5, planar=False)

@@ -35,23 +35,6 @@ def _get(model, name):
     return mod
 
 
-def _pack_other_bits(qm, lin, scales, zeros, g_idx, bits):
-    """RTN codes of a 2 / 3 / 5 / 6 / 7-bit module in the reference's checkpoint layout (continuous 2- / 3-bit words, planar 5 / 6 / 7:
-    the oracle's packers, pinned against the reference by tests/golden/ref_gptq_w*.npz); v2 zero-points."""
-    import numpy as np
-    from oracle import gptq_oracle as O
-    g = g_idx.long().to(lin.weight.device)
-    w = lin.weight.data.float().T                                   # [K, N]
-    codes = torch.clamp(torch.round(w / scales.T[g]) + zeros.T[g], 0, (1 << bits) - 1).to(torch.uint8).cpu().numpy()
-    dev = lin.weight.device
-    qm.qweight.data = torch.from_numpy(O.pack_rows_any(codes, bits)).to(dev)
-    qm.qzeros.data = torch.from_numpy(O.pack_cols_any(zeros.T.to(torch.uint8).cpu().numpy(), bits)).to(dev)
-    qm.scales.data = scales.T.contiguous().to(qm.scales.dtype).to(dev)
-    qm.g_idx.data = g_idx.to(torch.int32).to(dev)
-    qm.qzero_format(format=2)
-    assert qm.qweight.shape == (lin.in_features * bits // 32, lin.out_features)
-
-
 def _build(desc_act: bool, fuse, dtype, family="llama", gs=128, bits=4):
     from transformers import LlamaConfig, LlamaForCausalLM
     from gptqmodel_amd import ops
@@ -102,11 +85,10 @@ def _build(desc_act: bool, fuse, dtype, family="llama", gs=128, bits=4):
         # quantise the weight with its columns grouped by g_idx (group g = the columns whose g_idx == g)
         order = torch.argsort(g_idx.long(), stable=True).cuda()
         scales, zeros = _rtn(lin.weight.data[:, order], gs, bits)
+        qm.pack(lin, scales, zeros, g_idx)             # the device packer, every bit width (continuous 2 / 3 / 4 / 8, planar 5 / 6 / 7)
         if bits in (4, 8):
-            qm.pack(lin, scales, zeros, g_idx)
             w = ops.dequant(qm.qweight, qm.qzeros, qm.scales, qm.g_idx, gs, bits, dtype)       # [K, N]
         else:
-            _pack_other_bits(qm, lin, scales, zeros, g_idx, bits)
             w = qm.dequantize_weight().to(dtype)
         lin.weight.data.copy_(w.T)
     if fuse == "layers":

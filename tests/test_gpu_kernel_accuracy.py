@@ -1,8 +1,8 @@
 """The reference's CPU kernel unit parity test (tests/test_torch_kernel_accuracy.py) restated for HipGptqLinear: same cases
 (bits 2..8 x {gptq_p, gptq_v2}, batched shapes, planar == continuous, desc_act with a shuffled g_idx, symmetric zero-point, larger
-shapes), same input recipe (:46-58), same logical-code reference (:77-87) and the same tolerances (:104-125, :229).  The reference
-packs with its own pack_block; here the codes are packed by the oracle's packers (pinned to the reference by tests/golden/ref_gptq_w*)
--- the HIP class packs 4- / 8-bit only -- and for 4 / 8 bits ALSO by HipGptqLinear.pack_block, which must produce the same words."""
+shapes), same input recipe (:46-58), same logical-code reference (:77-87) and the same tolerances (:104-125, :229).  Like the
+reference's test the module is packed by its own pack_block (the device packer, every bit width and layout); the oracle's packers
+(pinned to the reference by tests/golden/ref_pack*.npz) must produce the same words."""
 import numpy as np
 import pytest
 import torch
@@ -53,20 +53,12 @@ def _module(bits, fmt, linear, scales, zeros, g_idx, group_size, desc_act=False,
                       format=FORMAT(fmt))
     planar = True if (fmt == "gptq_p" and bits == 3) else None
     assert bool(m.planar) == (bits in (5, 6, 7) or bool(planar))
+    m.pack_block(linear, scales.clone(), zeros.clone(), g_idx.clone())
     codes, _, _ = _codes(linear, scales, zeros, g_idx, bits)
-    m.qweight = torch.from_numpy(O.pack_rows_any(codes.T.contiguous().to(torch.uint8).numpy(), bits, planar))
-    m.qzeros = torch.from_numpy(O.pack_cols_any(zeros.T.contiguous().to(torch.uint8).numpy(), bits, planar))
-    m.scales = scales.T.contiguous().half()
-    m.g_idx = g_idx.clone()
-    m.bias = linear.bias.data.half()
-    m.qzero_format(format=2)
-    m = m.to(DEV).eval()
-    if bits in (4, 8):      # the class' own packer writes the same words
-        p = HipGptqLinear(bits=bits, group_size=group_size, sym=sym, desc_act=desc_act, in_features=k, out_features=n, bias=True,
-                          format=FORMAT(fmt))
-        p.pack_block(linear, scales.clone(), zeros.clone(), g_idx.clone())
-        assert torch.equal(p.qweight.cpu(), m.qweight.cpu()) and torch.equal(p.qzeros.cpu(), m.qzeros.cpu())
-    return m
+    assert np.array_equal(m.qweight.cpu().numpy(), O.pack_rows_any(codes.T.contiguous().to(torch.uint8).numpy(), bits, planar))
+    assert np.array_equal(m.qzeros.cpu().numpy(), O.pack_cols_any(zeros.T.contiguous().to(torch.uint8).numpy(), bits, planar))
+    assert tuple(m.qweight.shape) == (k * bits // 32, n) and tuple(m.qzeros.shape) == (k // group_size, n * bits // 32)
+    return m.to(DEV).eval()
 
 
 def _packed_module_and_reference(bits, fmt, in_features=64, out_features=32, group_size=32, desc_act=False, seed=0):

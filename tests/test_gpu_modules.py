@@ -197,6 +197,13 @@ def test_device_packer_bit_exact_and_roundtrip():
                                torch.from_numpy(g[t + "_zeros"]).to(DEV), torch.from_numpy(g[t + "_g_idx"]).to(DEV), bits)
         assert np.array_equal(qw.cpu().numpy(), g[t + "_qweight"]), t
         assert np.array_equal(qz.cpu().numpy(), g[t + "_qzeros"]), t
+    g2 = load_golden("ref_pack_bits.npz")      # every other width / layout the reference's pack_block writes
+    for t in sorted({k.rsplit("_", 1)[0] for k in g2.files if k.endswith("_qweight")}):
+        bits, planar = int(t.split("_")[0][1:]), t.endswith("_p")
+        qw, qz = ops.pack_gptq(torch.from_numpy(g2[t + "_weight"]).to(DEV), torch.from_numpy(g2[t + "_scales"]).to(DEV),
+                               torch.from_numpy(g2[t + "_zeros"]).to(DEV), torch.from_numpy(g2[t + "_g_idx"]).to(DEV), bits, planar=planar)
+        assert np.array_equal(qw.cpu().numpy(), g2[t + "_qweight"]), t
+        assert np.array_equal(qz.cpu().numpy(), g2[t + "_qzeros"]), t
     # larger random problem vs the oracle packer + end-to-end through the module API
     K, N, gs, bits = 1024, 256, 128, 4
     rng = np.random.RandomState(3)
@@ -451,8 +458,6 @@ def test_other_bit_widths_through_the_plugin_class(name):
     v1.post_init()
     assert torch.equal(v1(bits_to_torch(g["x"], act, DEV)), out)
 
-    with pytest.raises(NotImplementedError):      # quantisation-time packing stays 4- / 8-bit
-        lin.pack_block(nn.Linear(K, N), torch.ones(N, K // gs), torch.zeros(N, K // gs, dtype=torch.int32), torch.arange(K) // gs)
 
 
 def test_three_bit_needs_multiples_of_32():
