@@ -282,8 +282,9 @@ def make_hip_classes(ns, module_name: str):
         SUPPORTS_BACKENDS = [BACKEND.GPTQ_HIP]
         SUPPORTS_BACKEND_SELECTION = False
         SUPPORTS_METHODS = [METHOD.GPTQ]
-        SUPPORTS_FORMATS = {FORMAT.GPTQ: 120, FORMAT.GPTQ_V2: 120}
-        SUPPORTS_BITS = [4, 8]
+        SUPPORTS_FORMATS = ({FORMAT.GPTQ: 120, FORMAT.GPTQ_V2: 120, FORMAT.GPTQ_P: 120} if hasattr(FORMAT, "GPTQ_P")
+                            else {FORMAT.GPTQ: 120, FORMAT.GPTQ_V2: 120})
+        SUPPORTS_BITS = [2, 3, 4, 5, 6, 7, 8]      # like TorchQuantEmbeddings (torch.py:774); widened at post_init like the linear
         SUPPORTS_GROUP_SIZE = [-1, 32, 64, 128, 256, 512, 1024]
         SUPPORTS_DESC_ACT = [True, False]
         SUPPORTS_SYM = [True, False]

@@ -55,14 +55,13 @@ def assert_forward_close(got: np.ndarray, ref: np.ndarray, act: str, tag=None):
 def synth_gptq(seed, bits, k, n, gs, desc_act=False, sym=False, scale_dtype="fp16"):
     """Seeded synthetic GPTQ-v2 tensors following BASELINE.md §2 / SURVEY.md §8d."""
     rng = np.random.RandomState(seed)
-    pf = 32 // bits
     g = k // gs
-    qweight = rng.randint(-2**31, 2**31, size=(k // pf, n), dtype=np.int64).astype(np.int32)
+    # (any word pattern is a valid encoding at every bit width / layout: every bit belongs to some code)
+    qweight = rng.randint(-2**31, 2**31, size=(k * bits // 32, n), dtype=np.int64).astype(np.int32)
     if sym:
-        word = sum(((1 << (bits - 1)) << (bits * j)) for j in range(pf))
-        qzeros = np.full((g, n // pf), word, dtype=np.uint32).view(np.int32)
+        qzeros = O.pack_cols_any(np.full((g, n), 1 << (bits - 1), dtype=np.uint8), bits)
     else:
-        qzeros = rng.randint(-2**31, 2**31, size=(g, n // pf), dtype=np.int64).astype(np.int32)
+        qzeros = rng.randint(-2**31, 2**31, size=(g, n * bits // 32), dtype=np.int64).astype(np.int32)
     scales = O.round_to(rng.rand(g, n).astype(np.float32) * 0.01 + 0.005, scale_dtype)
     g_idx = ((rng.permutation(k) if desc_act else np.arange(k)) // gs).astype(np.int32)
     return qweight, qzeros, scales, g_idx

@@ -229,7 +229,7 @@ def test_device_packer_bit_exact_and_roundtrip():
                       torch.full((K,), 99, dtype=torch.int32, device=DEV), bits)
 
 
-@pytest.mark.parametrize("bits,desc_act", [(4, False), (4, True), (8, False)])
+@pytest.mark.parametrize("bits,desc_act", [(4, False), (4, True), (8, False), (3, True), (6, False)])
 def test_quant_embeddings_match_reference_semantics(bits, desc_act):
     """HipQuantEmbeddings.forward(ids) == F.embedding(ids, dequantize_weight()) -- the reference's TorchQuantEmbeddings
     (torch.py:764-797) -- bit for bit, without materialising the table."""
