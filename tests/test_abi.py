@@ -245,3 +245,33 @@ def test_host_packer_bit_exact_with_reference_pack_block(lib):
         ops.pack_gptq_host(torch.zeros(32, 32), torch.ones(1, 32), torch.zeros(1, 32), torch.full((32,), 5), 4)
     with pytest.raises(RuntimeError, match="only planar"):
         ops.pack_gptq_host(torch.zeros(32, 32), torch.ones(1, 32), torch.zeros(1, 32), torch.zeros(32), 5, planar=False)
+
+
+def test_host_packer_negative_g_idx_and_clamp_like_the_reference_tests(lib):
+    """The reference's tests/test_pack.py restated for the C++ host packer: negative g_idx entries wrap by +G (:157-173) and
+    reconstructed codes saturate BEFORE the integer conversion (:175-238: raw codes -8..23 plus +-1e20), here at every bit width."""
+    import numpy as np
+    import torch
+    from gptqmodel_amd import ops
+    from oracle import gptq_oracle as O
+    torch.manual_seed(5)
+    K, N, gs = 128, 32, 32
+    w = torch.randn(N, K) * 0.05
+    scales = torch.rand(K // gs, N) * 0.01 + 0.005
+    zeros = torch.randint(0, 16, (K // gs, N), dtype=torch.int32)
+    g_idx = (torch.arange(K) // gs).to(torch.int32)
+    g_neg = g_idx.clone()
+    g_neg[::7] -= K // gs
+    a = ops.pack_gptq_host(w, scales, zeros, g_idx, 4, 2)
+    b = ops.pack_gptq_host(w, scales, zeros, g_neg, 4, 2)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for bits in (2, 3, 4, 5, 6, 7, 8):
+        max_q, zero = 2 ** bits - 1, 2 ** (bits - 1)
+        raw = torch.arange(-8, 24, dtype=torch.float32).view(32, 1).expand(32, 32).contiguous()     # [in, out]
+        raw[0].fill_(-1e20)
+        raw[-1].fill_(1e20)
+        qw, qz = ops.pack_gptq_host((raw - zero).T.contiguous(), torch.ones(1, 32), torch.full((1, 32), zero, dtype=torch.int32),
+                                    torch.zeros(32, dtype=torch.int32), bits, 1)
+        codes = O.unpack_rows_any(qw.numpy(), bits)
+        assert np.array_equal(codes, raw.clamp(0, max_q).numpy().astype(np.uint8)), bits
+        assert np.array_equal(O.unpack_cols_any(qz.numpy(), bits), np.full((1, 32), zero, dtype=np.uint8))

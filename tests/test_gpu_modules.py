@@ -229,6 +229,26 @@ def test_device_packer_bit_exact_and_roundtrip():
                       torch.full((K,), 99, dtype=torch.int32, device=DEV), bits)
 
 
+@pytest.mark.parametrize("bits", [2, 3, 4, 5, 6, 7, 8])
+def test_pack_clamps_reconstructed_codes_like_the_reference_test(bits):
+    """tests/test_pack.py:175-238 for the device packer through the class: raw codes -8..23 plus +-1e20 saturate to [0, maxq] before
+    the integer conversion; dequantize_weight() of the packed module is exactly (clamped code - zero)."""
+    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+    max_q, zero = 2 ** bits - 1, 2 ** (bits - 1)
+    raw = torch.arange(-8, 24, dtype=torch.float32).view(32, 1).expand(32, 32).contiguous()
+    raw[0].fill_(-1e20)
+    raw[-1].fill_(1e20)
+    linear = nn.Linear(32, 32, bias=False)
+    linear.weight.data.copy_((raw - zero).T)
+    q = HipGptqLinear(bits=bits, group_size=32, sym=True, desc_act=False, in_features=32, out_features=32, bias=False)
+    q.pack_block(linear, torch.ones(32, 1), torch.full((32, 1), zero, dtype=torch.int32), torch.zeros(32, dtype=torch.int32))
+    expected = (raw.clamp(0, max_q) - zero).to(torch.float16)
+    assert torch.equal(q.dequantize_weight().cpu(), expected)
+    q.eval()
+    q.post_init()
+    assert torch.equal(q.dequantize_weight().cpu(), expected)
+
+
 @pytest.mark.parametrize("bits,desc_act", [(4, False), (4, True), (8, False), (3, True), (6, False)])
 def test_quant_embeddings_match_reference_semantics(bits, desc_act):
     """HipQuantEmbeddings.forward(ids) == F.embedding(ids, dequantize_weight()) -- the reference's TorchQuantEmbeddings
