@@ -92,9 +92,12 @@ def make_hip_classes(ns, module_name: str):
             self.source_bits = bits        # differs from `bits` after widen_in_place()
             if not hasattr(self, "planar"):
                 self.planar = bits in (5, 6, 7) or (_fmt_value(format) == "gptq_p" and bits == 3)
-            if (bits == 3 or self.planar) and (in_features % 32 != 0 or out_features % 32 != 0):
-                raise NotImplementedError(f"{bits}-bit (planar: {self.planar}) packing needs in / out features divisible by 32 "
-                                          f"(qlinear/__init__.py:780-786): got {in_features} x {out_features}")
+            if (bits not in (4, 8) or self.planar) and (in_features % 32 != 0 or out_features % 32 != 0):
+                # 3 / 5 / 6 / 7 bits and the planar layouts store whole 32-code blocks (qlinear/__init__.py:780-786); 2-bit rows of
+                # qzeros hold 16 columns per word and gptqhip_widen_codes works on 32-column groups.  NotImplementedError keeps the
+                # selection loop going (it means "this kernel cannot serve the shape")
+                raise NotImplementedError(f"{bits}-bit (planar: {self.planar}) packing needs in / out features divisible by 32: "
+                                          f"got {in_features} x {out_features}")
 
         @classmethod
         def validate_once(cls):

@@ -163,8 +163,10 @@ def test_constructor_registers_checkpoint_buffers(kernels_available):
         assert (o.kernel_bits, o.planar) == (4 if bits < 4 else 8, bits in (5, 6, 7))
     with pytest.raises(NotImplementedError):
         HipGptqLinear(bits=1, group_size=128, sym=True, desc_act=False, in_features=512, out_features=256)
-    with pytest.raises(NotImplementedError):        # 3 / 5 / 6 / 7 bits pack 32 codes into `bits` words: features in multiples of 32
-        HipGptqLinear(bits=3, group_size=128, sym=True, desc_act=False, in_features=512, out_features=264)
+    for bits in (2, 3, 6):                          # the other widths work on blocks of 32 codes: features in multiples of 32
+        with pytest.raises(NotImplementedError):
+            HipGptqLinear(bits=bits, group_size=128, sym=True, desc_act=False, in_features=512, out_features=264)
+    HipGptqLinear(bits=4, group_size=128, sym=True, desc_act=False, in_features=512, out_features=264)      # 4 / 8 bits: N % 8
     with pytest.raises(RuntimeError):
         lin(torch.zeros(1, 512, dtype=torch.float16))  # forward before post_init
     with pytest.raises(RuntimeError):
