@@ -34,8 +34,18 @@ def _bounds(total: int, rank: int, world: int, multiple: int, what: str):
     return rank * step, (rank + 1) * step
 
 
+def _whole_word_bits(bits: int) -> None:
+    """The shard helpers slice / permute whole 4- or 8-bit fields of the packed words.  2 / 3 / 5 / 6 / 7-bit (and split-plane)
+    checkpoints are sharded AFTER their codes are widened to that layout (ops.widen_codes / HipGptqLinear.widen_in_place: same code
+    values) -- slicing their words here would silently cut fields in two."""
+    if bits not in (4, 8):
+        raise NotImplementedError(f"tensor-parallel sharding works on 4- / 8-bit words (got bits={bits}): widen the codes first "
+                                  f"(gptqmodel_amd.ops.widen_codes)")
+
+
 def shard_gptq_column(t: Dict[str, torch.Tensor], rank: int, world: int, bits: int) -> Dict[str, torch.Tensor]:
     """Split along N (out_features).  t: qweight [K/pf,N], qzeros [G,N/pf], scales [G,N], g_idx [K], bias [N]|None."""
+    _whole_word_bits(bits)
     pf = 32 // bits
     n = t["scales"].shape[1]
     n0, n1 = _bounds(n, rank, world, 8, "out_features")
@@ -76,6 +86,7 @@ def shard_gptq_row(t: Dict[str, torch.Tensor], rank: int, world: int, bits: int,
     `input_index` (int64 [K/world]) and RowParallelQuantLinear all-gathers the sharded activation before selecting them
     (the alternative -- folding the permutation into the producing column-parallel layer -- only exists for MLPs, not for
     attention outputs).  act_order="reject" (default) raises instead."""
+    _whole_word_bits(bits)
     pf = 32 // bits
     k = t["qweight"].shape[0] * pf
     k0, k1 = _bounds(k, rank, world, max(group_size, 32), "in_features")
@@ -111,6 +122,7 @@ def shard_gptq_row(t: Dict[str, torch.Tensor], rank: int, world: int, bits: int,
 def select_gptq_columns(t: Dict[str, torch.Tensor], cols: torch.Tensor, bits: int) -> Dict[str, torch.Tensor]:
     """The GPTQ checkpoint tensors of the output columns `cols` (int64, any order, len % (32 / bits) == 0): qweight / scales / bias
     columns gathered, the N-packed zero-points unpacked, gathered and re-packed.  Exact: only integer codes move."""
+    _whole_word_bits(bits)
     pf = 32 // bits
     if cols.numel() % pf != 0:
         raise ValueError(f"column selection must keep whole packed zero-point words ({pf} columns)")

@@ -208,3 +208,17 @@ def test_shard_mlp_act_order_needs_no_exchange():
     down_seq = _tensors(23, bits, I, H, gs, bias=False)
     g_r, u_r, d_r = tp.shard_mlp_act_order(gate, up, down_seq, 1, 2, bits, gs)
     assert np.array_equal(deq(g_r), wg[:, I // 2:]) and np.array_equal(deq(d_r), deq(down_seq)[I // 2:])
+
+
+def test_shard_helpers_refuse_words_they_would_cut():
+    """2 / 3 / 5 / 6 / 7-bit words are sharded after widening (same code values in 4- / 8-bit fields): slicing them directly would cut
+    fields in two, so the helpers refuse instead."""
+    import pytest
+    import torch
+    from gptqmodel_amd.utils import tp
+    t = {"qweight": torch.zeros((24, 64), dtype=torch.int32), "qzeros": torch.zeros((2, 6), dtype=torch.int32),
+         "scales": torch.ones((2, 64), dtype=torch.float16), "g_idx": torch.arange(256, dtype=torch.int32) // 128, "bias": None}
+    for fn, args in ((tp.shard_gptq_column, (t, 0, 2, 3)), (tp.shard_gptq_row, (t, 0, 2, 3, 128)),
+                     (tp.select_gptq_columns, (t, torch.arange(32), 3))):
+        with pytest.raises(NotImplementedError, match="widen"):
+            fn(*args)
