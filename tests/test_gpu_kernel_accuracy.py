@@ -1,152 +1,119 @@
-"""The reference's CPU kernel unit parity test (tests/test_torch_kernel_accuracy.py) restated for HipGptqLinear: same cases
-(bits 2..8 x {gptq_p, gptq_v2}, batched shapes, planar == continuous, desc_act with a shuffled g_idx, symmetric zero-point, larger
-shapes), same input recipe (:46-58), same logical-code reference (:77-87) and the same tolerances (:104-125, :229).  Like the
-reference's test the module is packed by its own pack_block (the device packer, every bit width and layout); the oracle's packers
-(pinned to the reference by tests/golden/ref_pack*.npz) must produce the same words."""
+"""Unit parity of HipGptqLinear at EVERY bit width and word layout of the reference's torch kernel, in the manner of the reference's
+CPU kernel test (tests/test_torch_kernel_accuracy.py: bits 2..8 x {gptq_p, gptq_v2}; dequantize_weight against the weights rebuilt
+from the logical codes, atol 1e-4; forward against x @ W + b, atol 5e-3 / rtol 1e-2, 2e-2 on the larger layer; act-order with a
+shuffled g_idx; symmetric zero-point; split-plane and continuous words giving identical results).  The module is packed by its own
+pack_block (the device packer); the words must equal what the oracle's packers -- pinned to the reference's pack_block by
+tests/golden/ref_pack*.npz -- produce from the same codes."""
+import itertools
+
 import numpy as np
 import pytest
 import torch
-import torch.nn as nn
 
 from oracle import gptq_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-ALL_BITS = (2, 3, 4, 5, 6, 7, 8)
-DUAL_LAYOUT_BITS = (2, 3, 4, 8)
+WIDTHS = (2, 3, 4, 5, 6, 7, 8)
+BOTH_LAYOUTS = (2, 3, 4, 8)          # widths that exist as continuous AND as split-plane words
+LAYOUT_CASES = [(b, "gptq_p") for b in WIDTHS] + [(b, "gptq_v2") for b in BOTH_LAYOUTS]
 
 
-def _format_cases():
-    return [(b, "gptq_p") for b in ALL_BITS] + [(b, "gptq_v2") for b in DUAL_LAYOUT_BITS]
+def native_format(bits):
+    return "gptq_p" if bits in (3, 5, 6, 7) else "gptq_v2"
 
 
-def _make_inputs(bits, in_features, out_features, group_size, desc_act=False, seed=0):
-    torch.manual_seed(seed + bits)
-    maxq = (1 << bits) - 1
-    groups = in_features // group_size
-    linear = nn.Linear(in_features, out_features, bias=True)
-    scales = torch.rand(out_features, groups) * 0.01 + 0.005
-    zeros = torch.randint(0, maxq + 1, (out_features, groups)).float()
-    if desc_act:
-        g_idx = (torch.randperm(in_features) // group_size).to(torch.int32)
-    else:
-        g_idx = torch.arange(in_features, dtype=torch.int32) // group_size
-    return linear, scales, zeros, g_idx
+class Case:
+    """One quantised layer: a float Linear, per-(column, group) scales and zero-points, the group of every input row; the logical
+    codes the packer must store, and the dequantised [K, N] matrix they stand for (scales at the module's fp16 precision)."""
+
+    def __init__(self, bits, fmt, k=64, n=32, gs=32, shuffled=False, centred_zero=False, seed=0):
+        gen = torch.Generator().manual_seed(1009 * seed + 17 * bits + k)
+        self.bits, self.fmt, self.k, self.n, self.gs, self.shuffled, self.sym = bits, fmt, k, n, gs, shuffled, centred_zero
+        top = (1 << bits) - 1
+        self.linear = torch.nn.Linear(k, n, bias=True)
+        with torch.no_grad():
+            self.linear.weight.copy_(torch.empty(n, k).uniform_(-0.12, 0.12, generator=gen))
+            self.linear.bias.copy_(torch.empty(n).uniform_(-0.1, 0.1, generator=gen))
+        self.scales = torch.empty(n, k // gs).uniform_(0.005, 0.015, generator=gen)
+        self.zeros = (torch.full((n, k // gs), float((top + 1) // 2)) if centred_zero
+                      else torch.randint(0, top + 1, (n, k // gs), generator=gen).float())
+        rows = torch.randperm(k, generator=gen) if shuffled else torch.arange(k)
+        self.g_idx = (rows // gs).to(torch.int32)
+        s_row, z_row = self.scales[:, self.g_idx.long()], self.zeros[:, self.g_idx.long()]           # [N, K]
+        self.codes = torch.clamp(torch.round((self.linear.weight.data + z_row * s_row) / s_row), 0, top)
+        self.weight = ((self.codes - z_row) * s_row.half().float()).T.contiguous()                    # [K, N]
+        self.planar = True if (fmt == "gptq_p" and bits == 3) else None
+
+    def module(self):
+        from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
+        from gptqmodel_amd.utils.const import FORMAT
+        m = HipGptqLinear(bits=self.bits, group_size=self.gs, sym=self.sym, desc_act=self.shuffled, in_features=self.k,
+                          out_features=self.n, bias=True, format=FORMAT(self.fmt))
+        assert bool(m.planar) == (self.bits in (5, 6, 7) or bool(self.planar))
+        m.pack_block(self.linear, self.scales.clone(), self.zeros.clone(), self.g_idx.clone())
+        assert tuple(m.qweight.shape) == (self.k * self.bits // 32, self.n)
+        assert tuple(m.qzeros.shape) == (self.k // self.gs, self.n * self.bits // 32)
+        want_w = O.pack_rows_any(self.codes.T.contiguous().to(torch.uint8).numpy(), self.bits, self.planar)
+        want_z = O.pack_cols_any(self.zeros.T.contiguous().to(torch.uint8).numpy(), self.bits, self.planar)
+        assert np.array_equal(m.qweight.cpu().numpy(), want_w) and np.array_equal(m.qzeros.cpu().numpy(), want_z)
+        return m.to(DEV).eval()
+
+    def expect(self, x):
+        return x.float().reshape(-1, self.k) @ self.weight + self.linear.bias.data.float()
 
 
-def _codes(linear, scales, zeros, g_idx, bits):
-    maxq = (1 << bits) - 1
-    scale_full, zero_full = scales[:, g_idx.long()], zeros[:, g_idx.long()]
-    return torch.round((linear.weight.data + zero_full * scale_full) / scale_full).clamp(0, maxq), scale_full, zero_full
+def close(got, want, atol, rtol):
+    return torch.allclose(got.float().cpu(), want, atol=atol, rtol=rtol)
 
 
-def _reference_weight(linear, scales, zeros, g_idx, bits):
-    codes, scale_full, zero_full = _codes(linear, scales, zeros, g_idx, bits)
-    return ((codes - zero_full) * scale_full.to(torch.float16).float()).T.contiguous()      # [in, out]
+@pytest.mark.parametrize("bits,fmt", LAYOUT_CASES)
+def test_dequantize_weight_is_the_logical_codes(bits, fmt):
+    case = Case(bits, fmt)
+    m = case.module()
+    assert close(m.dequantize_weight(), case.weight, 1e-4, 0)          # from the checkpoint words ...
+    m.post_init()
+    assert close(m.dequantize_weight(), case.weight, 1e-4, 0)          # ... and from the kernel layout
 
 
-def _module(bits, fmt, linear, scales, zeros, g_idx, group_size, desc_act=False, sym=False):
-    from gptqmodel_amd.nn_modules.qlinear.hip_gptq import HipGptqLinear
-    from gptqmodel_amd.utils.const import FORMAT
-    k, n = linear.in_features, linear.out_features
-    m = HipGptqLinear(bits=bits, group_size=group_size, sym=sym, desc_act=desc_act, in_features=k, out_features=n, bias=True,
-                      format=FORMAT(fmt))
-    planar = True if (fmt == "gptq_p" and bits == 3) else None
-    assert bool(m.planar) == (bits in (5, 6, 7) or bool(planar))
-    m.pack_block(linear, scales.clone(), zeros.clone(), g_idx.clone())
-    codes, _, _ = _codes(linear, scales, zeros, g_idx, bits)
-    assert np.array_equal(m.qweight.cpu().numpy(), O.pack_rows_any(codes.T.contiguous().to(torch.uint8).numpy(), bits, planar))
-    assert np.array_equal(m.qzeros.cpu().numpy(), O.pack_cols_any(zeros.T.contiguous().to(torch.uint8).numpy(), bits, planar))
-    assert tuple(m.qweight.shape) == (k * bits // 32, n) and tuple(m.qzeros.shape) == (k // group_size, n * bits // 32)
-    return m.to(DEV).eval()
+@pytest.mark.parametrize("bits,fmt", LAYOUT_CASES)
+def test_forward_keeps_leading_dimensions(bits, fmt):
+    case = Case(bits, fmt)
+    m = case.module()
+    m.post_init()
+    x = torch.randn(2, 3, case.k, generator=torch.Generator().manual_seed(bits)).half() * 0.5
+    out = m(x.to(DEV))
+    assert out.shape == (2, 3, case.n) and out.dtype == torch.float16
+    assert close(out.reshape(-1, case.n), case.expect(x), 5e-3, 1e-2)
 
 
-def _packed_module_and_reference(bits, fmt, in_features=64, out_features=32, group_size=32, desc_act=False, seed=0):
-    linear, scales, zeros, g_idx = _make_inputs(bits, in_features, out_features, group_size, desc_act=desc_act, seed=seed)
-    return _module(bits, fmt, linear, scales, zeros, g_idx, group_size, desc_act=desc_act), _reference_weight(linear, scales, zeros, g_idx, bits), linear
+@pytest.mark.parametrize("bits", BOTH_LAYOUTS)
+def test_split_plane_and_continuous_words_are_the_same_layer(bits):
+    a, b = Case(bits, "gptq_p"), Case(bits, "gptq_v2")
+    ma, mb = a.module(), b.module()
+    assert torch.equal(a.codes, b.codes)
+    assert torch.equal(ma.qweight, mb.qweight) == (bits != 3)          # only 3-bit words differ between the layouts
+    assert torch.equal(ma.dequantize_weight(), mb.dequantize_weight())
+    ma.post_init()
+    mb.post_init()
+    x = (torch.randn(4, a.k, generator=torch.Generator().manual_seed(bits)).half() * 0.5).to(DEV)
+    assert torch.equal(ma(x), mb(x))
 
 
-@pytest.mark.parametrize("bits,fmt", _format_cases())
-def test_dequantize_weight_matches_reference(bits, fmt):
-    module, ref, _ = _packed_module_and_reference(bits, fmt)
-    for _ in range(2):                       # checkpoint layout, then the kernel layout
-        dequant = module.dequantize_weight().float().cpu()
-        assert dequant.shape == ref.shape
-        assert torch.allclose(dequant, ref, atol=1e-4, rtol=0)
-        module.post_init()
+VARIANTS = {"act_order": dict(shuffled=True, seed=7), "centred_zero": dict(centred_zero=True, seed=100),
+            "larger": dict(k=256, n=128, gs=64, seed=42)}
 
 
-@pytest.mark.parametrize("bits,fmt", _format_cases())
-def test_forward_batched_shapes(bits, fmt):
-    module, ref, linear = _packed_module_and_reference(bits, fmt)
-    module.post_init()
-    torch.manual_seed(bits)
-    x = torch.randn(2, 3, 64, dtype=torch.float16) * 0.5
-    out = module(x.to(DEV)).cpu()
-    ref_out = x.float().reshape(-1, 64) @ ref + linear.bias.data.float()
-    assert out.shape == (2, 3, 32)
-    assert torch.allclose(out.float().reshape(-1, 32), ref_out, atol=5e-3, rtol=1e-2)
-
-
-@pytest.mark.parametrize("bits", DUAL_LAYOUT_BITS)
-def test_planar_and_continuous_forward_identical(bits):
-    linear, scales, zeros, g_idx = _make_inputs(bits, 64, 32, 32)
-    m_planar = _module(bits, "gptq_p", linear, scales, zeros, g_idx, 32)
-    m_continuous = _module(bits, "gptq_v2", linear, scales, zeros, g_idx, 32)
-    assert torch.equal(m_planar.dequantize_weight(), m_continuous.dequantize_weight())
-    if bits == 3:
-        assert not torch.equal(m_planar.qweight, m_continuous.qweight)      # different words, same values
-    m_planar.post_init()
-    m_continuous.post_init()
-    torch.manual_seed(bits)
-    x = (torch.randn(4, 64, dtype=torch.float16) * 0.5).to(DEV)
-    assert torch.equal(m_planar(x), m_continuous(x))
-
-
-@pytest.mark.parametrize("bits", ALL_BITS)
-def test_forward_desc_act_shuffled_g_idx(bits):
-    fmt = "gptq_p" if bits in (3, 5, 6, 7) else "gptq_v2"
-    module, ref, linear = _packed_module_and_reference(bits, fmt, desc_act=True, seed=7)
-    module.post_init()
-    assert module.perm is not None
-    torch.manual_seed(bits)
-    x = torch.randn(4, 64, dtype=torch.float16) * 0.5
-    out = module(x.to(DEV)).cpu()
-    ref_out = x.float() @ ref + linear.bias.data.float()
-    assert torch.allclose(out.float(), ref_out, atol=5e-3, rtol=1e-2)
-
-
-@pytest.mark.parametrize("bits", ALL_BITS)
-def test_forward_sym_zero_point(bits):
-    fmt = "gptq_p" if bits in (3, 5, 6, 7) else "gptq_v2"
-    in_features, out_features, group_size = 64, 32, 32
-    maxq = (1 << bits) - 1
-    torch.manual_seed(100 + bits)
-    linear = nn.Linear(in_features, out_features, bias=True)
-    groups = in_features // group_size
-    scales = torch.rand(out_features, groups) * 0.01 + 0.005
-    zeros = torch.full((out_features, groups), float((maxq + 1) // 2))
-    g_idx = torch.arange(in_features, dtype=torch.int32) // group_size
-    module = _module(bits, fmt, linear, scales, zeros, g_idx, group_size, sym=True)
-    ref = _reference_weight(linear, scales, zeros, g_idx, bits)
-    assert torch.allclose(module.dequantize_weight().float().cpu(), ref, atol=1e-4, rtol=0)
-    module.post_init()
-    x = torch.randn(4, in_features, dtype=torch.float16) * 0.5
-    out = module(x.to(DEV)).cpu()
-    ref_out = x.float() @ ref + linear.bias.data.float()
-    assert torch.allclose(out.float(), ref_out, atol=5e-3, rtol=1e-2)
-
-
-@pytest.mark.parametrize("bits", ALL_BITS)
-def test_forward_larger_shapes(bits):
-    fmt = "gptq_p" if bits in (3, 5, 6, 7) else "gptq_v2"
-    in_features, out_features, group_size = 256, 128, 64
-    module, ref, linear = _packed_module_and_reference(bits, fmt, in_features=in_features, out_features=out_features,
-                                                       group_size=group_size, seed=42)
-    module.post_init()
-    torch.manual_seed(bits)
-    x = torch.randn(8, in_features, dtype=torch.float16) * 0.5
-    out = module(x.to(DEV)).cpu()
-    ref_out = x.float() @ ref + linear.bias.data.float()
-    assert out.shape == (8, out_features)
-    assert torch.allclose(out.float(), ref_out, atol=2e-2, rtol=1e-2)
+@pytest.mark.parametrize("bits,variant", list(itertools.product(WIDTHS, VARIANTS)))
+def test_forward_variants(bits, variant):
+    case = Case(bits, native_format(bits), **VARIANTS[variant])
+    m = case.module()
+    if variant == "centred_zero":
+        assert close(m.dequantize_weight(), case.weight, 1e-4, 0)
+    m.post_init()
+    assert (m.perm is not None) == case.shuffled
+    rows = 8 if variant == "larger" else 4
+    x = torch.randn(rows, case.k, generator=torch.Generator().manual_seed(bits)).half() * 0.5
+    out = m(x.to(DEV))
+    assert out.shape == (rows, case.n)
+    assert close(out, case.expect(x), 2e-2 if variant == "larger" else 5e-3, 1e-2)
