@@ -636,6 +636,7 @@ int gptqhip_pack_gptq_host(const float* weight, const float* scales, const int32
     const int groups = K / 32;                                  // 32 rows -> `bits` packed rows (gptqhip_codes.h)
     const float maxq = (float)((1 << bits) - 1);
     auto work = [&](int g0, int g1) {
+#pragma clang fp contract(off)      // multiply, then add, like the reference: no fma (matters on hosts compiled with FMA enabled)
         uint32_t c[32], out[8];
         for (int grp = g0; grp < g1; ++grp) {
             for (int n = 0; n < N; ++n) {

@@ -694,7 +694,8 @@ int launch_embedding(const int64_t* ids, const uint32_t* qw, const uint32_t* met
 
 // ---------------------------------------------------------------------------------------------
 // quantise-and-pack (reference: gptqmodel_ext/pack_block_cpu.cpp:105-190).  Thread (r, n) packs the pf codes of
-// packed row r, column n.  __fdiv_rn / rintf keep the IEEE fp32 semantics of the CPU packer (no fast-math).
+// packed row r, column n.  IEEE fp32 semantics of the CPU packer: correctly rounded divide, rint, and NO contraction of the multiply
+// and the add into an fma (HIP's __fmul_rn / __fadd_rn are plain operators, which hipcc fuses by default).
 // ---------------------------------------------------------------------------------------------
 template <int BITS>
 __global__ __launch_bounds__(256) void pack_qweight_kernel(const float* __restrict__ weight,
@@ -702,6 +703,7 @@ __global__ __launch_bounds__(256) void pack_qweight_kernel(const float* __restri
                                                            const int32_t* __restrict__ zeros,
                                                            const int32_t* __restrict__ g_idx,
                                                            int32_t* __restrict__ qweight, int K, int N, int G) {
+#pragma clang fp contract(off)      // the reference multiplies, THEN adds (two roundings): an fma here changes codes at rounding ties
     constexpr int PF = 32 / BITS;
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
@@ -714,9 +716,10 @@ __global__ __launch_bounds__(256) void pack_qweight_kernel(const float* __restri
         if (g < 0) g += G;
         g = g < 0 ? 0 : (g >= G ? G - 1 : g);  // range is validated on the host; never index out of bounds
         float scale = scales[(size_t)g * N + n];
-        const float offset = __fmul_rn((float)zeros[(size_t)g * N + n], scale);
-        if (scale == 0.0f) scale = 1e-6f;
-        float q = rintf(__fdiv_rn(__fadd_rn(weight[(size_t)n * K + k], offset), scale));
+        const float offset = (float)zeros[(size_t)g * N + n] * scale;      // plain operators: the pragma above governs THEM (the
+        if (scale == 0.0f) scale = 1e-6f;                                   // __fmul_rn / __fadd_rn wrappers carry the header's flags)
+        const float sum = weight[(size_t)n * K + k] + offset;
+        float q = rintf(sum / scale);
         q = fmaxf(0.0f, fminf(q, (float)((1 << BITS) - 1)));
         w |= ((uint32_t)(int)q) << (BITS * j);
     }
@@ -742,6 +745,7 @@ __global__ __launch_bounds__(256) void pack_qzeros_kernel(const int32_t* __restr
 __global__ __launch_bounds__(256) void pack_qweight_any_kernel(const float* __restrict__ weight, const float* __restrict__ scales,
                                                                const int32_t* __restrict__ zeros, const int32_t* __restrict__ g_idx,
                                                                int32_t* __restrict__ qweight, int K, int N, int G, int bits, int planar) {
+#pragma clang fp contract(off)      // see pack_qweight_kernel
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     const int grp = blockIdx.y;
     if (n >= N) return;
@@ -753,9 +757,10 @@ __global__ __launch_bounds__(256) void pack_qweight_any_kernel(const float* __re
         if (g < 0) g += G;
         g = g < 0 ? 0 : (g >= G ? G - 1 : g);
         float scale = scales[(size_t)g * N + n];
-        const float offset = __fmul_rn((float)zeros[(size_t)g * N + n], scale);
-        if (scale == 0.0f) scale = 1e-6f;
-        float q = rintf(__fdiv_rn(__fadd_rn(weight[(size_t)n * K + k], offset), scale));
+        const float offset = (float)zeros[(size_t)g * N + n] * scale;      // plain operators: the pragma above governs THEM (the
+        if (scale == 0.0f) scale = 1e-6f;                                   // __fmul_rn / __fadd_rn wrappers carry the header's flags)
+        const float sum = weight[(size_t)n * K + k] + offset;
+        float q = rintf(sum / scale);
         c[i] = (uint32_t)(int)fmaxf(0.0f, fminf(q, maxq));
     }
     encode_group32(c, bits, planar, out);
