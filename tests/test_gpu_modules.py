@@ -229,6 +229,24 @@ def test_device_packer_bit_exact_and_roundtrip():
                       torch.full((K,), 99, dtype=torch.int32, device=DEV), bits)
 
 
+@pytest.mark.parametrize("bits", [4, 8, 3, 6])
+def test_device_packer_equals_host_packer_at_layer_size(bits):
+    """16.8 M codes of a 4096 x 4096 layer through both packers: every word equal.  (Small fixtures cannot see a one-in-tens-of-
+    thousands divergence: the device packer once fused (zero * scale) + weight into an fma -- the reference rounds twice -- and
+    flipped 1 code of 32768 at 8 bits; the host packer is the reference's arithmetic, `profiles/r04_host_packer_speed.txt`.)"""
+    from gptqmodel_amd import ops
+    K = N = 4096
+    gs = 128
+    gen = torch.Generator().manual_seed(40 + bits)
+    w = torch.empty(N, K).uniform_(-0.1, 0.1, generator=gen)
+    scales = torch.empty(K // gs, N).uniform_(0.0004, 0.02, generator=gen)
+    zeros = torch.randint(0, 1 << bits, (K // gs, N), generator=gen, dtype=torch.int32)
+    g_idx = (torch.randperm(K, generator=gen) // gs).to(torch.int32)
+    hw, hz = ops.pack_gptq_host(w, scales, zeros, g_idx, bits)
+    dw, dz = ops.pack_gptq(w.to(DEV), scales.to(DEV), zeros.to(DEV), g_idx.to(DEV), bits)
+    assert torch.equal(dw.cpu(), hw) and torch.equal(dz.cpu(), hz)
+
+
 @pytest.mark.parametrize("bits", [2, 3, 4, 5, 6, 7, 8])
 def test_pack_clamps_reconstructed_codes_like_the_reference_test(bits):
     """tests/test_pack.py:175-238 for the device packer through the class: raw codes -8..23 plus +-1e20 saturate to [0, maxq] before
