@@ -295,6 +295,10 @@ def _reference_modules():
         if not reference_available():
             return None
         had = os.environ.get("CUDA_VISIBLE_DEVICES")
+        import logging
+        lg = logging.getLogger("refshim")      # the reference's module-level logger (oracle/ref_shim/logbar): keep it off this run's stderr
+        lg.addHandler(logging.NullHandler())
+        lg.propagate = False
         try:
             return load_reference()     # (the shim hides the GPUs from the reference's import-time probes: undo that for this process)
         finally:
@@ -566,6 +570,97 @@ def latest_pmc():
         return None, f"unavailable ({e})"
 
 
+RESULT_LINE_LIMIT = 4096     # bytes; the driver's parser lost round 4's 21 KB line (BENCH_r04.json: parsed null)
+T1_GATE_CASES = ("mlp_up_m72", "mlp_up_m128", "mlp_up_m136", "mlp_down_m128", "attn_m128")
+
+
+def _r(v, nd=4):
+    """Round floats for the result line (4 significant-ish digits are what the measurement supports)."""
+    if isinstance(v, float):
+        return float(f"{v:.{nd}g}") if abs(v) < 1.0 else round(v, max(0, nd - 1 - len(str(int(abs(v)))) + 2))
+    return v
+
+
+def result_line(detail):
+    """The ONE stdout line of a run: a compact (< RESULT_LINE_LIMIT bytes) JSON object with the contract's headline keys, `roofline`,
+    `cpu_baseline` and a one-record-per-case `configs_summary` (the shape of the reference's own benchmark records,
+    scripts/benchmark_marlin_a100.py:181-201).  Everything else of `detail` (per-config workload prose, the 28-case T1 table, the
+    e2e leg, the CPU thread sweep) goes to stderr and gpurun_out/bench_detail.json, not here.  Pure function (tests/test_host_logic.py)."""
+    keep = ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data")
+    line = {k: _r(detail[k]) for k in keep if k in detail}
+    cfg = detail.get("config", {})
+    line["config"] = {"workload": "Llama-3-8B GPTQ int4 g128 desc_act=False batch=1 decode: the 224 quantised linears of a token, "
+                                  "chained through the layer glue, M=1, random packed weights (BASELINE configs[1])"}
+    if "workload_short" in cfg:
+        line["config"]["workload"] = cfg["workload_short"]
+    for k in ("parallelism", "mode", "linears_per_step", "launches_per_step", "graph", "weight_bytes_per_token", "path", "allreduce"):
+        if k in cfg:
+            line["config"][k] = cfg[k]
+    rf = detail.get("roofline", {})
+    line["roofline"] = {k: _r(rf[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_us")
+                        if k in rf}
+    if "kernel" in rf:
+        line["roofline"]["kernel"] = rf["kernel"].split("<")[0].split(" ")[0]
+    if "traffic_source" in rf:
+        line["roofline"]["traffic_live"] = rf["traffic_source"].startswith("measured live")
+    cb = detail.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "cpu_model", "c1_ms", "model_tokens_per_s_from_per_shape")
+                                if k in cb}
+        line["cpu_baseline"]["sample"] = "1 of 32 decoder layers (7 linears, M=1, bf16), extrapolated x32; c1_ms = single 4096x4096 linear"
+    summ = []
+    for c in list(detail.get("configs", [])) + ([detail["prefill"]] if "prefill" in detail else []):
+        if "error" in c or "skipped" in c:
+            summ.append({"id": c.get("id", c.get("config")), "error": str(c.get("error", c.get("skipped")))[:80]})
+            continue
+        rec = {"id": c.get("id", c.get("config")), "config": c.get("config"), "value": _r(c.get("value")), "unit": c.get("unit"),
+               "frac": _r(c.get("roofline", {}).get("frac"))}
+        if c.get("config") == "_prefill_headline":
+            rec["id"], rec["config"] = "c2_layer_m8192", "C2"
+        if "tp" in c:
+            rec["tp"] = c["tp"]
+        if "hbm_frac" in c.get("roofline", {}):
+            rec["hbm_frac"] = _r(c["roofline"]["hbm_frac"])
+        summ.append(rec)
+        if c.get("config") == "T1":
+            by_id = {k["case_id"]: k for k in c.get("cases", [])}
+            for cid in T1_GATE_CASES:
+                if cid in by_id:
+                    k = by_id[cid]
+                    summ.append({"id": "t1_" + cid, "config": "T1", "us": _r(k["us_graph"]), "value": _r(k["tflops_graph"]), "unit": "TFLOP/s",
+                                 "frac": _r(k["roofline"]["mfma_frac"]), "hbm_frac": _r(k["roofline"]["hbm_frac"])})
+    if summ:
+        line["configs_summary"] = summ
+    e2e = detail.get("e2e")
+    if isinstance(e2e, dict):
+        line["e2e"] = {k: _r(v) for k, v in e2e.items() if isinstance(v, (int, float)) and not isinstance(v, bool)} or {"error": str(e2e.get("error", ""))[:80]}
+    if "note" in detail:
+        line["note"] = detail["note"][:160]
+    line["detail"] = "gpurun_out/bench_detail.json (also on stderr)"
+    txt = json.dumps(line, separators=(",", ":"))
+    if len(txt) >= RESULT_LINE_LIMIT:      # never lose the headline to an over-long line: drop the optional blocks, largest first
+        for k in ("e2e", "configs_summary"):
+            line.pop(k, None)
+            txt = json.dumps(line, separators=(",", ":"))
+            if len(txt) < RESULT_LINE_LIMIT:
+                break
+    return txt
+
+
+def emit(detail):
+    """stderr + gpurun_out/bench_detail.json get the full record; stdout gets the one compact result line, LAST."""
+    full = json.dumps(detail)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as f:
+            f.write(full + "\n")
+    except OSError:
+        pass
+    print("BENCH_DETAIL " + full, file=sys.stderr, flush=True)
+    print(result_line(detail), flush=True)
+
+
 def spawn_command(gpus, environ, argv):
     """The command that launches `gpus` ranks of this script, or None when this process IS a rank already (WORLD_SIZE set by a
     launcher) or a single rank is wanted.  Pure function of its arguments (tests/test_host_logic.py)."""
@@ -815,7 +910,7 @@ def main():
             torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, gs)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -852,14 +947,14 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
     res = []
     gs = 128
     t_start = time.perf_counter()
-    res.append(decode_entry("C2", f"headline ({mode})", cfg, ms_headline, n_launch, extra={"mode": mode}))
+    res.append(decode_entry("C2", f"headline ({mode})", cfg, ms_headline, n_launch, extra={"mode": mode, "id": f"c2_decode_{mode}"}))
     for other in ("chain", "modules"):
         if other == mode:
             continue
         try:
             st = make_step(other)
             ms, g = time_graph(st.run, stream, 50, 5)
-            res.append(decode_entry("C2", f"same token step, mode={other}", cfg, ms, n_launch, extra={"mode": other}))
+            res.append(decode_entry("C2", f"same token step, mode={other}", cfg, ms, n_launch, extra={"mode": other, "id": f"c2_decode_{other}"}))
             del g, st
         except Exception as e:  # noqa: BLE001
             res.append({"config": "C2", "mode": other, "error": str(e)[:300]})
@@ -874,7 +969,7 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
                 lin(x)
         ms, g = time_graph(indep, stream, 50, 5)
         res.append(decode_entry("C2", "round-1 method: the same 128 launches with a constant input, no glue, no data dependencies (not a "
-                                "decode step)", cfg, ms, n_launch, extra={"mode": "independent launches"}))
+                                "decode step)", cfg, ms, n_launch, extra={"mode": "independent launches", "id": "c2_decode_independent"}))
         del g
     except Exception as e:  # noqa: BLE001
         res.append({"config": "C2", "mode": "independent launches", "error": str(e)[:300]})
@@ -888,7 +983,7 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
             ms, g = time_graph(st.run, stream, 100, 10)
             res.append(decode_entry("C2", "bf16 decode chain with the OPT-IN exact-arithmetic dequant (GPTQHIP_GEMM_EXACT_BF16; leaves the "
                                     "reference's per-weight rounding chain -- not the default, not the headline)", cfg, ms, n_launch,
-                                    extra={"mode": "chain, exact-arithmetic opt-in"}))
+                                    extra={"mode": "chain, exact-arithmetic opt-in", "id": "c2_decode_exact_optin"}))
             del g, st
         except Exception as e:  # noqa: BLE001
             res.append({"config": "C2", "mode": "chain, exact-arithmetic opt-in", "error": str(e)[:300]})
@@ -905,10 +1000,12 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
         # at these sizes the op is neither purely HBM- nor MFMA-bound: both fractions are given
         bytes_layer = sum(algorithmic_bytes(m_mid, lin.in_features, lin.out_features, gs) for lin in lins)
         e["roofline"]["hbm_frac"] = bytes_layer / (e["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        e["id"] = f"c2_layer_m{m_mid}"
         res.append(e)
     # T1: the reference's own TFLOPS benchmark (M = 64..192), case by case
     try:
         res.append(t1_entry(dtype, dev, stream))
+        res[-1]["id"] = "t1_best"
     except Exception as e:  # noqa: BLE001
         res.append({"config": "T1", "error": str(e)[:300]})
     # C3: act-order prefill, batch 32 x 2048 ctx = 65536 tokens
@@ -917,6 +1014,7 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
         a44 = make_gptq(4096, 4096, gs, dev, gen, dtype, desc_act=True)
         res.append(prefill_entry("C3", "GPTQ int4 g128 desc_act=True (act-order g_idx gather), M=65536 (batch 32 x 2048 ctx), "
                                  "4096x4096 (q/o_proj shape)", [a44], 65536, dtype, dev))
+        res[-1]["id"] = "c3_4096x4096_actorder"
         del a44
         # the same layer WITHOUT act-order in the same run: what the x-gather pass (1 GiB of HBM traffic at M = 65536) costs
         p44 = make_gptq(4096, 4096, gs, dev, gen, dtype, desc_act=False)
@@ -926,6 +1024,7 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
         agu = make_gptq(4096, 2 * cfg["inter"], gs, dev, gen, dtype, desc_act=True)
         res.append(prefill_entry("C3", "GPTQ int4 g128 desc_act=True, M=65536, 4096x28672 (fused gate_up)", [agu], 65536, dtype, dev,
                                  iters=2))
+        res[-1]["id"] = "c3_gate_up_actorder"
         del agu
         # C3 the way a MODEL runs it (utils/hf_llama prefill path): one decoder layer of the act-order checkpoint at M = 65536 -- the
         # RMSNorm in front of q|k|v and of gate|up is ONE HIP kernel that writes the normalised activations already in the linear's
@@ -969,7 +1068,8 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 2
             tf = flops / ms / 1e9
-            res.append({"config": "C3", "workload": f"one Llama-3-8B decoder layer of a desc_act=True checkpoint at M={m_c3} (4 quantised "
+            res.append({"config": "C3", "id": "c3_layer_fused" if fused else "c3_layer_gather_passes",
+                        "workload": f"one Llama-3-8B decoder layer of a desc_act=True checkpoint at M={m_c3} (4 quantised "
                                                     f"linears + 2 RMSNorm kernels in the timed region): {what}",
                         "value": tf, "unit": "TFLOP/s", "ms": ms, "flops_counted": "the 4 GEMMs only",
                         "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
@@ -983,7 +1083,7 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
         st.x_in.copy_((torch.randn(cfg["hidden"], device=dev, generator=gen) * 0.5).to(dtype))
         ms, g = time_graph(st.run, stream, 100, 10)
         res.append(decode_entry("C3", "Llama-3-8B GPTQ int4 g128 desc_act=True batch=1 decode, decode chain (permutation applied in the "
-                                "kernel on the glued input row)", cfg, ms, n_launch))
+                                "kernel on the glued input row)", cfg, ms, n_launch, extra={"id": "c3_decode_actorder"}))
         del g, st, act_layers
     except Exception as e:  # noqa: BLE001
         res.append({"config": "C3", "error": str(e)[:300]})
@@ -996,11 +1096,12 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
         st.x_in.copy_((torch.randn(cfg["hidden"], device=dev, generator=gen) * 0.5).to(dtype))
         ms, g = time_graph(st.run, stream, 100, 10)
         res.append(decode_entry("C4", "Llama-3-8B AWQ int4 g128 sym=False (AWQ packing, asymmetric qzeros) batch=1 decode, decode chain",
-                                cfg, ms, n_launch))
+                                cfg, ms, n_launch, extra={"id": "c4_awq_decode"}))
         del g, st
         A0 = awq_layers[0]
         res.append(prefill_entry("C4", "AWQ int4 g128 asym, one decoder layer's linears (4 launches) at M=2048",
                                  [A0.qkv, A0.o, A0.gate_up, A0.down], 2048, dtype, dev, iters=5))
+        res[-1]["id"] = "c4_awq_layer_m2048"
         del awq_layers, A0
     except Exception as e:  # noqa: BLE001
         res.append({"config": "C4", "error": str(e)[:300]})
@@ -1025,7 +1126,7 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
             st.x_in.copy_((torch.randn(c70["hidden"], device=dev, generator=gen) * 0.5).to(dtype))
             ms, g = time_graph(st.run, stream, 20, 3)
             res.append(decode_entry("C5", "Llama-3-70B GPTQ int4 g128 batch=1 decode at TP=1 (560 linears / 320 launches per token), decode chain",
-                                    c70, ms, c70["layers"] * 4, extra={"tp": 1}))
+                                    c70, ms, c70["layers"] * 4, extra={"tp": 1, "id": "c5_70b_decode_tp1"}))
             del g, st, l70
         else:
             res.append({"config": "C5", "skipped": "time budget of the default run"})

@@ -234,7 +234,8 @@ def tp_decode_entry(args, rank, world, dev, dist, steps, warmup, log=None):
 
 def run_70b(args, rank, local_rank, world, dev, dist, ranks_seen=None):
     """bench.py --model llama3-70b: the TP decode step as the headline of its own JSON line."""
-    log = (lambda m: print(m, flush=True)) if rank == 0 else None
+    import sys
+    log = (lambda m: print(m, file=sys.stderr, flush=True)) if rank == 0 else None
     e = tp_decode_entry(args, rank, world, dev, dist, args.steps, args.warmup, log=log)
     if rank == 0:
         if not e["finite"] or not e["comm_status_ok"]:
@@ -249,4 +250,5 @@ def run_70b(args, rank, local_rank, world, dev, dist, ranks_seen=None):
                        "allreduce": e["allreduce"]},
             "roofline": e["roofline"], "gemm_tflops_equiv": e["gemm_tflops_equiv"],
         }
-        print(json.dumps(out), flush=True)
+        import bench as B
+        B.emit(out)

@@ -27,7 +27,7 @@ static thread_local int t_force_waves = 0;
 
 // process-wide DEFAULTS from the environment, read once and immutable afterwards (triage switches, like the env flags
 // the reference steers its kernels with, torch.py:172-190):
-//   GPTQHIP_FORCE_KERNEL=1|2|3  always the decode (skinny) / prefill (tiled) / opt-in stripe kernel;  GPTQHIP_FORCE_SPLIT_K=n;
+//   GPTQHIP_FORCE_KERNEL=1|2  always the decode (skinny) / prefill (tiled) kernel;  GPTQHIP_FORCE_SPLIT_K=n;
 //   GPTQHIP_FORCE_VARIANT=n   decode: waves per block; prefill: 1/2/3 = 256/128/64-row tiles
 struct EnvTuning {
     int split, kernel, waves;
@@ -65,30 +65,12 @@ constexpr int kSkinnyMaxM = 32;  // above: the MFMA-tiled kernel (split-K when i
 constexpr int kSkinnyMaxRows4 = 64;  // rows one decode-kernel launch takes with 4-bit weights (MT = 4 instantiations)
 constexpr size_t kCounterBytes = 64 * 1024;  // 16384 arrival counters
 
-// Measured crossover of the stripe kernel against min(decode kernel, prefill kernel); see its use in gptqhip_gemm.
-static bool stripe_preferred(int M, int K, int N, int bits) {
-    (void)K;
-    (void)N;
-    return false;   // (until measured)
-}
-
 struct WorkspaceLayout {
     size_t counters_off, counters_bytes;
     size_t gather_off, gather_bytes;
     size_t slabs_off, slabs_bytes;
     size_t total;
 };
-
-// The stripe kernel (gptqhip_stripe_kernel.h) takes the batch sizes between the decode kernel's and the prefill kernel's regimes.
-// Its queue heads live at the END of the fixed counter region, its arrival tickets at the start (all restored to zero by the kernel).
-constexpr int kStripeHeadSlots = (8 + 1) * 64;   // = kStripeHeadInts (gptqhip_stripe_kernel.h): 9 counters, 256 B apart
-static bool gemm_uses_stripe(int M, int K, int N, int group_size, int bits, int partial_f32) {
-    if (partial_f32 || g_force_kernel == 1 || g_force_kernel == 2) return false;
-    const StripePlan sp = plan_stripe(M, K, N, group_size, bits, g_force_kernel == 3 ? g_force_waves : 0, g_force_kernel == 3 ? g_force_split : 0);
-    if (!sp.ok || (size_t)sp.vstripes * sizeof(int) > kCounterBytes - kStripeHeadSlots * sizeof(int)) return false;
-    if (g_force_kernel == 3) return true;
-    return stripe_preferred(M, K, N, bits);
-}
 
 static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int bits, int has_perm) {
     WorkspaceLayout L;
@@ -112,10 +94,6 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
     if (M > 16 || g_force_kernel == 2) {
         const TiledPlan tp = plan_tiled(M, K, N, group_size, bits, g_force_waves, g_force_split);
         if (tp.slab_floats > floats) floats = tp.slab_floats;
-    }
-    if (gemm_uses_stripe(M, K, N, group_size, bits, 0)) {
-        const StripePlan sp = plan_stripe(M, K, N, group_size, bits, g_force_kernel == 3 ? g_force_waves : 0, g_force_kernel == 3 ? g_force_split : 0);
-        if (sp.slab_floats > floats) floats = sp.slab_floats;
     }
     L.slabs_bytes = align_up(floats * sizeof(float), 256);
     L.total = L.slabs_off + L.slabs_bytes;
@@ -299,18 +277,6 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     // 17..32 rows too when N < 65536 and K < 8192 or the blocks fit one round (4096x28672 at M=32 32.4 -> 24.4 us vs 27.3 us tiled,
     // 4096x8192 11.9 -> 8.7 vs 13.0, 8192x8192 13.5 vs 17.4; but 8192x10240 22.3 vs 19.9 tiled, 4096x128256 91.9 vs 80.7); above that the tiled kernel (4096x28672 at M=48: 28.7 vs 39.0 us).
     // profiles/r03_wide_layers.txt
-    if (gemm_uses_stripe(M, K, N, group_size, bits, partial_f32 ? 1 : 0)) {
-        // 65..256 rows: every packed word dequantised once per launch, stream-K items per XCD queue, split-K summed inside the
-        // launch by the last arriver out of the XCD's L2 (gptqhip_stripe_kernel.h)
-        a.x = xin;
-        a.out = out;
-        a.M = M;
-        const StripePlan sp = plan_stripe(M, K, N, group_size, bits, g_force_kernel == 3 ? g_force_waves : 0, g_force_kernel == 3 ? g_force_split : 0);
-        int* heads = counters + kCounterBytes / sizeof(int) - kStripeHeadSlots;
-        static const int env_wt = env_int("GPTQHIP_STRIPE_WRITE_THROUGH");
-        const int wt = g_force_split == 1 || env_wt == 1 ? 1 : 0;
-        return launch_stripe(a, sp, slabs, heads, counters, wt, stream);
-    }
     const bool use_tiled = gemm_uses_tiled(M, K, N, group_size, bits);
     // rows per decode-kernel launch: 32, or 64 with 4-bit weights (one launch, the weights are streamed once)
     const int rows_per_launch = bits == 4 ? kSkinnyMaxRows4 : kSkinnyMaxM;
@@ -369,15 +335,6 @@ int gptqhip_plan_describe(int M, int K, int N, int group_size, int bits, int has
     if (M <= 0) {
         set_error("gptqhip_plan_describe: M=%d", M);
         return GPTQHIP_EINVAL;
-    }
-    if (gemm_uses_stripe(M, K, N, group_size, bits, 0)) {
-        const StripePlan sp = plan_stripe(M, K, N, group_size, bits, g_force_kernel == 3 ? g_force_waves : 0, g_force_kernel == 3 ? g_force_split : 0);
-        int maxc = 0;
-        rc = stripe_selfcheck(sp, &maxc);
-        if (rc) return GPTQHIP_EINVAL;
-        snprintf(buf, (size_t)buf_len, "stripe mt=%d kg=%d panels=%d stripes=%d steps=%d items=%dx%d max_contrib=%d gather=%d", sp.mt, sp.kg,
-                 sp.panels, sp.stripes, sp.sps, sp.nq, sp.items, maxc, has_perm ? 1 : 0);
-        return GPTQHIP_OK;
     }
     if (gemm_uses_tiled(M, K, N, group_size, bits)) {
         const TiledPlan tp = plan_tiled(M, K, N, group_size, bits, g_force_waves, g_force_split);

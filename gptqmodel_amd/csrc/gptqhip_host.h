@@ -53,19 +53,6 @@ struct TiledPlan {
     int tail_cols = 0;  // trailing block columns (256 wide) handed to a second launch with 128-row tiles; 0: none
 };
 
-struct StripePlan {
-    int ok;        // 0: the shape is outside the stripe kernel (bits, K % 128, slab size)
-    int mt;        // 16-row tiles per row panel
-    int kg;        // K-groups per block: 2 = 64-column stripes, 1 = 128-column stripes
-    int gpc;       // meta words per chunk (1 or 4)
-    int panels;    // row panels
-    int stripes;   // column stripes
-    int vstripes;  // stripes * panels
-    int sps;       // pipeline steps per stripe
-    int nq, items; // queues (XCDs), items per queue
-    size_t slab_floats;
-};
-
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
@@ -76,10 +63,6 @@ int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* co
 
 TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_variant, int force_split);
 int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, hipStream_t stream);
-
-StripePlan plan_stripe(int M, int K, int N, int group_size, int bits, int force_kg, int force_items = 0);
-int launch_stripe(const GemmArgs& a, const StripePlan& pl, float* slabs, int* heads, int* tickets, int write_through, hipStream_t stream);
-int stripe_selfcheck(const StripePlan& pl, int* max_contrib);
 
 int launch_dequant(const int32_t* qweight, const int32_t* qzeros, const void* scales, const int32_t* g_idx, void* out,
                    int K, int N, int group_size, int bits, int scale_dtype, int out_dtype, hipStream_t stream);

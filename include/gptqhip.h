@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 16
+#define GPTQHIP_ABI_VERSION 17
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -299,18 +299,14 @@ int gptqhip_allgather_select(const void* x_local, void* const* peer_bufs, int ra
                              const int32_t* index, int n_out, void* out, int act_dtype, gptqhip_stream_t stream);
 
 /* Which kernel family and launch geometry gptqhip_gemm would use for this call, as text (triage / logging / tests; host logic, no
- * GPU): "skinny launches=1 mt=2 nt=4 waves=8 depth=2 regular=1 splits=1 gather=0", "tiled bm=64 splits=8 tail_cols=0 gather=1" or (forced)
- * "stripe mt=8 kg=2 panels=1 stripes=64 steps=16 items=8x32 max_contrib=4 gather=0" (its partition is self-checked on the way).
+ * GPU): "skinny launches=1 mt=2 nt=4 waves=8 depth=2 regular=1 splits=1 gather=0" or "tiled bm=64 splits=8 tail_cols=0 gather=1".
  * mt = 16-row tiles per block, nt = column tiles per block (4 / 2: the wide-layer form), gather = a separate act-order x gather pass
  * runs first.  The reference steers its kernels with thresholds too (ExllamaV2 switches to dequant + cuBLAS above 50 rows:
  * gptqmodel_ext/exllamav2/cuda/q_gemm.cu:118, config.h:4); here the crossover is measured per layer shape. */
 int gptqhip_plan_describe(int M, int K, int N, int group_size, int bits, int has_perm, char* buf, int buf_len);
 
 /* Tuning hook (benchmarks / tests): force the cross-block split-K factor and the waves per block of the skinny
- * kernel (0 = heuristic), or the kernel family (0 auto, 1 skinny, 2 tiled-prefill, 3 stripe: the opt-in stream-K kernel with the
- * split-K sum inside the launch, gptqmodel_amd/csrc/gptqhip_stripe_kernel.h -- with it force_split_k = 1 publishes the partial slabs
- * write-through, 2..32 sets the items per XCD queue, and force_waves = kg + 10 * max row tiles per panel picks the stripe shape; shapes
- * outside it (8-bit weights, K % 128 != 0, fp32 partial output) fall back to the automatic choice).  The overrides are THREAD-LOCAL
+ * kernel (0 = heuristic), or the kernel family (0 auto, 1 skinny, 2 tiled-prefill).  The overrides are THREAD-LOCAL
  * (they apply to gptqhip_gemm / gptqhip_workspace_bytes calls made by the calling thread only), so the library keeps
  * no process-global mutable state and stays re-entrant across threads, devices and streams. */
 int gptqhip_set_tuning(int force_split_k, int force_kernel, int force_waves);

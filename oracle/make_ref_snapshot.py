@@ -44,6 +44,19 @@ def make_snapshot(verbose: bool = True) -> int:
         "awq.optimize = lambda *a, **k: None\n"
         "awq = awq.eval(); awq.post_init()\n"
         "awq(torch.zeros(1, 256, dtype=torch.bfloat16))\n"
+        # ... and what tests/test_gpu_reference_dropin.py drives on the GPU box: QuantizeConfig -> make_quant -> gptqmodel_post_init
+        "import torch.nn as nn\n"
+        "from gptqmodel.quantization.config import QuantizeConfig\n"
+        "from gptqmodel.quantization import FORMAT, METHOD\n"
+        "from gptqmodel.utils.model import make_quant, gptqmodel_post_init\n"
+        "for method, fmt, be in ((METHOD.GPTQ, FORMAT.GPTQ_V2, ref.BACKEND.GPTQ_TORCH), (METHOD.AWQ, FORMAT.GEMM, ref.BACKEND.AWQ_TORCH)):\n"
+        "    q = QuantizeConfig(bits=4, group_size=128, desc_act=False, sym=False, method=method, format=fmt)\n"
+        "    blk = nn.Sequential(nn.Linear(256, 256, bias=True, dtype=torch.float16))\n"
+        "    make_quant(blk, q, quant_result={'0': {}}, backend=be, lm_head_name='lm_head', device=ref.DEVICE.CPU, from_quantized=True,\n"
+        "               dtype=torch.float16)\n"
+        "    blk[0].optimize = lambda *a, **k: None\n"
+        "    gptqmodel_post_init(blk, use_act_order=False, quantize_config=q)\n"
+        "    blk[0](torch.zeros(1, 256, dtype=torch.float16))\n"
         f"root = {LIVE!r} + os.sep\n"
         "for m in list(sys.modules.values()):\n"
         "    f = getattr(m, '__file__', None)\n"
@@ -53,7 +66,15 @@ def make_snapshot(verbose: bool = True) -> int:
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     if out.returncode != 0:
         raise RuntimeError("reference import failed:\n" + out.stderr[-2000:])
-    files = sorted({ln.strip() for ln in out.stdout.splitlines() if ln.strip().startswith(LIVE)})
+    files = {ln.strip() for ln in out.stdout.splitlines() if ln.strip().startswith(LIVE)}
+    # The drop-in test on the GPU box (tests/test_gpu_reference_dropin.py) runs the reference's selector with a device visible: every
+    # candidate kernel's validate_once() then lazily imports its own helper modules (gptqmodel/extension.py, utils/*), a set that cannot
+    # be recorded in this GPU-less container.  So the rest of the package's Python files travel too (4 MB; the model zoo stays out).
+    pkg = os.path.join(LIVE, "gptqmodel")
+    for d, dirs, names in os.walk(pkg):
+        dirs[:] = [x for x in dirs if x != "__pycache__" and os.path.join(d, x) != os.path.join(pkg, "models", "definitions")]
+        files.update(os.path.join(d, n) for n in names if n.endswith(".py"))
+    files = sorted(files)
     if os.path.isdir(SNAP):
         shutil.rmtree(SNAP)
     for f in files:

@@ -1,0 +1,190 @@
+"""The REAL drop-in on the GPU: the overlay classes, built on the reference's OWN GPTQQuantLinear /
+AWQuantLinear, selected and constructed by the reference's OWN code, executing a forward on the MI355X -- compared in the
+same process with the reference's TorchLinear.forward / AwqTorchLinear.forward on the CPU.  HIP vs the reference itself,
+not vs the oracle.
+
+Chain exercised, all of it upstream code except the two overlay files:
+    gptqmodel/utils/importer.py:495  select_quant_linear(device=DEVICE.ROCM, backend=BACKEND.AUTO)  -> overlay class
+    gptqmodel/utils/model.py:398     make_quant(nn.Module of nn.Linear, QuantizeConfig, ...)          -> module swap
+    gptqmodel/utils/model.py:1281    gptqmodel_post_init(model, use_act_order)                         -> post_init() on cuda:0
+    HipGptqLinear(GPTQQuantLinear).forward / HipAwqLinear(AWQuantLinear).forward                       -> libgptqhip.so
+    gptqmodel/nn_modules/qlinear/torch.py:302 TorchLinear.forward, torch_awq.py:157 AwqTorchLinear.forward on CPU = the expected value
+
+The reference tree is /root/reference where it is mounted, else the snapshot oracle/_ref that travels to the GPU box (skipped
+when neither exists).  It is copied to a temp dir and integration/apply_overlay.py patches the copy."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SOURCES = ["/root/reference", os.path.join(ROOT, "oracle", "_ref")]
+SRC = next((s for s in SOURCES if os.path.isdir(os.path.join(s, "gptqmodel", "nn_modules", "qlinear"))), None)
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(SRC is None, reason="no reference tree and no oracle/_ref snapshot")]
+
+_SCRIPT = r'''
+import json, os, sys
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import torch
+assert torch.cuda.is_available()
+torch.zeros(1, device="cuda:0")                      # bring the HIP runtime up BEFORE the shim hides the devices from import-time probes
+os.environ["GPTQ_REFERENCE_ROOT"] = {tree!r}
+from oracle.ref_import import load_reference
+ref = load_reference()
+os.environ.pop("CUDA_VISIBLE_DEVICES", None)
+import torch.nn as nn
+from gptqmodel.nn_modules.qlinear import hip as hipmod            # the overlay file, inside the reference package
+from gptqmodel.nn_modules.qlinear import GPTQQuantLinear, AWQuantLinear
+from gptqmodel.nn_modules.qlinear.torch import TorchLinear
+from gptqmodel.nn_modules.qlinear.torch_awq import AwqTorchLinear
+from gptqmodel.utils import importer
+from gptqmodel.utils.backend import BACKEND
+from gptqmodel.utils.model import make_quant, gptqmodel_post_init
+from gptqmodel.quantization import FORMAT, METHOD
+from gptqmodel.quantization.config import QuantizeConfig
+from gptqmodel.models._const import DEVICE
+from helpers import synth_full_case, REF_ATOL, REF_RTOL, NORM_TOL
+
+H, A = hipmod.HipGptqLinear, hipmod.HipAwqLinear
+out = {{"bases": [issubclass(H, GPTQQuantLinear), issubclass(A, AWQuantLinear)], "validate_once": [str(c.validate_once()) for c in (H, A)]}}
+TDT = {{"fp16": torch.float16, "bf16": torch.bfloat16}}
+
+
+class Block(nn.Module):
+    """What the reference's loader hands to make_quant: a module tree of plain nn.Linear on the CPU (models/loader.py)."""
+    def __init__(self, k, n, bias, dtype):
+        super().__init__()
+        self.proj = nn.Linear(k, n, bias=bias, dtype=dtype)
+
+
+def build(kind, k, n, gs, desc_act, sym, dtype, backend, device, bias):
+    method = METHOD.AWQ if kind == "awq" else METHOD.GPTQ
+    fmt = FORMAT.GEMM if kind == "awq" else FORMAT.GPTQ_V2
+    qcfg = QuantizeConfig(bits=4, group_size=gs, desc_act=desc_act, sym=sym, method=method, format=fmt)
+    blk = Block(k, n, bias, dtype)
+    cls = make_quant(blk, qcfg, quant_result={{"proj": {{}}}}, backend=backend, lm_head_name="lm_head", device=device,
+                     from_quantized=True, dtype=dtype)
+    return blk, cls, qcfg
+
+
+def load(lin, case, dtype_name, bias, dev):
+    lin.qweight.data = torch.from_numpy(case["qweight"]).to(dev)
+    lin.qzeros.data = torch.from_numpy(case["qzeros"]).to(dev)
+    lin.scales.data = torch.from_numpy(case["scales"]).to(TDT[dtype_name]).to(dev)
+    if case["g_idx"] is not None:
+        lin.g_idx.data = torch.from_numpy(case["g_idx"]).to(dev)
+    if bias is not None:
+        lin.bias.data = bias.to(dev)
+
+
+results = []
+CASES = {cases!r}
+for (tag, kind, k, n, gs, desc_act, sym, dt, with_bias, ms) in CASES:
+    dtype = TDT[dt]
+    case = synth_full_case(kind, 4242 + len(results), 4, k, n, gs, desc_act, sym, dt, dt, max(ms))
+    bias = (torch.randn(n) * 0.1).to(dtype) if with_bias else None
+    sel = importer.select_quant_linear(bits=4, group_size=gs, desc_act=desc_act, sym=sym, device=DEVICE.ROCM, backend=BACKEND.AUTO,
+                                       format=FORMAT.GEMM if kind == "awq" else FORMAT.GPTQ_V2,
+                                       quant_method=METHOD.AWQ if kind == "awq" else METHOD.GPTQ, pack_dtype=torch.int32)
+    # the product: AUTO on ROCm through make_quant -> overlay class on the reference's base; weights moved to cuda:0; post_init
+    blk, cls, qcfg = build(kind, k, n, gs, desc_act, sym, dtype, BACKEND.AUTO, DEVICE.ROCM, with_bias)
+    hip = blk.proj
+    load(hip, case, dt, bias, "cpu")
+    blk.to("cuda:0")
+    gptqmodel_post_init(blk, use_act_order=desc_act, quantize_config=qcfg)
+    # the expected value: the reference's own torch kernel through the same make_quant, on the CPU
+    rblk, rcls, _ = build(kind, k, n, gs, desc_act, sym, dtype, BACKEND.AWQ_TORCH if kind == "awq" else BACKEND.GPTQ_TORCH, DEVICE.CPU, with_bias)
+    rlin = rblk.proj
+    rlin.optimize = lambda *a, **kw: None             # eager dequant, the reference's own test trick (tests/test_torch.py:417)
+    load(rlin, case, dt, bias, "cpu")
+    gptqmodel_post_init(rblk, use_act_order=desc_act, quantize_config=qcfg)
+    rec = {{"tag": tag, "selected": sel.__name__, "made": type(hip).__name__, "made_module": type(hip).__module__, "ref_made": type(rlin).__name__,
+           "on_base": isinstance(hip, AWQuantLinear if kind == "awq" else GPTQQuantLinear), "device": str(hip.list_buffers()[0].device), "m": {{}}}}
+    x_all = torch.from_numpy(case["x"]).to(dtype)
+    for m in ms:
+        x = x_all[:m].contiguous()
+        with torch.inference_mode():
+            got = hip(x.to("cuda:0").view(1, m, k))                 # [batch, seq, K] like a model calls it
+            want = rlin(x.view(1, m, k))
+        torch.cuda.synchronize()
+        g = got.float().cpu().numpy().reshape(m, n)
+        w = want.float().numpy().reshape(m, n)
+        rel = float(np.abs(g - w).max() / max(float(np.abs(w).max()), 1e-12))
+        bad = int((np.abs(g - w) > REF_ATOL[dt] + REF_RTOL * np.abs(w)).sum())
+        rec["m"][str(m)] = {{"rel": rel, "outside_ref_allclose": bad, "shape": list(got.shape), "dtype": str(got.dtype), "dev": str(got.device),
+                            "finite": bool(np.isfinite(g).all()), "tol": NORM_TOL[dt]}}
+    # dequantize_weight() of the drop-in equals the reference's dequantised weight bit for bit (torch.py:700-717 / packing_utils.py:106)
+    try:
+        wd = hip.dequantize_weight().float().cpu()
+        wr = rlin.dequantize_weight().float() if kind != "awq" else None
+        if wr is not None:
+            if wr.shape != wd.shape:
+                wr = wr.T
+            rec["dequant_equal"] = bool(torch.equal(wd, wr))
+    except Exception as e:
+        rec["dequant_equal"] = "ERR:" + type(e).__name__ + ":" + str(e)[:200]
+    results.append(rec)
+    del blk, rblk, hip, rlin
+    torch.cuda.empty_cache()
+out["cases"] = results
+print("RESULT " + json.dumps(out))
+'''
+
+# (tag, kind, K, N, group, desc_act, sym, dtype, bias, rows): C1 = BASELINE configs[0] layer, C3 = act-order, C4 = AWQ asym
+CASES = [
+    ("C1_fp16", "gptq", 4096, 4096, 128, False, True, "fp16", False, (1, 33, 2048)),
+    ("C1_bf16", "gptq", 4096, 4096, 128, False, True, "bf16", True, (1, 33, 2048)),
+    ("C3_act_order_fp16", "gptq", 4096, 4096, 128, True, False, "fp16", True, (1, 33, 2048)),
+    ("C3_act_order_kv_bf16", "gptq", 4096, 1024, 128, True, False, "bf16", False, (1, 33, 2048)),
+    ("C4_awq_fp16", "awq", 4096, 4096, 128, False, False, "fp16", True, (1, 33, 2048)),
+    ("C4_awq_mlp_bf16", "awq", 4096, 14336, 128, False, False, "bf16", False, (1, 33)),
+]
+
+
+@pytest.fixture(scope="module")
+def overlaid_tree(tmp_path_factory):
+    tree = tmp_path_factory.mktemp("gptqmodel_overlaid_gpu")
+    shutil.copytree(os.path.join(SRC, "gptqmodel"), os.path.join(tree, "gptqmodel"), ignore=shutil.ignore_patterns("__pycache__"))
+    subprocess.run([sys.executable, os.path.join(ROOT, "integration", "apply_overlay.py"), str(tree)], check=True)
+    return str(tree)
+
+
+@pytest.fixture(scope="module")
+def dropin(overlaid_tree):
+    code = _SCRIPT.format(root=ROOT, tree=overlaid_tree, cases=CASES)
+    env = {k: v for k, v in os.environ.items() if k not in ("CUDA_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "GPTQHIP_DISABLE")}
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, env=env, cwd="/tmp")
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert line, res.stdout[-2000:] + res.stderr[-6000:]
+    return json.loads(line[-1][7:])
+
+
+def test_reference_selector_and_make_quant_pick_the_overlay_class_on_rocm(dropin):
+    assert dropin["bases"] == [True, True]
+    assert all(v.startswith("(True") for v in dropin["validate_once"]), dropin["validate_once"]
+    for c in dropin["cases"]:
+        want = "HipAwqLinear" if "awq" in c["tag"] else "HipGptqLinear"
+        assert c["selected"] == want and c["made"] == want, c
+        assert c["made_module"] == "gptqmodel.nn_modules.qlinear.hip" and c["on_base"] is True, c
+        assert c["ref_made"] == ("AwqTorchLinear" if "awq" in c["tag"] else "TorchLinear"), c
+        assert c["device"].startswith("cuda"), c
+
+
+@pytest.mark.parametrize("tag", [c[0] for c in CASES])
+def test_dropin_forward_on_the_gpu_matches_the_reference_forward_on_the_cpu(dropin, tag):
+    c = next(c for c in dropin["cases"] if c["tag"] == tag)
+    spec = next(s for s in CASES if s[0] == tag)
+    assert sorted(int(m) for m in c["m"]) == sorted(spec[9])
+    for m, r in c["m"].items():
+        assert r["finite"] and r["shape"] == [1, int(m), spec[3]] and r["dev"].startswith("cuda"), (tag, m, r)
+        assert r["dtype"] == ("torch.float16" if spec[7] == "fp16" else "torch.bfloat16"), (tag, m, r)
+        assert r["rel"] <= r["tol"], (tag, m, r)                          # north_star: <= 1e-3 relative fp16 error
+        assert r["outside_ref_allclose"] == 0, (tag, m, r)               # the reference's own allclose (test_torch_kernel_accuracy.py:111-125)
+    if "awq" not in tag:
+        assert c["dequant_equal"] is True, (tag, c["dequant_equal"])
