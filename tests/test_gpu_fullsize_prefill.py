@@ -4,7 +4,9 @@ and for the rmsnorm_gather -> forward_pregathered pair the C3 layer entry times.
 
 The oracle cannot form a 65576 x 28672 product in seconds; every output row depends only on its own input row, so rows are SAMPLED:
 rows of the first tiles, of every tile of the LAST round of the persistent loop (those run the steady-state code copy with the
-previous tile's stores still in flight), and of the ragged tail (the last row tile holds 40 rows)."""
+previous tile's stores still in flight), and of the ragged tail (the last row tile holds 40 rows).  The rows that are NOT sampled
+are covered by two size-independent properties: the output buffer starts out as NaNs and none may survive (nothing unwritten),
+and the column sums of the whole output equal (sum of all input rows) @ W (linearity) within the rounding bound."""
 import numpy as np
 import pytest
 import torch
@@ -60,14 +62,39 @@ def test_prefill_at_benchmark_size_sampled_rows(ops, K, N, desc_act, act):
     perm = torch.from_numpy(O.act_order_perm(g_idx)).to(DEV) if desc_act else None
     qw_t, meta = ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV), sc, perm, gs, 4)
     x = _device_rows(M_FULL, K, act, 11)
-    out = ops.gemm(x, qw_t, meta, None, perm, N, gs, 4, sc.dtype)
+    # the kernel writes into a buffer POISONED with NaNs: any element it leaves unwritten -- sampled row or not -- stays a NaN
+    out = torch.full((M_FULL, N), float("nan"), dtype=x.dtype, device=DEV)
+    guard = torch.full((4096,), float("nan"), dtype=x.dtype, device=DEV)       # (allocated right behind: an overrun would land here)
+    got = ops.gemm(x, qw_t, meta, None, perm, N, gs, 4, sc.dtype, out=out)
     torch.cuda.synchronize()
+    assert got.data_ptr() == out.data_ptr()
+    assert not bool(torch.isnan(out).any()), "the prefill kernel left output elements unwritten"
+    assert bool(torch.isnan(guard).all())
     rows = _rows_to_check(ops, M_FULL, K, N, gs, np.random.RandomState(5))
     idx = torch.from_numpy(rows).to(DEV)
     ref = O.forward_gptq(torch_to_f32(x[idx]), qweight, qzeros, scales, g_idx, 4, None, act, "fp16")
     assert_forward_close(torch_to_f32(out[idx]), ref, act, tag=(K, N, desc_act, act))
-    # nothing was left unwritten: a row-sum checksum over ALL rows is finite and the untouched tail of a poisoned buffer stays poisoned
-    assert bool(torch.isfinite(out.float().sum(dim=1)).all())
+    # ... and the UNSAMPLED rows: the GEMM is linear in x, so the column sums of the whole output must equal (sum of all x rows) @ W.
+    # Expected side in fp64 from the dequantised weights the reference's chain multiplies with (torch.py:716-717, then .to(x.dtype),
+    # torch.py:330); the only difference left is each output element's final rounding, independent and zero-mean: 8 sigma of their sum
+    # (ulp <= |out| * 2^-10 fp16 / 2^-7 bf16, variance ulp^2 / 12) + the fp32 accumulation slack.
+    w64 = ops.dequant_tiled(qw_t, meta, perm, K, N, gs, 4, sc.dtype).to(x.dtype).double()
+    xs = torch.zeros(K, dtype=torch.float64, device=DEV)
+    col = torch.zeros(N, dtype=torch.float64, device=DEV)
+    sq = torch.zeros(N, dtype=torch.float64, device=DEV)
+    ab = torch.zeros(N, dtype=torch.float64, device=DEV)
+    for r0 in range(0, M_FULL, 8192):
+        o = out[r0:r0 + 8192].double()
+        xs += x[r0:r0 + 8192].double().sum(0)
+        col += o.sum(0)
+        sq += (o * o).sum(0)
+        ab += o.abs().sum(0)
+        del o
+    want = xs @ w64
+    ulp = 2.0 ** (-10 if act == "fp16" else -7)
+    tol = 8.0 * torch.sqrt(sq / 12.0) * ulp + 2e-6 * ab
+    worst = ((col - want).abs() / tol).max().item()
+    assert worst <= 1.0, f"column sums over all {M_FULL} rows off by {worst:.2f} x the rounding bound"
 
 
 @pytest.mark.parametrize("act", ["fp16", "bf16"])

@@ -136,14 +136,19 @@ out["cases"] = results
 print("RESULT " + json.dumps(out))
 '''
 
-# (tag, kind, K, N, group, desc_act, sym, dtype, bias, rows): C1 = BASELINE configs[0] layer, C3 = act-order, C4 = AWQ asym
+# (tag, kind, K, N, group, desc_act, sym, dtype, bias, rows): C1 = BASELINE configs[0] layer, C3 = act-order, C4 = AWQ asym.
+# The expected side is the reference's CPU forward, and aten's CPU fp16 matmul is pathologically slow at M > 1 (2.6 s per call at M = 33,
+# 183 s at M = 2048 on a 4096^2 layer; upstream flags it, tests/test_q4_torch.py:52-53): the 2048-row prefill cases run bf16 at full
+# size (the dtype upstream's own CPU test uses) and fp16 on a 1024 x 512 layer.
 CASES = [
-    ("C1_fp16", "gptq", 4096, 4096, 128, False, True, "fp16", False, (1, 33, 2048)),
+    ("C1_fp16", "gptq", 4096, 4096, 128, False, True, "fp16", False, (1, 33)),
     ("C1_bf16", "gptq", 4096, 4096, 128, False, True, "bf16", True, (1, 33, 2048)),
-    ("C3_act_order_fp16", "gptq", 4096, 4096, 128, True, False, "fp16", True, (1, 33, 2048)),
-    ("C3_act_order_kv_bf16", "gptq", 4096, 1024, 128, True, False, "bf16", False, (1, 33, 2048)),
-    ("C4_awq_fp16", "awq", 4096, 4096, 128, False, False, "fp16", True, (1, 33, 2048)),
-    ("C4_awq_mlp_bf16", "awq", 4096, 14336, 128, False, False, "bf16", False, (1, 33)),
+    ("C3_act_order_fp16", "gptq", 4096, 4096, 128, True, False, "fp16", True, (1, 33)),
+    ("C3_act_order_bf16", "gptq", 4096, 4096, 128, True, False, "bf16", False, (1, 33, 2048)),
+    ("C3_act_order_small_fp16", "gptq", 1024, 512, 128, True, False, "fp16", True, (1, 33, 2048)),
+    ("C4_awq_fp16", "awq", 4096, 4096, 128, False, False, "fp16", True, (1, 33)),
+    ("C4_awq_bf16", "awq", 4096, 4096, 128, False, False, "bf16", False, (1, 33, 2048)),
+    ("C4_awq_small_fp16", "awq", 1024, 512, 128, False, False, "fp16", False, (1, 33, 2048)),
 ]
 
 
