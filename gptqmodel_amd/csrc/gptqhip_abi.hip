@@ -43,6 +43,8 @@ static const EnvTuning& env_tuning() {
 #define g_force_split (t_force_split ? t_force_split : env_tuning().split)
 #define g_force_kernel (t_force_kernel ? t_force_kernel : env_tuning().kernel)
 #define g_force_waves (t_force_waves ? t_force_waves : env_tuning().waves)
+// (values >= 32 of the variant override name a tile height of the prefill kernel, not a wave count of the decode kernel)
+#define g_skinny_waves (g_force_waves >= 32 ? 0 : g_force_waves)
 
 constexpr size_t kInKernelPermMaxRowBytes = 44 * 1024;   // AM_ROW1P keeps the x row in LDS next to 16 KiB of per-wave slots
 
@@ -86,9 +88,9 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
     // worst case over the split heuristics: the skinny plan for one row-chunk
     // the SAME plans gptqhip_gemm will make for this (shape, group_size, bits): both sides call these planners with
     // identical arguments, so the layout cannot drift from the launch
-    size_t floats = plan_skinny(mchunk, K, N, group_size, g_force_split, g_force_waves, false, bits).slab_floats;
+    size_t floats = plan_skinny(mchunk, K, N, group_size, g_force_split, g_skinny_waves, false, bits).slab_floats;
     {
-        const size_t f4 = plan_skinny(mchunk4, K, N, group_size, g_force_split, g_force_waves, false, bits).slab_floats;
+        const size_t f4 = plan_skinny(mchunk4, K, N, group_size, g_force_split, g_skinny_waves, false, bits).slab_floats;
         if (f4 > floats) floats = f4;
     }
     if (M > 16 || g_force_kernel == 2) {
@@ -106,7 +108,7 @@ static bool gemm_uses_tiled(int M, int K, int N, int group_size, int bits) {
     if (wide && M <= 32 && N < 65536 && g_force_kernel == 0) {
         // 17..32 rows on a wide layer: the decode kernel's wide form where it is plannable and either K is short or its blocks fit ONE
         // round of the chip (8192x8192: 256 blocks, 13.0-13.5 us vs 16.4-17.4 tiled; 8192x10240: 320 blocks, 19.1-22.3 vs 18.9-19.9)
-        const int nt = plan_skinny(M, K, N, group_size, g_force_split, g_force_waves, false, bits, 1).nt;
+        const int nt = plan_skinny(M, K, N, group_size, g_force_split, g_skinny_waves, false, bits, 1).nt;
         if (nt > 1 && (K < 8192 || ceil_div(ceil_div(N, kTileN), nt) <= 256)) wide = false;
     }
     // 33..64 rows in one launch of the decode kernel: 4-bit, short K, narrow layers (4096^2: 8.8-10.7 us vs 12.2-14.8 tiled; at
@@ -242,7 +244,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     // the regular straight-line pipeline; everything else gathers x once into the workspace first
     bool fused_perm = false;
     if (perm && M == 1 && g_force_kernel != 2) {
-        const SkinnyPlan pl1 = plan_skinny(1, K, N, group_size, g_force_split, g_force_waves, true);
+        const SkinnyPlan pl1 = plan_skinny(1, K, N, group_size, g_force_split, g_skinny_waves, true);
         // (the kernel keeps the x row in LDS next to 16 KiB of per-wave slots: stay inside the default 64 KiB of dynamic LDS)
         fused_perm = pl1.regular && pl1.gpc == 1 && pl1.depth == 4 && (size_t)K * 2 <= kInKernelPermMaxRowBytes;
     }
@@ -318,7 +320,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         a.x = reinterpret_cast<const char*>(xin) + (size_t)m0 * K * 2;
         a.out = reinterpret_cast<char*>(out) + (size_t)m0 * N * (partial_f32 ? 4 : 2);
         a.M = mc;
-        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves, fused_perm, bits, 1);
+        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_skinny_waves, fused_perm, bits, 1);
         rc = launch_skinny(a, pl, slabs, counters, stream);
         if (rc) return rc;
     }
@@ -345,10 +347,10 @@ int gptqhip_plan_describe(int M, int K, int N, int group_size, int bits, int has
     const int mc = M < rows ? M : rows;
     bool fused_perm = false;
     if (has_perm && M == 1) {
-        const SkinnyPlan pl1 = plan_skinny(1, K, N, group_size, g_force_split, g_force_waves, true);
+        const SkinnyPlan pl1 = plan_skinny(1, K, N, group_size, g_force_split, g_skinny_waves, true);
         fused_perm = pl1.regular && pl1.gpc == 1 && pl1.depth == 4 && (size_t)K * 2 <= kInKernelPermMaxRowBytes;
     }
-    const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_force_waves, fused_perm, bits, 1);
+    const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_skinny_waves, fused_perm, bits, 1);
     snprintf(buf, (size_t)buf_len, "skinny launches=%d mt=%d nt=%d waves=%d depth=%d regular=%d splits=%d gather=%d", ceil_div(M, rows), pl.mt,
              pl.nt, pl.waves, pl.depth, pl.regular, pl.splits, has_perm && !fused_perm ? 1 : 0);
     return GPTQHIP_OK;
@@ -413,7 +415,7 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
                          (op->in_glue == GPTQHIP_GLUE_RMSNORM || (op->in_glue == GPTQHIP_GLUE_NONE && op->out_glue == GPTQHIP_OUT_NONE)) &&
                          (op->out_glue == GPTQHIP_OUT_NONE || op->out_glue == GPTQHIP_OUT_SILU_MUL_PAIRED ||
                           (op->out_glue == GPTQHIP_OUT_PARTIAL_F32 && op->in_glue == GPTQHIP_GLUE_NONE));
-    const SkinnyPlan pl = plan_skinny(M, op->K, op->N, op->group_size, g_force_split, g_force_waves, op->perm != nullptr, op->bits,
+    const SkinnyPlan pl = plan_skinny(M, op->K, op->N, op->group_size, g_force_split, g_skinny_waves, op->perm != nullptr, op->bits,
                                       !wide_ok ? 0 : (op->in_glue == GPTQHIP_GLUE_RMSNORM ? 2 : 1));
     if (op->perm && !(pl.depth == 4 && (size_t)op->K * 2 <= kInKernelPermMaxRowBytes)) {
         set_error("gptqhip_decode_linear: K=%d is outside the in-kernel act-order variant (gather x and pass perm = NULL)", op->K);

@@ -71,9 +71,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // a..d per tile height, least squares over 926 timed (shape, M, tile height, split) points on one MI355X (tests/dev/tiled_plan_check.py,
 // tiled_model_check.py; 10 layer shapes of Llama-2/3 7B..70B, M = 96..2048): mean error 3 %, 90th percentile 6 %.  It only has to RANK
 // the candidates; measured against the round-2 rules on the same box it wins 5-32 % on 50 of 160 points and loses > 4 % on 3.
+// Round 5: refitted per tile height (now 32 .. 128 rows in steps of 16, and 256) on graph-replayed launches over rotating cold weights
+// (tests/dev/midm_heights.py -> midm_fit.py, profiles/r05_midm_heights_sweep*.txt), with one shared term for grids that leave more
+// than a quarter of the CUs idle: + 12.0 us x max(0, 0.75 - f).  1557 averaged points of two runs: relative fit error 4.9 % mean / 10 % p90
+// (the run-to-run spread of a point is +-5 %); replaying the search on them the model's pick is 1.5 % (mean) behind the best measured point.
 static double tiled_cost_us(int M, int K, int N, int bm, int s) {
-    static const double kCoef[3][4] = {{0.524, 6.140, 0.971, 0.139}, {2.563, 6.964, 1.254, 0.473}, {8.431, 4.717, 1.899, 1.208}};
-    const double* co = kCoef[bm == 64 ? 0 : bm == 128 ? 1 : 2];
+    static const int kHeights[8] = {32, 48, 64, 80, 96, 112, 128, 256};
+    static const double kCoef[8][4] = {{-11.195, 15.775, 1.071, -0.143}, {-11.033, 17.357, 1.182, -0.154}, {-10.220, 17.509, 1.198, -0.053},
+                                       {-5.854, 13.875, 1.239, -0.005},  {-5.169, 14.162, 1.408, 0.004},   {-4.918, 14.584, 1.607, -0.064},
+                                       {-4.659, 16.029, 1.635, -0.004},  {-4.415, 19.995, 2.805, 0.052}};
+    const double kIdle = 11.977;
+    int hi = 7;
+    for (int i = 0; i < 8; ++i)
+        if (kHeights[i] == bm) hi = i;
+    const double* co = kCoef[hi];
     const int chunks = ceil_div(K, kChunkK), cps = ceil_div(chunks, s), s_eff = ceil_div(chunks, cps);
     const long tiles = (long)ceil_div(N, kTiledBN) * ceil_div(M, bm), blocks = tiles * s_eff;
     double r, f;
@@ -85,7 +96,7 @@ static double tiled_cost_us(int M, int K, int N, int bm, int s) {
         r = blocks <= 256 ? 1.0 : (double)blocks / 256.0;
         f = blocks <= 256 ? (double)blocks / 256.0 : 1.0;
     }
-    const double main_us = co[0] + co[1] * f + r * cps * (co[2] + co[3] * f);
+    const double main_us = co[0] + co[1] * f + r * cps * (co[2] + co[3] * f) + kIdle * (f < 0.75 ? 0.75 - f : 0.0);
     const double slab_mb = (double)s_eff * M * N * 4.0 / 1e6;
     const double reduce_us = s_eff > 1 ? (slab_mb / 6.2 + 1.5 > 4.6 ? slab_mb / 6.2 + 1.5 : 4.6) : 0.0;
     return main_us + reduce_us;
@@ -133,6 +144,9 @@ TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_va
         pl.tail_cols = 0;
     }
     if (force_variant == 3) pl.bm = 64;
+    // the extra heights exist for 4-bit weights with one group constant per chunk (gptqhip_tiled_r<rows>.hip)
+    const bool any16 = bits == 4 && pl.gpc == 1;
+    if (force_variant >= 32 && any16 && force_variant <= 128 && force_variant % 16 == 0) pl.bm = force_variant;
     // split K across blocks when the (M, N) grid alone leaves most CUs idle (mid-size M, or K-heavy layers):
     // fp32 partial slabs + a tiny reduce kernel (a kernel boundary is cheaper than re-reading 100s of KB of slabs
     // through a last-arriver block -- MI355X_MICROARCH.md "handoff-payload")
@@ -153,11 +167,17 @@ TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_va
         // tiles + 3 are 15-20 % faster (4096x6144 at M=160..320), never combined 256-row tiles with split-K (14336x4096 at M=1280:
         // 174 -> 137 us, 8192x10240 at M=448: 101 -> 89) and kept 64-row tiles on very wide layers (8192x57344 at M<=128: 148 -> 113 us).
         double best = 1e30;
-        for (int bm : {64, 128, 256}) {
-            if (bm == 64 && M > 1024) continue;
+        for (int bm : {32, 48, 64, 80, 96, 112, 128, 256}) {
+            if (bm <= 64 && M > 1024) continue;
+            // (the in-between heights: 4-bit / one constant per chunk, and up to 512 rows -- beyond, whole 64- / 128- / 256-row tiles waste
+            // little and the sweep that calibrated the model ends)
+            if ((!any16 || M > 512) && bm != 64 && bm != 128 && bm != 256) continue;
             const long tiles = (long)nbx * ceil_div(M, bm);
             for (int sc = 1; sc <= 16; ++sc) {
                 if (sc > 1 && (sc > chunks / 4 || tiles * sc > cus || (size_t)sc * M * N > ((size_t)16 << 20))) break;
+                // (blocks of four chunks run ~5 % behind the model -- its residual by chunks per block, tests/dev/midm_fit.py -- and lose to
+                // five-chunk blocks on every shape of the sweep: not a candidate while K allows five)
+                if (sc > 1 && chunks >= 20 && ceil_div(chunks, sc) < 5) continue;
                 const double t = tiled_cost_us(M, K, N, bm, sc);
                 if (t < best) {
                     best = t;
@@ -204,9 +224,21 @@ int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, hipStream
     }
     // fp32 epilogue (split-K slabs, tensor-parallel partial sums) or the 16-bit rounding epilogue
     const bool f32 = p.splits > 1 || p.out_f32;
-    const int rc_main = a.bits != 4 ? launch_tiled_w8(p, a.act_dtype, a.scale_dtype, pl.gpc, pl.bm, stream)
-                        : f32   ? launch_tiled_w4_f32(p, a.act_dtype, a.scale_dtype, pl.gpc, pl.bm, stream)
-                                : launch_tiled_w4(p, a.act_dtype, a.scale_dtype, pl.gpc, pl.bm, stream);
+    int rc_main;
+    if (a.bits == 4 && pl.gpc == 1 && pl.bm != 64 && pl.bm != 128 && pl.bm != 256) {
+        switch (pl.bm) {
+            case 32: rc_main = launch_tiled_w4_r32(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;
+            case 48: rc_main = launch_tiled_w4_r48(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;
+            case 80: rc_main = launch_tiled_w4_r80(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;
+            case 96: rc_main = launch_tiled_w4_r96(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;
+            case 112: rc_main = launch_tiled_w4_r112(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;
+            default: set_error("tiled kernel: no %d-row tile", pl.bm); return -22;
+        }
+    } else {
+        rc_main = a.bits != 4 ? launch_tiled_w8(p, a.act_dtype, a.scale_dtype, pl.gpc, pl.bm, stream)
+                  : f32   ? launch_tiled_w4_f32(p, a.act_dtype, a.scale_dtype, pl.gpc, pl.bm, stream)
+                          : launch_tiled_w4(p, a.act_dtype, a.scale_dtype, pl.gpc, pl.bm, stream);
+    }
     if (rc_main != 0 || pl.splits <= 1) return rc_main;
     const size_t quads = (size_t)a.M * a.N / 4;
     const dim3 grid((unsigned)((quads + 255) / 256));

@@ -6,8 +6,9 @@
 // on NVIDIA (gptqmodel_ext/marlin/gptq_marlin.cu, gptqmodel_ext/exllamav2/cuda/q_gemm.cu:118-137) -- designed
 // for CDNA4 instead of translated:
 //
-//   block = 8 waves (2 per SIMD), output tile BM x 256 (BM = 256 or 128), K advanced one 128-row chunk at a time;
-//   one block per CU loops over the output tiles (persistent).
+//   block = 8 waves (2 per SIMD), output tile BM x 256 (BM = 256, 128, 64, or -- round 5, 4-bit / one group constant per chunk -- any
+//   multiple of 16 up to 128, so that a batch of 72 or 136 rows is not rounded up to 128 / 192), K advanced one 128-row chunk at a
+//   time; one block per CU loops over the output tiles (persistent).
 //   * B (weights) never touches LDS: wave w owns column tiles 2w, 2w+1 of the block (32 columns) for ALL BM rows,
 //     so every packed word is fetched (one dwordx4 per lane per tile-chunk, 1 KiB contiguous) and dequantised
 //     exactly once per block, in registers, straight into mfma_f32_16x16x32 B fragments.
@@ -156,9 +157,10 @@ __device__ __forceinline__ void stage_a_piece(const ATileSrc& a, char* lds_buf, 
                                              chunk * (kChunkK * 2) + I * a.piece_step, 0, 0);
 }
 
-template <int BM, int NT>
+// (BMP: the tile height rounded up to whole 32-row DMA pieces; rows past the descriptor come back as zeros and are never read)
+template <int BMP, int NT>
 __device__ __forceinline__ void stage_a_dma(const ATileSrc& a, char* lds_buf, int chunk, int wave) {
-    static_for<BM * 16 / NT>([&](auto ic) { stage_a_piece<BM, NT, decltype(ic)::value>(a, lds_buf, chunk, wave); });
+    static_for<BMP * 16 / NT>([&](auto ic) { stage_a_piece<BMP, NT, decltype(ic)::value>(a, lds_buf, chunk, wave); });
 }
 
 // ds_read_b128 the compiler does not track: completion is awaited by lds_wait<CNT>, whose "+v" operands make every
@@ -205,12 +207,15 @@ struct TileCtx {
 // between them inside the tile loop makes hipcc assume the smaller count (zero, after its CFG lowering) in every wait.
 template <int BITS, int ACT, int SCL, int GPC, int BM, int WAVES, int D, int OUTF>
 __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
+    static_assert(BM % 16 == 0 && BM >= 16 && BM <= 256, "row tiles of 16");
     constexpr int MT = BM / 16;
     constexpr int NT = 64 * WAVES;
+    constexpr int BMP = (BM + 31) / 32 * 32;  // LDS image / DMA height: whole 32-row pieces (NT / 64 waves x 4 rows each)
+    static_assert(NT == 512, "the 32-row DMA piece assumes 8 waves");
     constexpr int TPW = kTiledBN / kTileN / WAVES;  // column tiles per wave
     // D stage buffers for the A tile + a separate staging area for the epilogue transposes (BM x 16 B per wave), so a
     // tile's output can leave while the NEXT tile's first stages are already landing in the stage buffers
-    __shared__ __attribute__((aligned(16))) char lds_all[D * BM * 256];
+    __shared__ __attribute__((aligned(16))) char lds_all[D * BMP * 256];
     // staging per wave: TG row tiles per epilogue pass (16-bit: 64 B per row; fp32: 128 B per row)
     constexpr int TG16 = MT >= 4 ? MT / 4 : 1, TG32 = MT >= 8 ? MT / 8 : 1;
     constexpr int kEpi = OUTF ? TG32 * 16 * 128 : TG16 * 16 * 64;  // bytes per wave
@@ -257,11 +262,11 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     // matrix-pipe cycles per wave -- shorter than a loaded HBM round trip -- so D = 3 there; 256-row tiles (2 x 64 KiB
     // of LDS) keep D = 2.
 #if defined(GPTQHIP_ABLATE_BLOAD)
-    constexpr int OPS = BM * 16 / NT;
+    constexpr int OPS = BMP * 16 / NT;
 #elif defined(GPTQHIP_ABLATE_META)
-    constexpr int OPS = BM * 16 / NT + TPW * (BITS == 4 ? 1 : 2);
+    constexpr int OPS = BMP * 16 / NT + TPW * (BITS == 4 ? 1 : 2);
 #else
-    constexpr int OPS = BM * 16 / NT + TPW * ((BITS == 4 ? 1 : 2) + GPC);  // VMEM instructions per stage and wave
+    constexpr int OPS = BMP * 16 / NT + TPW * ((BITS == 4 ? 1 : 2) + GPC);  // VMEM instructions per stage and wave
 #endif
     constexpr int NST = OUTF ? BM / 8 : BM / 16;  // 16-byte store instructions per wave and tile in the epilogue
     // Every issue is UNCONDITIONAL (a chunk index past the end is clamped and re-fetches the last chunk into a stage
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     auto issue = [&](auto sc, const TileCtx& t, int chunk) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
         const int ck = min(chunk, c_end - 1);
-        stage_a_dma<BM, NT>(t.a, lds_all + s * (BM * 256), ck, wave);
+        stage_a_dma<BMP, NT>(t.a, lds_all + s * (BMP * 256), ck, wave);
         load_b<BITS, GPC, TPW>(bst[s], p, bsrc, t.tile0, ck);
     };
     auto prologue = [&](const TileCtx& t) __attribute__((always_inline)) {
@@ -338,22 +343,23 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         constexpr bool kIssue = kind != 2;
         constexpr bool kNext = !(kind == 2 && pos == D - 2);  // loads of a next chunk exist (clamped past the end)
         constexpr int sn = (s + 1) % D, si = (s + D - 1) % D;
-        constexpr int PF = BM == 128 ? 8 : 4;  // measured: deeper spills at BM=256, helps at BM=128; 64-row tiles: MT = 4.  (Round 4: reading the
+        // fragment group: 8 at BM = 128, 4 at 256 / 64, a whole K-step's MT fragments on the odd heights (PF must divide MT)
+        constexpr int PF = BM == 128 ? 8 : (MT % 4 == 0 ? 4 : MT);  // measured: deeper spills at BM=256, helps at BM=128; 64-row tiles: MT = 4.  (Round 4: reading the
         // fragments two at a time on the 256-row 8-bit / per-K-step-constant instantiations, to free the registers they spill, made hipcc
         // spill MORE -- 60-132 bytes instead of 20-72 -- and was dropped.)
         constexpr int NG = 4 * MT / PF;        // fragment groups per chunk
-        constexpr int NPIECE = BM * 16 / NT;
+        constexpr int NPIECE = BMP * 16 / NT;
 #ifdef GPTQHIP_TILED_INTERLEAVE
         constexpr int kInterleaveValu = GPTQHIP_TILED_INTERLEAVE;   // dev A/B builds
 #else
-        constexpr int kInterleaveValu = BM == 64 ? 4 : 0;
+        constexpr int kInterleaveValu = BM <= 112 ? 4 : 0;
 #endif
         static_assert(NPIECE <= NG, "one DMA piece per fragment group");
         u4_t abuf[2][PF];
 
         __builtin_amdgcn_s_barrier();
         // A fragment idx = j * MT + mt lives at row mt*16 + c, 16-byte segment (4j + rq) ^ c of this buffer
-        const uint32_t abase = lds_row_base + (uint32_t)(s * (BM * 256));
+        const uint32_t abase = lds_row_base + (uint32_t)(s * (BMP * 256));
         uint32_t aaddr[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) aaddr[j] = abase + (uint32_t)((j * 64 + rq * 16) ^ (c << 4));
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
                 });
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (kIssue && g < NPIECE) stage_a_piece<BM, NT, g>(t.a, lds_all + si * (BM * 256), ck, wave);
+            if constexpr (kIssue && g < NPIECE) stage_a_piece<BMP, NT, g>(t.a, lds_all + si * (BMP * 256), ck, wave);
             constexpr int j = (g * PF) / MT;            // K-step of this group (PF divides MT)
             constexpr bool last_of_step = ((g + 1) * PF) % MT == 0;
             if constexpr ((g * PF) % MT == 0) {  // VALU under this group's MFMAs
@@ -613,6 +619,12 @@ inline int launch_tiled_gpc(const TiledParams& p, int gpc, int bm, hipStream_t s
 int launch_tiled_w4(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int bm, hipStream_t stream);
 int launch_tiled_w4_f32(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int bm, hipStream_t stream);
 int launch_tiled_w8(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int bm, hipStream_t stream);
+// the extra tile heights (gptqhip_tiled_r<rows>.hip): 4-bit, one group constant per chunk
+int launch_tiled_w4_r32(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
+int launch_tiled_w4_r48(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
+int launch_tiled_w4_r80(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
+int launch_tiled_w4_r96(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
+int launch_tiled_w4_r112(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
 
 template <int BITS, int OUTF>
 inline int launch_tiled_bits(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int bm, hipStream_t stream) {

@@ -306,7 +306,8 @@ int gptqhip_allgather_select(const void* x_local, void* const* peer_bufs, int ra
 int gptqhip_plan_describe(int M, int K, int N, int group_size, int bits, int has_perm, char* buf, int buf_len);
 
 /* Tuning hook (benchmarks / tests): force the cross-block split-K factor and the waves per block of the skinny
- * kernel (0 = heuristic), or the kernel family (0 auto, 1 skinny, 2 tiled-prefill).  The overrides are THREAD-LOCAL
+ * kernel (0 = heuristic; with the prefill kernel 1 / 2 / 3 = 256- / 128- / 64-row tiles, 32..112 in steps of 16 = that tile height),
+ * or the kernel family (0 auto, 1 skinny, 2 tiled-prefill).  The overrides are THREAD-LOCAL
  * (they apply to gptqhip_gemm / gptqhip_workspace_bytes calls made by the calling thread only), so the library keeps
  * no process-global mutable state and stays re-entrant across threads, devices and streams. */
 int gptqhip_set_tuning(int force_split_k, int force_kernel, int force_waves);
