@@ -257,15 +257,4 @@ __device__ __forceinline__ f4_t mfma16(u4_t a, u4_t b, f4_t c) {
     }
 }
 
-// D(32x32) += A(32x16) * B(16x32); lane l: A[m=l&31][k=8*(l>>5)+j], B[k=8*(l>>5)+j][n=l&31],
-// D[m=(i&3)+8*(i>>2)+4*(l>>5)][n=l&31], i = 0..15  (cdna_hip_programming.md §3).
-template <int ACT>
-__device__ __forceinline__ f16_t mfma32(u4_t a, u4_t b, f16_t c) {
-    if constexpr (ACT == kFP16) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, a), __builtin_bit_cast(h8_t, b), c, 0, 0, 0);
-    } else {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8_t, a), __builtin_bit_cast(b8_t, b), c, 0, 0, 0);
-    }
-}
-
 }  // namespace gptqhip

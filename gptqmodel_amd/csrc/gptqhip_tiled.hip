@@ -1,7 +1,5 @@
 // Prefill kernel, host side: planner, launcher, split-K reduce, and the 4-bit / 16-bit-output instantiations of the kernel
 // template (gptqhip_tiled_kernel.h; fp32-output ones in gptqhip_tiled_f32.hip, 8-bit ones in gptqhip_tiled8.hip).
-#include <stdlib.h>
-
 #include "gptqhip_tiled_kernel.h"
 
 namespace gptqhip {
@@ -227,16 +225,7 @@ int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, hipStream
     // fp32 epilogue (split-K slabs, tensor-parallel partial sums) or the 16-bit rounding epilogue
     const bool f32 = p.splits > 1 || p.out_f32;
     int rc_main;
-    static const int w32 = [] {
-        const char* v = getenv("GPTQHIP_TILED_W32");
-        return (v && *v) ? atoi(v) : 0;
-    }();
-    if (a.bits == 4 && w32 && (pl.bm == 64 || pl.bm == 128 || pl.bm == 256)) {
-        // the 32x32x16-MFMA form of the kernel (gptqhip_tiled_w32_<rows>.hip)
-        rc_main = pl.bm == 256   ? launch_tiled_w4_w32_r256(p, a.act_dtype, a.scale_dtype, pl.gpc, f32 ? 1 : 0, stream)
-                  : pl.bm == 128 ? launch_tiled_w4_w32_r128(p, a.act_dtype, a.scale_dtype, pl.gpc, f32 ? 1 : 0, stream)
-                                 : launch_tiled_w4_w32_r64(p, a.act_dtype, a.scale_dtype, pl.gpc, f32 ? 1 : 0, stream);
-    } else if (a.bits == 4 && pl.gpc == 1 && pl.bm != 64 && pl.bm != 128 && pl.bm != 256) {
+    if (a.bits == 4 && pl.gpc == 1 && pl.bm != 64 && pl.bm != 128 && pl.bm != 256) {
         switch (pl.bm) {
             case 32: rc_main = launch_tiled_w4_r32(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;
             case 48: rc_main = launch_tiled_w4_r48(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;

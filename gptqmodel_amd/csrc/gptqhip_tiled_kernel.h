@@ -114,39 +114,6 @@ __device__ __forceinline__ void load_b(BStage<BITS, GPC, TPW>& st, const TiledPa
     }
 }
 
-// 32x32x16 form (W32): a wave's 32 columns are ONE B fragment per 16-row K-step -- lane (kh = lane >> 5, tsel = (lane >> 4) & 1, c)
-// holds column 16 * (tile0 + tsel) + c, rows 128 chunk + 16 ks + 8 kh + e.  In the tile-major layout that is word j = ks >> 1 of
-// lane' = (rq = 2 (ks & 1) + kh, c) of tile tile0 + tsel: the SAME stream, fetched as two dwordx4 per lane and chunk (p = ks & 1 = 0, 1:
-// 512 bytes apart), no re-layout.  One group constant per lane (its single column) instead of one per column tile.
-template <int GPC>
-struct BStage32 {
-    u4_t w[2];
-    uint32_t meta[GPC];
-};
-struct BLane32 {
-    uint32_t l32, c32;   // per-lane byte offsets into the weight stream / the group constants (depend on the tile only through the N clamp)
-};
-__device__ __forceinline__ BLane32 make_b_lane32(const TiledParams& p, int lane, int tile0) {
-    const int tsel = (lane >> 4) & 1, kh = lane >> 5, c = lane & 15;
-    const int ts = tile0 + tsel < p.tiles ? tsel : 0;   // ragged N (an odd number of column tiles): those columns are never stored
-    BLane32 b;
-    b.l32 = (uint32_t)(ts * p.chunks * 1024 + (kh * 16 + c) * 16);
-    b.c32 = (uint32_t)(ts * p.G * 64 + c * 4);
-    return b;
-}
-template <int GPC>
-__device__ __forceinline__ void load_b32(BStage32<GPC>& st, const TiledParams& p, const BSrc& bs, const BLane32& bl, int tile0, int chunk) {
-    const int tile = tile0 < p.tiles ? tile0 : p.tiles - 1;
-    const uint32_t soff = (uint32_t)(tile * p.chunks + chunk) * 1024u;
-    st.w[0] = __builtin_amdgcn_raw_buffer_load_b128(bs.qw, bl.l32, soff, 0);
-    st.w[1] = __builtin_amdgcn_raw_buffer_load_b128(bs.qw, bl.l32, soff + 512u, 0);
-    const uint32_t mrow = (uint32_t)(tile * p.G);
-#pragma unroll
-    for (int j = 0; j < GPC; ++j)
-        st.meta[j] = __builtin_amdgcn_raw_buffer_load_b32(bs.meta, bl.c32,
-                                                          (mrow + (uint32_t)tiled_group_of(p, chunk * kChunkK + j * (kChunkK / GPC))) * 64u, 0);
-}
-
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -233,22 +200,15 @@ struct TileCtx {
     int m0;     // first row of the tile
     int tile0;  // this wave's first 16-column weight tile
     ATileSrc a;
-    BLane32 b32;  // (32x32x16 form only)
 };
 
 // OUTF = 0: 16-bit output with the reference's rounding chain; 1: fp32 accumulators (split-K slabs, TP partial sums).  A
 // template parameter rather than a run-time branch: the two epilogues issue different numbers of stores, and a branch
 // between them inside the tile loop makes hipcc assume the smaller count (zero, after its CFG lowering) in every wait.
-// W32 = 1: the contraction runs on v_mfma_f32_32x32x16 (half the MFMA instructions for the same FLOPs: the kernel is bound by
-// instruction issue) -- 4-bit weights, tile heights that are multiples of 32.
-template <int BITS, int ACT, int SCL, int GPC, int BM, int WAVES, int D, int OUTF, int W32 = 0>
+template <int BITS, int ACT, int SCL, int GPC, int BM, int WAVES, int D, int OUTF>
 __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     static_assert(BM % 16 == 0 && BM >= 16 && BM <= 256, "row tiles of 16");
-    static_assert(!W32 || (BITS == 4 && BM % 32 == 0), "32x32x16 form: 4-bit weights, 32-row tiles");
     constexpr int MT = BM / 16;
-    constexpr int RT = W32 ? BM / 32 : MT;   // row tiles of the MFMA shape
-    constexpr int KS = W32 ? 8 : 4;          // K-steps per 128-row chunk
-    constexpr int NB = W32 ? 1 : kTiledBN / kTileN / WAVES;   // B fragments per K-step
     constexpr int NT = 64 * WAVES;
     constexpr int BMP = (BM + 31) / 32 * 32;  // LDS image / DMA height: whole 32-row pieces (NT / 64 waves x 4 rows each)
     static_assert(NT == 512, "the 32-row DMA piece assumes 8 waves");
@@ -257,11 +217,8 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     // tile's output can leave while the NEXT tile's first stages are already landing in the stage buffers
     __shared__ __attribute__((aligned(16))) char lds_all[D * BMP * 256];
     // staging per wave: TG row tiles per epilogue pass (16-bit: 64 B per row; fp32: 128 B per row)
-    // (32x32x16 form: TG counts 32-row tiles; a pass covers BM / 4 rows (16-bit) / 32 rows (fp32), at least one row tile)
-    constexpr int TG16 = W32 ? (BM == 256 ? 2 : 1) : (MT >= 4 ? MT / 4 : 1);
-    constexpr int TG32 = W32 ? 1 : (MT >= 8 ? MT / 8 : 1);
-    constexpr int kRowsPerTile = W32 ? 32 : 16;
-    constexpr int kEpi = OUTF ? TG32 * kRowsPerTile * 128 : TG16 * kRowsPerTile * 64;  // bytes per wave
+    constexpr int TG16 = MT >= 4 ? MT / 4 : 1, TG32 = MT >= 8 ? MT / 8 : 1;
+    constexpr int kEpi = OUTF ? TG32 * 16 * 128 : TG16 * 16 * 64;  // bytes per wave
     __shared__ __attribute__((aligned(16))) char lds_epi[WAVES * kEpi];
 
     const int tid = threadIdx.x;
@@ -286,22 +243,19 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         t.m0 = bm * BM;
         t.tile0 = bn * (kTiledBN / kTileN) + wave * TPW;
         t.a = make_a_src<BM, NT>(p, t.m0, wave, lane);
-        if constexpr (W32) t.b32 = make_b_lane32(p, lane, t.tile0);
         return t;
     };
 
-    f4_t acc[W32 ? 1 : MT][TPW];
-    f16_t acc32[W32 ? RT : 1];
+    f4_t acc[MT][TPW];
     const DequantConsts dk = make_dequant_consts<BITS>();
-    BStage<BITS, GPC, W32 ? 1 : TPW> bst[W32 ? 1 : D];
-    BStage32<GPC> bst32[W32 ? D : 1];
+    BStage<BITS, GPC, TPW> bst[D];
     const BSrc bsrc = make_b_src(p, lane, (size_t)p.tiles * p.chunks * (BITS == 4 ? 1024 : 2048), (size_t)p.tiles * p.G * 64);
 
     const int c_begin = blockIdx.z * p.chunks_per_split;
     const int c_end = min(p.chunks, c_begin + p.chunks_per_split);
 
     // LDS byte address of this lane's fragment row (the low 32 bits of a generic LDS pointer are the LDS offset)
-    const uint32_t lds_row_base = (uint32_t)(uintptr_t)lds_all + (uint32_t)((W32 ? (lane & 31) : c) * 256);
+    const uint32_t lds_row_base = (uint32_t)(uintptr_t)lds_all + (uint32_t)(c * 256);
 
     // D-stage pipeline over the 128-deep K chunks: chunk i lives in LDS buffer / register stage i % D, the loads of
     // chunks i+1 .. i+D-1 are in flight while chunk i is multiplied.  One chunk of a 128-row tile is only ~1000
@@ -312,7 +266,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
 #elif defined(GPTQHIP_ABLATE_META)
     constexpr int OPS = BMP * 16 / NT + TPW * (BITS == 4 ? 1 : 2);
 #else
-    constexpr int OPS = BMP * 16 / NT + (W32 ? 2 + GPC : TPW * ((BITS == 4 ? 1 : 2) + GPC));  // VMEM instructions per stage and wave
+    constexpr int OPS = BMP * 16 / NT + TPW * ((BITS == 4 ? 1 : 2) + GPC);  // VMEM instructions per stage and wave
 #endif
     constexpr int NST = OUTF ? BM / 8 : BM / 16;  // 16-byte store instructions per wave and tile in the epilogue
     // Every issue is UNCONDITIONAL (a chunk index past the end is clamped and re-fetches the last chunk into a stage
@@ -322,11 +276,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         constexpr int s = decltype(sc)::value;
         const int ck = min(chunk, c_end - 1);
         stage_a_dma<BMP, NT>(t.a, lds_all + s * (BMP * 256), ck, wave);
-        if constexpr (W32) {
-            load_b32<GPC>(bst32[s], p, bsrc, t.b32, t.tile0, ck);
-        } else {
-            load_b<BITS, GPC, TPW>(bst[s], p, bsrc, t.tile0, ck);
-        }
+        load_b<BITS, GPC, TPW>(bst[s], p, bsrc, t.tile0, ck);
     };
     auto prologue = [&](const TileCtx& t) __attribute__((always_inline)) {
         static_for<D - 1>([&](auto dc) { issue(dc, t, c_begin + decltype(dc)::value); });
@@ -335,29 +285,18 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     // K-step fragments of B: bnow is carried ACROSS chunks -- K-step 0 of the next chunk is dequantised under the last
     // K-step's MFMAs of the current one, so that after the barrier the matrix pipe restarts after one LDS round trip
     // instead of after a VMEM issue burst + a dequant pass (all 8 waves leave the barrier together: nobody covers).
-    u4_t bnow[NB], bnext[NB];
+    u4_t bnow[TPW], bnext[TPW];
     // The per-(group, column) constants are expanded from the meta word ONCE per chunk (K-step 0) and kept for its other three
     // K-steps.  (Round 4: the stage's sched_barrier fences kept hipcc from sharing the expansion between the K-steps, so it ran four
     // times per chunk and tile -- ~9 of the ~22 VALU a K-step of one tile costs; the PMC pass that looked for the "B-load cost"
     // found VALU / SALU issue slots, not memory: profiles/r04_pmc_tiled_vmem.jsonl.)
     // (Not on 256-row tiles with bf16 scales or the fp32 epilogue: the kept constants -- four or five registers per tile there -- do not
     // fit beside the 128 accumulators and come back as scratch traffic; those instantiations keep the per-K-step expansion.)
-    constexpr bool kHoistMeta = GPC == 1 && (W32 || !(BM == 256 && (SCL == kBF16 || OUTF == 1)));   // (32x32x16 form: one constant set per lane)
-    ColConst ccs[NB];
-    // (32x32x16 form: K-step ks of 16 rows = word ks >> 1 of the lane's load ks & 1; one column, one constant per lane)
-    auto dequant_step32 = [&](const BStage32<GPC>& bs, int ks, u4_t (&b)[NB]) __attribute__((always_inline)) {
-        ColConst cnow;
-        if constexpr (kHoistMeta) {
-            if (ks == 0) ccs[0] = expand_meta<BITS, SCL>(bs.meta[0]);
-        } else {
-            cnow = expand_meta<BITS, SCL>(bs.meta[GPC == 4 ? (ks >> 1) : 0]);
-        }
-        const ColConst& cc = kHoistMeta ? ccs[0] : cnow;
-        b[0] = dequant_word4<ACT, SCL>(bs.w[ks & 1][ks >> 1], cc, dk);
-    };
-    auto dequant_step = [&](const BStage<BITS, GPC, W32 ? 1 : TPW>& bs, int j, u4_t (&b)[NB]) __attribute__((always_inline)) {
+    constexpr bool kHoistMeta = GPC == 1 && !(BM == 256 && (SCL == kBF16 || OUTF == 1));
+    ColConst ccs[TPW];
+    auto dequant_step = [&](const BStage<BITS, GPC, TPW>& bs, int j, u4_t (&b)[TPW]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < NB; ++t) {
+        for (int t = 0; t < TPW; ++t) {
 #ifdef GPTQHIP_TILED_NO_HOIST      // dev A/B build: the round-3 form everywhere
             constexpr bool kHoist = false;
 #else
@@ -378,17 +317,9 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         }
     };
     // tile start: chunk 0's loads (a prologue stage: the previous tile's stores are younger) have landed -> K-step 0
-    auto dq = [&](auto sc, int ks, u4_t (&b)[NB]) __attribute__((always_inline)) {   // K-step ks of the chunk in stage slot sc
-        constexpr int s = decltype(sc)::value;
-        if constexpr (W32) {
-            dequant_step32(bst32[s], ks, b);
-        } else {
-            dequant_step(bst[s], ks, b);
-        }
-    };
     auto pre_first = [&]() __attribute__((always_inline)) {
         vm_wait<OPS, NST, D - 2>(D - 2, true);
-        dq(std::integral_constant<int, 0>{}, 0, bnow);
+        dequant_step(bst[0], 0, bnow);
     };
 
     // One pipeline stage = barrier, multiply chunk (stage slot s) while issuing chunk + D - 1 and preparing chunk + 1.
@@ -412,110 +343,86 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         constexpr bool kIssue = kind != 2;
         constexpr bool kNext = !(kind == 2 && pos == D - 2);  // loads of a next chunk exist (clamped past the end)
         constexpr int sn = (s + 1) % D, si = (s + D - 1) % D;
-        // fragment group: 8 at BM = 128, 4 at 256 / 64, a whole K-step's MT fragments on the odd heights (PF must divide RT)
-        constexpr int PF = W32 ? (RT >= 4 ? 4 : RT) : (BM == 128 ? 8 : (MT % 4 == 0 ? 4 : MT));  // measured: deeper spills at BM=256, helps at BM=128; 64-row tiles: MT = 4.  (Round 4: reading the
+        // fragment group: 8 at BM = 128, 4 at 256 / 64, a whole K-step's MT fragments on the odd heights (PF must divide MT)
+        constexpr int PF = BM == 128 ? 8 : (MT % 4 == 0 ? 4 : MT);  // measured: deeper spills at BM=256, helps at BM=128; 64-row tiles: MT = 4.  (Round 4: reading the
         // fragments two at a time on the 256-row 8-bit / per-K-step-constant instantiations, to free the registers they spill, made hipcc
         // spill MORE -- 60-132 bytes instead of 20-72 -- and was dropped.)
-        constexpr int NG = KS * RT / PF;       // fragment groups per chunk
+        constexpr int NG = 4 * MT / PF;        // fragment groups per chunk
         constexpr int NPIECE = BMP * 16 / NT;
-        constexpr int kRowTileBytes = W32 ? 8192 : 4096;   // LDS bytes between consecutive row tiles (32 / 16 rows x 256 B)
 #ifdef GPTQHIP_TILED_INTERLEAVE
         constexpr int kInterleaveValu = GPTQHIP_TILED_INTERLEAVE;   // dev A/B builds
 #else
         constexpr int kInterleaveValu = BM <= 112 ? 4 : 0;
 #endif
         static_assert(NPIECE <= NG, "one DMA piece per fragment group");
-        static_assert(RT % PF == 0, "a fragment group stays inside one K-step");
         u4_t abuf[2][PF];
 
         __builtin_amdgcn_s_barrier();
-        // 16x16x32: A fragment idx = j * MT + mt lives at row mt*16 + c, 16-byte segment (4j + rq) ^ c of this buffer
-        // 32x32x16: A fragment idx = ks * RT + rt lives at row rt*32 + (lane & 31), segment (2 ks + kh) ^ c   (c = row & 15 either way)
+        // A fragment idx = j * MT + mt lives at row mt*16 + c, 16-byte segment (4j + rq) ^ c of this buffer
         const uint32_t abase = lds_row_base + (uint32_t)(s * (BMP * 256));
-        uint32_t aaddr[KS];
+        uint32_t aaddr[4];
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            if constexpr (W32) {
-                aaddr[j] = abase + (uint32_t)((j * 32 + (lane >> 5) * 16) ^ (c << 4));
-            } else {
-                aaddr[j] = abase + (uint32_t)((j * 64 + rq * 16) ^ (c << 4));
-            }
-        }
+        for (int j = 0; j < 4; ++j) aaddr[j] = abase + (uint32_t)((j * 64 + rq * 16) ^ (c << 4));
         static_for<PF>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            lds_read_b128<(i % RT) * kRowTileBytes>(abuf[0][i], aaddr[i / RT]);
+            lds_read_b128<(i % MT) * 4096>(abuf[0][i], aaddr[i / MT]);
         });
         const int ck = min(chunk + D - 1, c_end - 1);
-        if constexpr (kIssue) {
-            if constexpr (W32) {
-                load_b32<GPC>(bst32[si], p, bsrc, t.b32, t.tile0, ck);
-            } else {
-                load_b<BITS, GPC, TPW>(bst[si], p, bsrc, t.tile0, ck);
-            }
-        }
+        if constexpr (kIssue) load_b<BITS, GPC, TPW>(bst[si], p, bsrc, t.tile0, ck);
         __builtin_amdgcn_sched_barrier(0);
         static_for<NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             if constexpr (g + 1 < NG) {
                 static_for<PF>([&](auto ic) {
                     constexpr int idx = (g + 1) * PF + decltype(ic)::value;
-                    lds_read_b128<(idx % RT) * kRowTileBytes>(abuf[(g + 1) & 1][decltype(ic)::value], aaddr[idx / RT]);
+                    lds_read_b128<(idx % MT) * 4096>(abuf[(g + 1) & 1][decltype(ic)::value], aaddr[idx / MT]);
                 });
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (kIssue && g < NPIECE) stage_a_piece<BMP, NT, g>(t.a, lds_all + si * (BMP * 256), ck, wave);
-            constexpr int j = (g * PF) / RT;            // K-step of this group (PF divides RT)
-            constexpr bool last_of_step = ((g + 1) * PF) % RT == 0;
-            if constexpr ((g * PF) % RT == 0) {  // VALU under this group's MFMAs
-                if constexpr (j < KS - 1) {
-                    dq(sc, j + 1, bnext);
+            constexpr int j = (g * PF) / MT;            // K-step of this group (PF divides MT)
+            constexpr bool last_of_step = ((g + 1) * PF) % MT == 0;
+            if constexpr ((g * PF) % MT == 0) {  // VALU under this group's MFMAs
+                if constexpr (j < 3) {
+                    dequant_step(bst[s], j + 1, bnext);
                 } else if constexpr (kNext) {
                     if constexpr (kind == 2) {
                         vm_wait<OPS, NST, D - 2>(D - 3 - pos, chunk + 1 - c_begin <= D - 2);
                     } else {
                         vm_wait<OPS, NST, D - 2>(D - 2, kind == 0 && pos + 1 <= D - 2);
                     }
-                    dq(std::integral_constant<int, sn>{}, 0, bnext);
+                    dequant_step(bst[sn], 0, bnext);
                 }
             }
             lds_wait<(g + 1 < NG) ? PF : 0, PF>(abuf[g & 1]);
             // 64-row tiles: the next K-step's dequant VALU (26 per 8 MFMAs there) is interleaved with this group's MFMAs instead of
             // running as one block in front of them (s_setprio is a scheduling boundary for hipcc, so such a group goes without it).
             // Measured (round 3, profiles/r03_tiled_ablation.txt): 4096x28672 at M=128 45 -> 41 us; no gain on 128- / 256-row tiles.
-            constexpr bool kInterleaved = kInterleaveValu > 0 && (g * PF) % RT == 0 && (j < KS - 1 || kNext);
+            constexpr bool kInterleaved = kInterleaveValu > 0 && (g * PF) % MT == 0 && (j < 3 || kNext);
             if constexpr (!kInterleaved) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
-                const int mt = (g * PF + i) % RT;
-                if constexpr (W32) {
-                    if constexpr (kFirst && j == 0) {
-                        const f16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc32[mt] = mfma32<ACT>(abuf[g & 1][i], bnow[0], zero16);
-                    } else {
-                        acc32[mt] = mfma32<ACT>(abuf[g & 1][i], bnow[0], acc32[mt]);
-                    }
-                } else {
+                const int mt = (g * PF + i) % MT;
 #pragma unroll
-                    for (int tt = 0; tt < TPW; ++tt) {
-                        if constexpr (kFirst && j == 0) {
-                            acc[mt][tt] = mfma16<ACT>(abuf[g & 1][i], bnow[tt], f4_t{0.f, 0.f, 0.f, 0.f});
-                        } else {
-                            acc[mt][tt] = mfma16<ACT>(abuf[g & 1][i], bnow[tt], acc[mt][tt]);
-                        }
+                for (int tt = 0; tt < TPW; ++tt) {
+                    if constexpr (kFirst && j == 0) {
+                        acc[mt][tt] = mfma16<ACT>(abuf[g & 1][i], bnow[tt], f4_t{0.f, 0.f, 0.f, 0.f});
+                    } else {
+                        acc[mt][tt] = mfma16<ACT>(abuf[g & 1][i], bnow[tt], acc[mt][tt]);
                     }
                 }
             }
             if constexpr (kInterleaved) {
-                static_for<PF * NB>([&](auto) {
+                static_for<PF * TPW>([&](auto) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA ...
                     __builtin_amdgcn_sched_group_barrier(0x002, kInterleaveValu, 0);   // ... then up to kInterleaveValu VALU
                 });
             }
             if constexpr (!kInterleaved) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (last_of_step && (j < KS - 1 || kNext)) {
+            if constexpr (last_of_step && (j < 3 || kNext)) {
 #pragma unroll
-                for (int tt = 0; tt < NB; ++tt) bnow[tt] = bnext[tt];
+                for (int tt = 0; tt < TPW; ++tt) bnow[tt] = bnext[tt];
             }
         });
     };
@@ -525,16 +432,16 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     // waits above rely on it.
     // bias of the tile's columns: fetched BEFORE the next tile's prologue is issued (the wait for these few bytes would
     // otherwise sit behind that prologue's loads)
-    auto load_bias = [&](const TileCtx& t, float (&bias)[NB]) __attribute__((always_inline)) {
+    auto load_bias = [&](const TileCtx& t, float (&bias)[TPW]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int tt = 0; tt < NB; ++tt) {
-            const int n = W32 ? t.tile0 * kTileN + (lane & 31) : (t.tile0 + tt) * kTileN + c;   // (32x32x16 form: one column per lane)
+        for (int tt = 0; tt < TPW; ++tt) {
+            const int n = (t.tile0 + tt) * kTileN + c;
             bias[tt] = (p.bias != nullptr && n < p.N) ? load16_as_f32<ACT>(p.bias, (size_t)n) : 0.f;
         }
 #pragma unroll
-        for (int tt = 0; tt < NB; ++tt) asm volatile("" : "+v"(bias[tt]));  // loaded (and waited for) here, not later
+        for (int tt = 0; tt < TPW; ++tt) asm volatile("" : "+v"(bias[tt]));  // loaded (and waited for) here, not later
     };
-    auto store_tile = [&](const TileCtx& t, const float (&bias)[NB]) __attribute__((always_inline)) {
+    auto store_tile = [&](const TileCtx& t, const float (&bias)[TPW]) __attribute__((always_inline)) {
         const int rows = min(p.M - t.m0, BM);
         // opaque copy of the lane id: keeps hipcc from hoisting the epilogue's address arithmetic out of the tile loop,
         // where it would occupy registers all through the main loop
@@ -550,35 +457,23 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
             const int n0 = t.tile0 * kTileN + (lane_e & 3) * 8;
             const uint32_t lane_off = n0 < p.N ? (uint32_t)((lane_e >> 2) * p.ldo * 2 + n0 * 2) : 0xFFFFFF00u;
 #pragma unroll
-            for (int h = 0; h < RT / TG16; ++h) {
-                if constexpr (W32) {
-                    // D(32x32): lane holds column lane & 31, rows (i & 3) + 8 (i >> 2) + 4 (lane >> 5) of its row tile
+            for (int h = 0; h < MT / TG16; ++h) {
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
                     for (int mh = 0; mh < TG16; ++mh)
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            float y = round_through<ACT>(acc32[h * TG16 + mh][i]);
-                            if (p.bias != nullptr) y = y + bias[0];
-                            slab[(mh * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane_e >> 5)) * 32 + (lane_e & 31)] = f32_to_16<ACT>(y);
+                        for (int i = 0; i < 4; ++i) {
+                            float y = round_through<ACT>(acc[h * TG16 + mh][tt][i]);
+                            if (p.bias != nullptr) y = y + bias[tt];
+                            slab[(mh * 16 + 4 * rq_e + i) * 32 + tt * 16 + c_e] = f32_to_16<ACT>(y);
                         }
-                } else {
-#pragma unroll
-                    for (int tt = 0; tt < TPW; ++tt)
-#pragma unroll
-                        for (int mh = 0; mh < TG16; ++mh)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                float y = round_through<ACT>(acc[h * TG16 + mh][tt][i]);
-                                if (p.bias != nullptr) y = y + bias[tt];
-                                slab[(mh * 16 + 4 * rq_e + i) * 32 + tt * 16 + c_e] = f32_to_16<ACT>(y);
-                            }
-                }
                 // same-wave LDS accesses execute in order: no barrier between this wave's writes and reads
 #pragma unroll
-                for (int pass = 0; pass < TG16 * (kRowsPerTile / 16); ++pass) {
+                for (int pass = 0; pass < TG16; ++pass) {
                     const int row = pass * 16 + (lane_e >> 2);
                     const u4_t v = *reinterpret_cast<const u4_t*>(slab + row * 32 + (lane_e & 3) * 8);
-                    const uint32_t off = lane_off + (uint32_t)((h * (TG16 * kRowsPerTile) + pass * 16) * p.ldo * 2);
+                    const uint32_t off = lane_off + (uint32_t)((h * (TG16 * 16) + pass * 16) * p.ldo * 2);
                     __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane_off >= 0xFFFFFF00u ? lane_off : off, 0, 0);
                 }
             }
@@ -593,23 +488,18 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
             const int n0 = t.tile0 * kTileN + (lane_e & 7) * 4;
             const uint32_t lane_off = n0 < p.N ? (uint32_t)((lane_e >> 3) * ld * 4 + n0 * 4) : 0xFFFFFF00u;
 #pragma unroll
-            for (int h = 0; h < RT / TG32; ++h) {
-                if constexpr (W32) {
+            for (int h = 0; h < MT / TG32; ++h) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) slab[((i & 3) + 8 * (i >> 2) + 4 * (lane_e >> 5)) * 32 + (lane_e & 31)] = acc32[h][i];
-                } else {
+                for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
-                    for (int tt = 0; tt < TPW; ++tt)
+                    for (int mh = 0; mh < TG32; ++mh)
 #pragma unroll
-                        for (int mh = 0; mh < TG32; ++mh)
+                        for (int i = 0; i < 4; ++i) slab[(mh * 16 + 4 * rq_e + i) * 32 + tt * 16 + c_e] = acc[h * TG32 + mh][tt][i];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) slab[(mh * 16 + 4 * rq_e + i) * 32 + tt * 16 + c_e] = acc[h * TG32 + mh][tt][i];
-                }
-#pragma unroll
-                for (int pass = 0; pass < TG32 * (kRowsPerTile / 8); ++pass) {
+                for (int pass = 0; pass < TG32 * 2; ++pass) {
                     const int row = pass * 8 + (lane_e >> 3);
                     const f4_t v = *reinterpret_cast<const f4_t*>(slab + row * 32 + (lane_e & 7) * 4);
-                    const uint32_t off = lane_off + (uint32_t)((h * (TG32 * kRowsPerTile) + pass * 8) * ld * 4);
+                    const uint32_t off = lane_off + (uint32_t)((h * (TG32 * 16) + pass * 8) * ld * 4);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs,
                                                            lane_off >= 0xFFFFFF00u ? lane_off : off, 0, 0);
                 }
@@ -645,17 +535,10 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         } else {
             f4_t zero = {0.f, 0.f, 0.f, 0.f};
             asm volatile("" : "+v"(zero));  // fewer than D chunks (tiny K): rare path, plain zeroing
-            if constexpr (W32) {
 #pragma unroll
-                for (int mt = 0; mt < RT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc32[mt][i] = zero[0];
-            } else {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int t = 0; t < TPW; ++t) acc[mt][t] = zero;
-            }
+                for (int t = 0; t < TPW; ++t) acc[mt][t] = zero;
         }
         // drain: the last c_end - chunk0 < D chunks; chunk0 - c_begin is a multiple of D, so chunk0 + i uses stage i
         static_for<D - 1>([&](auto ic) {
@@ -666,7 +549,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         // every wave is done reading the stage buffers -> the next tile's first stages may land in them while this
         // tile's output is rounded, transposed and stored; those stores then drain under the next tile's first chunks
         __builtin_amdgcn_s_barrier();
-        float bias[NB];
+        float bias[TPW];
         load_bias(cur, bias);
         if (v + G >= ntiles) {
             store_tile(cur, bias);
@@ -742,10 +625,6 @@ int launch_tiled_w4_r48(const TiledParams& p, int act_dtype, int scale_dtype, in
 int launch_tiled_w4_r80(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
 int launch_tiled_w4_r96(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
 int launch_tiled_w4_r112(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
-// the 32x32x16-MFMA form (gptqhip_tiled_w32_<rows>.hip)
-int launch_tiled_w4_w32_r256(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int out_f32, hipStream_t stream);
-int launch_tiled_w4_w32_r128(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int out_f32, hipStream_t stream);
-int launch_tiled_w4_w32_r64(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int out_f32, hipStream_t stream);
 
 template <int BITS, int OUTF>
 inline int launch_tiled_bits(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int bm, hipStream_t stream) {
