@@ -61,7 +61,8 @@ def main():
         qm.pack(lin, scales, zeros.clamp(min=1), g_idx)     # zero-points >= 1: representable in the v1 on-disk format
     out_dir = args.dir or tempfile.mkdtemp(prefix="gptqhip_ckpt_")
     files = save_quantized_checkpoint(model, out_dir, {"bits": 4, "group_size": 128, "desc_act": args.desc_act, "sym": False,
-                                                        "quant_method": "gptq", "checkpoint_format": "gptq"}, max_shard_bytes=16 << 20)
+                                                        "quant_method": "gptq", "checkpoint_format": "gptq",
+                                                        "meta": {"quantizer": ["gptqmodel:5.0.0"]}}, max_shard_bytes=16 << 20)
     model.config.save_pretrained(out_dir)
     print(f"wrote {len(files)} safetensors shard(s) + quantize_config.json to {out_dir}: {read_quantize_config(out_dir)}")
     del model, floats, mods

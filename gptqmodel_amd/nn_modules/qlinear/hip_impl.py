@@ -150,9 +150,14 @@ def make_hip_classes(ns, module_name: str):
                 raise NotImplementedError("stacked g_idx (num_itr > 1, torch.py:327) is not supported by the HIP kernel")
             qw, qz = self.qweight.data, self.qzeros.data
             if self.bits not in (4, 8):
+                # 2 / 3 / 5 / 6 / 7-bit checkpoints run on the 4- / 8-bit kernels: the codes are widened once, here.  Exact, but the
+                # RESIDENT weight bytes (and the decode HBM traffic) become those of a 4- / 8-bit model: 2-bit x2, 3-bit x1.33,
+                # 5 / 6 / 7-bit x1.6 / x1.33 / x1.14.  The narrow words are released before the tile-major copy is made.
                 qw, qz, wide = ops.widen_codes(qw, qz, self.bits, planar=bool(self.planar))
                 assert wide == self.kernel_bits
+                self.qweight.data = qw      # (qzeros keeps its checkpoint width)
             qw_t, meta = ops.repack_tiled(qw, qz, self.scales.data, perm, self.group_size, self.kernel_bits)
+            del qw
             self.qweight.data = qw_t  # tiled words; the checkpoint-layout copy is released
             self._set_derived("meta", meta)
             self._set_derived("perm", perm)

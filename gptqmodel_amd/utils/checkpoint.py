@@ -111,12 +111,12 @@ def _written_by_v2_aware_quantizer(cfg: Dict) -> bool:
         vals = [vals]
     for val in vals:
         parts = str(val).split(":")
-        if len(parts) >= 2 and parts[0].lower() in ("gptqmodel", "gptqmodel_amd"):
+        if len(parts) >= 2 and parts[0].lower() == "gptqmodel":
             digits = []
             for tok in parts[1].split("."):
                 num = "".join(ch for ch in tok if ch.isdigit())
                 digits.append(int(num) if num else 0)
-            if parts[0].lower() == "gptqmodel_amd" or tuple(digits[:3] + [0] * (3 - len(digits[:3]))) >= (0, 9, 0):
+            if tuple(digits[:3] + [0] * (3 - len(digits[:3]))) >= (0, 9, 0):
                 return True
     return False
 
@@ -192,14 +192,17 @@ def load_quantized_checkpoint(model: nn.Module, ckpt_dir: str, device="cuda", ba
         missing.remove(k)
     if missing:
         raise ValueError(f"the checkpoint lacks tensors of quantised modules: {missing[:8]}")
-    # every OTHER parameter / persistent buffer must have been loaded as well (norms, embeddings, an untied lm_head): a silently
-    # random-initialised tensor is worse than an error.  Tied parameters count as loaded when any alias was.
-    persistent = set(model.state_dict().keys())
+    # every OTHER parameter must have been loaded as well (norms, embeddings, an untied lm_head): a silently random-initialised tensor
+    # is worse than an error.  Tied parameters count as loaded when any alias was.  Buffers are NOT checked: models register persistent
+    # buffers that checkpoints never hold (older transformers' rotary inv_freq, GPT-2 / NeoX attention masks) and the reference's
+    # non-strict accelerate load accepts that.
+    params = {n for n, _ in model.named_parameters()}
     by_storage: Dict[int, List[str]] = {}
     for k, t in targets.items():
-        by_storage.setdefault(t.data_ptr(), []).append(k)
-    unloaded = [k for k in targets if k in persistent and k not in seen and k not in quant_owned
-                and not any(a in seen for a in by_storage[targets[k].data_ptr()])]
+        if t.numel() > 0:      # (zero-size tensors all report data_ptr() == 0: they alias nothing)
+            by_storage.setdefault(t.data_ptr(), []).append(k)
+    unloaded = [k for k in targets if k in params and k not in seen and k not in quant_owned
+                and not any(a in seen for a in by_storage.get(targets[k].data_ptr(), []))]
     if unloaded:
         raise ValueError(f"the checkpoint lacks model tensors: {unloaded[:8]}")
     if fmt == FORMAT.GPTQ and not cfg["sym"] and not _written_by_v2_aware_quantizer(cfg):
@@ -277,6 +280,11 @@ def save_quantized_checkpoint(model: nn.Module, ckpt_dir: str, quantize_config: 
         total = sum(t.numel() * t.element_size() for t in state.values())
         with open(os.path.join(ckpt_dir, SAFETENSORS_INDEX), "w", encoding="utf-8") as f:
             json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=1)
+    if cfg["format"] == "gptq" and not cfg["sym"] and "quantizer" not in cfg["meta"]:
+        # the reference only accepts sym=False v1 files whose producer entry is `gptqmodel:>=0.9.0` (quantization/config.py:2790,
+        # models/loader.py:1658-1663); a file stamped with this repo's own tag would round-trip here and be refused there
+        raise ValueError("saving sym=False with checkpoint_format=gptq (v1) needs an explicit meta.quantizer the reference recognises "
+                         "(e.g. ['gptqmodel:<version >= 0.9.0>']), or save as gptq_v2")
     payload = {"bits": cfg["bits"], "group_size": cfg["group_size"], "desc_act": cfg["desc_act"], "sym": cfg["sym"],
                "lm_head": cfg["lm_head"], "quant_method": cfg["method"], "checkpoint_format": cfg["format"], "pack_dtype": cfg["pack_dtype"],
                "meta": dict(cfg["meta"], quantizer=cfg["meta"].get("quantizer", ["gptqmodel_amd:test-writer"]))}

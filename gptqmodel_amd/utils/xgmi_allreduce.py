@@ -188,13 +188,17 @@ class OneShotAllReduce:
             g = torch.Generator(device=dev)
             g.manual_seed(31337 + self.rank)
             base = torch.randn(n, device=dev, generator=g).to(torch.float16).float()   # 11 significant bits: base + t is exact
-            bases = self._gather(base)                       # unconditional, like the final agreement below
+            # `ok` was AGREED across the ranks by the loop above, so skipping the gather + the burst after a failure is collective-safe
+            # (every rank skips): a lost peer must cost one bounded wait, not burst x timeout
+            bases = self._gather(base) if ok else []
             try:
                 bad = torch.zeros((), dtype=torch.int64, device=dev)
                 part = torch.empty(n, device=dev)
                 out = torch.empty(n, device=dev, dtype=torch.float16)
                 for t in range(burst if ok else 0):
-                    if t % 16 == 15 and not healthy():       # (a timed-out peer wait: stop launching, every further call would wait again)
+                    # (a timed-out peer wait: stop launching, every further call would wait again -- checked after the first launch,
+                    # then every 16th)
+                    if (t == 1 or t % 16 == 15) and not healthy():
                         ok = False
                         break
                     torch.add(base, float(t % 64), out=part)

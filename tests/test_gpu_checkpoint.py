@@ -35,7 +35,8 @@ def test_on_disk_gptq_checkpoint_round_trip(tmp_path, desc_act, fuse):
         M.gptqmodel_post_init = real_post_init
     assert all(not m._ready for m in quant.modules() if isinstance(m, HipGptqLinear))
     ckpt = str(tmp_path / "ckpt")
-    qcfg = {"bits": 4, "group_size": 128, "desc_act": desc_act, "sym": False, "quant_method": "gptq", "checkpoint_format": "gptq"}
+    qcfg = {"bits": 4, "group_size": 128, "desc_act": desc_act, "sym": False, "quant_method": "gptq", "checkpoint_format": "gptq",
+            "meta": {"quantizer": ["gptqmodel:5.0.0"]}}     # (a producer entry the reference's v1 loader accepts; the writer insists on one)
     files = save_quantized_checkpoint(quant, ckpt, qcfg, max_shard_bytes=(6 << 20) if fuse else (1 << 20))
     quant.config.save_pretrained(ckpt)
     assert len(files) >= 2 and os.path.exists(os.path.join(ckpt, "model.safetensors.index.json"))

@@ -661,12 +661,14 @@ def test_save_writes_each_module_at_its_own_width(kernels_available, tmp_path):
     for m in (net.a, net.b):
         m.qzeros.data = torch.randint(-2**31, 2**31 - 1, tuple(m.qzeros.shape), dtype=torch.int32, generator=gen)
         m.qzero_format(format=2)
-    save_quantized_checkpoint(net, str(tmp_path), {"bits": 4, "group_size": 128, "sym": False, "checkpoint_format": "gptq",
-                                                   "dynamic": {"+:b": {"bits": 3}}})
+    with pytest.raises(ValueError, match="meta.quantizer"):      # an asymmetric v1 file needs a producer entry the reference accepts
+        save_quantized_checkpoint(net, str(tmp_path), {"bits": 4, "group_size": 128, "sym": False, "checkpoint_format": "gptq"})
+    v1 = {"bits": 4, "group_size": 128, "sym": False, "checkpoint_format": "gptq", "meta": {"quantizer": ["gptqmodel:5.0.0"]}}
+    save_quantized_checkpoint(net, str(tmp_path), dict(v1, dynamic={"+:b": {"bits": 3}}))
     disk = load_file(str(tmp_path / "model.safetensors"))
     assert torch.equal(shift_v1_qzeros(disk["a.qzeros"], 4), net.a.qzeros) and torch.equal(shift_v1_qzeros(disk["b.qzeros"], 3), net.b.qzeros)
     assert not torch.equal(disk["b.qzeros"], net.b.qzeros)
     net.b.source_bits = 3
     net.b.bits = 4                     # what widen_in_place() leaves behind
     with pytest.raises(RuntimeError, match="widened"):
-        save_quantized_checkpoint(net, str(tmp_path), {"bits": 4, "group_size": 128, "sym": False, "checkpoint_format": "gptq"})
+        save_quantized_checkpoint(net, str(tmp_path), v1)

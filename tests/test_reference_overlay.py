@@ -200,7 +200,7 @@ print("RESULT " + json.dumps(out))
 '''
     payloads = [
         {"bits": 4, "group_size": 128, "desc_act": True, "sym": False, "lm_head": False, "quant_method": "gptq", "checkpoint_format": "gptq",
-         "pack_dtype": "int32", "meta": {"quantizer": ["gptqmodel_amd:test-writer"]}},                       # what the writer emits
+         "pack_dtype": "int32", "meta": {"quantizer": ["gptqmodel:5.0.0"]}},                                 # what the writer emits
         {"bits": 8, "group_size": 32, "desc_act": False, "sym": True, "quant_method": "gptq", "checkpoint_format": "gptq_v2"},
         {"w_bit": 4, "q_group_size": 64, "zero_point": True, "version": "gemm", "quant_method": "awq"},       # AutoAWQ-style keys
     ]
