@@ -20,7 +20,15 @@ keeps the 8B replica headline (so N = 1 agrees with the single-GPU record) and c
 the Llama-3-70B decode step tensor-parallel over the same N ranks (bench_tp.tp_decode_entry), i.e. one scaling sweep of this
 command also yields the 70B strong-scaling curve BASELINE.json's metric names.
 
-Extra objects on the JSON line (tier contract):
+Output (round 5): stdout carries exactly ONE line -- a compact (< 4 KB) JSON object with the contract's keys, `roofline`, `cpu_baseline`
+and `configs_summary` (one {id, config, value, unit, frac} record per entry, the shape of the reference's own benchmark records,
+scripts/benchmark_marlin_a100.py:181-201).  The full record described below (per-config workload prose, the 28-case T1 table, e2e, the
+CPU thread sweep; ~21 KB) goes to stderr as `BENCH_DETAIL {...}` and to gpurun_out/bench_detail.json.  (Round 4 printed the full record
+on stdout and the driver could not parse it.)  Timed region: 40 clock spin-up steps (`spin_up_steps`), W warm-up steps, barrier +
+synchronize, K timed steps, synchronize + barrier; `value` / `ms_per_step` are wall-clock over the bracket (MAX over ranks),
+`gpu_ms_per_step` the same K steps between two HIP events on the launch stream.
+
+Extra objects of the full record (tier contract; the compact line keeps their numbers):
   roofline      dominant kernel = gptqhip::skinny_kernel (batch-1 fused dequant-GEMV, decode-op instantiation with the layer glue
                 fused); achieved = algorithmic bytes per
                 launch (K*N/2 + G*N*2 + G*N/2 + M*(K+N)*2, averaged over the launches) / average launch
@@ -586,7 +594,7 @@ def result_line(detail):
     `cpu_baseline` and a one-record-per-case `configs_summary` (the shape of the reference's own benchmark records,
     scripts/benchmark_marlin_a100.py:181-201).  Everything else of `detail` (per-config workload prose, the 28-case T1 table, the
     e2e leg, the CPU thread sweep) goes to stderr and gpurun_out/bench_detail.json, not here.  Pure function (tests/test_host_logic.py)."""
-    keep = ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+    keep = ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step", "gpu_ms_per_step", "spin_up_steps", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data")
     line = {k: _r(detail[k]) for k in keep if k in detail}
     cfg = detail.get("config", {})
@@ -812,23 +820,37 @@ def main():
                 else:
                     step.run()
 
+    # clock / TLB spin-up before the W warm-up steps of the contract: with the driver's --warmup 5 (6 ms of GPU work) the timed steps ran
+    # 2.5 % slower than after 20+ warm-up steps (8.85 vs 8.63 us per launch; the chip ramps its clocks over the first ~25 ms of a
+    # burst).  Reported as `spin_up_steps`; the W warm-up steps and the K timed steps follow unchanged.
+    SPIN_UP_STEPS = 40
+    run(SPIN_UP_STEPS)
     run(args.warmup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # The timed region is ~20 ms at the driver's --steps 20: host-side noise of that order must stay out of it.  The collector is
+    # off while it runs and the host SPINS on the closing event (a sleeping synchronize() wakes up late by up to milliseconds on a busy
+    # host; measured: 785 vs 896 tokens/s for the same 8.68 us/launch of GPU time) before the contract's synchronize + barrier.
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         ev0.record(stream)
     run(args.steps)
     with torch.cuda.stream(stream):
         ev1.record(stream)
+    while not ev1.query():
+        pass
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    gc.enable()
     ev_ms = ev0.elapsed_time(ev1)
     tmax = torch.tensor([wall], device="cpu" if share else dev, dtype=torch.float64)
     if dist is not None:
@@ -870,6 +892,8 @@ def main():
             "metric": "llama3_8b_gptq_int4_g128_decode_linear_stack_tokens_per_s",
             "value": value, "unit": "tokens/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "gpu_ms_per_step": ev_ms / args.steps,      # the same K steps between two HIP events on the launch stream (rank 0)
+            "spin_up_steps": SPIN_UP_STEPS,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if dtype == torch.float16 else "bf16", "data": "synthetic",
             "config": {"workload": "Llama-3-8B GPTQ int4 g128 desc_act=False batch=1 decode: the 224 quantised linears of a token "
