@@ -8,11 +8,6 @@ if os.environ.get("GPTQHIP_LIB"):      # dev A/B builds (tests/dev/ablate/*.so)
 from gptqmodel_amd import ops
 dev = "cuda"; gs = 128
 KERNS = tuple(int(v) for v in os.environ.get("MIDM_KERNELS", "1,2").split(","))   # 1 decode kernel, 2 prefill kernel, 0 gptqhip_gemm's own choice
-def _stripe_desc(M, K, N):
-    ops.set_tuning(0, 3, 0)
-    d = ops.plan_describe(M, K, N, gs)
-    ops.set_tuning(0, 0, 0)
-    return d
 def gtime(fn, n_launch, reps=5):
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
@@ -42,21 +37,11 @@ for (K, N) in SHAPES:
         for kern in KERNS:
             if kern == 2 and M < 5: continue
             if kern == 1 and M > 256: continue
-            if kern >= 3 and M > 1024: continue
-            # 3: stripe kernel, 4: stripe kernel with write-through slab stores, 5: stripe kernel with the other stripe width
-            if kern == 5:
-                kg_now = 1 if "kg=1" in _stripe_desc(M, K, N) else 2
-                ops.set_tuning(0, 3, 3 - kg_now)
-            elif kern >= 10:        # stripe kernel with a forced (max row tiles, kg): 41 = 64-row panels on 128-column stripes
-                ops.set_tuning(0, 3, kern)
-            elif kern in (6, 7):    # 16 / 8 items per queue (half / a quarter of the blocks, longer items, fewer contributors per stripe)
-                ops.set_tuning(16 if kern == 6 else 8, 3, 0)
-            else:
-                ops.set_tuning(1 if kern == 4 else 0, 3 if kern == 4 else kern, 0)
+            ops.set_tuning(0, kern, 0)
             def fn():
                 for qw_t, meta in sets: ops.gemm(x, qw_t, meta, None, None, N, gs, 4, torch.float16, out=out)
             us = gtime(fn, len(sets))
-            res.append(f"{ {0: 'auto', 1: 'skinny', 2: 'tiled', 3: 'stripe', 4: 'stripe-wt', 5: 'stripe-altkg', 6: 'items16', 7: 'items8'}.get(kern, 'stripe%d' % kern) } {us:.1f}us {2*M*K*N/us/1e6:.0f}TF" + (f" [{ops.plan_describe(M, K, N, gs).split(' ')[0]}]" if kern == 0 else ""))
+            res.append(f"{ {0: 'auto', 1: 'skinny', 2: 'tiled'}[kern] } {us:.1f}us {2*M*K*N/us/1e6:.0f}TF" + (f" [{ops.plan_describe(M, K, N, gs).split(' ')[0]}]" if kern == 0 else ""))
         ops.set_tuning(0, 0, 0)
         print(f"K={K} N={N} M={M}: " + " | ".join(res), flush=True)
     del sets

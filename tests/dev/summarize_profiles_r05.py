@@ -1,6 +1,6 @@
-"""Turn gpurun_out/r04_* (written by collect_profiles_r04.sh on the GPU box) into the committed profiles/r04_* summaries."""
+"""Turn gpurun_out/r04_* (written by collect_profiles_r05.sh on the GPU box) into the committed profiles/r04_* summaries."""
 import collections, csv, json, os, re, shutil, sys
-tag = "r04"
+tag = "r05"
 src, dst = "gpurun_out/", "profiles/"
 os.makedirs(dst, exist_ok=True)
 rows = list(csv.reader(open(f"{src}{tag}_stats/bench_kernel_stats.csv")))
@@ -36,7 +36,7 @@ def pmc(d, name):
     return sum(vals) / len(vals) if vals else None
 fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
 summ = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-configs "
-                   "(kernel table and bench line from the SAME run); separate --pmc passes with --no-graph (tests/dev/collect_profiles_r04.sh)",
+                   "(kernel table and bench line from the SAME run); separate --pmc passes with --no-graph (tests/dev/collect_profiles_r05.sh)",
         "kernel": "gptqhip::skinny_kernel<...,GLUE> (batch-1 decode op)", "launches": len(allv),
         "avg_kernel_us_rocprof": sum(allv) / len(allv) / 1e3,
         "bench_line_same_run": {k: bench_prof[k] for k in ("value", "ms_per_step")} | {"avg_launch_us": bench_prof["roofline"]["avg_launch_us"],
@@ -57,7 +57,7 @@ if sq.get("SQ_INSTS_VALU") and summ["avg_kernel_us_rocprof"]:
                        "valu_share_of_avg_launch": sq["SQ_INSTS_VALU"] / 1024 * 4 / 2400 / summ["avg_kernel_us_rocprof"],
                        "note": "averaged over the four launch shapes of a layer; on gate_up alone the loop issues 66 VALU per 1 KiB chunk = 6.3 us of its 14.7"}
 json.dump(summ, open(f"{dst}{tag}_pmc_summary.json", "w"), indent=1)
-for f in ("bench.json", "bench_bf16.json", "bench_modules.json", "decode_ops.txt", "eager_overhead.txt", "e2e_llama8b.txt", "configs.txt", "torch_gpu_baseline.txt",
+for f in ("bench_line.json", "bench_detail.json", "bench_line_200steps.json", "bench.json", "bench_bf16.json", "bench_modules.json", "decode_ops.txt", "eager_overhead.txt", "e2e_llama8b.txt", "configs.txt", "torch_gpu_baseline.txt",
           "gemm_tflops.txt", "gemm_tflops_bf16.txt", "gemm_tflops_bf16_bf16scales.txt", "e2e_llama8b_actorder.txt", "e2e_llama8b_actorder_hfprefill.txt",
           "e2e_llama8b_hfprefill.txt", "mid_m_sweep.txt"):
     if os.path.exists(f"{src}{tag}_{f}"): shutil.copy(f"{src}{tag}_{f}", f"{dst}{tag}_{f}")
