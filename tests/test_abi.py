@@ -101,7 +101,13 @@ def test_prefill_planner_invariants_over_a_grid_of_shapes(lib):
                 pl = dict(kv.split("=") for kv in words[1:])
                 bm, s, tail = int(pl["bm"]), int(pl["splits"]), int(pl["tail_cols"])
                 chunks, nbx = -(-K // 128), -(-N // 256)
-                assert bm in (64, 128, 256) and 1 <= s <= max(1, chunks // 4) and 0 <= tail < nbx, (M, K, N, pl)
+                # tile heights: 64 / 128 / 256 everywhere; 32..112 in steps of 16 for 4-bit / one constant per chunk up to 512 rows (round 5)
+                assert bm in ((32, 48, 64, 80, 96, 112, 128, 256) if M <= 512 else (64, 128, 256)), (M, K, N, pl)
+                assert 1 <= s <= max(1, chunks // 4) and 0 <= tail < nbx, (M, K, N, pl)
+                for gs_other, bits_other in ((64, 4), (128, 8)):     # ... and never for the variants that have no such instantiation
+                    b2 = ctypes.create_string_buffer(256)
+                    assert lib.gptqhip_plan_describe(M, K, N, gs_other, bits_other, 0, b2, 256) == 0
+                    assert int(dict(kv.split("=") for kv in b2.value.decode().split()[1:])["bm"]) in (64, 128, 256), (M, K, N, b2.value)
                 if s > 1:
                     assert s * M * N * 4 <= 64 << 20 and nbx * -(-M // bm) * s <= 256 and tail == 0, (M, K, N, pl)
                     assert lib.gptqhip_workspace_bytes(M, K, N, 128, 4, 0) >= s * M * N * 4, (M, K, N, pl)
@@ -135,10 +141,14 @@ def test_kernel_family_crossover_is_host_logic(lib):
     assert d(16, 8192, 10240)["family"] == "skinny" and d(24, 8192, 10240)["family"] == "tiled"       # K >= 8192: tiled from 17 rows ...
     assert d(24, 8192, 8192)["family"] == "skinny" and d(24, 8192, 8192)["nt"] == "2"                   # ... unless the wide form fits one round
     assert d(48, 4096, 6144)["family"] == "tiled" and d(32, 4096, 6144)["family"] == "skinny"          # 33..64 rows in one launch: N < 6144 only
-    # mid M: tile height and split factor come from the launch model together (profiles/r03_tiled_planner.txt)
-    assert d(160, 4096, 6144)["bm"] == "64" and d(160, 4096, 6144)["splits"] == "3"
+    # mid M: tile height and split factor come from the launch model together (profiles/r03_tiled_planner.txt); since round 5 the height
+    # moves in steps of 16 rows up to 512 rows (profiles/r05_midm_heights_sweep*.txt): a 160-row batch is two 80-row tiles, a 96-row
+    # batch one 96-row tile, 72 / 136 rows on the reference benchmark's 4096x11008 layer one / two 80-row tiles (128 / 192 rows before)
+    assert d(160, 4096, 6144)["bm"] == "80" and d(160, 4096, 6144)["splits"] == "4"
     assert d(1280, 14336, 4096)["bm"] == "256" and d(1280, 14336, 4096)["splits"] == "3"
-    assert d(96, 8192, 57344)["bm"] == "128" and d(96, 8192, 57344)["splits"] == "1"
+    assert d(96, 8192, 57344)["bm"] == "96" and d(96, 8192, 57344)["splits"] == "1"
+    assert d(72, 4096, 11008)["bm"] == "80" and d(136, 4096, 11008)["bm"] == "80" and d(136, 4096, 11008)["splits"] == "2"
+    assert d(513, 4096, 4096)["bm"] in ("64", "128", "256") and d(160, 4096, 6144, gs=64)["bm"] in ("64", "128", "256")
     # prefill: 256- / 128- / 64-row tiles
     assert d(8192, 4096, 4096)["bm"] == "256" and d(128, 4096, 4096)["bm"] == "64"
     # act-order: in-kernel permutation at one row, a gather pass otherwise
