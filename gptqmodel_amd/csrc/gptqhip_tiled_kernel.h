@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
 #ifdef GPTQHIP_TILED_INTERLEAVE
         constexpr int kInterleaveValu = GPTQHIP_TILED_INTERLEAVE;   // dev A/B builds
 #else
-        constexpr int kInterleaveValu = BM <= 112 ? 4 : 0;
+        constexpr int kInterleaveValu = BM <= 80 ? 4 : 0;   // (round 5 A/B over the in-between heights: +2 % at 64 / 80 rows, 0 at 96, -2 % at 112)
 #endif
         static_assert(NPIECE <= NG, "one DMA piece per fragment group");
         u4_t abuf[2][PF];
