@@ -45,6 +45,7 @@ static const EnvTuning& env_tuning() {
 #define g_force_waves (t_force_waves ? t_force_waves : env_tuning().waves)
 // (values >= 32 of the variant override name a tile height of the prefill kernel, not a wave count of the decode kernel)
 #define g_skinny_waves (g_force_waves >= 32 ? 0 : g_force_waves)
+// (1064 / 1128: 128-column blocks of the prefill kernel)
 
 constexpr size_t kInKernelPermMaxRowBytes = 44 * 1024;   // AM_ROW1P keeps the x row in LDS next to 16 KiB of per-wave slots
 
@@ -113,7 +114,11 @@ static bool gemm_uses_tiled(int M, int K, int N, int group_size, int bits) {
     }
     // 33..64 rows in one launch of the decode kernel: 4-bit, short K, narrow layers (4096^2: 8.8-10.7 us vs 12.2-14.8 tiled; at
     // N = 6144 the prefill kernel is level or ahead since its round-3 retuning: 13.7-17.6 vs 15.2-18.0 us; profiles/r03_mid_m_sweep.txt)
-    const int skinny_max = (bits == 4 && K < 8192 && N < 6144) ? kSkinnyMaxRows4 : kSkinnyMaxM;
+    int skinny_max = (bits == 4 && K < 8192 && N < 6144) ? kSkinnyMaxRows4 : kSkinnyMaxM;
+    // round 5 (128-column blocks + the refitted planner): on K-heavy layers the prefill kernel leads from 17 rows -- 14336x4096 13.0 vs
+    // 15.8 us at M = 17, 13.1 vs 18.1 at 32; 11008x4096 11.8 vs 12.8 / 12.6 vs 15.1; 28672x8192 35.0 vs 39.5 / 33.9 vs 41.2 -- while 8192x8192
+    // and 8192x1024 stay with the decode kernel up to 32 rows (13.1-13.5 vs 13.7-14.1; 9.2-10.6 vs 10.4-10.9)
+    if (bits == 4 && group_size % kChunkK == 0 && K >= 10240) skinny_max = 16;
     return (g_force_kernel == 2) || (g_force_kernel == 0 && (M > skinny_max || wide));
 }
 
@@ -340,7 +345,10 @@ int gptqhip_plan_describe(int M, int K, int N, int group_size, int bits, int has
     }
     if (gemm_uses_tiled(M, K, N, group_size, bits)) {
         const TiledPlan tp = plan_tiled(M, K, N, group_size, bits, g_force_waves, g_force_split);
-        snprintf(buf, (size_t)buf_len, "tiled bm=%d splits=%d tail_cols=%d gather=%d", tp.bm, tp.splits, tp.tail_cols, has_perm ? 1 : 0);
+        if (tp.bn != 256)
+            snprintf(buf, (size_t)buf_len, "tiled bm=%d bn=%d splits=%d tail_cols=%d gather=%d", tp.bm, tp.bn, tp.splits, tp.tail_cols, has_perm ? 1 : 0);
+        else
+            snprintf(buf, (size_t)buf_len, "tiled bm=%d splits=%d tail_cols=%d gather=%d", tp.bm, tp.splits, tp.tail_cols, has_perm ? 1 : 0);
         return GPTQHIP_OK;
     }
     const int rows = bits == 4 ? kSkinnyMaxRows4 : kSkinnyMaxM;

@@ -51,6 +51,7 @@ struct TiledPlan {
     int chunks_per_split;
     size_t slab_floats;
     int tail_cols = 0;  // trailing block columns (256 wide) handed to a second launch with 128-row tiles; 0: none
+    int bn = 256;       // columns per block: 256, or 128 (one column tile per wave: 4-bit, one constant per chunk, bm 64 / 128)
 };
 
 void set_error(const char* fmt, ...);

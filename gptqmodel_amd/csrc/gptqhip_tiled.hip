@@ -73,20 +73,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // the candidates; measured against the round-2 rules on the same box it wins 5-32 % on 50 of 160 points and loses > 4 % on 3.
 // Round 5: refitted per tile height (now 32 .. 128 rows in steps of 16, and 256) on graph-replayed launches over rotating cold weights
 // (tests/dev/midm_heights.py -> midm_fit.py, profiles/r05_midm_heights_sweep*.txt), with one shared term for grids that leave more
-// than a quarter of the CUs idle: + 12.0 us x max(0, 0.75 - f).  1557 averaged points of two runs: relative fit error 4.9 % mean / 10 % p90
-// (the run-to-run spread of a point is +-5 %); replaying the search on them the model's pick is 1.5 % (mean) behind the best measured point.
-static double tiled_cost_us(int M, int K, int N, int bm, int s) {
+// than a quarter of the CUs idle: + 10.5 us x max(0, 0.75 - f); and, in the same fit, a second coefficient set for the 128-column-block
+// form of the kernel (one column tile per wave, gptqhip_tiled_n128_r<rows>.hip).  2610 averaged points of four runs: relative fit error
+// 5.1 % mean / 10.8 % p90 (the run-to-run spread of a point is +-5 %); replaying the search on them the model's pick is 1.6 % (mean) behind
+// the best measured point, where the round-4 planner's pick (256-column blocks, 64 / 128 / 256 rows) is 8.9 % behind.
+static double tiled_cost_us(int M, int K, int N, int bm, int s, int bn = kTiledBN) {
+    // rows 0..7: 256-column blocks, tile heights 32 .. 128, 256; rows 8..14: 128-column blocks (one column tile per wave), heights 32 .. 128
     static const int kHeights[8] = {32, 48, 64, 80, 96, 112, 128, 256};
-    static const double kCoef[8][4] = {{-11.195, 15.775, 1.071, -0.143}, {-11.033, 17.357, 1.182, -0.154}, {-10.220, 17.509, 1.198, -0.053},
-                                       {-5.854, 13.875, 1.239, -0.005},  {-5.169, 14.162, 1.408, 0.004},   {-4.918, 14.584, 1.607, -0.064},
-                                       {-4.659, 16.029, 1.635, -0.004},  {-4.415, 19.995, 2.805, 0.052}};
-    const double kIdle = 11.977;
+    static const double kCoef[15][4] = {{-9.852, 14.356, 1.078, -0.154}, {-10.261, 16.358, 1.189, -0.162}, {-7.146, 14.581, 1.156, -0.030},
+                                        {-5.052, 13.248, 1.251, -0.036}, {-4.863, 13.763, 1.425, -0.036},  {-4.958, 14.435, 1.612, -0.084},
+                                        {-4.297, 15.313, 1.660, -0.039}, {-3.555, 18.868, 2.810, 0.039},
+                                        {-2.231, 3.778, 0.475, 0.030},   {-3.270, 5.609, 0.541, 0.035},    {-4.710, 9.364, 0.596, 0.011},
+                                        {-5.189, 10.770, 0.697, -0.014}, {-5.634, 12.229, 0.823, -0.079},  {-5.392, 12.168, 0.909, -0.085},
+                                        {-4.968, 12.529, 0.990, -0.104}};
+    const double kIdle = 10.512;
     int hi = 7;
     for (int i = 0; i < 8; ++i)
         if (kHeights[i] == bm) hi = i;
-    const double* co = kCoef[hi];
+    const double* co = kCoef[bn == 128 ? 8 + (hi < 7 ? hi : 6) : hi];
     const int chunks = ceil_div(K, kChunkK), cps = ceil_div(chunks, s), s_eff = ceil_div(chunks, cps);
-    const long tiles = (long)ceil_div(N, kTiledBN) * ceil_div(M, bm), blocks = tiles * s_eff;
+    const long tiles = (long)ceil_div(N, bn) * ceil_div(M, bm), blocks = tiles * s_eff;
     double r, f;
     if (s_eff == 1) {
         const long full = tiles / 256, rem = tiles % 256;
@@ -101,6 +107,8 @@ static double tiled_cost_us(int M, int K, int N, int bm, int s) {
     const double reduce_us = s_eff > 1 ? (slab_mb / 6.2 + 1.5 > 4.6 ? slab_mb / 6.2 + 1.5 : 4.6) : 0.0;
     return main_us + reduce_us;
 }
+
+constexpr int kN128MaxRows = 512;   // 128-column blocks up to this many rows (the calibration sweep's range)
 
 TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_variant, int force_split) {
     TiledPlan pl;
@@ -147,11 +155,16 @@ TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_va
     // the extra heights exist for 4-bit weights with one group constant per chunk (gptqhip_tiled_r<rows>.hip)
     const bool any16 = bits == 4 && pl.gpc == 1;
     if (force_variant >= 32 && any16 && force_variant <= 128 && force_variant % 16 == 0) pl.bm = force_variant;
+    // (dev / tests: 1000 + rows = 128-column blocks with that tile height)
+    if (force_variant >= 1032 && force_variant <= 1128 && force_variant % 16 == 8 && any16) {
+        pl.bm = force_variant - 1000;
+        pl.bn = 128;
+    }
     // split K across blocks when the (M, N) grid alone leaves most CUs idle (mid-size M, or K-heavy layers):
     // fp32 partial slabs + a tiny reduce kernel (a kernel boundary is cheaper than re-reading 100s of KB of slabs
     // through a last-arriver block -- MI355X_MICROARCH.md "handoff-payload")
     const int chunks = ceil_div(K, kChunkK);
-    const long blocks = (long)ceil_div(M, pl.bm) * ceil_div(N, kTiledBN);
+    const long blocks = (long)ceil_div(M, pl.bm) * ceil_div(N, pl.bn);
     int s = 1;
     if (blocks <= 128 && chunks >= 8) {
         s = (int)(256 / blocks);  // measured: splitting grids that already have > 128 blocks loses to the reduce pass
@@ -167,22 +180,29 @@ TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_va
         // tiles + 3 are 15-20 % faster (4096x6144 at M=160..320), never combined 256-row tiles with split-K (14336x4096 at M=1280:
         // 174 -> 137 us, 8192x10240 at M=448: 101 -> 89) and kept 64-row tiles on very wide layers (8192x57344 at M<=128: 148 -> 113 us).
         double best = 1e30;
-        for (int bm : {32, 48, 64, 80, 96, 112, 128, 256}) {
-            if (bm <= 64 && M > 1024) continue;
-            // (the in-between heights: 4-bit / one constant per chunk, and up to 512 rows -- beyond, whole 64- / 128- / 256-row tiles waste
-            // little and the sweep that calibrated the model ends)
-            if ((!any16 || M > 512) && bm != 64 && bm != 128 && bm != 256) continue;
-            const long tiles = (long)nbx * ceil_div(M, bm);
-            for (int sc = 1; sc <= 16; ++sc) {
-                if (sc > 1 && (sc > chunks / 4 || tiles * sc > cus || (size_t)sc * M * N > ((size_t)16 << 20))) break;
-                // (blocks of four chunks run ~5 % behind the model -- its residual by chunks per block, tests/dev/midm_fit.py -- and lose to
-                // five-chunk blocks on every shape of the sweep: not a candidate while K allows five)
-                if (sc > 1 && chunks >= 20 && ceil_div(chunks, sc) < 5) continue;
-                const double t = tiled_cost_us(M, K, N, bm, sc);
-                if (t < best) {
-                    best = t;
-                    pl.bm = bm;
-                    s = sc;
+        for (int bn : {256, 128}) {
+            // (128-column blocks: 4-bit / one constant per chunk, up to 512 rows, like the in-between heights)
+            if (bn == 128 && (!any16 || M > kN128MaxRows)) continue;
+            const int nbx_c = ceil_div(N, bn);
+            for (int bm : {32, 48, 64, 80, 96, 112, 128, 256}) {
+                if (bm <= 64 && M > 1024) continue;
+                if (bn == 128 && bm == 256) continue;
+                // (the in-between heights: 4-bit / one constant per chunk, and up to 512 rows -- beyond, whole 64- / 128- / 256-row tiles waste
+                // little and the sweep that calibrated the model ends)
+                if ((!any16 || M > 512) && bm != 64 && bm != 128 && bm != 256) continue;
+                const long tiles = (long)nbx_c * ceil_div(M, bm);
+                for (int sc = 1; sc <= 16; ++sc) {
+                    if (sc > 1 && (sc > chunks / 4 || tiles * sc > cus || (size_t)sc * M * N > ((size_t)16 << 20))) break;
+                    // (blocks of four chunks run ~5 % behind the model -- its residual by chunks per block, tests/dev/midm_fit.py -- and lose to
+                    // five-chunk blocks on every shape of the sweep: not a candidate while K allows five)
+                    if (sc > 1 && chunks >= 20 && ceil_div(chunks, sc) < 5) continue;
+                    const double t = tiled_cost_us(M, K, N, bm, sc, bn);
+                    if (t < best) {
+                        best = t;
+                        pl.bm = bm;
+                        pl.bn = bn;
+                        s = sc;
+                    }
                 }
             }
         }
@@ -225,7 +245,18 @@ int launch_tiled(const GemmArgs& a, const TiledPlan& pl, float* slabs, hipStream
     // fp32 epilogue (split-K slabs, tensor-parallel partial sums) or the 16-bit rounding epilogue
     const bool f32 = p.splits > 1 || p.out_f32;
     int rc_main;
-    if (a.bits == 4 && pl.gpc == 1 && pl.bm != 64 && pl.bm != 128 && pl.bm != 256) {
+    if (pl.bn == 128) {
+        switch (pl.bm) {
+            case 32: rc_main = launch_tiled_w4_n128_r32(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;
+            case 48: rc_main = launch_tiled_w4_n128_r48(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;
+            case 64: rc_main = launch_tiled_w4_n128_r64(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;
+            case 80: rc_main = launch_tiled_w4_n128_r80(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;
+            case 96: rc_main = launch_tiled_w4_n128_r96(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;
+            case 112: rc_main = launch_tiled_w4_n128_r112(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;
+            case 128: rc_main = launch_tiled_w4_n128_r128(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;
+            default: set_error("tiled kernel: no %d-row tile with 128-column blocks", pl.bm); return -22;
+        }
+    } else if (a.bits == 4 && pl.gpc == 1 && pl.bm != 64 && pl.bm != 128 && pl.bm != 256) {
         switch (pl.bm) {
             case 32: rc_main = launch_tiled_w4_r32(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;
             case 48: rc_main = launch_tiled_w4_r48(p, a.act_dtype, a.scale_dtype, f32 ? 1 : 0, stream); break;

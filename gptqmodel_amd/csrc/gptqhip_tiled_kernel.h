@@ -205,20 +205,27 @@ struct TileCtx {
 // OUTF = 0: 16-bit output with the reference's rounding chain; 1: fp32 accumulators (split-K slabs, TP partial sums).  A
 // template parameter rather than a run-time branch: the two epilogues issue different numbers of stores, and a branch
 // between them inside the tile loop makes hipcc assume the smaller count (zero, after its CFG lowering) in every wait.
-template <int BITS, int ACT, int SCL, int GPC, int BM, int WAVES, int D, int OUTF>
+// BN: columns per block -- 256 (two column tiles per wave), or 128 (ONE column tile per wave; round 5): half the dequant VALU and MFMAs per
+// wave and chunk, twice the blocks for the same (M, N), so that wide layers at 64..192 rows fill the chip WITHOUT split-K slabs.
+template <int BITS, int ACT, int SCL, int GPC, int BM, int WAVES, int D, int OUTF, int BN = kTiledBN>
 __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     static_assert(BM % 16 == 0 && BM >= 16 && BM <= 256, "row tiles of 16");
     constexpr int MT = BM / 16;
     constexpr int NT = 64 * WAVES;
     constexpr int BMP = (BM + 31) / 32 * 32;  // LDS image / DMA height: whole 32-row pieces (NT / 64 waves x 4 rows each)
     static_assert(NT == 512, "the 32-row DMA piece assumes 8 waves");
-    constexpr int TPW = kTiledBN / kTileN / WAVES;  // column tiles per wave
+    constexpr int TPW = BN / kTileN / WAVES;  // column tiles per wave
+    static_assert(TPW == 1 || TPW == 2, "one or two column tiles per wave");
+    // epilogue geometry: a wave's output is BM rows x WC columns, staged through LDS and stored in 16-byte pieces
+    constexpr int WC = 16 * TPW;
+    constexpr int LPR16 = WC / 8, RPP16 = 64 / LPR16;    // 16-bit: lanes per row, rows per store instruction (4, 16 | 2, 32)
+    constexpr int LPR32 = WC / 4, RPP32 = 64 / LPR32;    // fp32:                                              (8, 8 | 4, 16)
     // D stage buffers for the A tile + a separate staging area for the epilogue transposes (BM x 16 B per wave), so a
     // tile's output can leave while the NEXT tile's first stages are already landing in the stage buffers
     __shared__ __attribute__((aligned(16))) char lds_all[D * BMP * 256];
     // staging per wave: TG row tiles per epilogue pass (16-bit: 64 B per row; fp32: 128 B per row)
-    constexpr int TG16 = MT >= 4 ? MT / 4 : 1, TG32 = MT >= 8 ? MT / 8 : 1;
-    constexpr int kEpi = OUTF ? TG32 * 16 * 128 : TG16 * 16 * 64;  // bytes per wave
+    constexpr int TG16 = TPW == 1 ? 2 : (MT >= 4 ? MT / 4 : 1), TG32 = TPW == 1 ? 1 : (MT >= 8 ? MT / 8 : 1);
+    constexpr int kEpi = OUTF ? TG32 * 16 * WC * 4 : TG16 * 16 * WC * 2;  // bytes per wave
     __shared__ __attribute__((aligned(16))) char lds_epi[WAVES * kEpi];
 
     const int tid = threadIdx.x;
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
     // XCD-aware order (cdna_hip_programming.md T1): hardware places block b on XCD b % 8 and G % 8 == 0 or G == ntiles,
     // so virtual block v also runs on XCD v % 8; remap so each XCD works on a contiguous run of (bm, bn) pairs -> the
     // blocks sharing one A row-panel reuse it from ONE L2.
-    const int nbx = ceil_div(p.N, kTiledBN);
+    const int nbx = ceil_div(p.N, BN);
     const int ntiles = nbx * ceil_div(p.M, BM);
     const int G = gridDim.x;
     auto make_ctx = [&](int v) __attribute__((always_inline)) {
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
         const int bn = lin - bm * nbx;
         TileCtx t;
         t.m0 = bm * BM;
-        t.tile0 = bn * (kTiledBN / kTileN) + wave * TPW;
+        t.tile0 = bn * (BN / kTileN) + wave * TPW;
         t.a = make_a_src<BM, NT>(p, t.m0, wave, lane);
         return t;
     };
@@ -268,7 +275,9 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
 #else
     constexpr int OPS = BMP * 16 / NT + TPW * ((BITS == 4 ? 1 : 2) + GPC);  // VMEM instructions per stage and wave
 #endif
-    constexpr int NST = OUTF ? BM / 8 : BM / 16;  // 16-byte store instructions per wave and tile in the epilogue
+    // 16-byte store instructions per wave and tile in the epilogue (one column tile per wave on an odd number of row tiles: the last
+    // 32-row store is half out of the tile's descriptor and dropped by the hardware)
+    constexpr int NST = OUTF ? BM / RPP32 : (BM + RPP16 - 1) / RPP16;
     // Every issue is UNCONDITIONAL (a chunk index past the end is clamped and re-fetches the last chunk into a stage
     // nobody reads): the instruction stream between any load and its use is then the same on every path, which is what
     // lets both the hand-written and hipcc's own vmcnt waits be exact counts instead of full drains.
@@ -454,26 +463,27 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
             uint16_t* slab = reinterpret_cast<uint16_t*>(lds_epi + wave * kEpi);
             char* base = reinterpret_cast<char*>(p.out) + (size_t)t.m0 * p.ldo * 2;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, rows * p.ldo * 2, 0x00020000);
-            const int n0 = t.tile0 * kTileN + (lane_e & 3) * 8;
-            const uint32_t lane_off = n0 < p.N ? (uint32_t)((lane_e >> 2) * p.ldo * 2 + n0 * 2) : 0xFFFFFF00u;
+            const int n0 = t.tile0 * kTileN + (lane_e % LPR16) * 8;
+            const uint32_t lane_off = n0 < p.N ? (uint32_t)((lane_e / LPR16) * p.ldo * 2 + n0 * 2) : 0xFFFFFF00u;
 #pragma unroll
-            for (int h = 0; h < MT / TG16; ++h) {
+            for (int h = 0; h < (MT + TG16 - 1) / TG16; ++h) {
 #pragma unroll
                 for (int tt = 0; tt < TPW; ++tt)
 #pragma unroll
                     for (int mh = 0; mh < TG16; ++mh)
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            float y = round_through<ACT>(acc[h * TG16 + mh][tt][i]);
+                            if (h * TG16 + mh >= MT) continue;      // (odd MT with two row tiles per pass: rows past the tile, dropped on the way out)
+                            float y = round_through<ACT>(acc[h * TG16 + mh < MT ? h * TG16 + mh : MT - 1][tt][i]);
                             if (p.bias != nullptr) y = y + bias[tt];
-                            slab[(mh * 16 + 4 * rq_e + i) * 32 + tt * 16 + c_e] = f32_to_16<ACT>(y);
+                            slab[(mh * 16 + 4 * rq_e + i) * WC + tt * 16 + c_e] = f32_to_16<ACT>(y);
                         }
                 // same-wave LDS accesses execute in order: no barrier between this wave's writes and reads
 #pragma unroll
-                for (int pass = 0; pass < TG16; ++pass) {
-                    const int row = pass * 16 + (lane_e >> 2);
-                    const u4_t v = *reinterpret_cast<const u4_t*>(slab + row * 32 + (lane_e & 3) * 8);
-                    const uint32_t off = lane_off + (uint32_t)((h * (TG16 * 16) + pass * 16) * p.ldo * 2);
+                for (int pass = 0; pass < TG16 * 16 / RPP16; ++pass) {
+                    const int row = pass * RPP16 + lane_e / LPR16;
+                    const u4_t v = *reinterpret_cast<const u4_t*>(slab + row * WC + (lane_e % LPR16) * 8);
+                    const uint32_t off = lane_off + (uint32_t)((h * (TG16 * 16) + pass * RPP16) * p.ldo * 2);
                     __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane_off >= 0xFFFFFF00u ? lane_off : off, 0, 0);
                 }
             }
@@ -485,8 +495,8 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
             char* base = p.splits > 1 ? reinterpret_cast<char*>(p.slabs + ((size_t)blockIdx.z * p.M + t.m0) * p.N)
                                       : reinterpret_cast<char*>(p.out) + (size_t)t.m0 * p.ldo * 4;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(rows * ld * 4), 0x00020000);
-            const int n0 = t.tile0 * kTileN + (lane_e & 7) * 4;
-            const uint32_t lane_off = n0 < p.N ? (uint32_t)((lane_e >> 3) * ld * 4 + n0 * 4) : 0xFFFFFF00u;
+            const int n0 = t.tile0 * kTileN + (lane_e % LPR32) * 4;
+            const uint32_t lane_off = n0 < p.N ? (uint32_t)((lane_e / LPR32) * ld * 4 + n0 * 4) : 0xFFFFFF00u;
 #pragma unroll
             for (int h = 0; h < MT / TG32; ++h) {
 #pragma unroll
@@ -494,12 +504,12 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
 #pragma unroll
                     for (int mh = 0; mh < TG32; ++mh)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) slab[(mh * 16 + 4 * rq_e + i) * 32 + tt * 16 + c_e] = acc[h * TG32 + mh][tt][i];
+                        for (int i = 0; i < 4; ++i) slab[(mh * 16 + 4 * rq_e + i) * WC + tt * 16 + c_e] = acc[h * TG32 + mh][tt][i];
 #pragma unroll
-                for (int pass = 0; pass < TG32 * 2; ++pass) {
-                    const int row = pass * 8 + (lane_e >> 3);
-                    const f4_t v = *reinterpret_cast<const f4_t*>(slab + row * 32 + (lane_e & 7) * 4);
-                    const uint32_t off = lane_off + (uint32_t)((h * (TG32 * 16) + pass * 8) * ld * 4);
+                for (int pass = 0; pass < TG32 * 16 / RPP32; ++pass) {
+                    const int row = pass * RPP32 + lane_e / LPR32;
+                    const f4_t v = *reinterpret_cast<const f4_t*>(slab + row * WC + (lane_e % LPR32) * 4);
+                    const uint32_t off = lane_off + (uint32_t)((h * (TG32 * 16) + pass * RPP32) * ld * 4);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs,
                                                            lane_off >= 0xFFFFFF00u ? lane_off : off, 0, 0);
                 }
@@ -625,6 +635,14 @@ int launch_tiled_w4_r48(const TiledParams& p, int act_dtype, int scale_dtype, in
 int launch_tiled_w4_r80(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
 int launch_tiled_w4_r96(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
 int launch_tiled_w4_r112(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
+// 128-column blocks (gptqhip_tiled_n128_r<rows>.hip): 4-bit, one group constant per chunk, 32..128-row tiles
+int launch_tiled_w4_n128_r32(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
+int launch_tiled_w4_n128_r48(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
+int launch_tiled_w4_n128_r64(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
+int launch_tiled_w4_n128_r80(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
+int launch_tiled_w4_n128_r96(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
+int launch_tiled_w4_n128_r112(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
+int launch_tiled_w4_n128_r128(const TiledParams& p, int act_dtype, int scale_dtype, int out_f32, hipStream_t stream);
 
 template <int BITS, int OUTF>
 inline int launch_tiled_bits(const TiledParams& p, int act_dtype, int scale_dtype, int gpc, int bm, hipStream_t stream) {

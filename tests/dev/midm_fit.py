@@ -22,10 +22,12 @@ RED_MIN, RED_A, RED_BW, IDLE_AT = 4.6, 1.5, 6.2, 0.75
 
 
 def feats(K, N, M, bm, s):
+    # bm >= 1000: the 128-column-block form with tile height bm - 1000 (tests/dev/midm_heights.py with BN=128)
+    bn, bm = (128, bm - 1000) if bm >= 1000 else (256, bm)
     chunks = -(-K // 128)
     cps = -(-chunks // s)
     s_eff = -(-chunks // cps)
-    tiles = -(-N // 256) * -(-M // bm)
+    tiles = -(-N // bn) * -(-M // bm)
     B = tiles * s_eff
     if s_eff == 1:
         full, rem = divmod(tiles, 256)
@@ -67,7 +69,7 @@ for (K, N, M, bm, s), us in meas.items():
         best[(K, N, M)] = (us, bm, s)
 loss, loss_auto = [], []
 for key in sorted(best):
-    cands = [(predict(*k), k[3], k[4]) for k in meas if k[:3] == key and (k[4] == 1 or -(-key[1] // 256) * -(-key[2] // k[3]) * k[4] <= MAXB)] if (MAXB := 256) else []
+    cands = [(predict(*k), k[3], k[4]) for k in meas if k[:3] == key]
     pred, bm, s = min(cands)
     got = meas[key + (bm, s)]
     loss.append(got / best[key][0] - 1)

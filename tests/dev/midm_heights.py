@@ -17,6 +17,7 @@ MS = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [72, 96,
 SHAPES = ([tuple(int(v) for v in t.split("x")) for t in os.environ["SHAPES"].split(",")] if os.environ.get("SHAPES")
           else [(4096, 11008), (11008, 4096), (4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096)])
 FORCE = {256: 1, 128: 2, 64: 3}
+BN = int(os.environ.get("BN", "256"))        # 128: the 128-column-block form (force code 1000 + rows); lines then read `P K N M bm s us` with bm = 1000 + rows
 
 
 def gtime(fn, n_launch, reps=4):
@@ -40,7 +41,7 @@ def gtime(fn, n_launch, reps=4):
 
 def splits_to_try(M, K, N, bm):
     chunks = -(-K // 128)
-    tiles = -(-N // 256) * -(-M // bm)
+    tiles = -(-N // BN) * -(-M // bm)
     smax = max(1, min(chunks // 4, 256 // max(1, tiles), 16))
     cand = {1, smax, max(1, smax - 1), max(1, smax // 2), max(1, (smax * 3) // 4)}
     if bm <= 64 and os.environ.get("OVERSUB"):      # two blocks per CU fit (<= 128 VGPRs, 48 KiB of LDS): up to 512 blocks
@@ -69,15 +70,15 @@ for (K, N) in SHAPES:
         for bm in HEIGHTS:
             if (bm < 64 and M > 4 * bm) or (bm <= 64 and M > 1024):
                 continue
-            if bm == 256 and M < 192:
+            if bm == 256 and (M < 192 or BN == 128):
                 continue
             for s in splits_to_try(M, K, N, bm):
-                ops.set_tuning(s, 2, FORCE.get(bm, bm))
+                ops.set_tuning(s, 2, 1000 + bm if BN == 128 else FORCE.get(bm, bm))
                 d = ops.plan_describe(M, K, N, gs)
-                if f"bm={bm} " not in d:
+                if f"bm={bm} " not in d or (BN == 128) != ("bn=128" in d):
                     continue
                 s_eff = int(d.split("splits=")[1].split(" ")[0])
-                print(f"P {K} {N} {M} {bm} {s_eff} {gtime(fn, len(sets)):.2f}", flush=True)
+                print(f"P {K} {N} {M} {1000 + bm if BN == 128 else bm} {s_eff} {gtime(fn, len(sets)):.2f}", flush=True)
         ops.set_tuning(0, 0, 0)
     del sets
     torch.cuda.empty_cache()

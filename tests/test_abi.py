@@ -99,15 +99,18 @@ def test_prefill_planner_invariants_over_a_grid_of_shapes(lib):
                 words = buf.value.decode().split()
                 assert words[0] == "tiled", (M, K, N, words)
                 pl = dict(kv.split("=") for kv in words[1:])
-                bm, s, tail = int(pl["bm"]), int(pl["splits"]), int(pl["tail_cols"])
-                chunks, nbx = -(-K // 128), -(-N // 256)
+                bm, s, tail, bn = int(pl["bm"]), int(pl["splits"]), int(pl["tail_cols"]), int(pl.get("bn", 256))
+                chunks, nbx = -(-K // 128), -(-N // bn)
+                # 128-column blocks (one column tile per wave): 4-bit / one constant per chunk, up to 512 rows (round 5)
+                assert bn == 256 or (bn == 128 and M <= 512 and bm <= 128 and tail == 0), (M, K, N, pl)
                 # tile heights: 64 / 128 / 256 everywhere; 32..112 in steps of 16 for 4-bit / one constant per chunk up to 512 rows (round 5)
                 assert bm in ((32, 48, 64, 80, 96, 112, 128, 256) if M <= 512 else (64, 128, 256)), (M, K, N, pl)
                 assert 1 <= s <= max(1, chunks // 4) and 0 <= tail < nbx, (M, K, N, pl)
                 for gs_other, bits_other in ((64, 4), (128, 8)):     # ... and never for the variants that have no such instantiation
                     b2 = ctypes.create_string_buffer(256)
                     assert lib.gptqhip_plan_describe(M, K, N, gs_other, bits_other, 0, b2, 256) == 0
-                    assert int(dict(kv.split("=") for kv in b2.value.decode().split()[1:])["bm"]) in (64, 128, 256), (M, K, N, b2.value)
+                    p2 = dict(kv.split("=") for kv in b2.value.decode().split()[1:])
+                    assert int(p2["bm"]) in (64, 128, 256) and "bn" not in p2, (M, K, N, b2.value)
                 if s > 1:
                     assert s * M * N * 4 <= 64 << 20 and nbx * -(-M // bm) * s <= 256 and tail == 0, (M, K, N, pl)
                     assert lib.gptqhip_workspace_bytes(M, K, N, 128, 4, 0) >= s * M * N * 4, (M, K, N, pl)
@@ -132,7 +135,10 @@ def test_kernel_family_crossover_is_host_logic(lib):
     p = d(64, 4096, 4096)
     assert p["family"] == "skinny" and p["mt"] == "4" and p["launches"] == "1" and p["splits"] == "1"
     assert d(65, 4096, 4096)["family"] == "tiled" and d(48, 4096, 4096, bits=8)["family"] == "tiled"
-    assert d(32, 14336, 4096)["family"] == "skinny" and d(40, 14336, 4096)["family"] == "tiled"      # long K: tiled above 32 rows
+    # K-heavy layers (K >= 10240, 4-bit g128): the prefill kernel from 17 rows since round 5 (14336x4096 13.0 vs 15.8 us at 17 rows);
+    # 8192-deep layers keep the decode kernel up to 32 rows, 8-bit weights and group_size 64 keep the old 32-row rule
+    assert d(16, 14336, 4096)["family"] == "skinny" and d(17, 14336, 4096)["family"] == "tiled" and d(40, 14336, 4096)["family"] == "tiled"
+    assert d(32, 8192, 1024)["family"] == "skinny" and d(32, 14336, 4096, bits=8)["family"] == "skinny" and d(32, 14336, 4096, gs=64)["family"] == "skinny"
     # wide layers: the wide form (4 / 2 column tiles per block) from 5 rows, up to 16 rows everywhere, up to 32 where measured ahead
     assert d(4, 4096, 28672)["nt"] == "1" and d(5, 4096, 28672)["nt"] == "4" and d(16, 4096, 28672)["nt"] == "4"
     assert d(32, 4096, 28672)["family"] == "skinny" and d(32, 4096, 28672)["nt"] == "4" and d(33, 4096, 28672)["family"] == "tiled"
@@ -144,13 +150,19 @@ def test_kernel_family_crossover_is_host_logic(lib):
     # mid M: tile height and split factor come from the launch model together (profiles/r03_tiled_planner.txt); since round 5 the height
     # moves in steps of 16 rows up to 512 rows (profiles/r05_midm_heights_sweep*.txt): a 160-row batch is two 80-row tiles, a 96-row
     # batch one 96-row tile, 72 / 136 rows on the reference benchmark's 4096x11008 layer one / two 80-row tiles (128 / 192 rows before)
-    assert d(160, 4096, 6144)["bm"] == "80" and d(160, 4096, 6144)["splits"] == "4"
-    assert d(1280, 14336, 4096)["bm"] == "256" and d(1280, 14336, 4096)["splits"] == "3"
+    # ... and so does the block width: 128-column blocks (one column tile per wave, `bn=128`) where twice the blocks spare the launch its
+    # split-K slabs -- the reference benchmark's 4096x11008 layer at 72 / 128 / 136 rows runs WITHOUT split-K (4 / 4 / 2 slabs before)
+    assert d(160, 4096, 6144).get("bn") == "128" and d(160, 4096, 6144)["splits"] == "1"
+    assert d(1280, 14336, 4096)["bm"] == "256" and d(1280, 14336, 4096)["splits"] == "3" and "bn" not in d(1280, 14336, 4096)
     assert d(96, 8192, 57344)["bm"] == "96" and d(96, 8192, 57344)["splits"] == "1"
-    assert d(72, 4096, 11008)["bm"] == "80" and d(136, 4096, 11008)["bm"] == "80" and d(136, 4096, 11008)["splits"] == "2"
-    assert d(513, 4096, 4096)["bm"] in ("64", "128", "256") and d(160, 4096, 6144, gs=64)["bm"] in ("64", "128", "256")
+    for m_ in (72, 128, 136):
+        assert d(m_, 4096, 11008).get("bn") == "128" and d(m_, 4096, 11008)["splits"] == "1", (m_, d(m_, 4096, 11008))
+    assert -(-72 // int(d(72, 4096, 11008)["bm"])) * int(d(72, 4096, 11008)["bm"]) <= 96 and d(136, 4096, 11008)["bm"] == "80"
+    assert d(128, 4096, 4096).get("bn") == "128" and int(d(128, 4096, 4096)["splits"]) <= 4
+    assert d(513, 4096, 4096)["bm"] in ("64", "128", "256") and "bn" not in d(513, 4096, 4096)
+    assert d(160, 4096, 6144, gs=64)["bm"] in ("64", "128", "256") and "bn" not in d(160, 4096, 6144, gs=64)
     # prefill: 256- / 128- / 64-row tiles
-    assert d(8192, 4096, 4096)["bm"] == "256" and d(128, 4096, 4096)["bm"] == "64"
+    assert d(8192, 4096, 4096)["bm"] == "256" and d(128, 4096, 4096, bits=8)["bm"] == "64"
     # act-order: in-kernel permutation at one row, a gather pass otherwise
     assert d(1, 4096, 4096, perm=1)["gather"] == "0" and d(1, 4096, 4096, perm=1)["depth"] == "4"
     assert d(8, 4096, 4096, perm=1)["gather"] == "1" and d(2048, 4096, 4096, perm=1)["gather"] == "1"

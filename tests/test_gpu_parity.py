@@ -378,6 +378,49 @@ def test_tiled_extra_tile_heights_vs_oracle(ops, bm, split, M, K, N, act, scl, d
     assert_forward_close(got, ref, act, tag=(bm, split, M, K, N, act, scl, desc_act))
 
 
+# 128-column blocks (one column tile per wave; round 5): every tile height, the 16-bit epilogue (no split) and the fp32 slabs (split-K),
+# odd numbers of row tiles (the last 32-row store is half outside the tile), ragged M / N / K, bf16, act-order
+N128_CASES = [
+    # bm, split, M, K, N, act, scl, desc_act
+    (32, 1, 17, 1024, 512, "fp16", "fp16", False),
+    (32, 3, 64, 2048, 1000, "bf16", "fp16", False),
+    (48, 1, 48, 4096, 4096, "fp16", "fp16", False),
+    (48, 2, 95, 2048, 520, "fp16", "bf16", True),
+    (64, 1, 128, 4096, 11008, "fp16", "fp16", False),
+    (64, 3, 128, 4096, 4096, "bf16", "bf16", False),
+    (64, 1, 65, 384, 40, "fp16", "fp16", False),
+    (80, 1, 72, 4096, 11008, "fp16", "fp16", False),
+    (80, 4, 161, 1536, 264, "bf16", "fp16", True),
+    (96, 1, 192, 4096, 6144, "fp16", "fp16", False),
+    (96, 2, 97, 1024, 1000, "fp16", "fp16", False),
+    (112, 1, 223, 2048, 768, "bf16", "bf16", False),
+    (112, 5, 112, 4096, 4096, "fp16", "fp16", True),
+    (128, 1, 256, 4096, 4096, "fp16", "fp16", False),
+    (128, 6, 129, 11008, 4096, "bf16", "fp16", False),
+    (80, 1, 80, 128, 256, "fp16", "fp16", False),       # a single chunk: fewer chunks than the 3 pipeline stages
+    (96, 1, 300, 256, 136, "fp16", "fp16", False),      # two chunks, several row tiles per block column
+]
+
+
+@pytest.mark.parametrize("bm,split,M,K,N,act,scl,desc_act", N128_CASES)
+def test_tiled_128_column_blocks_vs_oracle(ops, bm, split, M, K, N, act, scl, desc_act):
+    gs = 128
+    qweight, qzeros, scales, g_idx = synth_gptq(9500 + bm + M, 4, K, N, gs, desc_act=desc_act, scale_dtype=scl)
+    rng = np.random.RandomState(bm * 11 + M)
+    x = O.round_to(rng.randn(M, K).astype(np.float32) * 0.5, act)
+    bias = O.round_to(rng.randn(N).astype(np.float32) * 0.1, act)
+    try:
+        ops.set_tuning(split, 2, 1000 + bm)
+        assert ops.plan_describe(M, K, N, gs).startswith(f"tiled bm={bm} bn=128 "), ops.plan_describe(M, K, N, gs)
+        outs = [torch_to_bits(run_gptq(ops, x, qweight, qzeros, scales, g_idx, 4, gs, bias, act, scl)) for _ in range(2)]
+    finally:
+        ops.set_tuning(0, 0, 0)
+    assert np.array_equal(outs[0], outs[1])
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, bias, act, scl)
+    got = outs[0].view(np.float16).astype(np.float32) if act == "fp16" else O.bf16_from_bits(outs[0])
+    assert_forward_close(got, ref, act, tag=(bm, split, M, K, N, act, scl, desc_act))
+
+
 def test_planner_steps_in_16_rows_not_in_64(ops):
     """The staircase VERDICT r4 measured (M = 72 paid for 128 rows, M = 136 for 192) is gone from the PLAN: on the reference benchmark's
     shapes the rows the launch pays for (row tiles x tile height) never exceed the 64-row rounding and stay within 48 of M (host logic)."""
