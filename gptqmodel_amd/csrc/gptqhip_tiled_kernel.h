@@ -361,7 +361,9 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
 #ifdef GPTQHIP_TILED_INTERLEAVE
         constexpr int kInterleaveValu = GPTQHIP_TILED_INTERLEAVE;   // dev A/B builds
 #else
-        constexpr int kInterleaveValu = BM <= 80 ? 4 : 0;   // (round 5 A/B over the in-between heights: +2 % at 64 / 80 rows, 0 at 96, -2 % at 112)
+        // (round 5 A/B over the in-between heights: +2 % at 64 / 80 rows, 0 at 96, -2 % at 112; with one column tile per wave +2..3 % at
+        // 48..96 rows, -1..2 % at 32 and 128)
+        constexpr int kInterleaveValu = (TPW == 1 ? (BM >= 48 && BM <= 96) : BM <= 80) ? 4 : 0;
 #endif
         static_assert(NPIECE <= NG, "one DMA piece per fragment group");
         u4_t abuf[2][PF];
