@@ -299,14 +299,17 @@ int gptqhip_allgather_select(const void* x_local, void* const* peer_bufs, int ra
                              const int32_t* index, int n_out, void* out, int act_dtype, gptqhip_stream_t stream);
 
 /* Which kernel family and launch geometry gptqhip_gemm would use for this call, as text (triage / logging / tests; host logic, no
- * GPU): "skinny launches=1 mt=2 nt=4 waves=8 depth=2 regular=1 splits=1 gather=0" or "tiled bm=64 splits=8 tail_cols=0 gather=1".
+ * GPU): "skinny launches=1 mt=2 nt=4 waves=8 depth=2 regular=1 splits=1 gather=0", "tiled bm=64 splits=8 tail_cols=0 gather=1" or
+ * "tiled bm=80 bn=128 splits=1 tail_cols=0 gather=0" (bm = rows per block tile: 32..128 in steps of 16, or 256; bn = columns per block,
+ * printed when it is 128 = one 16-column tile per wave instead of two).
  * mt = 16-row tiles per block, nt = column tiles per block (4 / 2: the wide-layer form), gather = a separate act-order x gather pass
  * runs first.  The reference steers its kernels with thresholds too (ExllamaV2 switches to dequant + cuBLAS above 50 rows:
  * gptqmodel_ext/exllamav2/cuda/q_gemm.cu:118, config.h:4); here the crossover is measured per layer shape. */
 int gptqhip_plan_describe(int M, int K, int N, int group_size, int bits, int has_perm, char* buf, int buf_len);
 
 /* Tuning hook (benchmarks / tests): force the cross-block split-K factor and the waves per block of the skinny
- * kernel (0 = heuristic; with the prefill kernel 1 / 2 / 3 = 256- / 128- / 64-row tiles, 32..112 in steps of 16 = that tile height),
+ * kernel (0 = heuristic; with the prefill kernel 1 / 2 / 3 = 256- / 128- / 64-row tiles, 32..112 in steps of 16 = that tile height, 1000 +
+ * rows = that height with 128-column blocks),
  * or the kernel family (0 auto, 1 skinny, 2 tiled-prefill).  The overrides are THREAD-LOCAL
  * (they apply to gptqhip_gemm / gptqhip_workspace_bytes calls made by the calling thread only), so the library keeps
  * no process-global mutable state and stays re-entrant across threads, devices and streams. */
