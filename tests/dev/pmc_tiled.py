@@ -18,7 +18,9 @@ sc = (torch.rand((K // 128, N), device=dev) * 0.01 + 0.005).half()
 qw_t, meta = ops.repack_tiled(qw, qz, sc, None, 128, 4)
 x = (torch.randn(M, K, device=dev) * 0.5).half()
 out = torch.empty((M, N), dtype=torch.float16, device=dev)
-ops.set_tuning(0, 2, 0)
+# optional: argv[4] = forced variant (1 / 2 / 3 = 256 / 128 / 64 rows, 32..112, 1000 + rows = 128-column blocks), argv[5] = forced split-K
+ops.set_tuning(int(sys.argv[5]) if len(sys.argv) > 5 else 0, 2, int(sys.argv[4]) if len(sys.argv) > 4 else 0)
+print("PLAN", ops.plan_describe(M, K, N, 128), flush=True)
 for _ in range(6):
     ops.gemm(x, qw_t, meta, None, None, N, 128, 4, torch.float16, out=out)
 torch.cuda.synchronize()
