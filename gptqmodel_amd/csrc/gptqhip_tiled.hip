@@ -74,19 +74,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // Round 5: refitted per tile height (now 32 .. 128 rows in steps of 16, and 256) on graph-replayed launches over rotating cold weights
 // (tests/dev/midm_heights.py -> midm_fit.py, profiles/r05_midm_heights_sweep*.txt), with one shared term for grids that leave more
 // than a quarter of the CUs idle: + 10.5 us x max(0, 0.75 - f); and, in the same fit, a second coefficient set for the 128-column-block
-// form of the kernel (one column tile per wave, gptqhip_tiled_n128_r<rows>.hip).  2610 averaged points of four runs: relative fit error
-// 5.1 % mean / 10.8 % p90 (the run-to-run spread of a point is +-5 %); replaying the search on them the model's pick is 1.6 % (mean) behind
-// the best measured point, where the round-4 planner's pick (256-column blocks, 64 / 128 / 256 rows) is 8.9 % behind.
+// form of the kernel (one column tile per wave, gptqhip_tiled_n128_r<rows>.hip).  2703 averaged points of six runs (M = 64..2048): relative
+// fit error 5.1 % mean / 11 % p90 (the run-to-run spread of a point is +-5 %); replaying the search on them the model's pick is 1.5 % (mean)
+// behind the best measured point, where the round-4 planner's pick (256-column blocks, 64 / 128 / 256 rows) is 8.7 % behind.
 static double tiled_cost_us(int M, int K, int N, int bm, int s, int bn = kTiledBN) {
     // rows 0..7: 256-column blocks, tile heights 32 .. 128, 256; rows 8..14: 128-column blocks (one column tile per wave), heights 32 .. 128
     static const int kHeights[8] = {32, 48, 64, 80, 96, 112, 128, 256};
-    static const double kCoef[15][4] = {{-9.852, 14.356, 1.078, -0.154}, {-10.261, 16.358, 1.189, -0.162}, {-7.146, 14.581, 1.156, -0.030},
-                                        {-5.052, 13.248, 1.251, -0.036}, {-4.863, 13.763, 1.425, -0.036},  {-4.958, 14.435, 1.612, -0.084},
-                                        {-4.297, 15.313, 1.660, -0.039}, {-3.555, 18.868, 2.810, 0.039},
-                                        {-2.231, 3.778, 0.475, 0.030},   {-3.270, 5.609, 0.541, 0.035},    {-4.710, 9.364, 0.596, 0.011},
-                                        {-5.189, 10.770, 0.697, -0.014}, {-5.634, 12.229, 0.823, -0.079},  {-5.392, 12.168, 0.909, -0.085},
-                                        {-4.968, 12.529, 0.990, -0.104}};
-    const double kIdle = 10.512;
+    static const double kCoef[15][4] = {{-9.980, 14.492, 1.077, -0.152}, {-10.387, 16.491, 1.187, -0.159}, {-7.283, 14.738, 1.154, -0.029},
+                                        {-5.225, 13.447, 1.250, -0.035}, {-5.039, 13.967, 1.425, -0.035},  {-5.134, 14.638, 1.611, -0.083},
+                                        {-4.449, 15.450, 1.657, -0.030}, {-3.566, 19.111, 2.788, 0.015},
+                                        {-2.380, 3.950, 0.474, 0.030},   {-3.416, 5.773, 0.540, 0.036},    {-4.522, 8.763, 0.577, 0.054},
+                                        {-5.342, 10.944, 0.696, -0.013}, {-5.464, 11.440, 0.795, 0.001},   {-5.543, 12.336, 0.908, -0.084},
+                                        {-4.921, 11.782, 0.962, -0.008}};
+    const double kIdle = 10.819;
     int hi = 7;
     for (int i = 0; i < 8; ++i)
         if (kHeights[i] == bm) hi = i;
@@ -108,7 +108,7 @@ static double tiled_cost_us(int M, int K, int N, int bm, int s, int bn = kTiledB
     return main_us + reduce_us;
 }
 
-constexpr int kN128MaxRows = 512;   // 128-column blocks up to this many rows (the calibration sweep's range)
+constexpr int kN128MaxRows = 1024;  // 128-column blocks and the in-between tile heights up to this many rows (the calibration sweeps' range)
 
 TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_variant, int force_split) {
     TiledPlan pl;
@@ -181,15 +181,16 @@ TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_va
         // 174 -> 137 us, 8192x10240 at M=448: 101 -> 89) and kept 64-row tiles on very wide layers (8192x57344 at M<=128: 148 -> 113 us).
         double best = 1e30;
         for (int bn : {256, 128}) {
-            // (128-column blocks: 4-bit / one constant per chunk, up to 512 rows, like the in-between heights)
+            // (128-column blocks: 4-bit / one constant per chunk, up to 1024 rows, like the in-between heights)
             if (bn == 128 && (!any16 || M > kN128MaxRows)) continue;
             const int nbx_c = ceil_div(N, bn);
             for (int bm : {32, 48, 64, 80, 96, 112, 128, 256}) {
                 if (bm <= 64 && M > 1024) continue;
                 if (bn == 128 && bm == 256) continue;
-                // (the in-between heights: 4-bit / one constant per chunk, and up to 512 rows -- beyond, whole 64- / 128- / 256-row tiles waste
-                // little and the sweep that calibrated the model ends)
-                if ((!any16 || M > 512) && bm != 64 && bm != 128 && bm != 256) continue;
+                // (the in-between heights: 4-bit / one constant per chunk, and up to 1024 rows -- beyond, whole 64- / 128- / 256-row tiles
+                // waste little and the sweeps that calibrated the model end; 128-column blocks above 512 rows were swept at 64 / 96 / 128 rows)
+                if ((!any16 || M > kN128MaxRows) && bm != 64 && bm != 128 && bm != 256) continue;
+                if (bn == 128 && M > 512 && bm != 64 && bm != 96 && bm != 128) continue;
                 const long tiles = (long)nbx_c * ceil_div(M, bm);
                 for (int sc = 1; sc <= 16; ++sc) {
                     if (sc > 1 && (sc > chunks / 4 || tiles * sc > cus || (size_t)sc * M * N > ((size_t)16 << 20))) break;

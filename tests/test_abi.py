@@ -101,10 +101,11 @@ def test_prefill_planner_invariants_over_a_grid_of_shapes(lib):
                 pl = dict(kv.split("=") for kv in words[1:])
                 bm, s, tail, bn = int(pl["bm"]), int(pl["splits"]), int(pl["tail_cols"]), int(pl.get("bn", 256))
                 chunks, nbx = -(-K // 128), -(-N // bn)
-                # 128-column blocks (one column tile per wave): 4-bit / one constant per chunk, up to 512 rows (round 5)
-                assert bn == 256 or (bn == 128 and M <= 512 and bm <= 128 and tail == 0), (M, K, N, pl)
-                # tile heights: 64 / 128 / 256 everywhere; 32..112 in steps of 16 for 4-bit / one constant per chunk up to 512 rows (round 5)
-                assert bm in ((32, 48, 64, 80, 96, 112, 128, 256) if M <= 512 else (64, 128, 256)), (M, K, N, pl)
+                # 128-column blocks (one column tile per wave): 4-bit / one constant per chunk, up to 1024 rows (round 5; above 512 rows
+                # at the three heights the calibration sweep covered)
+                assert bn == 256 or (bn == 128 and M <= 1024 and bm <= 128 and tail == 0 and (M <= 512 or bm in (64, 96, 128))), (M, K, N, pl)
+                # tile heights: 64 / 128 / 256 everywhere; 32..112 in steps of 16 for 4-bit / one constant per chunk up to 1024 rows (round 5)
+                assert bm in ((32, 48, 64, 80, 96, 112, 128, 256) if M <= 1024 else (64, 128, 256)), (M, K, N, pl)
                 assert 1 <= s <= max(1, chunks // 4) and 0 <= tail < nbx, (M, K, N, pl)
                 for gs_other, bits_other in ((64, 4), (128, 8)):     # ... and never for the variants that have no such instantiation
                     b2 = ctypes.create_string_buffer(256)
@@ -159,7 +160,8 @@ def test_kernel_family_crossover_is_host_logic(lib):
         assert d(m_, 4096, 11008).get("bn") == "128" and d(m_, 4096, 11008)["splits"] == "1", (m_, d(m_, 4096, 11008))
     assert -(-72 // int(d(72, 4096, 11008)["bm"])) * int(d(72, 4096, 11008)["bm"]) <= 96 and d(136, 4096, 11008)["bm"] == "80"
     assert d(128, 4096, 4096).get("bn") == "128" and int(d(128, 4096, 4096)["splits"]) <= 4
-    assert d(513, 4096, 4096)["bm"] in ("64", "128", "256") and "bn" not in d(513, 4096, 4096)
+    assert d(1025, 4096, 4096)["bm"] in ("64", "128", "256") and "bn" not in d(1025, 4096, 4096)
+    assert d(768, 4096, 4096).get("bn") == "128" and d(768, 4096, 4096)["splits"] == "1"      # 640 / 768 rows on 4096^2: 35.0 / 36.4 -> 29.7 / 31.5 us
     assert d(160, 4096, 6144, gs=64)["bm"] in ("64", "128", "256") and "bn" not in d(160, 4096, 6144, gs=64)
     # prefill: 256- / 128- / 64-row tiles
     assert d(8192, 4096, 4096)["bm"] == "256" and d(128, 4096, 4096, bits=8)["bm"] == "64"
