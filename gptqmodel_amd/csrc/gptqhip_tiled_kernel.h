@@ -27,6 +27,14 @@
 
 #include <utility>
 
+// Cache policy of the fp32 (split-K slab / TP partial) stores: sc1 = write-through.  The slabs are read by the reduce kernel on other XCDs
+// right after the launch; written through, they do not wait in the writers' L2 for the end-of-kernel write-back (A/B round 5, same box, graph
+// replay: 11008x4096 at M = 128 with 8 slabs 23.1 -> 21.9 us, 14336x4096 26.7 -> 25.4, 4096^2 with 3 slabs 13.9 -> 13.7; `nt` instead:
+// no gain on the large slabs).  0 = plain, 2 = nt (dev A/B builds).
+#ifndef GPTQHIP_SLAB_AUX
+#define GPTQHIP_SLAB_AUX 16
+#endif
+
 #ifndef GPTQHIP_TILED_D64   // pipeline stages of the 64-row-tile instantiations (dev A/B builds override it)
 #define GPTQHIP_TILED_D64 2
 #endif
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(64 * WAVES) void tiled_kernel(TiledParams p) {
                     const f4_t v = *reinterpret_cast<const f4_t*>(slab + row * WC + (lane_e % LPR32) * 4);
                     const uint32_t off = lane_off + (uint32_t)((h * (TG32 * 16) + pass * RPP32) * ld * 4);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rs,
-                                                           lane_off >= 0xFFFFFF00u ? lane_off : off, 0, 0);
+                                                           lane_off >= 0xFFFFFF00u ? lane_off : off, 0, GPTQHIP_SLAB_AUX);
                 }
             }
         }
