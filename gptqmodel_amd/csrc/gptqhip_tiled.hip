@@ -14,6 +14,17 @@ int launch_tiled_w4(const TiledParams& p, int act_dtype, int scale_dtype, int gp
 // order either way.  The kernel takes 4.5-4.8 us for 2..8 slabs of a 128 x 4096 output whatever the load order (measured both
 // ways, profiles/r03_midm_trace.txt): it is bound by reading slabs that the producing blocks on OTHER XCDs wrote (the L2s are
 // per XCD and written back at the kernel boundary), i.e. 17 MB through the memory side at ~4 TB/s, not by latency.
+// Slab loads: non-temporal for up to four slabs (round 5 A/B, profiles/r05_slab_store_policy.txt: 4096^2 at M = 128 with 3 slabs 14.0 -> 13.7 us per
+// call, 4096x6144 at M = 72 with 4 slabs 14.1 -> 12.7, the other 3- / 4-slab cases +-1 %), plain above (8 slabs: 0..+3 % slower with nt).
+template <bool NT>
+__device__ __forceinline__ f4_t slab_load(const float* p) {
+    if constexpr (NT) {
+        return __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(p));
+    } else {
+        return *reinterpret_cast<const f4_t*>(p);
+    }
+}
+#define SLAB_LOAD(p_) slab_load<(SP > 0 && SP <= 4)>(p_)
 template <int ACT, int SP>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, const void* __restrict__ bias,
                                                             void* __restrict__ out, int M, int N, int ldo, int splits, int out_f32) {
@@ -31,21 +42,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if constexpr (SP > 0) {
         f4_t v[SP];
 #pragma unroll
-        for (int sp = 0; sp < SP; ++sp) v[sp] = *reinterpret_cast<const f4_t*>(src + (size_t)sp * stride);
+        for (int sp = 0; sp < SP; ++sp) v[sp] = SLAB_LOAD(src + (size_t)sp * stride);
         s = v[0];
 #pragma unroll
         for (int sp = 1; sp < SP; ++sp) s += v[sp];
     } else {
-        s = *reinterpret_cast<const f4_t*>(src);
+        s = SLAB_LOAD(src);
         int sp = 1;
         for (; sp + 8 <= splits; sp += 8) {
             f4_t v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f4_t*>(src + (size_t)(sp + j) * stride);
+            for (int j = 0; j < 8; ++j) v[j] = SLAB_LOAD(src + (size_t)(sp + j) * stride);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[j];
         }
-        for (; sp < splits; ++sp) s += *reinterpret_cast<const f4_t*>(src + (size_t)sp * stride);
+        for (; sp < splits; ++sp) s += SLAB_LOAD(src + (size_t)sp * stride);
     }
     if (out_f32) {
         *reinterpret_cast<f4_t*>(reinterpret_cast<float*>(out) + o) = s;
