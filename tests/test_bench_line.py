@@ -87,3 +87,15 @@ def test_emit_puts_exactly_one_line_on_stdout_and_the_detail_elsewhere(kept_reco
     assert err.getvalue().startswith("BENCH_DETAIL {")
     with open(tmp_path / "gpurun_out" / "bench_detail.json") as f:
         assert json.load(f)["configs"][5]["cases"][0]["case_id"] == "mlp_up_m64"
+
+
+def test_bench_legs_import_without_a_gpu_and_keep_the_oracle_out_of_the_timed_path():
+    """bench_legs.py (the legs outside the timed region) imports on a GPU-less box and exposes what bench.py calls lazily; bench.py itself
+    never imports the oracle -- only bench_legs.cpu_baseline does, as the thing timed beside the GPU path."""
+    import bench_legs
+    for name in ("extra_configs", "cpu_baseline", "t1_entry", "prefill_entry", "decode_entry", "ModulesStep", "T1_CASES"):
+        assert hasattr(bench_legs, name), name
+    assert len(bench_legs.T1_CASES) == 28           # the reference benchmark's grid (scripts/benchmark_marlin_a100.py:35-44)
+    with open(os.path.join(ROOT, "bench.py")) as f:
+        src = f.read()
+    assert "from oracle" not in src and "import oracle" not in src
