@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 # GPTQHIP_LIB: load another build of the library (dev A/B builds under tests/dev/ablate/; same ABI check as the product build)
 LIB_PATH = os.environ.get("GPTQHIP_LIB") or os.path.join(CSRC_DIR, "libgptqhip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # every symbol include/gptqhip.h declares: name -> (restype, argtypes)
 _c = ctypes
@@ -55,6 +55,7 @@ SIGNATURES = {
     "gptqhip_gather_cols": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "gptqhip_rmsnorm_gather": (_i, [_vp, _vp, _vp, _vp, _i, _i, _c.c_float, _i, _vp]),
     "gptqhip_set_tuning": (_i, [_i, _i, _i]),
+    "gptqhip_set_decode_form": (_i, [_i]),
 }
 
 class DecodeOp(ctypes.Structure):

@@ -24,6 +24,7 @@ static thread_local char g_err[512] = "";
 static thread_local int t_force_split = 0;
 static thread_local int t_force_kernel = 0;
 static thread_local int t_force_waves = 0;
+static thread_local int t_decode_form = -1;   // gptqhip_set_decode_form: -1 = the process default
 
 // process-wide DEFAULTS from the environment, read once and immutable afterwards (triage switches, like the env flags
 // the reference steers its kernels with, torch.py:172-190):
@@ -39,6 +40,15 @@ static int env_int(const char* name) {
 static const EnvTuning& env_tuning() {
     static const EnvTuning e = {env_int("GPTQHIP_FORCE_SPLIT_K"), env_int("GPTQHIP_FORCE_KERNEL"), env_int("GPTQHIP_FORCE_VARIANT")};
     return e;
+}
+// batch-1 decode form (include/gptqhip.h gptqhip_set_decode_form).  Process default: 3 (preload + algebraic dequant) for fp16 activations,
+// 4 (preload, the reference's per-weight rounding) for bf16 activations -- the algebraic form is outside the bf16 gate (8e-3) -- and 4 for
+// everything when GPTQHIP_DECODE_BITFAITHFUL=1 is in the environment.
+static int decode_form_for(int act_dtype, int scale_dtype) {
+    static const int bitfaithful = env_int("GPTQHIP_DECODE_BITFAITHFUL");
+    const bool exact_ok = act_dtype == GPTQHIP_FP16 && scale_dtype == GPTQHIP_FP16;   // the exact-arithmetic forms exist for fp16 x fp16 only
+    if (t_decode_form >= 0) return (t_decode_form == 1 && !exact_ok) ? 4 : t_decode_form;
+    return (bitfaithful || !exact_ok) ? 4 : 3;
 }
 #define g_force_split (t_force_split ? t_force_split : env_tuning().split)
 #define g_force_kernel (t_force_kernel ? t_force_kernel : env_tuning().kernel)
@@ -90,6 +100,10 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
     // the SAME plans gptqhip_gemm will make for this (shape, group_size, bits): both sides call these planners with
     // identical arguments, so the layout cannot drift from the launch
     size_t floats = plan_skinny(mchunk, K, N, group_size, g_force_split, g_skinny_waves, false, bits).slab_floats;
+    if (mchunk == 1) {   // the preload form of the batch-1 kernel plans without 2-deep rings (plan_skinny prefer_deep): cover both
+        const size_t f1 = plan_skinny(1, K, N, group_size, g_force_split, g_skinny_waves, false, bits, 0, true).slab_floats;
+        if (f1 > floats) floats = f1;
+    }
     {
         const size_t f4 = plan_skinny(mchunk4, K, N, group_size, g_force_split, g_skinny_waves, false, bits).slab_floats;
         if (f4 > floats) floats = f4;
@@ -136,6 +150,15 @@ int gptqhip_set_tuning(int force_split_k, int force_kernel, int force_waves) {
     t_force_split = force_split_k;
     t_force_kernel = force_kernel;
     t_force_waves = force_waves;
+    return GPTQHIP_OK;
+}
+
+int gptqhip_set_decode_form(int form) {
+    if (form < -1 || form > 4) {
+        set_error("gptqhip_set_decode_form: form=%d (0 bit-faithful, 1 stream, -1 process default)", form);
+        return GPTQHIP_EINVAL;
+    }
+    t_decode_form = form;
     return GPTQHIP_OK;
 }
 
@@ -260,6 +283,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         xin = gbuf;
     }
 
+    const int decode_form = decode_form_for(act_dtype, scale_dtype);
     GemmArgs a;
     a.qweight = qweight;
     a.meta = meta;
@@ -273,6 +297,8 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     a.out_f32 = partial_f32 ? 1 : 0;
     a.perm = fused_perm ? perm : nullptr;
     a.exact_bf16 = (flags & GPTQHIP_GEMM_EXACT_BF16) ? 1 : 0;
+    a.alg_fp16 = (decode_form == 2 || decode_form == 3) ? 1 : 0;
+    a.preload = (decode_form == 3 || decode_form == 4) ? 1 : 0;
 
     // measured crossover (profiles/r03_mid_m_sweep.txt, round 3: split-ring pipeline for 17..64 rows, 33..64 rows in one launch with
     // 4-bit weights): the decode kernel leads up to 64 rows on layers with K < 8192 and N < 6144 (4096^2 at M=64 10.7 us vs 14.8 us
@@ -319,13 +345,23 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         }
         return launch_tiled(a, tp, slabs, stream);
     }
+    // batch 1: the stream form (LDS-DMA ring + algebraic dequant, gptqhip_stream.hip) unless the caller asked for the bit-faithful chain
+    if (M == 1 && bits == 4 && !fused_perm && decode_form == 1 && g_force_kernel == 0 && g_force_split == 0 && !a.exact_bf16) {
+        const StreamPlan sp = plan_stream(K, N, group_size, bits, g_skinny_waves, false, bias != nullptr);
+        if (sp.ok) {
+            a.x = xin;
+            a.out = out;
+            a.M = 1;
+            return launch_stream(a, sp, stream);
+        }
+    }
     // skinny kernel, kSkinnyMaxM rows per launch
     for (int m0 = 0; m0 < M; m0 += rows_per_launch) {
         const int mc = (M - m0) < rows_per_launch ? (M - m0) : rows_per_launch;
         a.x = reinterpret_cast<const char*>(xin) + (size_t)m0 * K * 2;
         a.out = reinterpret_cast<char*>(out) + (size_t)m0 * N * (partial_f32 ? 4 : 2);
         a.M = mc;
-        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_skinny_waves, fused_perm, bits, 1);
+        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_skinny_waves, fused_perm, bits, 1, a.preload && mc == 1 && !fused_perm);
         rc = launch_skinny(a, pl, slabs, counters, stream);
         if (rc) return rc;
     }
@@ -417,14 +453,46 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
         set_error("gptqhip_decode_linear: M=%d outside 1..16, or M > 1 with perm / SiLU*mul input glue", M);
         return GPTQHIP_EINVAL;
     }
+    const int decode_form = decode_form_for(op->act_dtype, op->scale_dtype);
+    if (M == 1 && op->bits == 4 && !op->perm && op->in_glue != GPTQHIP_GLUE_SILU_MUL && decode_form == 1 && g_force_split == 0 &&
+        !(op->flags & GPTQHIP_GEMM_EXACT_BF16)) {
+        const StreamPlan sp = plan_stream(op->K, op->N, op->group_size, op->bits, g_skinny_waves, op->in_glue == GPTQHIP_GLUE_RMSNORM,
+                                           op->bias != nullptr || op->residual != nullptr);
+        if (sp.ok) {
+            GemmArgs a;
+            a.x = op->x;
+            a.qweight = op->qweight_t;
+            a.meta = op->meta;
+            a.bias = op->bias;
+            a.out = op->out;
+            a.M = 1;
+            a.K = op->K;
+            a.N = op->N;
+            a.group_size = op->group_size;
+            a.bits = op->bits;
+            a.act_dtype = op->act_dtype;
+            a.scale_dtype = op->scale_dtype;
+            a.out_f32 = op->out_glue == GPTQHIP_OUT_PARTIAL_F32 ? 1 : 0;
+            a.in_glue = op->in_glue;
+            a.glue_b = op->norm_weight;
+            a.residual = op->residual;
+            a.eps = op->eps;
+            a.stats_in = op->stats_in;
+            a.stats_n = op->stats_n;
+            a.stats_out = op->stats_out;
+            a.out_glue = op->out_glue == GPTQHIP_OUT_PARTIAL_F32 ? GPTQHIP_OUT_NONE : op->out_glue;
+            return launch_stream(a, sp, reinterpret_cast<hipStream_t>(stream));
+        }
+    }
     // wide layers at 5..16 rows: the decode kernel's wide form serves the RMSNorm-in / paired-SiLU-out ops (gate_up); residual /
     // statistics epilogues and the SiLU*mul input glue stay with the one-tile kernel
     const bool wide_ok = M >= 2 && !op->perm && !op->residual && !op->stats_out && op->bits == 4 && op->group_size % kChunkK == 0 &&
                          (op->in_glue == GPTQHIP_GLUE_RMSNORM || (op->in_glue == GPTQHIP_GLUE_NONE && op->out_glue == GPTQHIP_OUT_NONE)) &&
                          (op->out_glue == GPTQHIP_OUT_NONE || op->out_glue == GPTQHIP_OUT_SILU_MUL_PAIRED ||
                           (op->out_glue == GPTQHIP_OUT_PARTIAL_F32 && op->in_glue == GPTQHIP_GLUE_NONE));
+    const bool preload_form = (decode_form == 3 || decode_form == 4) && M == 1 && !op->perm && op->bits == 4;
     const SkinnyPlan pl = plan_skinny(M, op->K, op->N, op->group_size, g_force_split, g_skinny_waves, op->perm != nullptr, op->bits,
-                                      !wide_ok ? 0 : (op->in_glue == GPTQHIP_GLUE_RMSNORM ? 2 : 1));
+                                      !wide_ok ? 0 : (op->in_glue == GPTQHIP_GLUE_RMSNORM ? 2 : 1), preload_form);
     if (op->perm && !(pl.depth == 4 && (size_t)op->K * 2 <= kInKernelPermMaxRowBytes)) {
         set_error("gptqhip_decode_linear: K=%d is outside the in-kernel act-order variant (gather x and pass perm = NULL)", op->K);
         return GPTQHIP_EINVAL;
@@ -443,6 +511,8 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
     GemmArgs a;
     a.x = op->x;
     a.exact_bf16 = (op->flags & GPTQHIP_GEMM_EXACT_BF16) ? 1 : 0;
+    a.alg_fp16 = (decode_form == 2 || decode_form == 3) ? 1 : 0;
+    a.preload = (decode_form == 3 || decode_form == 4) ? 1 : 0;
     a.perm = op->perm;
     a.qweight = op->qweight_t;
     a.meta = op->meta;

@@ -18,6 +18,8 @@ struct GemmArgs {
     int out_f32;  // write unrounded fp32 accumulators (tensor-parallel partial sums)
     const int32_t* perm = nullptr;  // act-order permutation the kernel applies to x itself (decode, M == 1), else nullptr
     int exact_bf16 = 0;  // GPTQHIP_GEMM_EXACT_BF16 (decode kernel, bf16 activations)
+    int preload = 0;     // decode form 3: skinny1_kernel (x / constants of a wave's chunks parked in LDS up front: one VMEM instruction per chunk)
+    int alg_fp16 = 0;    // decode form 2: algebraic dequant in the skinny kernel (fp16 activations, M <= 4, 4-bit, one constant per chunk)
     int ldo = 0;  // output row stride in elements (0: N) -- lets a launch cover a column sub-range of a wider output
     // batch-1 decode op (gptqhip_decode_linear): fused decoder-layer glue of the skinny kernel's M == 1 variant
     int in_glue = 0;                 // GPTQHIP_GLUE_*
@@ -54,12 +56,29 @@ struct TiledPlan {
     int bn = 256;       // columns per block: 256, or 128 (one column tile per wave: 4-bit, one constant per chunk, bm 64 / 128)
 };
 
+// decode_stream_kernel (gptqhip_stream.hip): batch-1 decode op with the weights streamed HBM -> LDS by LDS-DMA
+struct StreamPlan {
+    int ok;                // the shape is served (4-bit, K % 128 == 0, one group constant per chunk, LDS map fits 160 KiB)
+    int chunks, tiles;
+    int waves;             // waves per block (in-block split-K)
+    int grid;              // blocks; block b works on tiles b, b + grid, ...
+    int tiles_per_block;
+    int x_rounds;          // 1 KiB pieces of the x row staged per wave
+    int ring_slots;        // 1 KiB slots of a wave's LDS ring
+    int off_nw, off_csum, off_stats, off_ring, off_red, off_epi, off_scr, off_meta, lds_bytes;   // LDS map
+    int meta_pieces;       // 1 KiB pieces of a tile's constant block
+};
+// with_norm: the call carries the RMSNorm input glue (norm weight + statistics staged in LDS); with_epi: a residual or bias
+StreamPlan plan_stream(int K, int N, int group_size, int bits, int force_waves, bool with_norm, bool with_epi);
+int launch_stream(const GemmArgs& a, const StreamPlan& pl, hipStream_t stream);
+
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
 // in_kernel_perm: the plan is for the batch-1 act-order variant (AM_ROW1P), which only exists with the 4-deep ring
 SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm = false, int bits = 4,
-                       int allow_wide = 0);   // 0: one column tile per block; 1: wide form from 5 rows; 2: decode op with glue (from 2 rows)
+                       int allow_wide = 0,    // 0: one column tile per block; 1: wide form from 5 rows; 2: decode op with glue (from 2 rows)
+                       bool prefer_deep = false);   // batch 1: no 2-deep ring plans on K >= 4096 (the preload form of the decode kernel)
 int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* counters, hipStream_t stream);
 
 TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_variant, int force_split);

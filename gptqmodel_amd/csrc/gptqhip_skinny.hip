@@ -68,6 +68,8 @@ struct SkinnyParams {
     int regular;           // every wave owns a multiple of D chunks: straight-line counted-wait pipeline
     int cpg_shift;         // log2(chunks per group) when group_size is 128 * 2^n, else -1 (integer division)
     int exact_bf16;        // GPTQHIP_GEMM_EXACT_BF16: see compute_stage
+    int alg_fp16;          // decode form 2: algebraic dequant for fp16 activations (compute_stage)
+    int slot_stride;       // skinny1_kernel: bytes of a wave's LDS slot
     // batch-1 decode op (gptqhip_decode_linear): decoder-layer glue fused into the GEMV (GLUE template parameter)
     const void* glue_b;    // RMSNORM: norm weight [K]; SILU_MUL: nullptr (up = x + K)
     const void* residual;  // [N] or nullptr: out = act(residual + y)
@@ -430,6 +432,46 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[0][i] = __builtin_fmaf(s, __builtin_fmaf(sg[i], -zc, ag[i]), acc[0][i]);
         return;
+    }
+    if constexpr (BITS == 4 && ACT == kFP16 && SCL == kFP16 && GPC == 1 && (AM == AM_ROW1 || AM == AM_ROW1P || AM == AM_ROW4)) {
+        if (p.alg_fp16) {
+            // decode forms 2 / 3 (round 6; block-uniform branch): GROUP-FACTORED dequant.  The code pairs become the exact small integers
+            // (q - z) in fp16 -- (w & 0x000F000F) | 0x6400 = 1024 + q and (w & 0x00F000F0) | 0x5400 = 64 + q, one packed add of the pre-baked
+            // -(1024 + z) | -(64 + z) each -- and go into the MFMA unscaled; the group's scale multiplies the fp32 partial sum once per chunk:
+            //     y = sum_g s_g * ( sum_{k in g} x_k (q_k - z_g) ).
+            // 9 VALU per packed word instead of 13 (no per-weight multiply).  Exact products, fp32 accumulation: this is the exact-arithmetic
+            // value of the reference's y = x @ (s (q - z)); it differs from the reference's chain only by the reference's own per-weight
+            // rounding fp16(s (q - z)) (2^-12 relative, random).  (Measured first and dropped: feeding 1024 + q / 64 + q straight into the MFMA
+            // and subtracting the offsets per chunk -- 5 VALU per word, +2 % on the chain, but the fp32 accumulator then carries 1024 x sum|x|
+            // and an activation row with outliers loses 0.25 absolute on outputs of a few hundred: outside the reference's element-wise atol.)
+            const uint32_t mw = st.meta[0];
+            const float s = bits16_to_f32<SCL>((uint16_t)(mw & 0xffffu));
+            const uint32_t zc = mw >> 16;                                  // 0xE400 | z = fp16 -(1024 + z)
+            const h2_t zlo = as_h2(zc | (zc << 16));
+            const uint32_t zh = 0xD400u | ((zc & 0xFu) << 4);              // fp16 -(64 + z)
+            const h2_t zhi = as_h2(zh | (zh << 16));
+            uint32_t magic_hi = 0x54005400u;
+            asm volatile("" : "+v"(magic_hi));
+            f4_t g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w = st.w[0][j], w8 = w >> 8;
+                u4_t b;
+                b.x = as_u32(as_h2(and_or(w, dk.lo, dk.magic)) + zlo);
+                b.y = as_u32(as_h2(and_or(w, dk.hi, magic_hi)) + zhi);
+                b.z = as_u32(as_h2(and_or(w8, dk.lo, dk.magic)) + zlo);
+                b.w = as_u32(as_h2(and_or(w8, dk.hi, magic_hi)) + zhi);
+                const u4_t av = aslot[abase + 4 * j + rq];
+                if (j & 1) {
+                    g1 = mfma16<ACT>(av, b, g1);
+                } else {
+                    g0 = mfma16<ACT>(av, b, g0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[0][i] = __builtin_fmaf(s, g0[i] + g1[i], acc[0][i]);
+            return;
+        }
     }
     ColConst cc = expand_meta<BITS, SCL>(st.meta[0]);
 #pragma unroll
@@ -982,6 +1024,233 @@ void skinny_kernel(SkinnyParams p) {
 
 
 // ------------------------------------------------------------------------------------------------
+// Batch 1, "preload" form (round 6; decode forms 2 / 3 of gptqhip_set_decode_form).  Same mapping as skinny_kernel's M = 1 regular pipeline
+// (one 16-column tile per block, W waves split the K range chunk by chunk, D-deep register ring of nt weight loads, in-block LDS
+// reduction, finish_outputs epilogue) with the two changes the round-6 counters asked for (profiles/r06_pmc_summary.json: the M = 1
+// kernel issues 82 VALU and 3 VMEM instructions per 1 KiB chunk; VALU busy 55 % of the launch on gate_up):
+//   * ONE VMEM instruction per chunk.  skinny_kernel's ring stage carries a 4-byte x load and a 4-byte constant load beside the 1 KiB
+//     weight load (round-2 ablation: those two cost 2.6 us of gate_up's 15).  Here a wave fetches the x pieces (16 B per lane: four chunks
+//     per instruction), the norm-weight pieces and the group constants of ALL its chunks in front of the weight ring (<= 16 chunks per
+//     wave: at most 12 instructions, once), applies the input glue once, and parks them in its private LDS slot; the ring then holds
+//     weights only and a chunk costs four ds_read_b128 + one ds_read_b32.
+//   * ALG = 1 (fp16 activations): group-factored dequant (see compute_stage's decode forms 2 / 3): exact (q - z) pairs into the MFMA,
+//     9 VALU per packed word, the scale once per chunk in fp32.  ALG = 0 keeps the bit-faithful per-weight rounding.
+// Replaces nothing upstream beyond what skinny_kernel does (TorchLinear._forward_eager, torch.py:326-347).
+// ------------------------------------------------------------------------------------------------
+template <int ACT, int SCL, int D, int GLUE, int ALG>
+__global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = blockDim.x >> 6;
+    const int c = lane & 15, rq = lane >> 4;
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(p.chunks, c_begin + p.chunks_per_split);
+    const int n_mine = p.n_mine;                       // chunks per wave incl. the padding of the last ring round
+    const int nq = (n_mine + 3) >> 2;                  // 16-byte x instructions (four chunks each)
+    char* const slot = reinterpret_cast<char*>(lds) + wave * p.slot_stride;
+    u4_t* const xs = reinterpret_cast<u4_t*>(slot);                                   // [4 nq][16] u4: the glued x pieces
+    uint32_t* const ms = reinterpret_cast<uint32_t*>(slot + nq * 1024);               // [4 nq][16] meta words
+    int* s_last = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + W * p.slot_stride);
+    float* scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + W * p.slot_stride + 16);
+    float(*red)[4][64] = reinterpret_cast<float(*)[4][64]>(lds);
+    const DequantConsts dk = make_dequant_consts<4>();
+    const char* wbase = reinterpret_cast<const char*>(p.qw) + (size_t)tile * p.chunks * 1024;
+    const char* mbase = reinterpret_cast<const char*>(p.meta + (size_t)tile * p.G * 16);
+    const uint32_t lane16 = (uint32_t)lane * 16u, c4 = (uint32_t)c * 4u;
+
+    uint32_t res_raw = 0u;
+    if (p.residual != nullptr && wave == 0 && rq == 0) {
+        const int coln = tile * kTileN + c;
+        res_raw = reinterpret_cast<const uint32_t*>(p.residual)[(size_t)(coln < p.N ? coln : 0) >> 1];
+    }
+    f4_t sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if constexpr (GLUE == kGlueRmsNorm) {
+        if (p.stats_in != nullptr && wave == 0) {
+            // the producer's per-tile sums of squares, in front of everything: ONE 16-byte load per lane covers 256 partial sums (a second
+            // one up to 512); entries past stats_n are outside the descriptor and read as zeros
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.stats_in), 0, p.stats_n * 4, 0x00020000);
+            sv[0] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, 0, 0));
+            if (p.stats_n > 256) sv[1] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, 1024, 0));
+        }
+    }
+    // this wave's x pieces / norm-weight pieces / group constants: lane (rq, c) of instruction q serves the wave's chunk 4 q + rq
+    u4_t xq[4], gq[4];
+    uint32_t mq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q < nq) {
+            int ck = c_begin + wave + (4 * q + rq) * W;
+            ck = ck < c_end ? ck : c_end - 1;           // padding chunks: any finite values (their stages are skipped)
+            xq[q] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.x) + (size_t)ck * 256 + c * 16);
+            if constexpr (GLUE == kGlueRmsNorm) gq[q] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (size_t)ck * 256 + c * 16);
+            mq[q] = *reinterpret_cast<const uint32_t*>(mbase + ((size_t)(ck >> p.cpg_shift) << 6) + c4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep them in FRONT of the ring
+    // weight ring
+    u4_t st[D];
+    int nxt = c_begin + wave;
+    auto load_w = [&](u4_t& dst) __attribute__((always_inline)) {
+        const int ck = nxt < c_end ? nxt : c_end - 1;
+        dst = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wbase + (size_t)ck * 1024 + lane16));
+        nxt += W;
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_w(st[d]);
+
+    float inv = 1.f;
+    if constexpr (GLUE == kGlueRmsNorm) {
+        if (p.stats_in != nullptr) {
+            if (wave == 0) {
+                float ssum = ((sv[0][0] + sv[0][1]) + (sv[0][2] + sv[0][3])) + ((sv[1][0] + sv[1][1]) + (sv[1][2] + sv[1][3]));   // fixed order
+#pragma unroll
+                for (int mk = 32; mk >= 1; mk >>= 1) ssum += __shfl_xor(ssum, mk, 64);
+                if (lane == 0) scratch[0] = rsqrtf(ssum / (float)p.K + p.eps);
+            }
+        } else {
+            // no producer statistics (first op of a step; the planner keeps splits == 1 here): the waves' pieces cover the row exactly once
+            float ss = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < nq && c_begin + wave + (4 * q + rq) * W < c_end) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = bits16_to_f32<ACT>((uint16_t)(xq[q][j] & 0xffffu)), b = bits16_to_f32<ACT>((uint16_t)(xq[q][j] >> 16));
+                        ss = __builtin_fmaf(a, a, ss);
+                        ss = __builtin_fmaf(b, b, ss);
+                    }
+                }
+            }
+#pragma unroll
+            for (int mk = 32; mk >= 1; mk >>= 1) ss += __shfl_xor(ss, mk, 64);
+            if (lane == 0) scratch[1 + wave] = ss;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float tot = 0.f;
+                for (int w = 0; w < W; ++w) tot += scratch[1 + w];
+                scratch[0] = rsqrtf(tot / (float)p.K + p.eps);
+            }
+        }
+        __syncthreads();
+        inv = scratch[0];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q < nq) {
+            u4_t g = xq[q];
+            if constexpr (GLUE == kGlueRmsNorm) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = glue_pair<ACT>(xq[q][j], gq[q][j], inv, GLUE);
+            }
+            xs[q * 64 + lane] = g;
+            ms[q * 64 + lane] = mq[q];
+        }
+    }
+
+    f4_t acc = {0.f, 0.f, 0.f, 0.f};
+    uint32_t magic_hi = 0x54005400u;
+    asm volatile("" : "+v"(magic_hi));
+    auto compute = [&](const u4_t& wv, int li) __attribute__((always_inline)) {
+        const uint32_t mw = ms[li * 16 + c];
+        const u4_t* xa = xs + li * 16 + rq;
+        if constexpr (ALG == 1 && ACT == kFP16 && SCL == kFP16) {
+            // group-factored dequant (compute_stage's decode forms 2 / 3): exact (q - z) pairs into the matrix pipe (two independent chains),
+            // the scale once per chunk in fp32.  Only output row 0 exists at M = 1: accumulator register 0.
+            const float sc = bits16_to_f32<SCL>((uint16_t)(mw & 0xffffu));
+            const uint32_t zc = mw >> 16;                                  // 0xE400 | z = fp16 -(1024 + z)
+            const h2_t zlo = as_h2(zc | (zc << 16));
+            const uint32_t zh = 0xD400u | ((zc & 0xFu) << 4);              // fp16 -(64 + z)
+            const h2_t zhi = as_h2(zh | (zh << 16));
+            f4_t g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w = wv[j], w8 = w >> 8;
+                u4_t b;
+                b.x = as_u32(as_h2(and_or(w, dk.lo, dk.magic)) + zlo);
+                b.y = as_u32(as_h2(and_or(w, dk.hi, magic_hi)) + zhi);
+                b.z = as_u32(as_h2(and_or(w8, dk.lo, dk.magic)) + zlo);
+                b.w = as_u32(as_h2(and_or(w8, dk.hi, magic_hi)) + zhi);
+                if (j & 1) {
+                    g1 = mfma16<ACT>(xa[4 * j], b, g1);
+                } else {
+                    g0 = mfma16<ACT>(xa[4 * j], b, g0);
+                }
+            }
+            acc[0] = __builtin_fmaf(sc, g0[0] + g1[0], acc[0]);
+        } else {
+            const ColConst cc = expand_meta<4, SCL>(mw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = mfma16<ACT>(xa[4 * j], dequant_word4<ACT, SCL>(wv[j], cc, dk), acc);
+        }
+    };
+    int cur = c_begin + wave, li = 0;
+    for (int it = D; it < n_mine; it += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            compute(st[d], li);
+            load_w(st[d]);
+#ifndef GPTQHIP_SK1_NOPIN
+            __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: hipcc otherwise sinks a round's four loads to its end and the ring drains to zero
+#endif
+            cur += W;
+            ++li;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        if (cur < c_end) compute(st[d], li);     // (only the last ring round can hold padding chunks: wave-uniform skip)
+        cur += W;
+        ++li;
+    }
+
+    // ---- in-block split-K reduction through LDS (the slots alias the reduction rows) ----
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    const bool reducer = wave < 4;
+    const int m = 4 * rq + wave;
+    const int n = tile * kTileN + c;
+    const bool live = reducer && m < p.M && n < p.N;
+    float v = 0.f;
+    if (reducer) {
+        for (int w = 0; w < W; ++w) v += red[w][wave][lane];
+    }
+    finish_outputs<ACT>(p, v, live, m, n, tile, split, wave, lane, res_raw, s_last);
+}
+
+constexpr int kPreloadMaxChunks = 16;   // chunks per wave the preload form parks (four 16-byte x instructions)
+
+// 0 when the call is outside the preload form
+template <int ACT, int SCL>
+static int launch_skinny1(const SkinnyParams& p0, const SkinnyPlan& pl, int alg, hipStream_t stream, bool* served) {
+    *served = false;
+    if (p0.M != 1 || pl.mt != 1 || pl.gpc != 1 || !pl.regular || pl.nt > 1 || p0.perm != nullptr || p0.n_mine > kPreloadMaxChunks) return 0;
+    if (p0.in_glue != kGlueNone && p0.in_glue != kGlueRmsNorm) return 0;
+    if (p0.in_glue == kGlueRmsNorm && p0.stats_in == nullptr && p0.splits > 1) return 0;
+    if (p0.exact_bf16 || (pl.depth != 2 && pl.depth != 4)) return 0;
+    SkinnyParams p = p0;
+    const int stride = ((p.n_mine + 3) >> 2) * 1280;     // x pieces + constants (>= the 1 KiB per wave the reduction rows need)
+    p.slot_stride = stride;
+    const dim3 grid(ceil_div(p.N, kTileN), p.splits), block(64 * pl.waves);
+    const size_t lds_bytes = (size_t)pl.waves * stride + 16 + 80;
+    const bool a1 = alg != 0 && ACT == kFP16 && SCL == kFP16;   // (bf16 scales: the reference rounds W to bf16 -- 2^-9 per weight -- keep its chain)
+#define GPTQHIP_L1(D_, G_, A_) hipLaunchKernelGGL((skinny1_kernel<ACT, SCL, D_, G_, A_>), grid, block, lds_bytes, stream, p)
+    if (pl.depth == 4) {
+        if (p.in_glue == kGlueRmsNorm) { if (a1) GPTQHIP_L1(4, kGlueRmsNorm, 1); else GPTQHIP_L1(4, kGlueRmsNorm, 0); }
+        else { if (a1) GPTQHIP_L1(4, kGlueNone, 1); else GPTQHIP_L1(4, kGlueNone, 0); }
+    } else {
+        if (p.in_glue == kGlueRmsNorm) { if (a1) GPTQHIP_L1(2, kGlueRmsNorm, 1); else GPTQHIP_L1(2, kGlueRmsNorm, 0); }
+        else { if (a1) GPTQHIP_L1(2, kGlueNone, 1); else GPTQHIP_L1(2, kGlueNone, 0); }
+    }
+#undef GPTQHIP_L1
+    *served = true;
+    return check_hip(hipGetLastError(), "skinny1_kernel launch");
+}
+
+// ------------------------------------------------------------------------------------------------
 // Wide layers (N >= 8192 columns: fused gate_up, lm_head, the 70B projections) at 5..32 rows.  skinny_kernel gives every 16-column tile its own
 // block, so each of the N/16 blocks stages the WHOLE activation tile (M x K) from L2 through LDS: 1792 x 256 KiB = 460 MB of
 // on-chip traffic for 61 MB of weights on a Llama-3-8B gate_up at M = 32 (profiles/r03_mid_m_sweep.txt: 32 us where the weights
@@ -1339,7 +1608,7 @@ static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStre
     }
 }
 
-SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm, int bits, int allow_wide) {
+SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm, int bits, int allow_wide, bool prefer_deep) {
     static const bool allow_depth2 = [] { const char* v = getenv("GPTQHIP_NO_DEPTH2"); return !(v && *v && *v != '0'); }();
     static const bool allow_pad = [] { const char* v = getenv("GPTQHIP_NO_PAD"); return !(v && *v && *v != '0'); }();   // A/B switch
     SkinnyPlan pl;
@@ -1372,7 +1641,8 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
         // gives whole rounds of the 4-deep ring, so those rows may ride the 2-deep pipeline of the 5..8-row variant (round 4: before,
         // the shape fell off the regular pipeline and gptqhip_decode_supported said no -- found by tests/test_gpu_tp8_shapes.py)
         const bool short_k_rows = M >= 2 && M <= 4 && pl.chunks < 16 && !in_kernel_perm;
-        const int depth_lo = ((M == 1 && allow_depth2 && !in_kernel_perm) || short_k_rows) ? 2 : pl.depth;
+        // (prefer_deep: the preload form, skinny1_kernel -- 8 waves x 4 chunks beat 16 x 2 on 4096^2: 4.39 vs 4.68 us, profiles/r06_decode_forms.txt)
+        const int depth_lo = ((M == 1 && allow_depth2 && !in_kernel_perm && !(prefer_deep && pl.chunks >= 32)) || short_k_rows) ? 2 : pl.depth;
         // pass 0: exact plans (every wave's chunks are whole ring rounds); pass 1: plans whose LAST round carries padding chunks
         // (clamped loads, skipped compute -- see Cursor) for chunk counts with awkward factors (Llama-2 down_proj: 86 = 2 * 43,
         // Qwen2-7B: 148 = 4 * 37), accepted up to 1/8 of wasted loads, least waste first
@@ -1528,6 +1798,7 @@ int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* co
         p.cpg_shift = a.group_size == 64 ? 1 : 0;   // GPC == 4 on the regular pipeline: K-steps (32 rows) per group, log2
     }
     p.exact_bf16 = a.exact_bf16;
+    p.alg_fp16 = a.alg_fp16;
     p.glue_b = a.glue_b;
     p.residual = a.residual;
     p.eps = a.eps;
@@ -1548,6 +1819,15 @@ int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* co
         if (a.act_dtype == kBF16 && a.scale_dtype == kFP16) return launch_wide<kBF16, kFP16>(p, pl, stream);
         if (a.act_dtype == kFP16 && a.scale_dtype == kBF16) return launch_wide<kFP16, kBF16>(p, pl, stream);
         return launch_wide<kBF16, kBF16>(p, pl, stream);
+    }
+    if (a.preload && a.bits == 4) {
+        bool served = false;
+        int rc = 0;
+        if (a.act_dtype == kFP16 && a.scale_dtype == kFP16) rc = launch_skinny1<kFP16, kFP16>(p, pl, a.alg_fp16, stream, &served);
+        else if (a.act_dtype == kBF16 && a.scale_dtype == kFP16) rc = launch_skinny1<kBF16, kFP16>(p, pl, a.alg_fp16, stream, &served);
+        else if (a.act_dtype == kFP16 && a.scale_dtype == kBF16) rc = launch_skinny1<kFP16, kBF16>(p, pl, a.alg_fp16, stream, &served);
+        else rc = launch_skinny1<kBF16, kBF16>(p, pl, a.alg_fp16, stream, &served);
+        if (served) return rc;
     }
 #define GPTQHIP_DISPATCH(B, A_, S_) return launch_skinny_mt<B, A_, S_>(p, pl, stream)
     if (a.bits == 4) {

@@ -449,3 +449,10 @@ def plan_describe(M: int, K: int, N: int, group_size: int, bits: int = 4, has_pe
 def set_tuning(force_split_k: int = 0, force_kernel: int = 0, force_waves: int = 0) -> None:
     _need_cache.clear()  # forced plans change the workspace layout
     _lib.check(_lib.load().gptqhip_set_tuning(force_split_k, force_kernel, force_waves), "gptqhip_set_tuning")
+
+
+def set_decode_form(form: int = -1) -> None:
+    """Batch-1 decode form for the calling thread (include/gptqhip.h gptqhip_set_decode_form): 1 = the stream kernel (LDS-DMA weight ring,
+    algebraic dequant on the matrix pipe; default), 0 = the bit-faithful skinny kernel (the reference's per-weight rounding chain),
+    -1 = the process default (GPTQHIP_DECODE_BITFAITHFUL=1 in the environment makes that 0)."""
+    _lib.check(_lib.load().gptqhip_set_decode_form(form), "gptqhip_set_decode_form")

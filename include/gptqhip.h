@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GPTQHIP_ABI_VERSION 17
+#define GPTQHIP_ABI_VERSION 18
 
 /* error codes */
 #define GPTQHIP_OK 0
@@ -314,6 +314,19 @@ int gptqhip_plan_describe(int M, int K, int N, int group_size, int bits, int has
  * (they apply to gptqhip_gemm / gptqhip_workspace_bytes calls made by the calling thread only), so the library keeps
  * no process-global mutable state and stays re-entrant across threads, devices and streams. */
 int gptqhip_set_tuning(int force_split_k, int force_kernel, int force_waves);
+
+/* Batch-1 decode form (round 6; gptqhip_gemm at M = 1 and gptqhip_decode_linear at M = 1, 4-bit, group_size % 128 == 0, no in-kernel
+ * act-order permutation):
+ *   1 (default)  decode_stream_kernel (gptqmodel_amd/csrc/gptqhip_stream.hip): weights streamed HBM -> LDS by LDS-DMA, the raw code pairs
+ *                (1024 + q | 64 + q in fp16, 128 + q in bf16) contracted with x on the matrix pipe and the offsets / zero-points / scale
+ *                taken out per 128-row chunk in fp32: y = sum_g s_g * (sum_k x_k (o_k + q_k) - sum_k x_k (o_k + z_g)).  That is the
+ *                exact-arithmetic value of the reference's y = x @ (s * (q - z)) (TorchLinear._forward_eager, torch.py:326-347) WITHOUT
+ *                the reference's per-weight rounding fp16(s * (q - z)) (torch.py:716-717): inside north_star's 1e-3 bar on every golden,
+ *                not bit-identical to the bit-faithful form.
+ *   0            the bit-faithful skinny_kernel (every weight rounded like the reference before the contraction), ~15 % slower.
+ *  -1            back to the process default (1, or 0 when GPTQHIP_DECODE_BITFAITHFUL=1 is in the environment).
+ * THREAD-LOCAL like gptqhip_set_tuning.  The reference has the same kind of switch for its own kernels (env flags, torch.py:172-190). */
+int gptqhip_set_decode_form(int form);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,123 @@
+"""GPU tests of the batch-1 decode FORMS (include/gptqhip.h gptqhip_set_decode_form; round 6):
+  0  skinny_kernel, the reference's per-weight rounding            (bit-faithful)
+  4  skinny1_kernel (preload), the reference's per-weight rounding (bit-faithful; the bf16 default)
+  3  skinny1_kernel (preload) + group-factored dequant             (the fp16 default: exact (q - z), scale per chunk in fp32)
+  2  skinny_kernel + group-factored dequant
+  1  decode_stream_kernel (LDS-DMA weight ring, offsets / zero-points taken out per chunk)   -- opt-in, measured slower
+Every form against the numpy oracle (TorchLinear semantics, oracle/gptq_oracle.py) on the decode ops a Llama layer runs, with the glue the
+decode chain uses; the bit-faithful forms under the UNSCALED element-wise gate of the reference's own test."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_forward_close, f32_to_torch, synth_gptq, torch_to_f32
+from oracle import gptq_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FORMS = {0: True, 4: True, 3: False, 2: False, 1: False}     # form -> strict element-wise atol
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gptqmodel_amd import ops as _ops
+    yield _ops
+    _ops.set_decode_form(-1)
+
+
+def _tiled(ops, qweight, qzeros, scales, gs, sdt="fp16"):
+    sc = f32_to_torch(scales, sdt, DEV)
+    return ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV), sc, None, gs, 4) + (sc,)
+
+
+@pytest.mark.parametrize("form", sorted(FORMS))
+@pytest.mark.parametrize("K,N,gs", [(4096, 4096, 128), (4096, 6144, 128), (14336, 4096, 128), (4096, 1024, 128), (8192, 1024, 256),
+                                    (11008, 4096, 128), (4096, 512, 4096)])
+@pytest.mark.parametrize("act,sdt", [("fp16", "fp16"), ("bf16", "bf16"), ("fp16", "bf16")])
+def test_plain_op_every_form_vs_oracle(ops, form, K, N, gs, act, sdt):
+    if act == "bf16" and not FORMS[form]:
+        pytest.skip("bf16 activations keep the reference's per-weight rounding: the exact-arithmetic forms are outside the bf16 gate (8e-3)")
+    qweight, qzeros, scales, g_idx = synth_gptq(500 + K // 128 + N // 16 + gs, 4, K, N, gs, scale_dtype=sdt)
+    rng = np.random.RandomState(5)
+    x = O.round_to(rng.randn(1, K).astype(np.float32) * 0.5, act)
+    bias = O.round_to(rng.randn(N).astype(np.float32) * 0.1, act)
+    qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, gs, sdt)
+    ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, bias, act, sdt)
+    ops.set_decode_form(form)
+    try:
+        out = ops.decode_linear(f32_to_torch(x[0], act, DEV), qw_t, meta, f32_to_torch(bias, act, DEV), K, N, gs, 4, sc.dtype)
+        gen = ops.gemm(f32_to_torch(x, act, DEV), qw_t, meta, f32_to_torch(bias, act, DEV), None, N, gs, 4, sc.dtype)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_decode_form(-1)
+    assert_forward_close(torch_to_f32(out)[None], ref, act, tag=("decode op", form), strict_atol=FORMS[form])
+    assert_forward_close(torch_to_f32(gen), ref, act, tag=("gemm M=1", form), strict_atol=FORMS[form])
+    assert torch.equal(out, gen[0]), "the plugin path (gptqhip_gemm at M = 1) and the decode op must run the same form"
+
+
+@pytest.mark.parametrize("form", sorted(FORMS))
+def test_bit_faithful_forms_agree_bit_for_bit(ops, form):
+    """Forms 0 and 4 share the rounding chain and the summation order of a tile's K range: identical bits on a plain op."""
+    if not FORMS[form]:
+        pytest.skip("exact-arithmetic form")
+    K, N, gs = 4096, 4096, 128
+    qweight, qzeros, scales, g_idx = synth_gptq(77, 4, K, N, gs)
+    x = f32_to_torch(O.round_to(np.random.RandomState(6).randn(K).astype(np.float32), "fp16"), "fp16", DEV)
+    qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, gs)
+    outs = {}
+    try:
+        for f in (0, form):
+            ops.set_decode_form(f)
+            outs[f] = ops.decode_linear(x, qw_t, meta, None, K, N, gs, 4, sc.dtype).clone()
+    finally:
+        ops.set_decode_form(-1)
+    torch.cuda.synchronize()
+    if form == 4:   # (16 x 2 chunks in form 0 vs 8 x 4 in the preload form on this shape: same chunks, different wave grouping)
+        assert_forward_close(torch_to_f32(outs[4])[None], torch_to_f32(outs[0])[None], "fp16", strict_atol=True)
+    else:
+        assert torch.equal(outs[0], outs[form])
+
+
+@pytest.mark.parametrize("form", sorted(FORMS))
+@pytest.mark.parametrize("act", ["fp16", "bf16"])
+def test_layer_ops_with_glue_every_form(ops, form, act):
+    """The four ops of a decoder layer the way the chain runs them (RMSNorm from producer statistics, residual + stats_out, paired
+    SiLU*mul epilogue), reference-scale activations, every form against the oracle's composition of the same steps."""
+    if act == "bf16" and not FORMS[form]:
+        pytest.skip("bf16 activations keep the reference's per-weight rounding")
+    gs, hidden, inter = 128, 4096, 1024
+    rng = np.random.RandomState(31)
+    h = O.round_to(rng.randn(hidden).astype(np.float32) * 0.5, act)
+    w = O.round_to(1.0 + rng.randn(hidden).astype(np.float32) * 0.1, act)
+    a_in = O.round_to(rng.randn(hidden).astype(np.float32) * 0.3, act)
+    strict = FORMS[form]
+    ops.set_decode_form(form)
+    try:
+        # o_proj-like: h1 = h + a @ Wo, statistics out
+        qw_o, qz_o, sc_o, gi_o = synth_gptq(43, 4, hidden, hidden, gs)
+        qwo_t, meta_o, sco = _tiled(ops, qw_o, qz_o, sc_o, gs)
+        stats = torch.zeros(hidden // 16, dtype=torch.float32, device=DEV)
+        h1 = ops.decode_linear(f32_to_torch(a_in, act, DEV), qwo_t, meta_o, None, hidden, hidden, gs, 4, sco.dtype,
+                               residual=f32_to_torch(h, act, DEV), stats_out=stats)
+        h1_np = torch_to_f32(h1)
+        y_o = O.forward_gptq(a_in[None], qw_o, qz_o, sc_o, gi_o, 4, None, act, "fp16")
+        assert_forward_close(h1_np[None], O.residual_add_ref(h[None], y_o, act), act, tag=("residual+stats", form), strict_atol=strict)
+        assert np.allclose(stats.cpu().numpy(), (h1_np.astype(np.float64) ** 2).reshape(-1, 16).sum(axis=1), rtol=1e-5)
+        # gate_up-like: a = silu(g) * u, g|u = rmsnorm(h1) @ Wgu, columns interleaved in blocks of 8; statistics in (and, separately, none)
+        qweight, qzeros, scales, g_idx = synth_gptq(41, 4, hidden, 2 * inter, gs)
+        order = np.stack([np.arange(inter).reshape(-1, 8), (inter + np.arange(inter)).reshape(-1, 8)], axis=1).reshape(-1)
+        qw_i, sc_i = np.ascontiguousarray(qweight[:, order]), np.ascontiguousarray(scales[:, order])
+        qz_i = O.pack_cols(O.unpack_cols(qzeros, 4)[:, order], 4)
+        qwi_t, meta_i, sci = _tiled(ops, qw_i, qz_i, sc_i, gs)
+        xn1 = O.rmsnorm_ref(h1_np, w, 1e-5, act)
+        gu1 = O.forward_gptq(xn1[None], qweight, qzeros, scales, g_idx, 4, None, act, "fp16")[0]
+        a_ref = O.silu_mul_ref(gu1[:inter], gu1[inter:], act)
+        for st_in in (stats, None):
+            a_dev = torch.zeros(2 * inter, dtype=h1.dtype, device=DEV)
+            ops.decode_linear(h1, qwi_t, meta_i, None, hidden, 2 * inter, gs, 4, sci.dtype, out=a_dev, in_glue=ops.GLUE_RMSNORM,
+                              norm_weight=f32_to_torch(w, act, DEV), eps=1e-5, out_glue=ops.OUT_SILU_MUL_PAIRED, stats_in=st_in)
+            assert_forward_close(torch_to_f32(a_dev)[None, :inter], a_ref[None], act, tag=("rmsnorm + paired silu", form, st_in is not None),
+                                 strict_atol=strict)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_decode_form(-1)
