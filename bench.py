@@ -32,19 +32,20 @@ The legs outside the timed region (configs[], T1, e2e, cpu_baseline) live in ben
 headline's timed region, the roofline and the result line.
 
 Extra objects of the full record (tier contract; the compact line keeps their numbers):
-  roofline      dominant kernel = gptqhip::skinny_kernel (batch-1 fused dequant-GEMV, decode-op instantiation with the layer glue
-                fused); achieved = algorithmic bytes per
-                launch (K*N/2 + G*N*2 + G*N/2 + M*(K+N)*2, averaged over the launches) / average launch
-                duration measured with HIP events on the launch stream over the timed region.  traffic = HBM bytes per
-                launch from the committed rocprofv3 --pmc passes (traffic_source says which file; it is NOT measured in
-                this run -- PMC counters cannot be read from inside the process).
+  roofline      dominant kernel = gptqhip::skinny1_kernel (round 6: the batch-1 fused dequant-GEMV in its preload form, decode-op
+                instantiation with the layer glue fused; bf16 runs and GPTQHIP_DECODE_BITFAITHFUL=1 use its bit-faithful instantiation);
+                achieved = algorithmic bytes per launch (K*N/2 + G*N*2 + G*N/2 + M*(K+N)*2, averaged over the launches) /
+                average launch duration measured with HIP events on the launch stream over the timed region.  traffic = HBM bytes per
+                launch measured LIVE by default: two separate `rocprofv3 --kernel-trace --pmc` passes (FETCH_SIZE, WRITE_SIZE) over a
+                3-step eager run of this same command on this box (live_pmc below; --no-live-pmc falls back to the committed
+                profiles/*_pmc_summary.json and says so in traffic_source).
   configs       one object per BASELINE.json config with its own workload / value / roofline (outside the timed region):
                 C2 variant (per-module launches + torch glue kernels), C3 act-order prefill at M=65536, C4 AWQ decode +
                 M=2048 prefill, C5 Llama-3-70B decode at TP=1.
   e2e           tokens/s of a whole HF LlamaForCausalLM with Llama-3-8B shapes (random init, real attention / KV cache / norms /
                 lm_head) decoding through the plugin classes: eager generate() and one HIP graph per decode step.
-  cpu_baseline  the oracle's torch-CPU PORT of BACKEND.TORCH (oracle/gptq_oracle.py:torch_cpu_forward_gptq) on this
-                host's cores, thread count swept, rank 0 at N=1 only: C1 (single 4096x4096 linear, M in {1,32,2048}, fp16 and
+  cpu_baseline  kind "reference": the reference's OWN TorchLinear / AwqTorchLinear modules (oracle/_ref snapshot through oracle/ref_import.py;
+                bench_legs.cpu_baseline) on this host's cores, thread count swept, rank 0 at N=1 only: C1 (single 4096x4096 linear, M in {1,32,2048}, fp16 and
                 bf16), the AWQ leg (C4: the AwqTorchLinear op sequence, torch_awq.py:157-195, bf16, M in {1,32}), one decoder layer
                 at M=1 extrapolated to tokens/s, and the model-level figure from the per-shape timings; `measured` / `extrapolated`
                 say which numbers are which.
@@ -63,6 +64,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import re
+DECODE_KERNEL_RE = re.compile(r"gptqhip::(skinny1?_kernel|decode_stream_kernel)")   # the batch-1 decode kernels (forms 0 / 2, 3 / 4, 1)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16
 
@@ -202,9 +205,9 @@ def live_pmc(dtype_flag, limit_s=100):
                     if fn.endswith("counter_collection.csv"):
                         with open(os.path.join(root, fn)) as f:
                             rows += [float(r["Counter_Value"]) for r in csv.DictReader(f)
-                                     if "skinny_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+                                     if DECODE_KERNEL_RE.search(r["Kernel_Name"]) and r["Counter_Name"] == counter]
             if not rows:
-                return None, f"live PMC pass {counter} produced no skinny_kernel rows"
+                return None, f"live PMC pass {counter} produced no decode-kernel rows"
             vals[counter] = sum(rows) / len(rows)
         except Exception as e:  # noqa: BLE001
             return None, f"live PMC failed: {str(e)[:120]}"
@@ -490,20 +493,22 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
-        ev0.record(stream)
-    run(args.steps)
-    with torch.cuda.stream(stream):
-        ev1.record(stream)
-    while not ev1.query():
-        pass
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    gc.enable()
+    try:
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            ev0.record(stream)
+        run(args.steps)
+        with torch.cuda.stream(stream):
+            ev1.record(stream)
+        while not ev1.query():
+            pass
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    finally:
+        gc.enable()
     ev_ms = ev0.elapsed_time(ev1)
     tmax = torch.tensor([wall], device="cpu" if share else dev, dtype=torch.float64)
     if dist is not None:
@@ -539,8 +544,8 @@ def main():
         launch_us = ev_ms * 1e3 / (args.steps * n_launch)   # average launch duration incl. whatever the ops do not overlap
         bytes_per_launch = step_bytes / n_launch
         achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
-        kernel = {"chain": "gptqhip::skinny_kernel<BITS=4,ACT,SCL,MT=1,GPC=1,AM_ROW1,D=4,GLUE> (decode op, glue fused)",
-                  "modules": "gptqhip::skinny_kernel<BITS=4,ACT,SCL,MT=1,GPC=1,AM_ROW1,D=4>"}[mode]
+        kernel = {"chain": "gptqhip::skinny1_kernel<ACT,SCL,D=4,GLUE,ALG> (decode op, preload form, glue fused; ALG=1 group-factored dequant for fp16)",
+                  "modules": "gptqhip::skinny1_kernel<ACT,SCL,D=4,GLUE=0,ALG>"}[mode]
         out = {
             "metric": "llama3_8b_gptq_int4_g128_decode_linear_stack_tokens_per_s",
             "value": value, "unit": "tokens/s",

@@ -296,8 +296,9 @@ def cpu_baseline(cfg, gs=128, budget_s=24.0):
         "extrapolated": ["value = 1000 / (ms_per_layer x layers)", "model_tokens_per_s_from_per_shape = 1000 / (layers x sum of per_shape_ms)"],
         "per_shape_ms": per_shape, "per_shape_workload": "each distinct linear shape of the model alone, warm, M=1, bf16, best_threads",
         "model_tokens_per_s_from_per_shape": 1e3 / model_ms,
-        "c4_awq_ms": c4, "c4_workload": "AWQ reference path: AwqTorchLinear.forward op sequence (oracle torch_cpu_forward_awq: column "
-                                         "unpack, AWQ reverse order, (w - z) * s, matmul) on 4096x4096 g128 asym, bf16, best_threads",
+        "c4_awq_ms": c4, "c4_workload": "AWQ reference path: the reference's own AwqTorchLinear.forward (torch_awq.py:157-195: column unpack, AWQ reverse "
+                                         "order, (w - z) * s, matmul) when kind is 'reference', else the oracle's pinned torch port of it; 4096x4096 g128 "
+                                         "asym, bf16, best_threads",
         "trust": "c1_ms / c4_awq_ms / per_shape_ms are warm single-layer timings and the figures to compare with; `value` (layer pass "
                  "x layers) includes the cache thrash of streaming 7 layers' codes per pass and reads ~2x lower",
         "c1_compiled_note": compiled_note,
