@@ -479,7 +479,7 @@ def main():
     # clock / TLB spin-up before the W warm-up steps of the contract: with the driver's --warmup 5 (6 ms of GPU work) the timed steps ran
     # 2.5 % slower than after 20+ warm-up steps (8.85 vs 8.63 us per launch; the chip ramps its clocks over the first ~25 ms of a
     # burst).  Reported as `spin_up_steps`; the W warm-up steps and the K timed steps follow unchanged.
-    SPIN_UP_STEPS = 40
+    SPIN_UP_STEPS = int(os.environ.get("GPTQHIP_BENCH_SPIN_UP", "40"))
     run(SPIN_UP_STEPS)
     run(args.warmup)
     torch.cuda.synchronize()

@@ -23,6 +23,8 @@
 //     -- cdna_hip_programming.md §5 "in-launch split-K reduction".
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gptqhip_device.h"
 #include "gptqhip_host.h"
 
@@ -500,6 +502,24 @@ __device__ __forceinline__ void compute_stage(const Stage<BITS, GPC, MT, AM>& st
     }
 }
 
+// Sum over the 16 lanes of a DPP row, every lane of the row gets the total (fixed order; four v_add_f32 with a DPP operand, no LDS).
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122 /* row_ror:2 */, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+    return v;
+}
+// ... and over the whole wave (the four row totals through v_readlane: wave-uniform result, no LDS)
+__device__ __forceinline__ float wave64_sum(float v) {
+    v = row16_sum(v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // Cross-block split-K hand-off (last arriver reduces) + the epilogue: the reference's rounding chain and the decode op's output
 // glue.  `v` = this lane's fp32 sum for output (m, n) of its block's K range; `live` = the lane owns a real output.
 template <int ACT>
@@ -547,7 +567,8 @@ __device__ __forceinline__ void finish_outputs(const SkinnyParams& p, float v, b
             if (p.out_glue == kOutSiluMul) {
                 // interleaved gate|up tile (fuse_gate_up_interleaved): lanes 0..7 of a group hold gate columns j, lanes 8..15 the
                 // matching up columns; HF LlamaMLP: act(silu(gate)) * up, each rounded in the activation dtype
-                const float up = __shfl_down(y, 8, 64);
+                // (DPP row_shl:8 = lane i reads lane i + 8 of its 16-lane row: no LDS round trip on the launch's tail)
+                const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x108, 0xf, 0xf, false));
                 const float a = round_through<ACT>(y / (1.0f + expf(-y))) * up;
                 const int j = tile * 8 + c16;
                 if (live && c16 < 8 && j < p.N / 2) reinterpret_cast<uint16_t*>(p.out)[(size_t)m * (p.N / 2) + j] = f32_to_16<ACT>(a);
@@ -555,9 +576,8 @@ __device__ __forceinline__ void finish_outputs(const SkinnyParams& p, float v, b
                 if (p.residual != nullptr) y = bits16_to_f32<ACT>((uint16_t)(res_raw >> ((lane & 1) * 16))) + y;
                 const float h = round_through<ACT>(y);
                 if (live) reinterpret_cast<uint16_t*>(p.out)[(size_t)m * p.N + n] = f32_to_16<ACT>(h);
-                float sq = live ? h * h : 0.f;  // RMSNorm statistic of the NEXT op: fixed shuffle tree over the 16 columns
-#pragma unroll
-                for (int mk = 8; mk >= 1; mk >>= 1) sq += __shfl_xor(sq, mk, 64);
+                float sq = live ? h * h : 0.f;  // RMSNorm statistic of the NEXT op: fixed rotate tree over the 16 columns (DPP row_ror)
+                sq = row16_sum(sq);
                 if (c16 == 0 && m < p.M) p.stats_out[(size_t)m * tiles + tile] = sq;
             }
         }
@@ -1054,7 +1074,7 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
     uint32_t* const ms = reinterpret_cast<uint32_t*>(slot + nq * 1024);               // [4 nq][16] meta words
     int* s_last = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + W * p.slot_stride);
     float* scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + W * p.slot_stride + 16);
-    float(*red)[4][64] = reinterpret_cast<float(*)[4][64]>(lds);
+    float(*red)[64] = reinterpret_cast<float(*)[64]>(reinterpret_cast<char*>(lds) + W * p.slot_stride + 96);   // beside the slots: one barrier
     const DequantConsts dk = make_dequant_consts<4>();
     const char* wbase = reinterpret_cast<const char*>(p.qw) + (size_t)tile * p.chunks * 1024;
     const char* mbase = reinterpret_cast<const char*>(p.meta + (size_t)tile * p.G * 16);
@@ -1067,9 +1087,11 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
     }
     f4_t sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if constexpr (GLUE == kGlueRmsNorm) {
-        if (p.stats_in != nullptr && wave == 0) {
+        if (p.stats_in != nullptr) {
             // the producer's per-tile sums of squares, in front of everything: ONE 16-byte load per lane covers 256 partial sums (a second
-            // one up to 512); entries past stats_n are outside the descriptor and read as zeros
+            // one up to 512); entries past stats_n are outside the descriptor and read as zeros.  EVERY wave fetches and reduces them (one
+            // L2-hit instruction per wave, DPP adds): no LDS hand-over and no block barrier between the launch and its first multiply.
+            // (skinny_kernel lets one wave do it: with its eight 4-byte loads per lane, per-wave copies doubled the 70B gate_up's VMEM count.)
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.stats_in), 0, p.stats_n * 4, 0x00020000);
             sv[0] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, 0, 0));
             if (p.stats_n > 256) sv[1] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, 1024, 0));
@@ -1103,12 +1125,8 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
     float inv = 1.f;
     if constexpr (GLUE == kGlueRmsNorm) {
         if (p.stats_in != nullptr) {
-            if (wave == 0) {
-                float ssum = ((sv[0][0] + sv[0][1]) + (sv[0][2] + sv[0][3])) + ((sv[1][0] + sv[1][1]) + (sv[1][2] + sv[1][3]));   // fixed order
-#pragma unroll
-                for (int mk = 32; mk >= 1; mk >>= 1) ssum += __shfl_xor(ssum, mk, 64);
-                if (lane == 0) scratch[0] = rsqrtf(ssum / (float)p.K + p.eps);
-            }
+            const float ssum = wave64_sum(((sv[0][0] + sv[0][1]) + (sv[0][2] + sv[0][3])) + ((sv[1][0] + sv[1][1]) + (sv[1][2] + sv[1][3])));   // fixed order
+            inv = rsqrtf(ssum / (float)p.K + p.eps);
         } else {
             // no producer statistics (first op of a step; the planner keeps splits == 1 here): the waves' pieces cover the row exactly once
             float ss = 0.f;
@@ -1132,9 +1150,9 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
                 for (int w = 0; w < W; ++w) tot += scratch[1 + w];
                 scratch[0] = rsqrtf(tot / (float)p.K + p.eps);
             }
+            __syncthreads();
+            inv = scratch[0];
         }
-        __syncthreads();
-        inv = scratch[0];
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1205,20 +1223,176 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
         ++li;
     }
 
-    // ---- in-block split-K reduction through LDS (the slots alias the reduction rows) ----
+    // ---- in-block split-K reduction through LDS: only output row 0 exists (accumulator register 0 of the lanes with rq == 0) ----
+    red[wave][lane] = acc[0];
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[i];
-    __syncthreads();
-    const bool reducer = wave < 4;
     const int m = 4 * rq + wave;
     const int n = tile * kTileN + c;
-    const bool live = reducer && m < p.M && n < p.N;
+    const bool live = wave == 0 && m < p.M && n < p.N;
     float v = 0.f;
-    if (reducer) {
-        for (int w = 0; w < W; ++w) v += red[w][wave][lane];
+    if (wave == 0) {
+        for (int w = 0; w < W; ++w) v += red[w][lane];
     }
     finish_outputs<ACT>(p, v, live, m, n, tile, split, wave, lane, res_raw, s_last);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The preload form on layers with several 16-column tiles per CU (the fused gate_up: 1792 tiles = 7 per CU).  With one tile per block,
+// 47 % of that layer's VMEM instructions are the per-block preloads (x pieces, norm-weight pieces, statistics, constants: 7 per wave
+// next to 8 weight loads) and every one of the 1792 blocks pays a launch, a prologue and an epilogue.  Here ONE block per CU (W = K / 512
+// waves, each owning four chunks of every tile = one ring round per tile) walks tiles b, b + grid, ...: the glued x pieces are parked
+// once, the weight ring runs on across tile boundaries (a tile's loads are in flight while the previous one is reduced), a tile costs
+// one constants load per wave (prefetched a tile ahead into registers, parked in the wave's own double-buffered LDS rows: no barrier),
+// and its 16 outputs leave through finish_outputs on wave (tile index % W) after ONE block barrier (reduction rows double-buffered by
+// tile parity).  No residual / bias / cross-block split here: the layers that have them (o_proj, down_proj) have one tile per CU.
+// ------------------------------------------------------------------------------------------------
+template <int ACT, int SCL, int GLUE, int ALG>
+__global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
+    constexpr int D = 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = blockDim.x >> 6;
+    const int c = lane & 15, rq = lane >> 4;
+    const int tiles = (p.N + kTileN - 1) / kTileN;
+    char* const slot = reinterpret_cast<char*>(lds) + wave * 1536;
+    u4_t* const xs = reinterpret_cast<u4_t*>(slot);                            // [4][16] u4: this wave's four glued x pieces
+    uint32_t* const ms = reinterpret_cast<uint32_t*>(slot + 1024);             // [2][4][16] constants, double-buffered by tile parity
+    float* scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + W * 1536);
+    float(*red)[16][64] = reinterpret_cast<float(*)[16][64]>(reinterpret_cast<char*>(lds) + W * 1536 + 96);    // [2][W <= 16][64]
+    const DequantConsts dk = make_dequant_consts<4>();
+    const uint32_t lane16 = (uint32_t)lane * 16u, c4 = (uint32_t)c * 4u;
+    const int ck_lane = wave + rq * W;              // the chunk lane (rq, c) serves in the four-chunk preload instructions
+    const size_t tile_w = (size_t)p.chunks * 1024, tile_m = (size_t)p.G * 64;
+
+    f4_t sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if constexpr (GLUE == kGlueRmsNorm) {
+        if (p.stats_in != nullptr) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.stats_in), 0, p.stats_n * 4, 0x00020000);
+            sv[0] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, 0, 0));
+            if (p.stats_n > 256) sv[1] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, 1024, 0));
+        }
+    }
+    u4_t xq = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.x) + (size_t)ck_lane * 256 + c * 16), gq = {0u, 0u, 0u, 0u};
+    if constexpr (GLUE == kGlueRmsNorm) gq = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (size_t)ck_lane * 256 + c * 16);
+    int tile = blockIdx.x;
+    const char* mrow = reinterpret_cast<const char*>(p.meta) + (size_t)tile * tile_m + ((size_t)(ck_lane >> p.cpg_shift) << 6) + c4;
+    uint32_t mq = *reinterpret_cast<const uint32_t*>(mrow);
+    __builtin_amdgcn_sched_barrier(0);
+    const char* wsrc = reinterpret_cast<const char*>(p.qw) + (size_t)tile * tile_w + (size_t)wave * 1024 + lane16;
+    const size_t wstep = (size_t)W * 1024, tstep_w = (size_t)gridDim.x * tile_w, tstep_m = (size_t)gridDim.x * tile_m;
+    u4_t st[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) st[d] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wsrc + d * wstep));
+
+    float inv = 1.f;
+    if constexpr (GLUE == kGlueRmsNorm) {
+        if (p.stats_in != nullptr) {
+            const float ssum = wave64_sum(((sv[0][0] + sv[0][1]) + (sv[0][2] + sv[0][3])) + ((sv[1][0] + sv[1][1]) + (sv[1][2] + sv[1][3])));
+            inv = rsqrtf(ssum / (float)p.K + p.eps);
+        } else {
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = bits16_to_f32<ACT>((uint16_t)(xq[j] & 0xffffu)), b = bits16_to_f32<ACT>((uint16_t)(xq[j] >> 16));
+                ss = __builtin_fmaf(a, a, ss);
+                ss = __builtin_fmaf(b, b, ss);
+            }
+            ss = wave64_sum(ss);
+            if (lane == 0) scratch[1 + wave] = ss;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float tot = 0.f;
+                for (int w = 0; w < W; ++w) tot += scratch[1 + w];
+                scratch[0] = rsqrtf(tot / (float)p.K + p.eps);
+            }
+            __syncthreads();
+            inv = scratch[0];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xq[j] = glue_pair<ACT>(xq[j], gq[j], inv, GLUE);
+    }
+    xs[lane] = xq;
+
+    uint32_t magic_hi = 0x54005400u;
+    asm volatile("" : "+v"(magic_hi));
+    float acc = 0.f;
+    auto compute = [&](const u4_t& wv, int li, const uint32_t* mcur) __attribute__((always_inline)) {
+        const uint32_t mw = mcur[li * 16 + c];
+        const u4_t* xa = xs + li * 16 + rq;
+        if constexpr (ALG == 1 && ACT == kFP16 && SCL == kFP16) {
+            const float sc = bits16_to_f32<SCL>((uint16_t)(mw & 0xffffu));
+            const uint32_t zc = mw >> 16;
+            const h2_t zlo = as_h2(zc | (zc << 16));
+            const uint32_t zh = 0xD400u | ((zc & 0xFu) << 4);
+            const h2_t zhi = as_h2(zh | (zh << 16));
+            f4_t g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w = wv[j], w8 = w >> 8;
+                u4_t b;
+                b.x = as_u32(as_h2(and_or(w, dk.lo, dk.magic)) + zlo);
+                b.y = as_u32(as_h2(and_or(w, dk.hi, magic_hi)) + zhi);
+                b.z = as_u32(as_h2(and_or(w8, dk.lo, dk.magic)) + zlo);
+                b.w = as_u32(as_h2(and_or(w8, dk.hi, magic_hi)) + zhi);
+                if (j & 1) {
+                    g1 = mfma16<ACT>(xa[4 * j], b, g1);
+                } else {
+                    g0 = mfma16<ACT>(xa[4 * j], b, g0);
+                }
+            }
+            acc = __builtin_fmaf(sc, g0[0] + g1[0], acc);
+        } else {
+            const ColConst cc = expand_meta<4, SCL>(mw);
+            f4_t g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g = mfma16<ACT>(xa[4 * j], dequant_word4<ACT, SCL>(wv[j], cc, dk), g);
+            acc += g[0];
+        }
+    };
+    // One tile: MORE = another tile follows (its loads are issued UNCONDITIONALLY behind each stage, so hipcc's waits stay counted;
+    // with `if (more)` around them it fell back to vmcnt(0) in the middle of the round).  The last tile runs the drain instantiation.
+    int ti = 0;
+    auto do_tile = [&](auto more_c) __attribute__((always_inline)) {
+        constexpr bool MORE = decltype(more_c)::value;
+        uint32_t* mcur = ms + (ti & 1) * 64;
+        mcur[lane] = mq;                                     // this tile's constants (wave-private rows: no barrier)
+        if constexpr (MORE) {                                // the next tile's: one instruction, a tile ahead
+            mrow += tstep_m;
+            mq = *reinterpret_cast<const uint32_t*>(mrow);
+            wsrc += tstep_w;
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            compute(st[d], d, mcur);
+            if constexpr (MORE) st[d] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wsrc + d * wstep));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // in-block split-K reduction, rows double-buffered by tile parity: ONE barrier per tile; the waves take turns with the epilogue
+        red[ti & 1][wave][lane] = acc;
+        acc = 0.f;
+        __syncthreads();
+        if (wave == ti % W) {
+            float v = 0.f;
+            for (int w = 0; w < W; ++w) v += red[ti & 1][w][lane];
+            const int n = tile * kTileN + c;
+            finish_outputs<ACT>(p, v, rq == 0 && n < p.N, 4 * rq, n, tile, 0, 0, lane, 0u, nullptr);
+        }
+        tile += (int)gridDim.x;
+        ++ti;
+    };
+    while (tile + (int)gridDim.x < tiles) do_tile(std::true_type{});
+    do_tile(std::false_type{});
+}
+
+// tiles per block of the persistent variant; 0: not applicable
+static int skinny1p_grid(const SkinnyParams& p, const SkinnyPlan& pl) {
+    static const bool off = [] { const char* v = getenv("GPTQHIP_NO_PERSIST"); return v && *v && *v != '0'; }();
+    const int tiles = ceil_div(p.N, kTileN), cus = 256;
+    if (off || p.splits != 1 || p.residual != nullptr || p.bias != nullptr || p.out_f32) return 0;
+    if (tiles < 2 * cus || tiles % cus != 0 || p.N % kTileN != 0) return 0;
+    if (p.chunks % 4 != 0 || p.chunks / 4 < 4 || p.chunks / 4 > 16) return 0;
+    return cus;
 }
 
 constexpr int kPreloadMaxChunks = 16;   // chunks per wave the preload form parks (four 16-byte x instructions)
@@ -1232,11 +1406,22 @@ static int launch_skinny1(const SkinnyParams& p0, const SkinnyPlan& pl, int alg,
     if (p0.in_glue == kGlueRmsNorm && p0.stats_in == nullptr && p0.splits > 1) return 0;
     if (p0.exact_bf16 || (pl.depth != 2 && pl.depth != 4)) return 0;
     SkinnyParams p = p0;
+    const bool a1 = alg != 0 && ACT == kFP16 && SCL == kFP16;   // (bf16 scales: the reference rounds W to bf16 -- 2^-9 per weight -- keep its chain)
+    if (const int pg = skinny1p_grid(p0, pl)) {
+        const int waves = p.chunks / 4;
+        const dim3 grid(pg), block(64 * waves);
+        const size_t lds_bytes = (size_t)waves * 1536 + 96 + 2 * 16 * 256;
+#define GPTQHIP_L1P(G_, A_) hipLaunchKernelGGL((skinny1p_kernel<ACT, SCL, G_, A_>), grid, block, lds_bytes, stream, p)
+        if (p.in_glue == kGlueRmsNorm) { if (a1) GPTQHIP_L1P(kGlueRmsNorm, 1); else GPTQHIP_L1P(kGlueRmsNorm, 0); }
+        else { if (a1) GPTQHIP_L1P(kGlueNone, 1); else GPTQHIP_L1P(kGlueNone, 0); }
+#undef GPTQHIP_L1P
+        *served = true;
+        return check_hip(hipGetLastError(), "skinny1p_kernel launch");
+    }
     const int stride = ((p.n_mine + 3) >> 2) * 1280;     // x pieces + constants (>= the 1 KiB per wave the reduction rows need)
     p.slot_stride = stride;
     const dim3 grid(ceil_div(p.N, kTileN), p.splits), block(64 * pl.waves);
-    const size_t lds_bytes = (size_t)pl.waves * stride + 16 + 80;
-    const bool a1 = alg != 0 && ACT == kFP16 && SCL == kFP16;   // (bf16 scales: the reference rounds W to bf16 -- 2^-9 per weight -- keep its chain)
+    const size_t lds_bytes = (size_t)pl.waves * stride + 96 + (size_t)pl.waves * 256;   // slots | last-arriver flag + statistics scratch | reduction rows
 #define GPTQHIP_L1(D_, G_, A_) hipLaunchKernelGGL((skinny1_kernel<ACT, SCL, D_, G_, A_>), grid, block, lds_bytes, stream, p)
     if (pl.depth == 4) {
         if (p.in_glue == kGlueRmsNorm) { if (a1) GPTQHIP_L1(4, kGlueRmsNorm, 1); else GPTQHIP_L1(4, kGlueRmsNorm, 0); }
