@@ -257,7 +257,7 @@ def result_line(detail):
                                   "chained through the layer glue, M=1, random packed weights (BASELINE configs[1])"}
     if "workload_short" in cfg:
         line["config"]["workload"] = cfg["workload_short"]
-    for k in ("parallelism", "mode", "linears_per_step", "launches_per_step", "graph", "weight_bytes_per_token", "path", "allreduce"):
+    for k in ("parallelism", "mode", "decode_form", "linears_per_step", "launches_per_step", "graph", "weight_bytes_per_token", "path", "allreduce"):
         if k in cfg:
             line["config"][k] = cfg[k]
     rf = detail.get("roofline", {})
@@ -558,6 +558,11 @@ def main():
                                    "(q,k,v,o,gate,up,down x 32) with true data dependencies through the layer glue (RMSNorm, "
                                    "SiLU*mul, residual adds fused into the ops; attention stand-in = q), M=1, random packed weights",
                        "parallelism": f"replicas x{world}", "mode": mode,
+                       # include/gptqhip.h gptqhip_set_decode_form: the process default of this dtype (GPTQHIP_DECODE_BITFAITHFUL=1 -> 4)
+                       "decode_form": (4 if (dtype != torch.float16 or os.environ.get("GPTQHIP_DECODE_BITFAITHFUL", "0") not in ("", "0")) else 3),
+                       "loader_path": "mode=chain is what gptqmodel_post_init yields on HF Llama-family layers by itself since round 6 "
+                                      "(utils.hf_llama.auto_fuse; the reference's own post_init through integration/gptqmodel_overlay/utils/model.patch); "
+                                      "mode=modules is the GPTQHIP_AUTO_FUSE=0 path: plugin forward() per linear + torch glue kernels",
                        "linears_per_step": n_linear, "launches_per_step": n_launch, "fused_siblings": True,
                        "graph": used_graph, "replicas": world, "weight_bytes_per_token": step_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -411,6 +411,22 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
             del g, st
         except Exception as e:  # noqa: BLE001
             res.append({"config": "C2", "mode": other, "error": str(e)[:300]})
+    # the same chain with the reference's per-weight rounding kept (decode form 4 = what GPTQHIP_DECODE_BITFAITHFUL=1 selects; the bf16
+    # default): the price of bit-faithfulness next to the fp16 default's group-factored dequant (form 3)
+    if dtype == torch.float16 and mode == "chain":
+        try:
+            from gptqmodel_amd import ops as _ops
+            _ops.set_decode_form(4)
+            try:
+                st = make_step("chain")
+                ms, g = time_graph(st.run, stream, 50, 5)
+            finally:
+                _ops.set_decode_form(-1)
+            res.append(decode_entry("C2", "same token step, decode form 4 (bit-faithful per-weight rounding, preload kernel)", cfg, ms, n_launch,
+                                    extra={"mode": "chain, bit-faithful", "id": "c2_decode_chain_bitfaithful"}))
+            del g, st
+        except Exception as e:  # noqa: BLE001
+            res.append({"config": "C2", "mode": "chain, bit-faithful", "error": str(e)[:300]})
     # round 1's way of timing the same 128 launches (kept for continuity, NOT a decode step): constant input, no glue, no data
     # dependencies between the launches -- shows what the dependent chain + fused glue cost on the same kernels
     try:

@@ -4,7 +4,7 @@
   1. build the model (Llama-3-8B shapes with --size 8b, a small one by default), weights created on the GPU;
   2. quantise every decoder nn.Linear to 4-bit g128 (RTN) and pack it ON THE DEVICE through the module's pack()
      (reference API: PackableQuantLinear.pack_block, qlinear/__init__.py:1036);
-  3. swap the modules with make_quant (BACKEND.AUTO -> HipGptqLinear), fuse q/k/v and gate/up, gptqmodel_post_init;
+  3. swap the modules with make_quant (BACKEND.AUTO -> HipGptqLinear), gptqmodel_post_init (which itself moves the decoder layers onto the fused decode ops);
   4. greedy-decode with HF generate (eager; Python-bound) and with ONE captured HIP graph per decode step over a static
      KV cache (what a serving stack would do), and report tokens/s for both.
 
@@ -101,17 +101,20 @@ def run(size="8b", dtype_name="fp16", new_tokens=64, fuse=True, quant_lm_head=Fa
         qm.pack(lin, scales, zeros, g_idx)
     del floats
     res["layer_path"] = "per-module launches"
-    if not args.no_fuse and decode_ops:
-        # decoder layers on the decode ops: 4 launches per layer with the norms / SiLU*mul / residual adds fused (batch-1 decode)
-        from gptqmodel_amd.utils.hf_llama import fuse_llama_decoder_layers
-        fused_layers, skipped = fuse_llama_decoder_layers(model)
-        res["layer_path"] = f"decode ops in {len(fused_layers)} layers ({len(skipped)} skipped)"
-    elif not args.no_fuse:
+    if args.no_fuse:
+        model._gptqhip_auto_fuse = False      # opt out of gptqmodel_post_init's decoder-layer pass (same as GPTQHIP_AUTO_FUSE=0)
+    elif not decode_ops:
         for layer in model.model.layers:
             fuse_siblings(layer.self_attn, ["q_proj", "k_proj", "v_proj"])
             fuse_siblings(layer.mlp, ["gate_proj", "up_proj"])
         res["layer_path"] = "fused siblings (q|k|v, gate|up), torch glue"
+    # round 6: NO manual rewrite on the default path -- gptqmodel_post_init itself (utils.hf_llama.auto_fuse; the reference's own
+    # gptqmodel_post_init does the same through integration/gptqmodel_overlay/utils/model.patch) puts every recognised decoder layer
+    # on the four fused decode ops: this is what a loader returns
     gptqmodel_post_init(model)
+    if getattr(model, "_gptqhip_fused_layers", 0):
+        res["layer_path"] = (f"decode ops in {model._gptqhip_fused_layers} layers ({len(getattr(model, '_gptqhip_skipped_layers', []))} skipped), "
+                             "applied by gptqmodel_post_init itself")
     torch.cuda.synchronize()
     del mods, qm, lin   # (the pre-fusion modules are no longer part of the model: release their checkpoint-layout tensors)
     import gc

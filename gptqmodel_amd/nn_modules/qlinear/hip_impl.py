@@ -461,6 +461,7 @@ def make_hip_classes(ns, module_name: str):
                                      self.bits, self.scales.dtype)
 
     for cls in (HipGptqLinear, HipQuantEmbeddings, HipAwqLinear):
+        cls._GPTQHIP_KERNEL_CLASS = True   # whichever contract base it was built on (this package's mirror or the reference's own)
         cls.__module__ = module_name       # importable / picklable under the module that exposes them
         cls.__qualname__ = cls.__name__
     return HipGptqLinear, HipQuantEmbeddings, HipAwqLinear

@@ -216,6 +216,8 @@ def load_quantized_checkpoint(model: nn.Module, ckpt_dir: str, device="cuda", ba
     if fuse_decoder_layers:
         from .hf_llama import fuse_llama_decoder_layers
         fuse_llama_decoder_layers(model)
+    else:
+        model._gptqhip_auto_fuse = False   # the caller said no: gptqmodel_post_init's own pass (utils.hf_llama.auto_fuse) stays off too
     gptqmodel_post_init(model, use_act_order=cfg["desc_act"])
     model.eval()
     return model

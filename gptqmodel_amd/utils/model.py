@@ -212,10 +212,14 @@ def make_quant(model: nn.Module, names: Iterable[str], bits: int, group_size: in
 
 
 def gptqmodel_post_init(model: nn.Module, use_act_order: bool = False, **_kw) -> nn.Module:
-    """Call post_init() on every QuantLinear once its tensors are on the device (utils/model.py:1281-1344)."""
+    """Call post_init() on every QuantLinear once its tensors are on the device (utils/model.py:1281-1344).  Round 6: recognised
+    decoder layers are first rewritten onto the fused decode ops (utils.hf_llama.auto_fuse; GPTQHIP_AUTO_FUSE=0 opts out), so the
+    model a loader returns takes the fast path by itself."""
     if isinstance(model, BaseQuantLinear):
         model.post_init()
         return model
+    from .hf_llama import auto_fuse
+    auto_fuse(model)
     for m in model.modules():
         if isinstance(m, BaseQuantLinear):
             m.post_init()
