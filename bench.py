@@ -283,6 +283,8 @@ def result_line(detail):
             rec["id"], rec["config"] = "c2_layer_m8192", "C2"
         if "tp" in c:
             rec["tp"] = c["tp"]
+        if "exchange" in c:
+            rec["exchange"] = c["exchange"]
         if "hbm_frac" in c.get("roofline", {}):
             rec["hbm_frac"] = _r(c["roofline"]["hbm_frac"])
         summ.append(rec)

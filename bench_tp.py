@@ -215,9 +215,11 @@ def tp_decode_entry(args, rank, world, dev, dist, steps, warmup, log=None):
         "path": ("DecodeStep (decode ops, glue fused)" if tp == 1 else
                  ("TPDecodeStep (decode ops + fused one-shot all-reduce)" if chain is not None else "modules + torch glue + all_reduce")),
         "graph": graph is not None, "allreduce": comm_note, "allreduce_per_token": 2 * cfg["layers"] if tp > 1 else 0,
+        # which exchange actually ran: the hand-written one-shot peer-to-peer kernel over xGMI, RCCL's all_reduce, or none
+        "exchange": "none" if tp == 1 else ("oneshot" if comm is not None else "rccl"),
         "finite": finite, "comm_status_ok": status_ok, "weight_bytes_per_token": step_bytes,
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": B.HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / B.HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "gptqhip::skinny_kernel (per rank)", "bytes_per_launch": step_bytes / tp / n_launch,
+                     "traffic": None, "kernel": "gptqhip::skinny1_kernel / skinny_kernel (per rank)", "bytes_per_launch": step_bytes / tp / n_launch,
                      "avg_launch_us": ms * 1e3 / n_launch,
                      "note": "per-GPU HBM rate: each rank streams 1/tp of the packed weights per token"},
         "gemm_tflops_equiv": step_flops / (ms * 1e-3) / 1e12,

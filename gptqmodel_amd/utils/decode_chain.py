@@ -122,6 +122,29 @@ class DecodeStep:
         return self.out
 
 
+def tp_layer_plan(gather_o_input: bool):
+    """The tensor-parallel decode step of ONE decoder layer as symbolic steps over named buffers -- the orchestration TPDecodeStep binds to
+    device pointers, and the one tests/test_tp_gloo.py executes on two gloo ranks with the oracle as local compute and dist.all_reduce as
+    the exchange (same list, so the order of ops, what feeds what and where the reductions sit are tested without a GPU).
+
+    Buffers: h_in / st_in (the residual stream entering the layer and its per-tile sums of squares), qkv_out, o_in (act-order o_proj
+    shards only), partial (fp32 [hidden]), h1 / st1, gu_out, h2 / st2.
+    Steps:  ("op", which, x, out, in_glue, norm, out_glue, stats_in)      which in qkv | o | gate_up | down
+            ("ag", x_local, index, out)                                    all-gather the ranks' attention outputs, select this rank's rows' features
+            ("ar", residual, bias, out, stats_out)                         out = act(residual + act(act(sum_r partial) + bias)), stats of out"""
+    steps = [("op", "qkv", "h_in", "qkv_out", "rmsnorm", "w_in", "none", "st_in")]
+    o_x = "qkv_out_local"                                   # stand-in attention: a_r = this rank's q columns
+    if gather_o_input:
+        steps.append(("ag", "qkv_out_local", "o_input_index", "o_in"))
+        o_x = "o_in"
+    steps += [("op", "o", o_x, "partial", "none", None, "partial_f32", None),
+              ("ar", "h_in", "o_bias", "h1", "st1"),
+              ("op", "gate_up", "h1", "gu_out", "rmsnorm", "w_post", "silu_mul_paired", "st1"),
+              ("op", "down", "gu_out", "partial", "none", None, "partial_f32", None),
+              ("ar", "h1", "down_bias", "h2", "st2")]
+    return steps
+
+
 class TPDecodeStep:
     """The same chain for one rank of a tensor-parallel group (Megatron split, utils/tp.py): qkv and gate_up are this rank's
     COLUMN shards (gate_up interleaved per shard), o and down its ROW shards.  Per layer 4 decode ops + 2 one-shot xGMI
@@ -182,15 +205,19 @@ class TPDecodeStep:
                                                         norm_weight=nw, eps=eps, workspace=self.workspace, out_glue=oglue,
                                                         stats_in=s_in, perm=perm)))
 
+        glue = {"rmsnorm": ops.GLUE_RMSNORM, "none": ops.GLUE_NONE}
+        oglue = {"none": ops.OUT_NONE, "partial_f32": ops.OUT_PARTIAL_F32, "silu_mul_paired": ops.OUT_SILU_MUL_PAIRED}
         h_in, st_in = self.x_in, None
         for li, L in enumerate(self.layers):
             if not getattr(L.gate_up, "gate_up_interleaved", False):
                 raise ValueError("TPDecodeStep needs gate_up shards fused with fuse_gate_up_interleaved")
             if L.o.in_features != q_dim_local or L.o.out_features != hidden or L.down.out_features != hidden:
                 raise ValueError("row-parallel shard shapes do not match hidden / q_dim_local")
-            h1, h2, st1, st2 = self.h[li, 0], self.h[li, 1], self.stats[li, 0], self.stats[li, 1]
-            bind(L.qkv, h_in, self.qkv_out, ops.GLUE_RMSNORM, L.input_norm, ops.OUT_NONE, st_in)
-            o_in = self.qkv_out                                                                     # stand-in attention: a = q_r
+            buf = {"h_in": h_in, "st_in": st_in, "qkv_out": self.qkv_out, "qkv_out_local": self.qkv_out[:q_dim_local] if L.o_input_index is not None
+                   else self.qkv_out, "partial": self.partial, "h1": self.h[li, 0], "st1": self.stats[li, 0], "gu_out": self.gu_out,
+                   "h2": self.h[li, 1], "st2": self.stats[li, 1], "w_in": L.input_norm, "w_post": L.post_norm, "o_bias": L.o_bias,
+                   "down_bias": L.down_bias, None: None}
+            lins = {"qkv": L.qkv, "o": L.o, "gate_up": L.gate_up, "down": L.down}
             if L.o_input_index is not None:
                 # act-order o_proj shard: its sorted rows consume features of the FULL attention output
                 idx = L.o_input_index.to(device=dev, dtype=torch.int32).contiguous()
@@ -199,14 +226,16 @@ class TPDecodeStep:
                 if self.o_in is None:
                     self.o_in = torch.zeros(q_dim_local, dtype=dtype, device=dev)
                 self._keep.append(idx)
-                self.steps.append(("ag", self.qkv_out[:q_dim_local], idx, self.o_in))
-                o_in = self.o_in
-            bind(L.o, o_in, self.partial, ops.GLUE_NONE, None, ops.OUT_PARTIAL_F32, None)
-            self.steps.append(("ar", h_in, L.o_bias, h1, st1))
-            bind(L.gate_up, h1, self.gu_out, ops.GLUE_RMSNORM, L.post_norm, ops.OUT_SILU_MUL_PAIRED, st1)
-            bind(L.down, self.gu_out, self.partial, ops.GLUE_NONE, None, ops.OUT_PARTIAL_F32, None)
-            self.steps.append(("ar", h1, L.down_bias, h2, st2))
-            h_in, st_in = h2, st2
+                buf["o_input_index"], buf["o_in"] = idx, self.o_in
+            for st in tp_layer_plan(L.o_input_index is not None):
+                if st[0] == "op":
+                    _, which, x, out, g, norm, og, s_in = st
+                    bind(lins[which], buf[x], buf[out], glue[g], buf[norm], oglue[og], buf[s_in])
+                elif st[0] == "ag":
+                    self.steps.append(("ag", buf[st[1]], buf[st[2]], buf[st[3]]))
+                else:
+                    self.steps.append(("ar", buf[st[1]], buf[st[2]], buf[st[3]], buf[st[4]]))
+            h_in, st_in = buf["h2"], buf["st2"]
         self.out = h_in
 
     def run(self) -> torch.Tensor:
@@ -227,4 +256,4 @@ class TPDecodeStep:
         self.comm.check_status()
 
 
-__all__ = ["DecodeLayer", "DecodeStep", "TPDecodeStep"]
+__all__ = ["DecodeLayer", "DecodeStep", "TPDecodeStep", "tp_layer_plan"]

@@ -222,3 +222,88 @@ def test_shard_helpers_refuse_words_they_would_cut():
                      (tp.select_gptq_columns, (t, torch.arange(32), 3))):
         with pytest.raises(NotImplementedError, match="widen"):
             fn(*args)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 6: the ORCHESTRATION of the tensor-parallel decode step -- utils.decode_chain.tp_layer_plan, the very
+# list TPDecodeStep binds to device pointers -- executed on two gloo ranks with the oracle as local compute and dist.all_reduce /
+# dist.all_gather as the exchange, against the single-process chain oracle over the same shards.
+# ---------------------------------------------------------------------------------------------------------------------
+def _run_tp_plan(rank, world, layers, shards, x, eps=1e-5, act="fp16"):
+    """Execute tp_layer_plan for every layer on this rank: numpy buffers by name, ops = the oracle's linear on the rank's shard with the
+    decode op's glue semantics (include/gptqhip.h gptqhip_decode_op), "ar" = fp32 SUM all-reduce + the one-shot kernel's epilogue
+    (one rounding of the sum, + bias, residual add, per-16 sums of squares), "ag" = all_gather + index select."""
+    from chain_oracle import deq
+    from gptqmodel_amd.utils.decode_chain import tp_layer_plan
+    h_in, st_in = x.copy(), None
+    for li, L in enumerate(layers):
+        sh = shards[rank][li]
+        buf = {"h_in": h_in, "st_in": st_in, "w_in": L["w_in"], "w_post": L["w_post"], "o_bias": None, "down_bias": None,
+               "o_input_index": sh["o_index"], None: None}
+        W = {"qkv": np.concatenate([deq(sh[n]) for n in ("q", "k", "v")], axis=1), "o": deq(sh["o"]),
+             "gate": deq(sh["gate"]), "up": deq(sh["up"]), "down": deq(sh["down"])}
+        q_local = sh["q"]["qweight"].shape[1]
+        for st in tp_layer_plan(sh["o_index"] is not None):
+            if st[0] == "op":
+                _, which, xn, out, g, norm, og, s_in = st
+                xv = buf[xn]
+                if g == "rmsnorm":
+                    if buf[s_in] is not None:      # the producer's statistics must BE the sums of squares of the vector they travel with
+                        assert np.allclose(buf[s_in].sum(), (xv.astype(np.float64) ** 2).sum(), rtol=1e-5)
+                    xv = O.rmsnorm_ref(xv, buf[norm], eps, act)
+                if which == "gate_up":
+                    assert og == "silu_mul_paired"
+                    y = O.silu_mul_ref(O.matmul_round(xv[None], W["gate"], None, act), O.matmul_round(xv[None], W["up"], None, act), act)[0]
+                elif og == "partial_f32":
+                    y = (xv[None].astype(np.float32) @ W[which])[0]             # unrounded fp32 partial sums of this rank's K-shard
+                else:
+                    y = O.matmul_round(xv[None], W[which], None, act)[0]
+                buf[out] = y
+                if which == "qkv":
+                    buf["qkv_out_local"] = y[:q_local]
+            elif st[0] == "ag":
+                _, xn, idx, out = st
+                parts = [torch.empty(q_local, dtype=torch.float32) for _ in range(world)]
+                dist.all_gather(parts, torch.from_numpy(np.ascontiguousarray(buf[xn], dtype=np.float32)))
+                buf[out] = torch.cat(parts).numpy()[buf[idx]]
+            else:
+                _, res, bias, out, stats = st
+                t = torch.from_numpy(np.ascontiguousarray(buf["partial"], dtype=np.float32))
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                y = O.round_to(t.numpy(), act)
+                if buf[bias] is not None:
+                    y = O.round_to(y + buf[bias], act)
+                buf[out] = O.residual_add_ref(buf[res][None], y[None], act)[0]
+                buf[stats] = (buf[out].astype(np.float64) ** 2).reshape(-1, 16).sum(axis=1).astype(np.float32)
+        h_in, st_in = buf["h2"], buf["st2"]
+    return h_in
+
+
+def _tp_plan_worker(rank, world, port, desc_act, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from chain_oracle import build_layers, oracle_chain
+        hidden, inter, q_dim, kv_dim, gs = 512, 1024, 512, 128, 64
+        layers, shards = build_layers(world, 2, hidden, inter, q_dim, kv_dim, gs, desc_act, seed=7)
+        x = O.round_to(np.random.RandomState(3).randn(hidden).astype(np.float32) * 0.5, "fp16")
+        got = _run_tp_plan(rank, world, layers, shards, x)
+        want = oracle_chain(x, layers, "fp16", 1e-5)          # the single-process composition over the same shards, rank-ordered sums
+        # two ranks: a + b is the all-reduce's sum whatever its order, so the distributed run must equal the composition bit for bit
+        ret[rank] = (bool(np.array_equal(got, want)), float(np.abs(got - want).max()), float(np.abs(want).max()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("desc_act", [False, True])
+def test_tp2_decode_step_plan_on_gloo_matches_the_chain_oracle(desc_act):
+    world = 2
+    port = 31500 + (os.getpid() % 2000) + (7 if desc_act else 0)
+    ret = mp.Manager().dict()
+    mp.spawn(_tp_plan_worker, args=(world, port, desc_act, ret), nprocs=world, join=True)
+    assert sorted(ret.keys()) == [0, 1]
+    for r in (0, 1):
+        equal, err, scale = ret[r]
+        assert equal, (r, err, scale)
+        assert scale > 0.1
