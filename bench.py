@@ -65,7 +65,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import re
-DECODE_KERNEL_RE = re.compile(r"gptqhip::(skinny1?_kernel|decode_stream_kernel)")   # the batch-1 decode kernels (forms 0 / 2, 3 / 4, 1)
+DECODE_KERNEL_RE = re.compile(r"gptqhip::(skinny1?p?_kernel|decode_stream_kernel)")   # the batch-1 decode kernels (forms 0 / 2, 3 / 4, 1)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/fp16
 
