@@ -113,7 +113,10 @@ static double tiled_cost_us(int M, int K, int N, int bm, int s, int bn = kTiledB
         r = blocks <= 256 ? 1.0 : (double)blocks / 256.0;
         f = blocks <= 256 ? (double)blocks / 256.0 : 1.0;
     }
-    const double main_us = co[0] + co[1] * f + r * cps * (co[2] + co[3] * f) + kIdle * (f < 0.75 ? 0.75 - f : 0.0);
+    // (the fit has negative intercepts: clamp at the cost of one chunk pass so that short-K plans -- outside the 4-bit / g128 / M = 64 .. 2048 sweeps
+    // that calibrated it -- cannot come out free or negative)
+    double main_us = co[0] + co[1] * f + r * cps * (co[2] + co[3] * f) + kIdle * (f < 0.75 ? 0.75 - f : 0.0);
+    if (main_us < 1.0 + 0.5 * r * cps) main_us = 1.0 + 0.5 * r * cps;
     const double slab_mb = (double)s_eff * M * N * 4.0 / 1e6;
     const double reduce_us = s_eff > 1 ? (slab_mb / 6.2 + 1.5 > 4.6 ? slab_mb / 6.2 + 1.5 : 4.6) : 0.0;
     return main_us + reduce_us;

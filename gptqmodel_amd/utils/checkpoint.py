@@ -238,6 +238,12 @@ def save_quantized_checkpoint(model: nn.Module, ckpt_dir: str, quantize_config: 
     from safetensors.torch import save_file
     from ..nn_modules.qlinear import BaseQuantLinear
     cfg = normalize_quantize_config(quantize_config)
+    # validated BEFORE anything in ckpt_dir is removed or written (a refused save must not cost a valid checkpoint already there): the
+    # reference only accepts sym=False v1 files whose producer entry is `gptqmodel:>=0.9.0` (quantization/config.py:2790,
+    # models/loader.py:1658-1663); a file stamped with this repo's own tag -- or with any producer both loaders refuse -- would be unreadable
+    if cfg["format"] == "gptq" and not cfg["sym"] and not _written_by_v2_aware_quantizer(cfg):
+        raise ValueError("saving sym=False with checkpoint_format=gptq (v1) needs an explicit meta.quantizer the reference recognises "
+                         "(e.g. ['gptqmodel:<version >= 0.9.0>']), or save as gptq_v2")
     os.makedirs(ckpt_dir, exist_ok=True)
     state = {}
     v1_owners, planar_of, bits_of = set(), {}, {}
@@ -282,11 +288,6 @@ def save_quantized_checkpoint(model: nn.Module, ckpt_dir: str, quantize_config: 
         total = sum(t.numel() * t.element_size() for t in state.values())
         with open(os.path.join(ckpt_dir, SAFETENSORS_INDEX), "w", encoding="utf-8") as f:
             json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=1)
-    if cfg["format"] == "gptq" and not cfg["sym"] and "quantizer" not in cfg["meta"]:
-        # the reference only accepts sym=False v1 files whose producer entry is `gptqmodel:>=0.9.0` (quantization/config.py:2790,
-        # models/loader.py:1658-1663); a file stamped with this repo's own tag would round-trip here and be refused there
-        raise ValueError("saving sym=False with checkpoint_format=gptq (v1) needs an explicit meta.quantizer the reference recognises "
-                         "(e.g. ['gptqmodel:<version >= 0.9.0>']), or save as gptq_v2")
     payload = {"bits": cfg["bits"], "group_size": cfg["group_size"], "desc_act": cfg["desc_act"], "sym": cfg["sym"],
                "lm_head": cfg["lm_head"], "quant_method": cfg["method"], "checkpoint_format": cfg["format"], "pack_dtype": cfg["pack_dtype"],
                "meta": dict(cfg["meta"], quantizer=cfg["meta"].get("quantizer", ["gptqmodel_amd:test-writer"]))}

@@ -157,8 +157,11 @@ class OneShotAllReduce:
             self.set_timeout_ms(int(timeout_ms))
         except Exception:  # noqa: BLE001
             ok = False
+        # (a local set_timeout failure must be AGREED before anything below is skipped on its account: with calls == 0 the loop that
+        # agrees once per iteration never runs, and one rank skipping the burst's all_gather would hang its peers)
+        ok = agree(ok)
         with torch.cuda.device(dev):
-            for it in range(calls):
+            for it in range(calls if ok else 0):
                 g = torch.Generator(device=dev)
                 g.manual_seed(7919 * it + self.rank)
                 part = torch.randn(n, device=dev, generator=g) * 3.0

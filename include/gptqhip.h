@@ -308,24 +308,33 @@ int gptqhip_allgather_select(const void* x_local, void* const* peer_bufs, int ra
 int gptqhip_plan_describe(int M, int K, int N, int group_size, int bits, int has_perm, char* buf, int buf_len);
 
 /* Tuning hook (benchmarks / tests): force the cross-block split-K factor and the waves per block of the skinny
- * kernel (0 = heuristic; with the prefill kernel 1 / 2 / 3 = 256- / 128- / 64-row tiles, 32..112 in steps of 16 = that tile height, 1000 +
- * rows = that height with 128-column blocks),
+ * kernel (0 = heuristic; with the prefill kernel 1 / 2 / 3 = 256- / 128- / 64-row tiles, 32..128 in steps of 16 = that tile height, 1000 +
+ * rows (1032..1128) = that height with 128-column blocks),
  * or the kernel family (0 auto, 1 skinny, 2 tiled-prefill).  The overrides are THREAD-LOCAL
  * (they apply to gptqhip_gemm / gptqhip_workspace_bytes calls made by the calling thread only), so the library keeps
  * no process-global mutable state and stays re-entrant across threads, devices and streams. */
 int gptqhip_set_tuning(int force_split_k, int force_kernel, int force_waves);
 
-/* Batch-1 decode form (round 6; gptqhip_gemm at M = 1 and gptqhip_decode_linear at M = 1, 4-bit, group_size % 128 == 0, no in-kernel
- * act-order permutation):
- *   1 (default)  decode_stream_kernel (gptqmodel_amd/csrc/gptqhip_stream.hip): weights streamed HBM -> LDS by LDS-DMA, the raw code pairs
- *                (1024 + q | 64 + q in fp16, 128 + q in bf16) contracted with x on the matrix pipe and the offsets / zero-points / scale
- *                taken out per 128-row chunk in fp32: y = sum_g s_g * (sum_k x_k (o_k + q_k) - sum_k x_k (o_k + z_g)).  That is the
- *                exact-arithmetic value of the reference's y = x @ (s * (q - z)) (TorchLinear._forward_eager, torch.py:326-347) WITHOUT
- *                the reference's per-weight rounding fp16(s * (q - z)) (torch.py:716-717): inside north_star's 1e-3 bar on every golden,
- *                not bit-identical to the bit-faithful form.
- *   0            the bit-faithful skinny_kernel (every weight rounded like the reference before the contraction), ~15 % slower.
- *  -1            back to the process default (1, or 0 when GPTQHIP_DECODE_BITFAITHFUL=1 is in the environment).
- * THREAD-LOCAL like gptqhip_set_tuning.  The reference has the same kind of switch for its own kernels (env flags, torch.py:172-190). */
+/* Batch-1 decode form (round 6): which kernel serves gptqhip_gemm at M = 1 and gptqhip_decode_linear at M = 1 (4-bit, one group constant per
+ * 128-row chunk, no in-kernel act-order permutation; everything else keeps skinny_kernel).  All forms compute the reference's
+ * y = x @ (s * (q - z)) (TorchLinear._forward_eager, torch.py:326-347); they differ in the kernel structure and in whether every weight is
+ * rounded to the scales' dtype BEFORE the contraction like the reference does (torch.py:716-717):
+ *   3  DEFAULT for fp16 activations with fp16 scales.  skinny1_kernel ("preload": a wave parks the glued x pieces and the group constants of
+ *      all its chunks in LDS up front, so the ring carries ONE VMEM instruction per 1 KiB chunk) + GROUP-FACTORED dequant: the exact integers
+ *      (q - z) go into the MFMA and the group's scale multiplies the fp32 partial sum once per chunk,
+ *      y = sum_g s_g * (sum_{k in g} x_k (q_k - z_g)).  This is the exact-arithmetic value of the reference's expression; it differs from
+ *      the reference's own output only by the reference's per-weight rounding fp16(s (q - z)) (2^-12 relative, random): inside north_star's
+ *      1e-3 bar on every golden, NOT bit-identical to forms 0 / 4.  +6 % over form 4.
+ *   4  DEFAULT for bf16 activations or bf16 scales, and for everything when GPTQHIP_DECODE_BITFAITHFUL=1 is in the environment: skinny1_kernel
+ *      with the reference's per-weight rounding kept (same bits as form 0 up to the fp32 summation order).  +6 % over form 0.
+ *   0  skinny_kernel, per-weight rounding (the rounds 1-5 kernel).
+ *   2  skinny_kernel + group-factored dequant (fp16 x fp16).
+ *   1  decode_stream_kernel (gptqmodel_amd/csrc/gptqhip_stream.hip): weights streamed HBM -> LDS by LDS-DMA into per-wave rings, raw code
+ *      pairs (1024 + q | 64 + q) contracted on the matrix pipe, offsets / zero-points / scale taken out per chunk; fp16 x fp16 only (other
+ *      dtypes fall to form 4).  Built for VERDICT r5 item 1b, measured 15-20 % SLOWER than form 0 (profiles/r06_stream_kernel_ablation.txt):
+ *      opt-in, kept as the record of that experiment.
+ *  -1  back to the process default.
+ * THREAD-LOCAL like gptqhip_set_tuning.  The reference steers its own kernels with the same kind of switch (env flags, torch.py:172-190). */
 int gptqhip_set_decode_form(int form);
 
 #ifdef __cplusplus
