@@ -20,7 +20,7 @@
 //   * per K-step (32 rows) a wave issues 2 dequants (~26 VALU) + BM/16 ds_read_b128 + 2*BM/16 MFMAs.
 //   * epilogue: round like the reference (round(acc), + bias, round) or keep fp32 (split-K slabs, tensor-parallel
 //     partial sums), transposed through LDS into 16-byte buffer stores; it overlaps the next tile's first loads.
-// DESIGN.md section 4.2 has the measurements behind each of these choices.
+// docs/history/DESIGN_rounds_1-5.md section 4.2 has the measurements behind each of these choices.
 #pragma once
 #include "gptqhip_device.h"
 #include "gptqhip_host.h"

@@ -21,7 +21,7 @@ squares (stats_out), the normalising consumer sums those 256 partials per wave i
 
 (An in-launch dependency scheme -- consecutive ops on two streams, op i+1 prefetching its packed weights while spinning on
 op i's arrival counters -- was built and measured in round 2: bit-identical results but 2x SLOWER than plain stream order
-(437 vs 820 tokens/s) and not robust under foreign load; the kernel lives in git history, commits b17792b..f84fc07.)
+(437 vs 820 tokens/s) and not robust under foreign load; see docs/history/DESIGN_rounds_1-5.md 4.1.1; the kernel lives in git history, commits b17792b..f84fc07.)
 """
 from __future__ import annotations
 

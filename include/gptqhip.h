@@ -110,7 +110,7 @@ int gptqhip_repack_tiled(const int32_t* qweight, const int32_t* qzeros, const vo
  *            M <= 4: accumulate the exact products s*(q-z)*x instead of first rounding every weight to bf16 like
  *            torch.py:326-335 does (gfx950 has no packed bf16 VALU; 7 instead of 16 VALU per packed word).  The result is
  *            the exact-arithmetic value, up to 2 output ulps away from the reference's chain; ignored elsewhere
- *            (fp16 activations included: measured there, it does not pay -- DESIGN.md 4.1.1). */
+ *            (fp16 activations included: measured there, it does not pay -- docs/history/DESIGN_rounds_1-5.md 4.1.1). */
 #define GPTQHIP_GEMM_PARTIAL_F32 1
 #define GPTQHIP_GEMM_EXACT_BF16 2
 int gptqhip_gemm(const void* x, const uint32_t* qweight_t, const uint32_t* meta,
@@ -304,7 +304,7 @@ int gptqhip_allgather_select(const void* x_local, void* const* peer_bufs, int ra
  * printed when it is 128 = one 16-column tile per wave instead of two).
  * mt = 16-row tiles per block, nt = column tiles per block (4 / 2: the wide-layer form), gather = a separate act-order x gather pass
  * runs first.  The reference steers its kernels with thresholds too (ExllamaV2 switches to dequant + cuBLAS above 50 rows:
- * gptqmodel_ext/exllamav2/cuda/q_gemm.cu:118, config.h:4); here the crossover is measured per layer shape. */
+ * gptqmodel_ext/exllamav2/cuda/q_gemm.cu:118, config.h:4); here the crossover is measured per layer shape (docs/history/DESIGN_rounds_1-5.md 4.1.1). */
 int gptqhip_plan_describe(int M, int K, int N, int group_size, int bits, int has_perm, char* buf, int buf_len);
 
 /* Tuning hook (benchmarks / tests): force the cross-block split-K factor and the waves per block of the skinny

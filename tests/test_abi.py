@@ -121,7 +121,7 @@ def test_prefill_planner_invariants_over_a_grid_of_shapes(lib):
 
 def test_kernel_family_crossover_is_host_logic(lib):
     """gptqhip_plan_describe = the planner's decisions without a GPU: the measured crossover between the decode kernel (one / several
-    row tiles, one / several column tiles per block) and the MFMA-tiled prefill kernel (profiles/r03_mid_m_sweep.txt,
+    row tiles, one / several column tiles per block) and the MFMA-tiled prefill kernel (docs/history/DESIGN_rounds_1-5.md 4.1.1, profiles/r03_mid_m_sweep.txt,
     r03_wide_layers.txt).  Pinned here so that a planner edit that silently re-routes a regime shows up on the CPU."""
     def d(M, K, N, gs=128, bits=4, perm=0):
         buf = ctypes.create_string_buffer(256)
