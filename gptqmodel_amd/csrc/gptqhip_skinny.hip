@@ -1057,7 +1057,10 @@ void skinny_kernel(SkinnyParams p) {
 //     9 VALU per packed word, the scale once per chunk in fp32.  ALG = 0 keeps the bit-faithful per-weight rounding.
 // Replaces nothing upstream beyond what skinny_kernel does (TorchLinear._forward_eager, torch.py:326-347).
 // ------------------------------------------------------------------------------------------------
-template <int ACT, int SCL, int D, int GLUE, int ALG>
+// PERM: act-order checkpoints (the permutation applied inside the kernel, like skinny_kernel's AM_ROW1P): the block stages the GLUED x row in
+// LDS once, every wave gathers the eight elements per lane of each of its chunks from there at park time (the eight indices = two 16-byte
+// loads per lane and quad, in front of the ring) -- the main loop is unchanged.
+template <int ACT, int SCL, int D, int GLUE, int ALG, bool PERM = false>
 __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -1100,14 +1103,32 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
     // this wave's x pieces / norm-weight pieces / group constants: lane (rq, c) of instruction q serves the wave's chunk 4 q + rq
     u4_t xq[4], gq[4];
     uint32_t mq[4];
+    u4_t pq[PERM ? 4 : 1][2];          // PERM: perm[k'] of the lane's eight rows of each chunk
+    u4_t xr[2], gr[2];                 // PERM: this thread's 16-byte pieces of the x row / norm weight (staged once per block)
+    uint16_t* const xbuf = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(lds) + W * p.slot_stride + 96 + W * 256);
+    const int n16 = p.K / 8;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (q < nq) {
             int ck = c_begin + wave + (4 * q + rq) * W;
             ck = ck < c_end ? ck : c_end - 1;           // padding chunks: any finite values (their stages are skipped)
-            xq[q] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.x) + (size_t)ck * 256 + c * 16);
-            if constexpr (GLUE == kGlueRmsNorm) gq[q] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (size_t)ck * 256 + c * 16);
+            if constexpr (PERM) {
+                const u4_t* pp = reinterpret_cast<const u4_t*>(p.perm + (size_t)ck * 128 + c * 8);
+                pq[q][0] = pp[0];
+                pq[q][1] = pp[1];
+            } else {
+                xq[q] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.x) + (size_t)ck * 256 + c * 16);
+                if constexpr (GLUE == kGlueRmsNorm) gq[q] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (size_t)ck * 256 + c * 16);
+            }
             mq[q] = *reinterpret_cast<const uint32_t*>(mbase + ((size_t)(ck >> p.cpg_shift) << 6) + c4);
+        }
+    }
+    if constexpr (PERM) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = (int)threadIdx.x + i * (int)blockDim.x;
+            xr[i] = reinterpret_cast<const u4_t*>(p.x)[idx < n16 ? idx : 0];
+            if constexpr (GLUE == kGlueRmsNorm) gr[i] = reinterpret_cast<const u4_t*>(p.glue_b)[idx < n16 ? idx : 0];
         }
     }
     __builtin_amdgcn_sched_barrier(0);   // keep them in FRONT of the ring
@@ -1130,16 +1151,23 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
         } else {
             // no producer statistics (first op of a step; the planner keeps splits == 1 here): the waves' pieces cover the row exactly once
             float ss = 0.f;
+            auto sq4 = [&](const u4_t& h) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q < nq && c_begin + wave + (4 * q + rq) * W < c_end) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float a = bits16_to_f32<ACT>((uint16_t)(xq[q][j] & 0xffffu)), b = bits16_to_f32<ACT>((uint16_t)(xq[q][j] >> 16));
-                        ss = __builtin_fmaf(a, a, ss);
-                        ss = __builtin_fmaf(b, b, ss);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const float a = bits16_to_f32<ACT>((uint16_t)(h[j] & 0xffffu)), b = bits16_to_f32<ACT>((uint16_t)(h[j] >> 16));
+                    ss = __builtin_fmaf(a, a, ss);
+                    ss = __builtin_fmaf(b, b, ss);
                 }
+            };
+            if constexpr (PERM) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    if ((int)threadIdx.x + i * (int)blockDim.x < n16) sq4(xr[i]);
+                for (int idx = (int)threadIdx.x + 2 * (int)blockDim.x; idx < n16; idx += (int)blockDim.x) sq4(reinterpret_cast<const u4_t*>(p.x)[idx]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < nq && c_begin + wave + (4 * q + rq) * W < c_end) sq4(xq[q]);
             }
 #pragma unroll
             for (int mk = 32; mk >= 1; mk >>= 1) ss += __shfl_xor(ss, mk, 64);
@@ -1154,6 +1182,41 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
             inv = scratch[0];
         }
     }
+    if constexpr (PERM) {
+        // the glued row into LDS once per block (natural order), then every lane gathers its rows of each chunk by their indices
+        auto glued = [&](const u4_t& xv, const u4_t& gv) __attribute__((always_inline)) {
+            u4_t r = xv;
+            if constexpr (GLUE == kGlueRmsNorm) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] = glue_pair<ACT>(xv[j], gv[j], inv, GLUE);
+            }
+            return r;
+        };
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = (int)threadIdx.x + i * (int)blockDim.x;
+            if (idx < n16) reinterpret_cast<u4_t*>(xbuf)[idx] = glued(xr[i], gr[i]);
+        }
+        for (int idx = (int)threadIdx.x + 2 * (int)blockDim.x; idx < n16; idx += (int)blockDim.x) {   // (rows longer than 32 B x threads: rare)
+            u4_t gv = {0u, 0u, 0u, 0u};
+            if constexpr (GLUE == kGlueRmsNorm) gv = reinterpret_cast<const u4_t*>(p.glue_b)[idx];
+            reinterpret_cast<u4_t*>(xbuf)[idx] = glued(reinterpret_cast<const u4_t*>(p.x)[idx], gv);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < nq) {
+                u4_t g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t i0 = pq[q][j >> 1][(j & 1) * 2], i1 = pq[q][j >> 1][(j & 1) * 2 + 1];
+                    g[j] = (uint32_t)xbuf[i0] | ((uint32_t)xbuf[i1] << 16);
+                }
+                xs[q * 64 + lane] = g;
+                ms[q * 64 + lane] = mq[q];
+            }
+        }
+    } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (q < nq) {
@@ -1165,6 +1228,7 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
             xs[q * 64 + lane] = g;
             ms[q * 64 + lane] = mq[q];
         }
+    }
     }
 
     f4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -1389,7 +1453,7 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
 static int skinny1p_grid(const SkinnyParams& p, const SkinnyPlan& pl) {
     static const bool off = [] { const char* v = getenv("GPTQHIP_NO_PERSIST"); return v && *v && *v != '0'; }();
     const int tiles = ceil_div(p.N, kTileN), cus = 256;
-    if (off || p.splits != 1 || p.residual != nullptr || p.bias != nullptr || p.out_f32) return 0;
+    if (off || p.splits != 1 || p.residual != nullptr || p.bias != nullptr || p.out_f32 || p.perm != nullptr) return 0;
     if (tiles < 2 * cus || tiles % cus != 0 || p.N % kTileN != 0) return 0;
     if (p.chunks % 4 != 0 || p.chunks / 4 < 4 || p.chunks / 4 > 16) return 0;
     return cus;
@@ -1401,7 +1465,9 @@ constexpr int kPreloadMaxChunks = 16;   // chunks per wave the preload form park
 template <int ACT, int SCL>
 static int launch_skinny1(const SkinnyParams& p0, const SkinnyPlan& pl, int alg, hipStream_t stream, bool* served) {
     *served = false;
-    if (p0.M != 1 || pl.mt != 1 || pl.gpc != 1 || !pl.regular || pl.nt > 1 || p0.perm != nullptr || p0.n_mine > kPreloadMaxChunks) return 0;
+    if (p0.M != 1 || pl.mt != 1 || pl.gpc != 1 || !pl.regular || pl.nt > 1 || p0.n_mine > kPreloadMaxChunks) return 0;
+    const bool perm = p0.perm != nullptr;
+    if (perm && (pl.depth != 4 || p0.splits != 1 || (size_t)p0.K * 2 > 100 * 1024)) return 0;      // (the planner hands act-order calls the 4-deep ring)
     if (p0.in_glue != kGlueNone && p0.in_glue != kGlueRmsNorm) return 0;
     if (p0.in_glue == kGlueRmsNorm && p0.stats_in == nullptr && p0.splits > 1) return 0;
     if (p0.exact_bf16 || (pl.depth != 2 && pl.depth != 4)) return 0;
@@ -1421,9 +1487,24 @@ static int launch_skinny1(const SkinnyParams& p0, const SkinnyPlan& pl, int alg,
     const int stride = ((p.n_mine + 3) >> 2) * 1280;     // x pieces + constants (>= the 1 KiB per wave the reduction rows need)
     p.slot_stride = stride;
     const dim3 grid(ceil_div(p.N, kTileN), p.splits), block(64 * pl.waves);
-    const size_t lds_bytes = (size_t)pl.waves * stride + 96 + (size_t)pl.waves * 256;   // slots | last-arriver flag + statistics scratch | reduction rows
+    const size_t lds_bytes = (size_t)pl.waves * stride + 96 + (size_t)pl.waves * 256 + (perm ? (size_t)p.K * 2 : 0);   // slots | flag + scratch | reduction rows | x row (act-order)
 #define GPTQHIP_L1(D_, G_, A_) hipLaunchKernelGGL((skinny1_kernel<ACT, SCL, D_, G_, A_>), grid, block, lds_bytes, stream, p)
-    if (pl.depth == 4) {
+    if (perm) {
+        // (the staged x row can push the block past the default 64 KiB of dynamic LDS: raise the limit once per instantiation)
+        auto go = [&](auto kern) {
+            static bool attr_done = false;
+            if (!attr_done && lds_bytes > 64 * 1024) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return check_hip(e, "skinny1_kernel: hipFuncSetAttribute");
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, p);
+            return check_hip(hipGetLastError(), "skinny1_kernel (act-order) launch");
+        };
+        *served = true;
+        if (p.in_glue == kGlueRmsNorm) return a1 ? go(skinny1_kernel<ACT, SCL, 4, kGlueRmsNorm, 1, true>) : go(skinny1_kernel<ACT, SCL, 4, kGlueRmsNorm, 0, true>);
+        return a1 ? go(skinny1_kernel<ACT, SCL, 4, kGlueNone, 1, true>) : go(skinny1_kernel<ACT, SCL, 4, kGlueNone, 0, true>);
+    } else if (pl.depth == 4) {
         if (p.in_glue == kGlueRmsNorm) { if (a1) GPTQHIP_L1(4, kGlueRmsNorm, 1); else GPTQHIP_L1(4, kGlueRmsNorm, 0); }
         else { if (a1) GPTQHIP_L1(4, kGlueNone, 1); else GPTQHIP_L1(4, kGlueNone, 0); }
     } else {
