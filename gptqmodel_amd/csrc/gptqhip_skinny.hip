@@ -1310,23 +1310,25 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
 // and its 16 outputs leave through finish_outputs on wave (tile index % W) after ONE block barrier (reduction rows double-buffered by
 // tile parity).  No residual / bias / cross-block split here: the layers that have them (o_proj, down_proj) have one tile per CU.
 // ------------------------------------------------------------------------------------------------
-template <int ACT, int SCL, int GLUE, int ALG>
+template <int ACT, int SCL, int GLUE, int ALG, int D = 4>
 __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
-    constexpr int D = 4;
+    static_assert(D == 4 || D == 8, "ring depth = chunks per wave and tile");
+    constexpr int NQ = D / 4;                       // 16-byte preload instructions per wave (four chunks each)
+    constexpr int kSlot = D * 384;                  // x pieces (D * 256 B) + constants double-buffered by tile parity (2 * D * 64 B)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int W = blockDim.x >> 6;
     const int c = lane & 15, rq = lane >> 4;
     const int tiles = (p.N + kTileN - 1) / kTileN;
-    char* const slot = reinterpret_cast<char*>(lds) + wave * 1536;
-    u4_t* const xs = reinterpret_cast<u4_t*>(slot);                            // [4][16] u4: this wave's four glued x pieces
-    uint32_t* const ms = reinterpret_cast<uint32_t*>(slot + 1024);             // [2][4][16] constants, double-buffered by tile parity
-    float* scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + W * 1536);
-    float(*red)[16][64] = reinterpret_cast<float(*)[16][64]>(reinterpret_cast<char*>(lds) + W * 1536 + 96);    // [2][W <= 16][64]
+    char* const slot = reinterpret_cast<char*>(lds) + wave * kSlot;
+    u4_t* const xs = reinterpret_cast<u4_t*>(slot);                            // [D][16] u4: this wave's D glued x pieces
+    uint32_t* const ms = reinterpret_cast<uint32_t*>(slot + D * 256);          // [2][D][16] constants, double-buffered by tile parity
+    float* scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + W * kSlot);
+    float(*red)[16][64] = reinterpret_cast<float(*)[16][64]>(reinterpret_cast<char*>(lds) + W * kSlot + 96);    // [2][W <= 16][64]
     const DequantConsts dk = make_dequant_consts<4>();
     const uint32_t lane16 = (uint32_t)lane * 16u, c4 = (uint32_t)c * 4u;
-    const int ck_lane = wave + rq * W;              // the chunk lane (rq, c) serves in the four-chunk preload instructions
+    // the chunk lane (rq, c) serves in preload instruction q: wave + (4 q + rq) * W
     const size_t tile_w = (size_t)p.chunks * 1024, tile_m = (size_t)p.G * 64;
 
     f4_t sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -1337,11 +1339,19 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
             if (p.stats_n > 256) sv[1] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, 1024, 0));
         }
     }
-    u4_t xq = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.x) + (size_t)ck_lane * 256 + c * 16), gq = {0u, 0u, 0u, 0u};
-    if constexpr (GLUE == kGlueRmsNorm) gq = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (size_t)ck_lane * 256 + c * 16);
+    u4_t xq[NQ], gq[NQ];
+    uint32_t mq[NQ];
     int tile = blockIdx.x;
-    const char* mrow = reinterpret_cast<const char*>(p.meta) + (size_t)tile * tile_m + ((size_t)(ck_lane >> p.cpg_shift) << 6) + c4;
-    uint32_t mq = *reinterpret_cast<const uint32_t*>(mrow);
+    const char* mrow[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int ck_lane = wave + (4 * q + rq) * W;
+        xq[q] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.x) + (size_t)ck_lane * 256 + c * 16);
+        gq[q] = u4_t{0u, 0u, 0u, 0u};
+        if constexpr (GLUE == kGlueRmsNorm) gq[q] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (size_t)ck_lane * 256 + c * 16);
+        mrow[q] = reinterpret_cast<const char*>(p.meta) + (size_t)tile * tile_m + ((size_t)(ck_lane >> p.cpg_shift) << 6) + c4;
+        mq[q] = *reinterpret_cast<const uint32_t*>(mrow[q]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     const char* wsrc = reinterpret_cast<const char*>(p.qw) + (size_t)tile * tile_w + (size_t)wave * 1024 + lane16;
     const size_t wstep = (size_t)W * 1024, tstep_w = (size_t)gridDim.x * tile_w, tstep_m = (size_t)gridDim.x * tile_m;
@@ -1357,10 +1367,13 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
         } else {
             float ss = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a = bits16_to_f32<ACT>((uint16_t)(xq[j] & 0xffffu)), b = bits16_to_f32<ACT>((uint16_t)(xq[j] >> 16));
-                ss = __builtin_fmaf(a, a, ss);
-                ss = __builtin_fmaf(b, b, ss);
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = bits16_to_f32<ACT>((uint16_t)(xq[q][j] & 0xffffu)), b = bits16_to_f32<ACT>((uint16_t)(xq[q][j] >> 16));
+                    ss = __builtin_fmaf(a, a, ss);
+                    ss = __builtin_fmaf(b, b, ss);
+                }
             }
             ss = wave64_sum(ss);
             if (lane == 0) scratch[1 + wave] = ss;
@@ -1374,9 +1387,13 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
             inv = scratch[0];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xq[j] = glue_pair<ACT>(xq[j], gq[j], inv, GLUE);
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xq[q][j] = glue_pair<ACT>(xq[q][j], gq[q][j], inv, GLUE);
+        }
     }
-    xs[lane] = xq;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) xs[q * 64 + lane] = xq[q];
 
     uint32_t magic_hi = 0x54005400u;
     asm volatile("" : "+v"(magic_hi));
@@ -1419,11 +1436,15 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
     int ti = 0;
     auto do_tile = [&](auto more_c) __attribute__((always_inline)) {
         constexpr bool MORE = decltype(more_c)::value;
-        uint32_t* mcur = ms + (ti & 1) * 64;
-        mcur[lane] = mq;                                     // this tile's constants (wave-private rows: no barrier)
-        if constexpr (MORE) {                                // the next tile's: one instruction, a tile ahead
-            mrow += tstep_m;
-            mq = *reinterpret_cast<const uint32_t*>(mrow);
+        uint32_t* mcur = ms + (ti & 1) * (D * 16);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) mcur[q * 64 + lane] = mq[q];     // this tile's constants (wave-private rows: no barrier)
+        if constexpr (MORE) {                                // the next tile's: one instruction per four chunks, a tile ahead
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                mrow[q] += tstep_m;
+                mq[q] = *reinterpret_cast<const uint32_t*>(mrow[q]);
+            }
             wsrc += tstep_w;
         }
 #pragma unroll
@@ -1450,12 +1471,17 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
 }
 
 // tiles per block of the persistent variant; 0: not applicable
+static int skinny1p_depth() {   // dev A/B switch: GPTQHIP_SK1P_D8=1 runs chunks / 8 waves with an 8-deep ring
+    static const int d = [] { const char* v = getenv("GPTQHIP_SK1P_D8"); return (v && *v && *v != '0') ? 8 : 4; }();
+    return d;
+}
 static int skinny1p_grid(const SkinnyParams& p, const SkinnyPlan& pl) {
     static const bool off = [] { const char* v = getenv("GPTQHIP_NO_PERSIST"); return v && *v && *v != '0'; }();
     const int tiles = ceil_div(p.N, kTileN), cus = 256;
     if (off || p.splits != 1 || p.residual != nullptr || p.bias != nullptr || p.out_f32 || p.perm != nullptr) return 0;
     if (tiles < 2 * cus || tiles % cus != 0 || p.N % kTileN != 0) return 0;
-    if (p.chunks % 4 != 0 || p.chunks / 4 < 4 || p.chunks / 4 > 16) return 0;
+    const int d = skinny1p_depth();
+    if (p.chunks % d != 0 || p.chunks / d < 4 || p.chunks / d > 16) return 0;
     return cus;
 }
 
@@ -1474,20 +1500,35 @@ static int launch_skinny1(const SkinnyParams& p0, const SkinnyPlan& pl, int alg,
     SkinnyParams p = p0;
     const bool a1 = alg != 0 && ACT == kFP16 && SCL == kFP16;   // (bf16 scales: the reference rounds W to bf16 -- 2^-9 per weight -- keep its chain)
     if (const int pg = skinny1p_grid(p0, pl)) {
-        const int waves = p.chunks / 4;
+        const int d = skinny1p_depth();
+        const int waves = p.chunks / d;
         const dim3 grid(pg), block(64 * waves);
-        const size_t lds_bytes = (size_t)waves * 1536 + 96 + 2 * 16 * 256;
-#define GPTQHIP_L1P(G_, A_) hipLaunchKernelGGL((skinny1p_kernel<ACT, SCL, G_, A_>), grid, block, lds_bytes, stream, p)
-        if (p.in_glue == kGlueRmsNorm) { if (a1) GPTQHIP_L1P(kGlueRmsNorm, 1); else GPTQHIP_L1P(kGlueRmsNorm, 0); }
-        else { if (a1) GPTQHIP_L1P(kGlueNone, 1); else GPTQHIP_L1P(kGlueNone, 0); }
+        const size_t lds_bytes = (size_t)waves * d * 384 + 96 + 2 * 16 * 256;
+#define GPTQHIP_L1P(G_, A_, D_) hipLaunchKernelGGL((skinny1p_kernel<ACT, SCL, G_, A_, D_>), grid, block, lds_bytes, stream, p)
+        if (d == 8) {
+            if (p.in_glue == kGlueRmsNorm) { if (a1) GPTQHIP_L1P(kGlueRmsNorm, 1, 8); else GPTQHIP_L1P(kGlueRmsNorm, 0, 8); }
+            else { if (a1) GPTQHIP_L1P(kGlueNone, 1, 8); else GPTQHIP_L1P(kGlueNone, 0, 8); }
+        } else {
+            if (p.in_glue == kGlueRmsNorm) { if (a1) GPTQHIP_L1P(kGlueRmsNorm, 1, 4); else GPTQHIP_L1P(kGlueRmsNorm, 0, 4); }
+            else { if (a1) GPTQHIP_L1P(kGlueNone, 1, 4); else GPTQHIP_L1P(kGlueNone, 0, 4); }
+        }
 #undef GPTQHIP_L1P
         *served = true;
         return check_hip(hipGetLastError(), "skinny1p_kernel launch");
     }
+    // Geometry: the planner's (waves, depth), or -- dev A/B switch GPTQHIP_SK1_D8=1 -- half the waves with an 8-deep ring (every wave's eight
+    // chunks requested up front: the same bytes in flight per CU from half the waves to start)
+    static const int d8_mode = [] { const char* v = getenv("GPTQHIP_SK1_D8"); return (v && *v) ? atoi(v) : 0; }();
+    int waves = pl.waves, depth = pl.depth;
+    if (d8_mode > 0 && !perm && p.splits == 1 && p.chunks % 8 == 0 && p.chunks / 8 >= 4 && p.chunks / 8 <= 16 && (d8_mode >= 2 || p.chunks / 8 <= 8)) {
+        waves = p.chunks / 8;
+        depth = 8;
+        p.n_mine = 8;
+    }
     const int stride = ((p.n_mine + 3) >> 2) * 1280;     // x pieces + constants (>= the 1 KiB per wave the reduction rows need)
     p.slot_stride = stride;
-    const dim3 grid(ceil_div(p.N, kTileN), p.splits), block(64 * pl.waves);
-    const size_t lds_bytes = (size_t)pl.waves * stride + 96 + (size_t)pl.waves * 256 + (perm ? (size_t)p.K * 2 : 0);   // slots | flag + scratch | reduction rows | x row (act-order)
+    const dim3 grid(ceil_div(p.N, kTileN), p.splits), block(64 * waves);
+    const size_t lds_bytes = (size_t)waves * stride + 96 + (size_t)waves * 256 + (perm ? (size_t)p.K * 2 : 0);   // slots | flag + scratch | reduction rows | x row (act-order)
 #define GPTQHIP_L1(D_, G_, A_) hipLaunchKernelGGL((skinny1_kernel<ACT, SCL, D_, G_, A_>), grid, block, lds_bytes, stream, p)
     if (perm) {
         // (the staged x row can push the block past the default 64 KiB of dynamic LDS: raise the limit once per instantiation)
@@ -1504,7 +1545,10 @@ static int launch_skinny1(const SkinnyParams& p0, const SkinnyPlan& pl, int alg,
         *served = true;
         if (p.in_glue == kGlueRmsNorm) return a1 ? go(skinny1_kernel<ACT, SCL, 4, kGlueRmsNorm, 1, true>) : go(skinny1_kernel<ACT, SCL, 4, kGlueRmsNorm, 0, true>);
         return a1 ? go(skinny1_kernel<ACT, SCL, 4, kGlueNone, 1, true>) : go(skinny1_kernel<ACT, SCL, 4, kGlueNone, 0, true>);
-    } else if (pl.depth == 4) {
+    } else if (depth == 8) {
+        if (p.in_glue == kGlueRmsNorm) { if (a1) GPTQHIP_L1(8, kGlueRmsNorm, 1); else GPTQHIP_L1(8, kGlueRmsNorm, 0); }
+        else { if (a1) GPTQHIP_L1(8, kGlueNone, 1); else GPTQHIP_L1(8, kGlueNone, 0); }
+    } else if (depth == 4) {
         if (p.in_glue == kGlueRmsNorm) { if (a1) GPTQHIP_L1(4, kGlueRmsNorm, 1); else GPTQHIP_L1(4, kGlueRmsNorm, 0); }
         else { if (a1) GPTQHIP_L1(4, kGlueNone, 1); else GPTQHIP_L1(4, kGlueNone, 0); }
     } else {

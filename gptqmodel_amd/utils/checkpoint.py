@@ -205,6 +205,13 @@ def load_quantized_checkpoint(model: nn.Module, ckpt_dir: str, device="cuda", ba
                 and not any(a in seen for a in by_storage.get(targets[k].data_ptr(), []))]
     if unloaded:
         raise ValueError(f"the checkpoint lacks model tensors: {unloaded[:8]}")
+    # ... but say which PERSISTENT buffers kept their initial values (running statistics would be wrong, rotary tables are fine)
+    nonpersistent = {f"{mn}.{bn}" if mn else bn for mn, m in model.named_modules() for bn in getattr(m, "_non_persistent_buffers_set", ())}
+    stale = [k for k, _ in model.named_buffers() if k in targets and k not in seen and k not in quant_owned and k not in nonpersistent
+             and not any(a in seen for a in by_storage.get(targets[k].data_ptr(), []))]
+    if stale:
+        log.warning("load_quantized_checkpoint: persistent buffers not in the checkpoint keep their initial values: %s%s", stale[:8],
+                    " ..." if len(stale) > 8 else "")
     if fmt == FORMAT.GPTQ and not cfg["sym"] and not _written_by_v2_aware_quantizer(cfg):
         # v1 files of asymmetric models from producers older than the v2-aware code base store zero-points this conversion would
         # shift by one: the reference refuses them (models/loader.py:1658-1663), so does this loader

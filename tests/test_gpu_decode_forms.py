@@ -121,3 +121,40 @@ def test_layer_ops_with_glue_every_form(ops, form, act):
         torch.cuda.synchronize()
     finally:
         ops.set_decode_form(-1)
+
+
+@pytest.mark.parametrize("K,N", [(4096, 4096), (14336, 4096), (4096, 6144)])
+def test_group_factored_default_is_no_further_from_exact_arithmetic_than_the_reference(ops, K, N):
+    """The fp16 default (form 3) leaves the reference's per-weight rounding: y = sum_g s_g * sum_k x_k (q_k - z_g) with the integers exact and the
+    scale applied once per group in fp32.  That is the exact value of the reference's expression up to fp32 accumulation; the reference's own output
+    differs from it by its per-weight fp16 rounding (2^-12 relative per weight).  Pinned here against float64 arithmetic on the integer codes:
+    the default's distance from the exact result is no larger than the reference chain's (oracle = TorchLinear semantics), on BASELINE's shapes."""
+    gs = 128
+    qweight, qzeros, scales, g_idx = synth_gptq(77 + K // 128 + N // 16, 4, K, N, gs, scale_dtype="fp16")
+    rng = np.random.RandomState(11)
+    x = O.round_to(rng.randn(1, K).astype(np.float32) * 0.5, "fp16")
+    codes = O.unpack_rows(qweight, 4).astype(np.int64)
+    zeros = O.unpack_cols(qzeros, 4).astype(np.int64)
+    g = O.normalize_g_idx(g_idx, scales.shape[0])
+    w_exact = np.asarray(scales, np.float64)[g] * (codes - zeros[g]).astype(np.float64)
+    y_exact = x.astype(np.float64) @ w_exact                                   # no rounding anywhere
+    y_ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, None, "fp16", "fp16").astype(np.float64)
+    qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, gs, "fp16")
+    outs = {}
+    for form in (3, 4):
+        ops.set_decode_form(form)
+        try:
+            outs[form] = torch_to_f32(ops.decode_linear(f32_to_torch(x[0], "fp16", DEV), qw_t, meta, None, K, N, gs, 4, sc.dtype)).astype(np.float64)[None]
+            torch.cuda.synchronize()
+        finally:
+            ops.set_decode_form(-1)
+    scale = np.abs(y_exact).max()
+    err_ref = np.abs(y_ref - y_exact).max() / scale
+    err_f3 = np.abs(outs[3] - y_exact).max() / scale
+    err_f4 = np.abs(outs[4] - y_exact).max() / scale
+    rms = lambda a: float(np.sqrt(np.mean((a - y_exact) ** 2)) / scale)   # noqa: E731
+    # both are dominated by the final rounding of y to fp16 (2^-11 relative); the default must not be worse than the reference chain
+    assert err_f3 <= err_ref * 1.05 + 1e-6, (err_f3, err_ref)
+    assert rms(outs[3]) <= rms(y_ref) * 1.02 + 1e-7, (rms(outs[3]), rms(y_ref))
+    assert err_f4 <= err_ref * 1.5 + 1e-6, (err_f4, err_ref)                    # bit-faithful form: the reference's own noise level
+    assert err_f3 <= 1e-3 and err_ref <= 1e-3
