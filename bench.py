@@ -561,7 +561,7 @@ def main():
                                    "SiLU*mul, residual adds fused into the ops; attention stand-in = q), M=1, random packed weights",
                        "parallelism": f"replicas x{world}", "mode": mode,
                        # include/gptqhip.h gptqhip_set_decode_form: the process default of this dtype (GPTQHIP_DECODE_BITFAITHFUL=1 -> 4)
-                       "decode_form": (4 if (dtype != torch.float16 or os.environ.get("GPTQHIP_DECODE_BITFAITHFUL", "0") not in ("", "0")) else 3),
+                       "decode_form": (4 if (dtype != torch.float16 or os.environ.get("GPTQHIP_DECODE_BITFAITHFUL", "0") not in ("", "0")) else 5),
                        "loader_path": "mode=chain is what gptqmodel_post_init yields on HF Llama-family layers by itself since round 6 "
                                       "(utils.hf_llama.auto_fuse; the reference's own post_init through integration/gptqmodel_overlay/utils/model.patch); "
                                       "mode=modules is the GPTQHIP_AUTO_FUSE=0 path: plugin forward() per linear + torch glue kernels",

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 # GPTQHIP_LIB: load another build of the library (dev A/B builds under tests/dev/ablate/; same ABI check as the product build)
 LIB_PATH = os.environ.get("GPTQHIP_LIB") or os.path.join(CSRC_DIR, "libgptqhip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 # every symbol include/gptqhip.h declares: name -> (restype, argtypes)
 _c = ctypes

@@ -41,14 +41,14 @@ static const EnvTuning& env_tuning() {
     static const EnvTuning e = {env_int("GPTQHIP_FORCE_SPLIT_K"), env_int("GPTQHIP_FORCE_KERNEL"), env_int("GPTQHIP_FORCE_VARIANT")};
     return e;
 }
-// batch-1 decode form (include/gptqhip.h gptqhip_set_decode_form).  Process default: 3 (preload + algebraic dequant) for fp16 activations,
-// 4 (preload, the reference's per-weight rounding) for bf16 activations -- the algebraic form is outside the bf16 gate (8e-3) -- and 4 for
-// everything when GPTQHIP_DECODE_BITFAITHFUL=1 is in the environment.
+// batch-1 decode form (include/gptqhip.h gptqhip_set_decode_form).  Process default: 5 (preload + raw codes as fp16 denormals) for fp16 activations
+// with fp16 scales, 4 (preload, the reference's per-weight rounding) for bf16 activations or scales -- the exact-arithmetic forms are outside the bf16
+// gate (8e-3) -- and 4 for everything when GPTQHIP_DECODE_BITFAITHFUL=1 is in the environment.
 static int decode_form_for(int act_dtype, int scale_dtype) {
     static const int bitfaithful = env_int("GPTQHIP_DECODE_BITFAITHFUL");
     const bool exact_ok = act_dtype == GPTQHIP_FP16 && scale_dtype == GPTQHIP_FP16;   // the exact-arithmetic forms exist for fp16 x fp16 only
-    if (t_decode_form >= 0) return (t_decode_form == 1 && !exact_ok) ? 4 : t_decode_form;
-    return (bitfaithful || !exact_ok) ? 4 : 3;
+    if (t_decode_form >= 0) return ((t_decode_form == 1 || t_decode_form == 5) && !exact_ok) ? 4 : t_decode_form;
+    return (bitfaithful || !exact_ok) ? 4 : 5;
 }
 #define g_force_split (t_force_split ? t_force_split : env_tuning().split)
 #define g_force_kernel (t_force_kernel ? t_force_kernel : env_tuning().kernel)
@@ -154,8 +154,8 @@ int gptqhip_set_tuning(int force_split_k, int force_kernel, int force_waves) {
 }
 
 int gptqhip_set_decode_form(int form) {
-    if (form < -1 || form > 4) {
-        set_error("gptqhip_set_decode_form: form=%d (0 bit-faithful, 1 stream, -1 process default)", form);
+    if (form < -1 || form > 5) {
+        set_error("gptqhip_set_decode_form: form=%d (0..5, -1 = process default; see include/gptqhip.h)", form);
         return GPTQHIP_EINVAL;
     }
     t_decode_form = form;
@@ -296,9 +296,9 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
     a.scale_dtype = scale_dtype;
     a.out_f32 = partial_f32 ? 1 : 0;
     a.perm = fused_perm ? perm : nullptr;
-    a.exact_bf16 = (flags & GPTQHIP_GEMM_EXACT_BF16) ? 1 : 0;
-    a.alg_fp16 = (decode_form == 2 || decode_form == 3) ? 1 : 0;
-    a.preload = (decode_form == 3 || decode_form == 4) ? 1 : 0;
+    a.exact_bf16 = ((flags & GPTQHIP_GEMM_EXACT_BF16) && act_dtype == GPTQHIP_BF16) ? 1 : 0;   // (no fp16 form: the flag changes nothing there)
+    a.alg_fp16 = decode_form == 5 ? 2 : ((decode_form == 2 || decode_form == 3) ? 1 : 0);
+    a.preload = (decode_form == 3 || decode_form == 4 || decode_form == 5) ? 1 : 0;
 
     // measured crossover (profiles/r03_mid_m_sweep.txt, round 3: split-ring pipeline for 17..64 rows, 33..64 rows in one launch with
     // 4-bit weights): the decode kernel leads up to 64 rows on layers with K < 8192 and N < 6144 (4096^2 at M=64 10.7 us vs 14.8 us
@@ -490,7 +490,7 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
                          (op->in_glue == GPTQHIP_GLUE_RMSNORM || (op->in_glue == GPTQHIP_GLUE_NONE && op->out_glue == GPTQHIP_OUT_NONE)) &&
                          (op->out_glue == GPTQHIP_OUT_NONE || op->out_glue == GPTQHIP_OUT_SILU_MUL_PAIRED ||
                           (op->out_glue == GPTQHIP_OUT_PARTIAL_F32 && op->in_glue == GPTQHIP_GLUE_NONE));
-    const bool preload_form = (decode_form == 3 || decode_form == 4) && M == 1 && !op->perm && op->bits == 4;
+    const bool preload_form = (decode_form == 3 || decode_form == 4 || decode_form == 5) && M == 1 && !op->perm && op->bits == 4;
     const SkinnyPlan pl = plan_skinny(M, op->K, op->N, op->group_size, g_force_split, g_skinny_waves, op->perm != nullptr, op->bits,
                                       !wide_ok ? 0 : (op->in_glue == GPTQHIP_GLUE_RMSNORM ? 2 : 1), preload_form);
     if (op->perm && !(pl.depth == 4 && (size_t)op->K * 2 <= kInKernelPermMaxRowBytes)) {
@@ -510,9 +510,9 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
     char* ws = reinterpret_cast<char*>(op->workspace);
     GemmArgs a;
     a.x = op->x;
-    a.exact_bf16 = (op->flags & GPTQHIP_GEMM_EXACT_BF16) ? 1 : 0;
-    a.alg_fp16 = (decode_form == 2 || decode_form == 3) ? 1 : 0;
-    a.preload = (decode_form == 3 || decode_form == 4) ? 1 : 0;
+    a.exact_bf16 = ((op->flags & GPTQHIP_GEMM_EXACT_BF16) && op->act_dtype == GPTQHIP_BF16) ? 1 : 0;
+    a.alg_fp16 = decode_form == 5 ? 2 : ((decode_form == 2 || decode_form == 3) ? 1 : 0);
+    a.preload = (decode_form == 3 || decode_form == 4 || decode_form == 5) ? 1 : 0;
     a.perm = op->perm;
     a.qweight = op->qweight_t;
     a.meta = op->meta;

@@ -1060,6 +1060,9 @@ void skinny_kernel(SkinnyParams p) {
 // PERM: act-order checkpoints (the permutation applied inside the kernel, like skinny_kernel's AM_ROW1P): the block stages the GLUED x row in
 // LDS once, every wave gathers the eight elements per lane of each of its chunks from there at park time (the eight indices = two 16-byte
 // loads per lane and quad, in front of the ring) -- the main loop is unchanged.
+#ifndef GPTQHIP_SK1_ABLATE   // dev timing builds (tests/dev/sk1_ablate_build.sh; WRONG results): 1 no small-operand loads, 2 no dequant / MFMA,
+#define GPTQHIP_SK1_ABLATE 0 // 4 no reduction / epilogue, 8 no weight loads
+#endif
 template <int ACT, int SCL, int D, int GLUE, int ALG, bool PERM = false>
 __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1072,9 +1075,15 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
     const int c_end = min(p.chunks, c_begin + p.chunks_per_split);
     const int n_mine = p.n_mine;                       // chunks per wave incl. the padding of the last ring round
     const int nq = (n_mine + 3) >> 2;                  // 16-byte x instructions (four chunks each)
+    // ALG = 2 ("raw codes", decode form 5): the 4-bit codes go into the MFMA as they are -- (w & 0x000F000F) is a pair of fp16 DENORMALS q * 2^-24,
+    // (w & 0x00F000F0) a pair q * 2^-20 (the matrix pipe takes fp16 denormals at face value: tests/dev/mfma_denorm_probe.hip) -- one v_and_b32 per
+    // two weights, no zero-point subtraction: y = sum_g s_g (2^24 lo_g + 2^20 hi_g - z_g Sx_g) with lo / hi the two MFMA chains of a chunk and
+    // Sx_g the sum of the chunk's 128 (glued) activations, taken once per wave at park time.  The two classes need their own A fragments:
+    // the x pieces are parked re-paired ([k0 k1 | k4 k5] of two K-steps, [k2 k3 | k6 k7] of two K-steps) so a fragment is still one ds_read_b128.
+    constexpr bool RAW = ALG == 2 && ACT == kFP16 && SCL == kFP16;
     char* const slot = reinterpret_cast<char*>(lds) + wave * p.slot_stride;
     u4_t* const xs = reinterpret_cast<u4_t*>(slot);                                   // [4 nq][16] u4: the glued x pieces
-    uint32_t* const ms = reinterpret_cast<uint32_t*>(slot + nq * 1024);               // [4 nq][16] meta words
+    uint32_t* const ms = reinterpret_cast<uint32_t*>(slot + nq * 1024);               // [4 nq][16] meta words (RAW: [4 nq][16] float2 = s 2^24, s 2^20)
     int* s_last = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + W * p.slot_stride);
     float* scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + W * p.slot_stride + 16);
     float(*red)[64] = reinterpret_cast<float(*)[64]>(reinterpret_cast<char*>(lds) + W * p.slot_stride + 96);   // beside the slots: one barrier
@@ -1084,13 +1093,13 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
     const uint32_t lane16 = (uint32_t)lane * 16u, c4 = (uint32_t)c * 4u;
 
     uint32_t res_raw = 0u;
-    if (p.residual != nullptr && wave == 0 && rq == 0) {
+    if (p.residual != nullptr && wave == 0 && rq == 0 && !(GPTQHIP_SK1_ABLATE & 1)) {
         const int coln = tile * kTileN + c;
         res_raw = reinterpret_cast<const uint32_t*>(p.residual)[(size_t)(coln < p.N ? coln : 0) >> 1];
     }
     f4_t sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if constexpr (GLUE == kGlueRmsNorm) {
-        if (p.stats_in != nullptr) {
+        if (p.stats_in != nullptr && !(GPTQHIP_SK1_ABLATE & 1)) {
             // the producer's per-tile sums of squares, in front of everything: ONE 16-byte load per lane covers 256 partial sums (a second
             // one up to 512); entries past stats_n are outside the descriptor and read as zeros.  EVERY wave fetches and reduces them (one
             // L2-hit instruction per wave, DPP adds): no LDS hand-over and no block barrier between the launch and its first multiply.
@@ -1112,6 +1121,13 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
         if (q < nq) {
             int ck = c_begin + wave + (4 * q + rq) * W;
             ck = ck < c_end ? ck : c_end - 1;           // padding chunks: any finite values (their stages are skipped)
+#if GPTQHIP_SK1_ABLATE & 1
+            xq[q] = u4_t{0x3c003c00u + (uint32_t)ck, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+            gq[q] = xq[q];
+            mq[q] = 0xE4082000u + (uint32_t)ck;
+            if constexpr (PERM) { pq[q][0] = xq[q]; pq[q][1] = xq[q]; }
+            continue;
+#endif
             if constexpr (PERM) {
                 const u4_t* pp = reinterpret_cast<const u4_t*>(p.perm + (size_t)ck * 128 + c * 8);
                 pq[q][0] = pp[0];
@@ -1137,7 +1153,11 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
     int nxt = c_begin + wave;
     auto load_w = [&](u4_t& dst) __attribute__((always_inline)) {
         const int ck = nxt < c_end ? nxt : c_end - 1;
+#if GPTQHIP_SK1_ABLATE & 8
+        dst = u4_t{(uint32_t)ck, lane16, (uint32_t)ck ^ lane16, (uint32_t)ck + lane16};
+#else
         dst = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wbase + (size_t)ck * 1024 + lane16));
+#endif
         nxt += W;
     };
 #pragma unroll
@@ -1182,6 +1202,29 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
             inv = scratch[0];
         }
     }
+    float tsum = 0.f;    // RAW: -sum over this lane's park chunks of s z Sx (column c of chunk 4 q + rq)
+    auto park = [&](int q, const u4_t& g) __attribute__((always_inline)) {
+        if constexpr (RAW) {
+            const int li = 4 * q + rq, j = c >> 2;        // this lane holds piece c = K-step j, k-group c & 3 of chunk li
+            char* base = reinterpret_cast<char*>(xs) + li * 256 + (c & 3) * 64 + (j >> 1) * 32 + (j & 1) * 8;
+            *reinterpret_cast<u2_t*>(base) = u2_t{g[0], g[2]};          // (k0 k1 | k4 k5): the low-nibble class
+            *reinterpret_cast<u2_t*>(base + 16) = u2_t{g[1], g[3]};     // (k2 k3 | k6 k7): the high-nibble class
+            const h2_t ones = as_h2(0x3C003C00u);
+            float s8 = __builtin_amdgcn_fdot2(as_h2(g[0]), ones, 0.f, false);
+            s8 = __builtin_amdgcn_fdot2(as_h2(g[1]), ones, s8, false);
+            s8 = __builtin_amdgcn_fdot2(as_h2(g[2]), ones, s8, false);
+            s8 = __builtin_amdgcn_fdot2(as_h2(g[3]), ones, s8, false);
+            s8 = row16_sum(s8);                                          // Sx of chunk li (the row's 16 lanes hold its 16 pieces)
+            const uint32_t mw = mq[q];
+            const float sc = bits16_to_f32<SCL>((uint16_t)(mw & 0xffffu));
+            const float z = (float)((mw >> 16) & 0xFu);                  // meta = scale16 | (0xE400 | zero) << 16
+            reinterpret_cast<float2*>(ms)[q * 64 + lane] = float2{sc * 16777216.f, sc * 1048576.f};
+            if (c_begin + wave + li * W < c_end) tsum = __builtin_fmaf(-(sc * z), s8, tsum);      // (padding chunks: skipped like their stages)
+        } else {
+            xs[q * 64 + lane] = g;
+            ms[q * 64 + lane] = mq[q];
+        }
+    };
     if constexpr (PERM) {
         // the glued row into LDS once per block (natural order), then every lane gathers its rows of each chunk by their indices
         auto glued = [&](const u4_t& xv, const u4_t& gv) __attribute__((always_inline)) {
@@ -1212,8 +1255,7 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
                     const uint32_t i0 = pq[q][j >> 1][(j & 1) * 2], i1 = pq[q][j >> 1][(j & 1) * 2 + 1];
                     g[j] = (uint32_t)xbuf[i0] | ((uint32_t)xbuf[i1] << 16);
                 }
-                xs[q * 64 + lane] = g;
-                ms[q * 64 + lane] = mq[q];
+                park(q, g);
             }
         }
     } else {
@@ -1225,16 +1267,43 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) g[j] = glue_pair<ACT>(xq[q][j], gq[q][j], inv, GLUE);
             }
-            xs[q * 64 + lane] = g;
-            ms[q * 64 + lane] = mq[q];
+            park(q, g);
         }
     }
     }
 
     f4_t acc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (RAW) {
+        // column c's zero-point term over ALL the wave's chunks: the four rows hold chunks 4 q + 0..3 -> butterfly over the rows
+        tsum += __shfl_xor(tsum, 16, 64);
+        tsum += __shfl_xor(tsum, 32, 64);
+        acc[0] = tsum;
+    }
     uint32_t magic_hi = 0x54005400u;
     asm volatile("" : "+v"(magic_hi));
     auto compute = [&](const u4_t& wv, int li) __attribute__((always_inline)) {
+#if GPTQHIP_SK1_ABLATE & 2
+        asm volatile("" ::"v"(wv));     // (the loaded registers are consumed: the waits stay)
+        acc[0] += (float)li;
+        return;
+#endif
+        if constexpr (RAW) {
+            const float2 ab = reinterpret_cast<const float2*>(ms)[li * 16 + c];
+            const u4_t* xr = xs + li * 16 + rq * 4;                         // [lo of K-steps 0|1, hi of 0|1, lo of 2|3, hi of 2|3]
+            const f4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+            f4_t glo = zero4, ghi = zero4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t w0 = wv[2 * h], w1 = wv[2 * h + 1], w0s = w0 >> 8, w1s = w1 >> 8;
+                const u4_t blo = {w0 & dk.lo, w0s & dk.lo, w1 & dk.lo, w1s & dk.lo};
+                const u4_t bhi = {w0 & dk.hi, w0s & dk.hi, w1 & dk.hi, w1s & dk.hi};
+                glo = mfma16<ACT>(xr[2 * h], blo, glo);
+                ghi = mfma16<ACT>(xr[2 * h + 1], bhi, ghi);
+            }
+            acc[0] = __builtin_fmaf(ab.x, glo[0], acc[0]);
+            acc[0] = __builtin_fmaf(ab.y, ghi[0], acc[0]);
+            return;
+        }
         const uint32_t mw = ms[li * 16 + c];
         const u4_t* xa = xs + li * 16 + rq;
         if constexpr (ALG == 1 && ACT == kFP16 && SCL == kFP16) {
@@ -1287,6 +1356,10 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
         ++li;
     }
 
+#if GPTQHIP_SK1_ABLATE & 4
+    if (__builtin_bit_cast(uint32_t, acc[0]) == 0x12345678u) reinterpret_cast<uint16_t*>(p.out)[blockIdx.x] = 1;
+    return;
+#endif
     // ---- in-block split-K reduction through LDS: only output row 0 exists (accumulator register 0 of the lanes with rq == 0) ----
     red[wave][lane] = acc[0];
     __syncthreads();
@@ -1314,7 +1387,8 @@ template <int ACT, int SCL, int GLUE, int ALG, int D = 4>
 __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
     static_assert(D == 4 || D == 8, "ring depth = chunks per wave and tile");
     constexpr int NQ = D / 4;                       // 16-byte preload instructions per wave (four chunks each)
-    constexpr int kSlot = D * 384;                  // x pieces (D * 256 B) + constants double-buffered by tile parity (2 * D * 64 B)
+    constexpr bool RAW = ALG == 2 && ACT == kFP16 && SCL == kFP16;     // raw codes as fp16 denormals (see skinny1_kernel)
+    constexpr int kSlot = D * (RAW ? 512 : 384);    // x pieces (D * 256 B) + constants double-buffered by tile parity (2 * D * 64 B; RAW: float2)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1392,13 +1466,46 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
             for (int j = 0; j < 4; ++j) xq[q][j] = glue_pair<ACT>(xq[q][j], gq[q][j], inv, GLUE);
         }
     }
+    float sx[NQ];      // RAW: Sx of chunk wave + (4 q + rq) W (the same for every tile)
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) xs[q * 64 + lane] = xq[q];
+    for (int q = 0; q < NQ; ++q) {
+        if constexpr (RAW) {
+            const int li = 4 * q + rq, j = c >> 2;
+            char* base = reinterpret_cast<char*>(xs) + li * 256 + (c & 3) * 64 + (j >> 1) * 32 + (j & 1) * 8;
+            *reinterpret_cast<u2_t*>(base) = u2_t{xq[q][0], xq[q][2]};
+            *reinterpret_cast<u2_t*>(base + 16) = u2_t{xq[q][1], xq[q][3]};
+            const h2_t ones = as_h2(0x3C003C00u);
+            float s8 = __builtin_amdgcn_fdot2(as_h2(xq[q][0]), ones, 0.f, false);
+            s8 = __builtin_amdgcn_fdot2(as_h2(xq[q][1]), ones, s8, false);
+            s8 = __builtin_amdgcn_fdot2(as_h2(xq[q][2]), ones, s8, false);
+            s8 = __builtin_amdgcn_fdot2(as_h2(xq[q][3]), ones, s8, false);
+            sx[q] = row16_sum(s8);
+        } else {
+            xs[q * 64 + lane] = xq[q];
+        }
+    }
 
     uint32_t magic_hi = 0x54005400u;
     asm volatile("" : "+v"(magic_hi));
     float acc = 0.f;
     auto compute = [&](const u4_t& wv, int li, const uint32_t* mcur) __attribute__((always_inline)) {
+        if constexpr (RAW) {
+            const float2 ab = reinterpret_cast<const float2*>(mcur)[li * 16 + c];
+            const u4_t* xr = xs + li * 16 + rq * 4;
+            const f4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+            f4_t glo = zero4, ghi = zero4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t w0 = wv[2 * h], w1 = wv[2 * h + 1], w0s = w0 >> 8, w1s = w1 >> 8;
+                const u4_t blo = {w0 & dk.lo, w0s & dk.lo, w1 & dk.lo, w1s & dk.lo};
+                const u4_t bhi = {w0 & dk.hi, w0s & dk.hi, w1 & dk.hi, w1s & dk.hi};
+                glo = mfma16<ACT>(xr[2 * h], blo, glo);
+                ghi = mfma16<ACT>(xr[2 * h + 1], bhi, ghi);
+            }
+            acc = __builtin_fmaf(ab.x, glo[0], acc);
+            acc = __builtin_fmaf(ab.y, ghi[0], acc);
+            return;
+        }
         const uint32_t mw = mcur[li * 16 + c];
         const u4_t* xa = xs + li * 16 + rq;
         if constexpr (ALG == 1 && ACT == kFP16 && SCL == kFP16) {
@@ -1436,9 +1543,23 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
     int ti = 0;
     auto do_tile = [&](auto more_c) __attribute__((always_inline)) {
         constexpr bool MORE = decltype(more_c)::value;
-        uint32_t* mcur = ms + (ti & 1) * (D * 16);
+        uint32_t* mcur = ms + (ti & 1) * (D * 16) * (RAW ? 2 : 1);
+        if constexpr (RAW) {
+            float tsum = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const float sc = bits16_to_f32<SCL>((uint16_t)(mq[q] & 0xffffu));
+                const float z = (float)((mq[q] >> 16) & 0xFu);
+                reinterpret_cast<float2*>(mcur)[q * 64 + lane] = float2{sc * 16777216.f, sc * 1048576.f};
+                tsum = __builtin_fmaf(-(sc * z), sx[q], tsum);
+            }
+            tsum += __shfl_xor(tsum, 16, 64);
+            tsum += __shfl_xor(tsum, 32, 64);
+            acc = tsum;          // (the previous tile's sum left through `red` and acc was reset)
+        } else {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) mcur[q * 64 + lane] = mq[q];     // this tile's constants (wave-private rows: no barrier)
+        }
         if constexpr (MORE) {                                // the next tile's: one instruction per four chunks, a tile ahead
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -1499,13 +1620,16 @@ static int launch_skinny1(const SkinnyParams& p0, const SkinnyPlan& pl, int alg,
     if (p0.exact_bf16 || (pl.depth != 2 && pl.depth != 4)) return 0;
     SkinnyParams p = p0;
     const bool a1 = alg != 0 && ACT == kFP16 && SCL == kFP16;   // (bf16 scales: the reference rounds W to bf16 -- 2^-9 per weight -- keep its chain)
+    const bool a2 = alg == 2 && a1;                             // raw codes as fp16 denormals (decode form 5)
     if (const int pg = skinny1p_grid(p0, pl)) {
         const int d = skinny1p_depth();
         const int waves = p.chunks / d;
         const dim3 grid(pg), block(64 * waves);
-        const size_t lds_bytes = (size_t)waves * d * 384 + 96 + 2 * 16 * 256;
+        const size_t lds_bytes = (size_t)waves * d * (a2 ? 512 : 384) + 96 + 2 * 16 * 256;
 #define GPTQHIP_L1P(G_, A_, D_) hipLaunchKernelGGL((skinny1p_kernel<ACT, SCL, G_, A_, D_>), grid, block, lds_bytes, stream, p)
-        if (d == 8) {
+        if (a2 && d == 4) {
+            if (p.in_glue == kGlueRmsNorm) GPTQHIP_L1P(kGlueRmsNorm, 2, 4); else GPTQHIP_L1P(kGlueNone, 2, 4);
+        } else if (d == 8) {
             if (p.in_glue == kGlueRmsNorm) { if (a1) GPTQHIP_L1P(kGlueRmsNorm, 1, 8); else GPTQHIP_L1P(kGlueRmsNorm, 0, 8); }
             else { if (a1) GPTQHIP_L1P(kGlueNone, 1, 8); else GPTQHIP_L1P(kGlueNone, 0, 8); }
         } else {
@@ -1525,7 +1649,8 @@ static int launch_skinny1(const SkinnyParams& p0, const SkinnyPlan& pl, int alg,
         depth = 8;
         p.n_mine = 8;
     }
-    const int stride = ((p.n_mine + 3) >> 2) * 1280;     // x pieces + constants (>= the 1 KiB per wave the reduction rows need)
+    const bool raw = a2 && depth != 8;
+    const int stride = ((p.n_mine + 3) >> 2) * (raw ? 1536 : 1280);     // x pieces + constants (>= the 1 KiB per wave the reduction rows need)
     p.slot_stride = stride;
     const dim3 grid(ceil_div(p.N, kTileN), p.splits), block(64 * waves);
     const size_t lds_bytes = (size_t)waves * stride + 96 + (size_t)waves * 256 + (perm ? (size_t)p.K * 2 : 0);   // slots | flag + scratch | reduction rows | x row (act-order)
@@ -1543,17 +1668,18 @@ static int launch_skinny1(const SkinnyParams& p0, const SkinnyPlan& pl, int alg,
             return check_hip(hipGetLastError(), "skinny1_kernel (act-order) launch");
         };
         *served = true;
+        if (raw) return p.in_glue == kGlueRmsNorm ? go(skinny1_kernel<ACT, SCL, 4, kGlueRmsNorm, 2, true>) : go(skinny1_kernel<ACT, SCL, 4, kGlueNone, 2, true>);
         if (p.in_glue == kGlueRmsNorm) return a1 ? go(skinny1_kernel<ACT, SCL, 4, kGlueRmsNorm, 1, true>) : go(skinny1_kernel<ACT, SCL, 4, kGlueRmsNorm, 0, true>);
         return a1 ? go(skinny1_kernel<ACT, SCL, 4, kGlueNone, 1, true>) : go(skinny1_kernel<ACT, SCL, 4, kGlueNone, 0, true>);
     } else if (depth == 8) {
         if (p.in_glue == kGlueRmsNorm) { if (a1) GPTQHIP_L1(8, kGlueRmsNorm, 1); else GPTQHIP_L1(8, kGlueRmsNorm, 0); }
         else { if (a1) GPTQHIP_L1(8, kGlueNone, 1); else GPTQHIP_L1(8, kGlueNone, 0); }
     } else if (depth == 4) {
-        if (p.in_glue == kGlueRmsNorm) { if (a1) GPTQHIP_L1(4, kGlueRmsNorm, 1); else GPTQHIP_L1(4, kGlueRmsNorm, 0); }
-        else { if (a1) GPTQHIP_L1(4, kGlueNone, 1); else GPTQHIP_L1(4, kGlueNone, 0); }
+        if (p.in_glue == kGlueRmsNorm) { if (raw) GPTQHIP_L1(4, kGlueRmsNorm, 2); else if (a1) GPTQHIP_L1(4, kGlueRmsNorm, 1); else GPTQHIP_L1(4, kGlueRmsNorm, 0); }
+        else { if (raw) GPTQHIP_L1(4, kGlueNone, 2); else if (a1) GPTQHIP_L1(4, kGlueNone, 1); else GPTQHIP_L1(4, kGlueNone, 0); }
     } else {
-        if (p.in_glue == kGlueRmsNorm) { if (a1) GPTQHIP_L1(2, kGlueRmsNorm, 1); else GPTQHIP_L1(2, kGlueRmsNorm, 0); }
-        else { if (a1) GPTQHIP_L1(2, kGlueNone, 1); else GPTQHIP_L1(2, kGlueNone, 0); }
+        if (p.in_glue == kGlueRmsNorm) { if (raw) GPTQHIP_L1(2, kGlueRmsNorm, 2); else if (a1) GPTQHIP_L1(2, kGlueRmsNorm, 1); else GPTQHIP_L1(2, kGlueRmsNorm, 0); }
+        else { if (raw) GPTQHIP_L1(2, kGlueNone, 2); else if (a1) GPTQHIP_L1(2, kGlueNone, 1); else GPTQHIP_L1(2, kGlueNone, 0); }
     }
 #undef GPTQHIP_L1
     *served = true;

@@ -4,6 +4,8 @@
   3  skinny1_kernel (preload) + group-factored dequant             (the fp16 default: exact (q - z), scale per chunk in fp32)
   2  skinny_kernel + group-factored dequant
   1  decode_stream_kernel (LDS-DMA weight ring, offsets / zero-points taken out per chunk)   -- opt-in, measured slower
+  5  skinny1_kernel (preload) + RAW codes: the 4-bit codes enter the MFMA as fp16 denormals (one AND per two weights), zero-points through the
+     chunk's activation sum
 Every form against the numpy oracle (TorchLinear semantics, oracle/gptq_oracle.py) on the decode ops a Llama layer runs, with the glue the
 decode chain uses; the bit-faithful forms under the UNSCALED element-wise gate of the reference's own test."""
 import numpy as np
@@ -15,7 +17,7 @@ from oracle import gptq_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-FORMS = {0: True, 4: True, 3: False, 2: False, 1: False}     # form -> strict element-wise atol
+FORMS = {0: True, 4: True, 3: False, 2: False, 1: False, 5: False}     # form -> strict element-wise atol
 
 
 @pytest.fixture(scope="module")
@@ -141,7 +143,7 @@ def test_group_factored_default_is_no_further_from_exact_arithmetic_than_the_ref
     y_ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, None, "fp16", "fp16").astype(np.float64)
     qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, gs, "fp16")
     outs = {}
-    for form in (3, 4):
+    for form in (3, 4, 5):
         ops.set_decode_form(form)
         try:
             outs[form] = torch_to_f32(ops.decode_linear(f32_to_torch(x[0], "fp16", DEV), qw_t, meta, None, K, N, gs, 4, sc.dtype)).astype(np.float64)[None]
@@ -158,3 +160,27 @@ def test_group_factored_default_is_no_further_from_exact_arithmetic_than_the_ref
     assert rms(outs[3]) <= rms(y_ref) * 1.02 + 1e-7, (rms(outs[3]), rms(y_ref))
     assert err_f4 <= err_ref * 1.5 + 1e-6, (err_f4, err_ref)                    # bit-faithful form: the reference's own noise level
     assert err_f3 <= 1e-3 and err_ref <= 1e-3
+    err_f5 = np.abs(outs[5] - y_exact).max() / scale
+    assert err_f5 <= err_ref * 1.05 + 1e-6 and rms(outs[5]) <= rms(y_ref) * 1.02 + 1e-7, (err_f5, err_ref, rms(outs[5]), rms(y_ref))
+
+
+@pytest.mark.parametrize("form", [3, 4, 5])
+@pytest.mark.parametrize("glue", ["rmsnorm", "none"])
+def test_persistent_tile_variant_every_preload_form(ops, form, glue):
+    """skinny1p_kernel (layers with >= 2 column tiles per CU, no bias / residual: the fused gate_up) -- 8192 columns = 512 tiles = two per block."""
+    K, N, gs, act = 4096, 8192, 128, "fp16"
+    qweight, qzeros, scales, g_idx = synth_gptq(91, 4, K, N, gs)
+    rng = np.random.RandomState(17)
+    h = O.round_to(rng.randn(K).astype(np.float32) * 0.5, act)
+    w = O.round_to(1.0 + rng.randn(K).astype(np.float32) * 0.1, act)
+    qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, gs)
+    x_ref = O.rmsnorm_ref(h, w, 1e-5, act) if glue == "rmsnorm" else h
+    ref = O.forward_gptq(x_ref[None], qweight, qzeros, scales, g_idx, 4, None, act, "fp16")
+    ops.set_decode_form(form)
+    try:
+        kw = dict(in_glue=ops.GLUE_RMSNORM, norm_weight=f32_to_torch(w, act, DEV), eps=1e-5) if glue == "rmsnorm" else {}
+        out = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, None, K, N, gs, 4, sc.dtype, **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_decode_form(-1)
+    assert_forward_close(torch_to_f32(out)[None], ref, act, tag=("persistent tiles", form, glue), strict_atol=FORMS[form])
