@@ -82,12 +82,13 @@ def test_bit_faithful_forms_agree_bit_for_bit(ops, form):
 
 @pytest.mark.parametrize("form", sorted(FORMS))
 @pytest.mark.parametrize("act", ["fp16", "bf16"])
-def test_layer_ops_with_glue_every_form(ops, form, act):
+@pytest.mark.parametrize("inter", [1024, 8192])      # 8192: 1024 column tiles = four per CU -> skinny1p_kernel (GPTQHIP_WAVETILE=1: the wave-per-tile kernel, forms 4 / 5)
+def test_layer_ops_with_glue_every_form(ops, form, act, inter):
     """The four ops of a decoder layer the way the chain runs them (RMSNorm from producer statistics, residual + stats_out, paired
     SiLU*mul epilogue), reference-scale activations, every form against the oracle's composition of the same steps."""
     if act == "bf16" and not FORMS[form]:
         pytest.skip("bf16 activations keep the reference's per-weight rounding")
-    gs, hidden, inter = 128, 4096, 1024
+    gs, hidden = 128, 4096
     rng = np.random.RandomState(31)
     h = O.round_to(rng.randn(hidden).astype(np.float32) * 0.5, act)
     w = O.round_to(1.0 + rng.randn(hidden).astype(np.float32) * 0.1, act)
@@ -166,9 +167,12 @@ def test_group_factored_default_is_no_further_from_exact_arithmetic_than_the_ref
 
 @pytest.mark.parametrize("form", [3, 4, 5])
 @pytest.mark.parametrize("glue", ["rmsnorm", "none"])
-def test_persistent_tile_variant_every_preload_form(ops, form, glue):
-    """skinny1p_kernel (layers with >= 2 column tiles per CU, no bias / residual: the fused gate_up) -- 8192 columns = 512 tiles = two per block."""
-    K, N, gs, act = 4096, 8192, 128, "fp16"
+@pytest.mark.parametrize("N", [8192, 16384, 17600])
+def test_persistent_tile_variant_every_preload_form(ops, form, glue, N):
+    """skinny1p_kernel (layers with >= 2 column tiles per CU, no bias / residual: the fused gate_up) -- 8192 columns = 512 tiles = two per block;
+    16384 / 17600 columns = 1024 / 1100 tiles: with GPTQHIP_WAVETILE=1 in the environment the opt-in wave-per-tile kernel where it applies
+    (forms 4 / 5 with producer statistics or no glue; this test passes no statistics, so the RMSNorm cases stay on skinny1p_kernel)."""
+    K, gs, act = 4096, 128, "fp16"
     qweight, qzeros, scales, g_idx = synth_gptq(91, 4, K, N, gs)
     rng = np.random.RandomState(17)
     h = O.round_to(rng.randn(K).astype(np.float32) * 0.5, act)
