@@ -1060,8 +1060,11 @@ void skinny_kernel(SkinnyParams p) {
 // PERM: act-order checkpoints (the permutation applied inside the kernel, like skinny_kernel's AM_ROW1P): the block stages the GLUED x row in
 // LDS once, every wave gathers the eight elements per lane of each of its chunks from there at park time (the eight indices = two 16-byte
 // loads per lane and quad, in front of the ring) -- the main loop is unchanged.
+#ifndef GPTQHIP_SK1_RING_FIRST
+#define GPTQHIP_SK1_RING_FIRST 0
+#endif
 #ifndef GPTQHIP_SK1_ABLATE   // dev timing builds (tests/dev/sk1_ablate_build.sh; WRONG results): 1 no small-operand loads, 2 no dequant / MFMA,
-#define GPTQHIP_SK1_ABLATE 0 // 4 no reduction / epilogue, 8 no weight loads
+#define GPTQHIP_SK1_ABLATE 0 // 4 no reduction / epilogue, 8 no weight loads, 16 no statistics load, 32 no norm-weight load
 #endif
 template <int ACT, int SCL, int D, int GLUE, int ALG, bool PERM = false>
 __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
@@ -1092,6 +1095,24 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
     const char* mbase = reinterpret_cast<const char*>(p.meta + (size_t)tile * p.G * 16);
     const uint32_t lane16 = (uint32_t)lane * 16u, c4 = (uint32_t)c * 4u;
 
+    // weight ring
+    u4_t st[D];
+    int nxt = c_begin + wave;
+    auto load_w = [&](u4_t& dst) __attribute__((always_inline)) {
+        const int ck = nxt < c_end ? nxt : c_end - 1;
+#if GPTQHIP_SK1_ABLATE & 8
+        dst = u4_t{(uint32_t)ck, lane16, (uint32_t)ck ^ lane16, (uint32_t)ck + lane16};
+#else
+        dst = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wbase + (size_t)ck * 1024 + lane16));
+#endif
+        nxt += W;
+    };
+#if GPTQHIP_SK1_RING_FIRST   // dev A/B: the ring's first round requested BEFORE the small operands (they then retire behind it): SLOWER -- o 4.22 -> 4.52, qkv 5.47 -> 5.97,
+                             // down 7.74 -> 8.0 us (the park no longer hides under the ring's first round trip); profiles/r06_decode_forms.txt
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_w(st[d]);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     uint32_t res_raw = 0u;
     if (p.residual != nullptr && wave == 0 && rq == 0 && !(GPTQHIP_SK1_ABLATE & 1)) {
         const int coln = tile * kTileN + c;
@@ -1099,7 +1120,7 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
     }
     f4_t sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if constexpr (GLUE == kGlueRmsNorm) {
-        if (p.stats_in != nullptr && !(GPTQHIP_SK1_ABLATE & 1)) {
+        if (p.stats_in != nullptr && !(GPTQHIP_SK1_ABLATE & 17)) {
             // the producer's per-tile sums of squares, in front of everything: ONE 16-byte load per lane covers 256 partial sums (a second
             // one up to 512); entries past stats_n are outside the descriptor and read as zeros.  EVERY wave fetches and reduces them (one
             // L2-hit instruction per wave, DPP adds): no LDS hand-over and no block barrier between the launch and its first multiply.
@@ -1134,7 +1155,11 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
                 pq[q][1] = pp[1];
             } else {
                 xq[q] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.x) + (size_t)ck * 256 + c * 16);
+#if GPTQHIP_SK1_ABLATE & 32
+                gq[q] = u4_t{0x3c003c00u + (uint32_t)ck, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+#else
                 if constexpr (GLUE == kGlueRmsNorm) gq[q] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (size_t)ck * 256 + c * 16);
+#endif
             }
             mq[q] = *reinterpret_cast<const uint32_t*>(mbase + ((size_t)(ck >> p.cpg_shift) << 6) + c4);
         }
@@ -1147,21 +1172,11 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
             if constexpr (GLUE == kGlueRmsNorm) gr[i] = reinterpret_cast<const u4_t*>(p.glue_b)[idx < n16 ? idx : 0];
         }
     }
+#if !GPTQHIP_SK1_RING_FIRST
     __builtin_amdgcn_sched_barrier(0);   // keep them in FRONT of the ring
-    // weight ring
-    u4_t st[D];
-    int nxt = c_begin + wave;
-    auto load_w = [&](u4_t& dst) __attribute__((always_inline)) {
-        const int ck = nxt < c_end ? nxt : c_end - 1;
-#if GPTQHIP_SK1_ABLATE & 8
-        dst = u4_t{(uint32_t)ck, lane16, (uint32_t)ck ^ lane16, (uint32_t)ck + lane16};
-#else
-        dst = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wbase + (size_t)ck * 1024 + lane16));
-#endif
-        nxt += W;
-    };
 #pragma unroll
     for (int d = 0; d < D; ++d) load_w(st[d]);
+#endif
 
     float inv = 1.f;
     if constexpr (GLUE == kGlueRmsNorm) {
