@@ -188,3 +188,42 @@ def test_persistent_tile_variant_every_preload_form(ops, form, glue, N):
     finally:
         ops.set_decode_form(-1)
     assert_forward_close(torch_to_f32(out)[None], ref, act, tag=("persistent tiles", form, glue), strict_atol=FORMS[form])
+
+
+@pytest.mark.parametrize("case", ["positive_large", "tiny", "zero_point_extremes", "one_hot"])
+def test_raw_code_form_adversarial_inputs(ops, case):
+    """Form 5 takes the zero-points out through the chunk's activation sum (y = s (sum x q - z sum x)) and feeds the codes as fp16 denormals:
+    inputs built to stress exactly that -- same-sign activations of large magnitude (sum x q and z sum x nearly cancel), activations near
+    the fp16 denormal range, all zero-points at 0 / 15, a single non-zero activation -- against float64 arithmetic and the reference chain."""
+    K, N, gs = 4096, 4096, 128
+    qweight, qzeros, scales, g_idx = synth_gptq(313, 4, K, N, gs, scale_dtype="fp16")
+    rng = np.random.RandomState(23)
+    if case == "positive_large":
+        x = np.abs(rng.randn(1, K).astype(np.float32)) * 40.0 + 20.0
+    elif case == "tiny":
+        x = rng.randn(1, K).astype(np.float32) * 3e-4
+    elif case == "one_hot":
+        x = np.zeros((1, K), np.float32)
+        x[0, 1234] = 3.0
+    else:
+        x = rng.randn(1, K).astype(np.float32) * 0.5
+        z = np.where(rng.rand(K // gs, N) < 0.5, 0, 15).astype(np.int32)
+        qzeros = O.pack_cols(z, 4)
+    x = O.round_to(x, "fp16")
+    codes = O.unpack_rows(qweight, 4).astype(np.int64)
+    zeros = O.unpack_cols(qzeros, 4).astype(np.int64)
+    g = O.normalize_g_idx(g_idx, scales.shape[0])
+    y_exact = x.astype(np.float64) @ (np.asarray(scales, np.float64)[g] * (codes - zeros[g]).astype(np.float64))
+    y_ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, None, "fp16", "fp16").astype(np.float64)
+    qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, gs, "fp16")
+    ops.set_decode_form(5)
+    try:
+        out = torch_to_f32(ops.decode_linear(f32_to_torch(x[0], "fp16", DEV), qw_t, meta, None, K, N, gs, 4, sc.dtype)).astype(np.float64)[None]
+        torch.cuda.synchronize()
+    finally:
+        ops.set_decode_form(-1)
+    assert np.isfinite(out).all()
+    scale = np.abs(y_exact).max()
+    err, err_ref = np.abs(out - y_exact).max() / scale, np.abs(y_ref - y_exact).max() / scale
+    assert err <= max(err_ref * 1.05, 2.0 ** -11) + 1e-7, (case, err, err_ref)       # no further from exact arithmetic than the reference (or one fp16 rounding)
+    assert np.abs(out - y_ref).max() / np.abs(y_ref).max() <= 1e-3, case              # north_star's bar against the reference itself
