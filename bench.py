@@ -546,7 +546,7 @@ def main():
         launch_us = ev_ms * 1e3 / (args.steps * n_launch)   # average launch duration incl. whatever the ops do not overlap
         bytes_per_launch = step_bytes / n_launch
         achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
-        kernel = {"chain": "gptqhip::skinny1_kernel<ACT,SCL,D=4,GLUE,ALG> (decode op, preload form, glue fused; ALG=1 group-factored dequant for fp16)",
+        kernel = {"chain": "gptqhip::skinny1_kernel<ACT,SCL,D=4,GLUE,ALG> (decode op, preload form, glue fused; ALG=2 raw 4-bit codes as fp16 denormals for fp16 x fp16, ALG=0 per-weight rounding for bf16)",
                   "modules": "gptqhip::skinny1_kernel<ACT,SCL,D=4,GLUE=0,ALG>"}[mode]
         out = {
             "metric": "llama3_8b_gptq_int4_g128_decode_linear_stack_tokens_per_s",
