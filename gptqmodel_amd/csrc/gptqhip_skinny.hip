@@ -2311,7 +2311,13 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
         // per block -- about 16 per CU (4096 in flight), each with a long K run (>= 2 ring rounds): fewer, longer-lived blocks
         // amortise the ramp, the statistics / reduce prologue and the tail.  Llama-3-70B gate_up (3584 tiles, K=8192): 16 waves
         // per block 61 us, 4 waves 47 us; qkv 15.5 -> 12.8 (8 waves); down (K=28672) 29.5 -> 27.0 (8 waves).
-        int target = 4096 / (tiles > 0 ? tiles : 1);
+        // (the preload form: A/B switch GPTQHIP_SK1_WAVE_TARGET = waves on the chip the plan aims for)
+        static const int deep_target = [] { const char* v = getenv("GPTQHIP_SK1_WAVE_TARGET"); return (v && *v) ? atoi(v) : 4096; }();
+        int target = (prefer_deep ? deep_target : 4096) / (tiles > 0 ? tiles : 1);
+        // between one and two blocks per CU (Llama-3-8B q|k|v: 384 tiles) the preload form does better with half the waves per block and two
+        // ring rounds each -- 4 x 8 chunks 5.28-5.29 us vs 8 x 4 chunks 5.45-5.49 (profiles/r06_decode_forms.txt); a chip-wide target of 2048
+        // waves instead loses on the long-K layers (down_proj 7.63 -> 7.82, 70B 22.99 -> 24.79), so only this band takes it
+        if (prefer_deep && tiles > 256 && tiles < 512 && deep_target == 4096) target = 2048 / tiles;
         target = target < 4 ? 4 : (target > 16 ? 16 : target);
         int best = 0, best_depth = pl.depth;
         // batch 1 may also run a 2-deep ring (16 waves x 2 chunks on K = 4096: twice the waves dequantise the same bytes
