@@ -101,8 +101,10 @@ static WorkspaceLayout layout_workspace(int M, int K, int N, int group_size, int
     // identical arguments, so the layout cannot drift from the launch
     size_t floats = plan_skinny(mchunk, K, N, group_size, g_force_split, g_skinny_waves, false, bits).slab_floats;
     if (mchunk == 1) {   // the preload form of the batch-1 kernel plans without 2-deep rings (plan_skinny prefer_deep): cover both
-        const size_t f1 = plan_skinny(1, K, N, group_size, g_force_split, g_skinny_waves, false, bits, 0, true).slab_floats;
-        if (f1 > floats) floats = f1;
+        for (int deep = 1; deep <= 2; ++deep) {
+            const size_t f1 = plan_skinny(1, K, N, group_size, g_force_split, g_skinny_waves, false, bits, 0, deep).slab_floats;
+            if (f1 > floats) floats = f1;
+        }
     }
     {
         const size_t f4 = plan_skinny(mchunk4, K, N, group_size, g_force_split, g_skinny_waves, false, bits).slab_floats;
@@ -361,7 +363,7 @@ int gptqhip_gemm(const void* x, const uint32_t* qweight, const uint32_t* meta,
         a.x = reinterpret_cast<const char*>(xin) + (size_t)m0 * K * 2;
         a.out = reinterpret_cast<char*>(out) + (size_t)m0 * N * (partial_f32 ? 4 : 2);
         a.M = mc;
-        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_skinny_waves, fused_perm, bits, 1, a.preload && mc == 1 && !fused_perm);
+        const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_skinny_waves, fused_perm, bits, 1, (a.preload && mc == 1 && !fused_perm) ? (a.alg_fp16 == 2 ? 2 : 1) : 0);
         rc = launch_skinny(a, pl, slabs, counters, stream);
         if (rc) return rc;
     }
@@ -492,7 +494,7 @@ int gptqhip_decode_linear(const gptqhip_decode_op* op, gptqhip_stream_t stream) 
                           (op->out_glue == GPTQHIP_OUT_PARTIAL_F32 && op->in_glue == GPTQHIP_GLUE_NONE));
     const bool preload_form = (decode_form == 3 || decode_form == 4 || decode_form == 5) && M == 1 && !op->perm && op->bits == 4;
     const SkinnyPlan pl = plan_skinny(M, op->K, op->N, op->group_size, g_force_split, g_skinny_waves, op->perm != nullptr, op->bits,
-                                      !wide_ok ? 0 : (op->in_glue == GPTQHIP_GLUE_RMSNORM ? 2 : 1), preload_form);
+                                      !wide_ok ? 0 : (op->in_glue == GPTQHIP_GLUE_RMSNORM ? 2 : 1), preload_form ? (decode_form == 5 ? 2 : 1) : 0);
     if (op->perm && !(pl.depth == 4 && (size_t)op->K * 2 <= kInKernelPermMaxRowBytes)) {
         set_error("gptqhip_decode_linear: K=%d is outside the in-kernel act-order variant (gather x and pass perm = NULL)", op->K);
         return GPTQHIP_EINVAL;

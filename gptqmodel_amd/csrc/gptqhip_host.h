@@ -78,7 +78,7 @@ int check_hip(hipError_t e, const char* what);
 // in_kernel_perm: the plan is for the batch-1 act-order variant (AM_ROW1P), which only exists with the 4-deep ring
 SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm = false, int bits = 4,
                        int allow_wide = 0,    // 0: one column tile per block; 1: wide form from 5 rows; 2: decode op with glue (from 2 rows)
-                       bool prefer_deep = false);   // batch 1: no 2-deep ring plans on K >= 4096 (the preload form of the decode kernel)
+                       int prefer_deep = 0);   // batch 1: 1 = no 2-deep ring plans on K >= 4096 (the preload form of the decode kernel), 2 = ... with the raw-code dequant (form 5)
 int launch_skinny(const GemmArgs& a, const SkinnyPlan& pl, float* slabs, int* counters, hipStream_t stream);
 
 TiledPlan plan_tiled(int M, int K, int N, int group_size, int bits, int force_variant, int force_split);

@@ -72,6 +72,7 @@ struct SkinnyParams {
     int exact_bf16;        // GPTQHIP_GEMM_EXACT_BF16: see compute_stage
     int alg_fp16;          // decode form 2: algebraic dequant for fp16 activations (compute_stage)
     int slot_stride;       // skinny1_kernel: bytes of a wave's LDS slot
+    int nb_tiles;          // skinny1p_kernel: > 0 = tiles per block, reduction rows kept per tile and combined WITHOUT block barriers
     // batch-1 decode op (gptqhip_decode_linear): decoder-layer glue fused into the GEMV (GLUE template parameter)
     const void* glue_b;    // RMSNORM: norm weight [K]; SILU_MUL: nullptr (up = x + K)
     const void* residual;  // [N] or nullptr: out = act(residual + y)
@@ -1414,7 +1415,16 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
     u4_t* const xs = reinterpret_cast<u4_t*>(slot);                            // [D][16] u4: this wave's D glued x pieces
     uint32_t* const ms = reinterpret_cast<uint32_t*>(slot + D * 256);          // [2][D][16] constants, double-buffered by tile parity
     float* scratch = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + W * kSlot);
-    float(*red)[16][64] = reinterpret_cast<float(*)[16][64]>(reinterpret_cast<char*>(lds) + W * kSlot + 96);    // [2][W <= 16][64]
+    float(*red)[16][64] = reinterpret_cast<float(*)[16][64]>(reinterpret_cast<char*>(lds) + W * kSlot + 96);    // [2][W <= 16][64]  (nb_tiles: [tiles per block][16][64])
+    // p.nb_tiles > 0: no block barrier per tile.  Every tile of the block has its own reduction rows and an arrival counter in LDS; a wave
+    // writes its partial sums, counts itself in (release) and goes on with the next tile; the tile's owner (tile index % W) combines the rows
+    // ONE TILE LATER -- after its own stages of the next tile, when the others have normally arrived -- spinning on the counter if not.
+    const int nb = p.nb_tiles;
+    int* const cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(lds) + W * kSlot + 96 + (size_t)(nb > 0 ? nb : 2) * 16 * 256);
+    if (nb > 0) {
+        if ((int)threadIdx.x < nb) cnt[threadIdx.x] = 0;
+        __syncthreads();
+    }
     const DequantConsts dk = make_dequant_consts<4>();
     const uint32_t lane16 = (uint32_t)lane * 16u, c4 = (uint32_t)c * 4u;
     // the chunk lane (rq, c) serves in preload instruction q: wave + (4 q + rq) * W
@@ -1556,6 +1566,13 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
     // One tile: MORE = another tile follows (its loads are issued UNCONDITIONALLY behind each stage, so hipcc's waits stay counted;
     // with `if (more)` around them it fell back to vmcnt(0) in the middle of the round).  The last tile runs the drain instantiation.
     int ti = 0;
+    auto combine = [&](int t_idx, int tile_id) __attribute__((always_inline)) {
+        while (__hip_atomic_load(cnt + t_idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < W) __builtin_amdgcn_s_sleep(1);
+        float v = 0.f;
+        for (int w = 0; w < W; ++w) v += red[t_idx][w][lane];
+        const int n = tile_id * kTileN + c;
+        finish_outputs<ACT>(p, v, rq == 0 && n < p.N, 4 * rq, n, tile_id, 0, 0, lane, 0u, nullptr);
+    };
     auto do_tile = [&](auto more_c) __attribute__((always_inline)) {
         constexpr bool MORE = decltype(more_c)::value;
         uint32_t* mcur = ms + (ti & 1) * (D * 16) * (RAW ? 2 : 1);
@@ -1589,6 +1606,12 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
             if constexpr (MORE) st[d] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wsrc + d * wstep));
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (nb > 0) {
+            red[ti][wave][lane] = acc;
+            acc = 0.f;
+            if (lane == 0) __hip_atomic_fetch_add(cnt + ti, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ti >= 1 && wave == (ti - 1) % W) combine(ti - 1, tile - (int)gridDim.x);
+        } else {
         // in-block split-K reduction, rows double-buffered by tile parity: ONE barrier per tile; the waves take turns with the epilogue
         red[ti & 1][wave][lane] = acc;
         acc = 0.f;
@@ -1599,11 +1622,13 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
             const int n = tile * kTileN + c;
             finish_outputs<ACT>(p, v, rq == 0 && n < p.N, 4 * rq, n, tile, 0, 0, lane, 0u, nullptr);
         }
+        }
         tile += (int)gridDim.x;
         ++ti;
     };
     while (tile + (int)gridDim.x < tiles) do_tile(std::true_type{});
     do_tile(std::false_type{});
+    if (nb > 0 && wave == (ti - 1) % W) combine(ti - 1, tile - (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1868,7 +1893,13 @@ static int launch_skinny1(const SkinnyParams& p0, const SkinnyPlan& pl, int alg,
         const int d = skinny1p_depth();
         const int waves = p.chunks / d;
         const dim3 grid(pg), block(64 * waves);
-        const size_t lds_bytes = (size_t)waves * d * (a2 ? 512 : 384) + 96 + 2 * 16 * 256;
+        // reduction rows per tile + arrival counters instead of a block barrier per tile, when they fit the default dynamic LDS (A/B: GPTQHIP_SK1P_BARRIER=1)
+        // OPT-IN (GPTQHIP_SK1P_NOBARRIER=1): same-box A/B on the 8B gate_up 12.58-12.67 vs 12.68-12.81 us fp16 (inside the noise), 15.99 vs 15.62 bf16 (slower)
+        static const bool force_barrier = [] { const char* v = getenv("GPTQHIP_SK1P_NOBARRIER"); return !(v && *v && *v != '0'); }();
+        const int tpb = ceil_div(ceil_div(p.N, kTileN), pg);
+        const size_t lds_nb = (size_t)waves * d * (a2 ? 512 : 384) + 96 + (size_t)tpb * 16 * 256 + 64;
+        p.nb_tiles = (!force_barrier && tpb <= 16 && lds_nb <= 64 * 1024) ? tpb : 0;
+        const size_t lds_bytes = p.nb_tiles > 0 ? lds_nb : (size_t)waves * d * (a2 ? 512 : 384) + 96 + 2 * 16 * 256 + 64;
 #define GPTQHIP_L1P(G_, A_, D_) hipLaunchKernelGGL((skinny1p_kernel<ACT, SCL, G_, A_, D_>), grid, block, lds_bytes, stream, p)
         if (a2 && d == 4) {
             if (p.in_glue == kGlueRmsNorm) GPTQHIP_L1P(kGlueRmsNorm, 2, 4); else GPTQHIP_L1P(kGlueNone, 2, 4);
@@ -2289,7 +2320,7 @@ static int launch_skinny_mt(const SkinnyParams& p, const SkinnyPlan& pl, hipStre
     }
 }
 
-SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm, int bits, int allow_wide, bool prefer_deep) {
+SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int force_waves, bool in_kernel_perm, int bits, int allow_wide, int prefer_deep) {
     static const bool allow_depth2 = [] { const char* v = getenv("GPTQHIP_NO_DEPTH2"); return !(v && *v && *v != '0'); }();
     static const bool allow_pad = [] { const char* v = getenv("GPTQHIP_NO_PAD"); return !(v && *v && *v != '0'); }();   // A/B switch
     SkinnyPlan pl;
@@ -2314,10 +2345,11 @@ SkinnyPlan plan_skinny(int M, int K, int N, int group_size, int force_split, int
         // (the preload form: A/B switch GPTQHIP_SK1_WAVE_TARGET = waves on the chip the plan aims for)
         static const int deep_target = [] { const char* v = getenv("GPTQHIP_SK1_WAVE_TARGET"); return (v && *v) ? atoi(v) : 4096; }();
         int target = (prefer_deep ? deep_target : 4096) / (tiles > 0 ? tiles : 1);
-        // between one and two blocks per CU (Llama-3-8B q|k|v: 384 tiles) the preload form does better with half the waves per block and two
-        // ring rounds each -- 4 x 8 chunks 5.28-5.29 us vs 8 x 4 chunks 5.45-5.49 (profiles/r06_decode_forms.txt); a chip-wide target of 2048
-        // waves instead loses on the long-K layers (down_proj 7.63 -> 7.82, 70B 22.99 -> 24.79), so only this band takes it
-        if (prefer_deep && tiles > 256 && tiles < 512 && deep_target == 4096) target = 2048 / tiles;
+        // between one and two blocks per CU (Llama-3-8B q|k|v: 384 tiles) the raw-code form (20 VALU per chunk) does better with half the waves
+        // per block and two ring rounds each -- 4 x 8 chunks 5.28-5.29 us vs 8 x 4 chunks 5.45-5.49 (profiles/r06_decode_forms.txt); a chip-wide
+        // target of 2048 waves instead loses on the long-K layers (down_proj 7.63 -> 7.82, 70B 22.99 -> 24.79), and the bit-faithful bf16 form
+        // (more VALU per chunk) loses on q|k|v too (6.25 -> 6.42), so only this band of this form takes it
+        if (prefer_deep == 2 && tiles > 256 && tiles < 512 && deep_target == 4096) target = 2048 / tiles;
         target = target < 4 ? 4 : (target > 16 ? 16 : target);
         int best = 0, best_depth = pl.depth;
         // batch 1 may also run a 2-deep ring (16 waves x 2 chunks on K = 4096: twice the waves dequantise the same bytes
