@@ -31,6 +31,10 @@
 #ifndef GPTQHIP_ABLATE   // dev-only timing ablations (tests/dev/ablate.sh); the product build never defines it
 #define GPTQHIP_ABLATE 0
 #endif
+#ifndef GPTQHIP_OUT_WRITE_THROUGH   // dev A/B (see finish_outputs): write-through output stores measured SLOWER (o 4.19 -> 4.37, down 7.87 -> 7.98 us)
+#define GPTQHIP_OUT_WRITE_THROUGH 0
+#endif
+
 namespace gptqhip {
 
 // Threads a block may have (the instantiation's __launch_bounds__): 1024 (16 waves, 128 VGPRs) up to 16 rows, 512 (8 waves) for
@@ -572,14 +576,26 @@ __device__ __forceinline__ void finish_outputs(const SkinnyParams& p, float v, b
                 const float up = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), 0x108, 0xf, 0xf, false));
                 const float a = round_through<ACT>(y / (1.0f + expf(-y))) * up;
                 const int j = tile * 8 + c16;
+#if GPTQHIP_OUT_WRITE_THROUGH
+                if (live && c16 < 8 && j < p.N / 2) __hip_atomic_store(reinterpret_cast<uint16_t*>(p.out) + (size_t)m * (p.N / 2) + j, f32_to_16<ACT>(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
                 if (live && c16 < 8 && j < p.N / 2) reinterpret_cast<uint16_t*>(p.out)[(size_t)m * (p.N / 2) + j] = f32_to_16<ACT>(a);
+#endif
             } else {
                 if (p.residual != nullptr) y = bits16_to_f32<ACT>((uint16_t)(res_raw >> ((lane & 1) * 16))) + y;
                 const float h = round_through<ACT>(y);
+#if GPTQHIP_OUT_WRITE_THROUGH   // dev A/B: the residual-stream outputs + statistics stored write-through (sc1) -- nothing dirty left for the end-of-kernel write-back
+                if (live) __hip_atomic_store(reinterpret_cast<uint16_t*>(p.out) + (size_t)m * p.N + n, f32_to_16<ACT>(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
                 if (live) reinterpret_cast<uint16_t*>(p.out)[(size_t)m * p.N + n] = f32_to_16<ACT>(h);
+#endif
                 float sq = live ? h * h : 0.f;  // RMSNorm statistic of the NEXT op: fixed rotate tree over the 16 columns (DPP row_ror)
                 sq = row16_sum(sq);
+#if GPTQHIP_OUT_WRITE_THROUGH
+                if (c16 == 0 && m < p.M) __hip_atomic_store(reinterpret_cast<uint32_t*>(p.stats_out) + (size_t)m * tiles + tile, __builtin_bit_cast(uint32_t, sq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
                 if (c16 == 0 && m < p.M) p.stats_out[(size_t)m * tiles + tile] = sq;
+#endif
             }
         }
     } else if (live) {
