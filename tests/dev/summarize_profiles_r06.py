@@ -45,7 +45,7 @@ def derive(e, chunks=None):
     return d
 
 
-chunks_of = {"grid=196608": 384 * 32, "grid=131072 wg=512": 256 * 32, "grid=131072": 256 * 32, "grid=229376": 256 * 112, "grid=458752": 1792 * 32, "grid=262144": 256 * 32}
+chunks_of = {"grid=98304": 384 * 32, "grid=196608": 384 * 32, "grid=131072 wg=512": 256 * 32, "grid=131072": 256 * 32, "grid=229376": 256 * 112, "grid=458752": 1792 * 32, "grid=262144": 256 * 32}
 for k, e in dec.items():
     ch = next((v for kk, v in chunks_of.items() if kk in k), None)
     if "wg=896" in k or ("skinny1" in k and "grid=229376" in k): ch = 256 * 112
