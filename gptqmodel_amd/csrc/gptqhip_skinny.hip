@@ -525,6 +525,17 @@ __device__ __forceinline__ float wave64_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// Sum of the W (<= 16) waves' reduction rows for this lane, in wave order.  A rolled loop on purpose: hipcc emits ds_read_b32 -> s_waitcnt -> v_add per
+// row (W serialized LDS round trips), but issuing all sixteen reads back to back (rows past W clamped and masked) measured SLOWER on the same box --
+// o 4.23 -> 4.37, gate_up 12.85 -> 13.5 us, chain 1052 -> 1020 tokens/s (profiles/r06_decode_forms.txt): sixteen more live registers and ~40
+// instructions of clamped addressing in every tile's epilogue cost more than the round trips, which overlap the other waves' work.
+__device__ __forceinline__ float sum_wave_rows(const float* rows, int stride, int W, int lane) {   // stride: floats between two waves' rows
+    float v = 0.f;
+    for (int w = 0; w < W; ++w) v += rows[(size_t)w * stride + lane];
+    return v;
+}
+__device__ __forceinline__ float sum_wave_rows(const float (*rows)[64], int W, int lane) { return sum_wave_rows(&rows[0][0], 64, W, lane); }
+
 // Cross-block split-K hand-off (last arriver reduces) + the epilogue: the reference's rounding chain and the decode op's output
 // glue.  `v` = this lane's fp32 sum for output (m, n) of its block's K range; `live` = the lane owns a real output.
 template <int ACT>
@@ -1051,7 +1062,7 @@ void skinny_kernel(SkinnyParams p) {
     const bool live = reducer && m < p.M && n < p.N;
     float v = 0.f;
     if (reducer) {
-        for (int w = 0; w < W; ++w) v += red[w][wave][lane];
+        v = sum_wave_rows(&red[0][wave][0], MT * 4 * 64, W, lane);
     }
 
     finish_outputs<ACT>(p, v, live, m, n, tile, split, wave, lane, res_raw, s_last);
@@ -1399,9 +1410,7 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
     const int n = tile * kTileN + c;
     const bool live = wave == 0 && m < p.M && n < p.N;
     float v = 0.f;
-    if (wave == 0) {
-        for (int w = 0; w < W; ++w) v += red[w][lane];
-    }
+    if (wave == 0) v = sum_wave_rows(red, W, lane);
     finish_outputs<ACT>(p, v, live, m, n, tile, split, wave, lane, res_raw, s_last);
 }
 
@@ -1584,8 +1593,7 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
     int ti = 0;
     auto combine = [&](int t_idx, int tile_id) __attribute__((always_inline)) {
         while (__hip_atomic_load(cnt + t_idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < W) __builtin_amdgcn_s_sleep(1);
-        float v = 0.f;
-        for (int w = 0; w < W; ++w) v += red[t_idx][w][lane];
+        const float v = sum_wave_rows(red[t_idx], W, lane);
         const int n = tile_id * kTileN + c;
         finish_outputs<ACT>(p, v, rq == 0 && n < p.N, 4 * rq, n, tile_id, 0, 0, lane, 0u, nullptr);
     };
@@ -1633,8 +1641,7 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
         acc = 0.f;
         __syncthreads();
         if (wave == ti % W) {
-            float v = 0.f;
-            for (int w = 0; w < W; ++w) v += red[ti & 1][w][lane];
+            const float v = sum_wave_rows(red[ti & 1], W, lane);
             const int n = tile * kTileN + c;
             finish_outputs<ACT>(p, v, rq == 0 && n < p.N, 4 * rq, n, tile, 0, 0, lane, 0u, nullptr);
         }
