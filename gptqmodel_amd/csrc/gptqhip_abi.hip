@@ -47,8 +47,14 @@ static const EnvTuning& env_tuning() {
 static int decode_form_for(int act_dtype, int scale_dtype) {
     static const int bitfaithful = env_int("GPTQHIP_DECODE_BITFAITHFUL");
     const bool exact_ok = act_dtype == GPTQHIP_FP16 && scale_dtype == GPTQHIP_FP16;   // the exact-arithmetic forms exist for fp16 x fp16 only
-    if (t_decode_form >= 0) return ((t_decode_form == 1 || t_decode_form == 5) && !exact_ok) ? 4 : t_decode_form;
-    return (bitfaithful || !exact_ok) ? 4 : 5;
+    const bool raw_ok = exact_ok || act_dtype == GPTQHIP_BF16;                        // ... the raw-code form also for bf16 activations (any scale dtype)
+    static const int bf16_exact = env_int("GPTQHIP_DECODE_BF16_EXACT");               // opt-in: bf16 activations take form 5 by default
+    if (t_decode_form >= 0) {
+        if (t_decode_form == 5) return raw_ok ? 5 : 4;
+        return (t_decode_form == 1 && !exact_ok) ? 4 : t_decode_form;
+    }
+    if (bitfaithful) return 4;
+    return exact_ok ? 5 : ((bf16_exact && raw_ok) ? 5 : 4);
 }
 #define g_force_split (t_force_split ? t_force_split : env_tuning().split)
 #define g_force_kernel (t_force_kernel ? t_force_kernel : env_tuning().kernel)

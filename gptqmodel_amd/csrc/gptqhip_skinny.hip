@@ -525,6 +525,37 @@ __device__ __forceinline__ float wave64_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// bf16 activations on the RAW-code path (decode form 5): the f16 matrix pipe is the one that takes the codes as denormals, so a wave turns its
+// (glued) bf16 x pieces into fp16 -- exactly: a bf16 value has 8 significant bits -- after dividing them by a power of two chosen from the wave's
+// own largest |x| (so that nothing overflows fp16's 2^15 range whatever the input; elements more than 2^29 below the wave's largest lose bits,
+// their products are below fp32's resolution of the sum anyway).  The power of two goes back in through the chunk constants.
+__device__ __forceinline__ uint32_t wave_max_abs_bf16(const u4_t* g, int n) {       // largest |x| of the wave's pieces, as bf16 bits (sign cleared)
+    uint32_t m = 0u;
+    for (int q = 0; q < n; ++q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t a = g[q][j] & 0x7fff7fffu;
+            const uint32_t hi = a >> 16, lo = a & 0xffffu;
+            m = m > hi ? m : hi;
+            m = m > lo ? m : lo;
+        }
+    }
+#pragma unroll
+    for (int mk = 32; mk >= 1; mk >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)m, mk, 64);
+        m = m > o ? m : o;
+    }
+    return m;
+}
+__device__ __forceinline__ int bf16_down_shift(uint32_t max_abs_bits) {              // k >= 0 with |x| 2^-k < 2^15 for every element
+    const int e = (int)(max_abs_bits >> 7) - 127;
+    return e > 14 ? e - 14 : 0;
+}
+__device__ __forceinline__ uint32_t bf16pair_to_f16pair(uint32_t u, float dn) {
+    const float lo = __builtin_bit_cast(float, u << 16) * dn, hi = __builtin_bit_cast(float, u & 0xffff0000u) * dn;
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi));
+}
+
 // Sum of the W (<= 16) waves' reduction rows for this lane, in wave order.  A rolled loop on purpose: hipcc emits ds_read_b32 -> s_waitcnt -> v_add per
 // row (W serialized LDS round trips), but issuing all sixteen reads back to back (rows past W clamped and masked) measured SLOWER on the same box --
 // o 4.23 -> 4.37, gate_up 12.85 -> 13.5 us, chain 1052 -> 1020 tokens/s (profiles/r06_decode_forms.txt): sixteen more live registers and ~40
@@ -1111,7 +1142,8 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
     // two weights, no zero-point subtraction: y = sum_g s_g (2^24 lo_g + 2^20 hi_g - z_g Sx_g) with lo / hi the two MFMA chains of a chunk and
     // Sx_g the sum of the chunk's 128 (glued) activations, taken once per wave at park time.  The two classes need their own A fragments:
     // the x pieces are parked re-paired ([k0 k1 | k4 k5] of two K-steps, [k2 k3 | k6 k7] of two K-steps) so a fragment is still one ds_read_b128.
-    constexpr bool RAW = ALG == 2 && ACT == kFP16 && SCL == kFP16;
+    constexpr bool RAW = ALG == 2 && ((ACT == kFP16 && SCL == kFP16) || ACT == kBF16);
+    constexpr bool XCVT = RAW && ACT == kBF16;      // bf16 activations ride the f16 matrix pipe (see bf16pair_to_f16pair)
     char* const slot = reinterpret_cast<char*>(lds) + wave * p.slot_stride;
     u4_t* const xs = reinterpret_cast<u4_t*>(slot);                                   // [4 nq][16] u4: the glued x pieces
     uint32_t* const ms = reinterpret_cast<uint32_t*>(slot + nq * 1024);               // [4 nq][16] meta words (RAW: [4 nq][16] float2 = s 2^24, s 2^20)
@@ -1246,6 +1278,22 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
         }
     }
     float tsum = 0.f;    // RAW: -sum over this lane's park chunks of s z Sx (column c of chunk 4 q + rq)
+    float up = 1.f;      // XCVT: 2^k, the power of two taken out of this wave's x pieces
+    u4_t gg[4];          // the wave's glued x pieces (parked below; XCVT converts them in between)
+    auto convert_pieces = [&]() __attribute__((always_inline)) {
+        if constexpr (XCVT) {
+            const int k = bf16_down_shift(wave_max_abs_bf16(gg, nq));
+            const float dn = __builtin_bit_cast(float, (uint32_t)(127 - k) << 23);
+            up = __builtin_bit_cast(float, (uint32_t)(127 + k) << 23);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < nq) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gg[q][j] = bf16pair_to_f16pair(gg[q][j], dn);
+                }
+            }
+        }
+    };
     auto park = [&](int q, const u4_t& g) __attribute__((always_inline)) {
         if constexpr (RAW) {
             const int li = 4 * q + rq, j = c >> 2;        // this lane holds piece c = K-step j, k-group c & 3 of chunk li
@@ -1261,7 +1309,7 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
             const uint32_t mw = mq[q];
             const float sc = bits16_to_f32<SCL>((uint16_t)(mw & 0xffffu));
             const float z = (float)((mw >> 16) & 0xFu);                  // meta = scale16 | (0xE400 | zero) << 16
-            reinterpret_cast<float2*>(ms)[q * 64 + lane] = float2{sc * 16777216.f, sc * 1048576.f};
+            reinterpret_cast<float2*>(ms)[q * 64 + lane] = float2{sc * 16777216.f * up, sc * 1048576.f * up};
             if (c_begin + wave + li * W < c_end) tsum = __builtin_fmaf(-(sc * z), s8, tsum);      // (padding chunks: skipped like their stages)
         } else {
             xs[q * 64 + lane] = g;
@@ -1298,7 +1346,7 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
                     const uint32_t i0 = pq[q][j >> 1][(j & 1) * 2], i1 = pq[q][j >> 1][(j & 1) * 2 + 1];
                     g[j] = (uint32_t)xbuf[i0] | ((uint32_t)xbuf[i1] << 16);
                 }
-                park(q, g);
+                gg[q] = g;
             }
         }
     } else {
@@ -1310,9 +1358,14 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) g[j] = glue_pair<ACT>(xq[q][j], gq[q][j], inv, GLUE);
             }
-            park(q, g);
+            gg[q] = g;
         }
     }
+    }
+    convert_pieces();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q < nq) park(q, gg[q]);
     }
 
     f4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -1320,7 +1373,7 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
         // column c's zero-point term over ALL the wave's chunks: the four rows hold chunks 4 q + 0..3 -> butterfly over the rows
         tsum += __shfl_xor(tsum, 16, 64);
         tsum += __shfl_xor(tsum, 32, 64);
-        acc[0] = tsum;
+        acc[0] = tsum * up;
     }
     uint32_t magic_hi = 0x54005400u;
     asm volatile("" : "+v"(magic_hi));
@@ -1340,8 +1393,8 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
                 const uint32_t w0 = wv[2 * h], w1 = wv[2 * h + 1], w0s = w0 >> 8, w1s = w1 >> 8;
                 const u4_t blo = {w0 & dk.lo, w0s & dk.lo, w1 & dk.lo, w1s & dk.lo};
                 const u4_t bhi = {w0 & dk.hi, w0s & dk.hi, w1 & dk.hi, w1s & dk.hi};
-                glo = mfma16<ACT>(xr[2 * h], blo, glo);
-                ghi = mfma16<ACT>(xr[2 * h + 1], bhi, ghi);
+                glo = mfma16<kFP16>(xr[2 * h], blo, glo);
+                ghi = mfma16<kFP16>(xr[2 * h + 1], bhi, ghi);
             }
             acc[0] = __builtin_fmaf(ab.x, glo[0], acc[0]);
             acc[0] = __builtin_fmaf(ab.y, ghi[0], acc[0]);
@@ -1428,7 +1481,8 @@ template <int ACT, int SCL, int GLUE, int ALG, int D = 4>
 __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
     static_assert(D == 4 || D == 8, "ring depth = chunks per wave and tile");
     constexpr int NQ = D / 4;                       // 16-byte preload instructions per wave (four chunks each)
-    constexpr bool RAW = ALG == 2 && ACT == kFP16 && SCL == kFP16;     // raw codes as fp16 denormals (see skinny1_kernel)
+    constexpr bool RAW = ALG == 2 && ((ACT == kFP16 && SCL == kFP16) || ACT == kBF16);     // raw codes as fp16 denormals (see skinny1_kernel)
+    constexpr bool XCVT = RAW && ACT == kBF16;      // bf16 activations ride the f16 matrix pipe (see bf16pair_to_f16pair)
     constexpr int kSlot = D * (RAW ? 512 : 384);    // x pieces (D * 256 B) + constants double-buffered by tile parity (2 * D * 64 B; RAW: float2)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -1517,6 +1571,17 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
         }
     }
     float sx[NQ];      // RAW: Sx of chunk wave + (4 q + rq) W (the same for every tile)
+    float up = 1.f;    // XCVT: 2^k, the power of two taken out of this wave's x pieces
+    if constexpr (XCVT) {
+        const int k = bf16_down_shift(wave_max_abs_bf16(xq, NQ));
+        const float dn = __builtin_bit_cast(float, (uint32_t)(127 - k) << 23);
+        up = __builtin_bit_cast(float, (uint32_t)(127 + k) << 23);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xq[q][j] = bf16pair_to_f16pair(xq[q][j], dn);
+        }
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         if constexpr (RAW) {
@@ -1549,8 +1614,8 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
                 const uint32_t w0 = wv[2 * h], w1 = wv[2 * h + 1], w0s = w0 >> 8, w1s = w1 >> 8;
                 const u4_t blo = {w0 & dk.lo, w0s & dk.lo, w1 & dk.lo, w1s & dk.lo};
                 const u4_t bhi = {w0 & dk.hi, w0s & dk.hi, w1 & dk.hi, w1s & dk.hi};
-                glo = mfma16<ACT>(xr[2 * h], blo, glo);
-                ghi = mfma16<ACT>(xr[2 * h + 1], bhi, ghi);
+                glo = mfma16<kFP16>(xr[2 * h], blo, glo);
+                ghi = mfma16<kFP16>(xr[2 * h + 1], bhi, ghi);
             }
             acc = __builtin_fmaf(ab.x, glo[0], acc);
             acc = __builtin_fmaf(ab.y, ghi[0], acc);
@@ -1606,12 +1671,12 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
             for (int q = 0; q < NQ; ++q) {
                 const float sc = bits16_to_f32<SCL>((uint16_t)(mq[q] & 0xffffu));
                 const float z = (float)((mq[q] >> 16) & 0xFu);
-                reinterpret_cast<float2*>(mcur)[q * 64 + lane] = float2{sc * 16777216.f, sc * 1048576.f};
+                reinterpret_cast<float2*>(mcur)[q * 64 + lane] = float2{sc * 16777216.f * up, sc * 1048576.f * up};
                 tsum = __builtin_fmaf(-(sc * z), sx[q], tsum);
             }
             tsum += __shfl_xor(tsum, 16, 64);
             tsum += __shfl_xor(tsum, 32, 64);
-            acc = tsum;          // (the previous tile's sum left through `red` and acc was reset)
+            acc = tsum * up;     // (the previous tile's sum left through `red` and acc was reset)
         } else {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) mcur[q * 64 + lane] = mq[q];     // this tile's constants (wave-private rows: no barrier)
@@ -1890,7 +1955,7 @@ static int launch_skinny1(const SkinnyParams& p0, const SkinnyPlan& pl, int alg,
     if (p0.exact_bf16 || (pl.depth != 2 && pl.depth != 4)) return 0;
     SkinnyParams p = p0;
     const bool a1 = alg != 0 && ACT == kFP16 && SCL == kFP16;   // (bf16 scales: the reference rounds W to bf16 -- 2^-9 per weight -- keep its chain)
-    const bool a2 = alg == 2 && a1;                             // raw codes as fp16 denormals (decode form 5)
+    const bool a2 = alg == 2 && (a1 || ACT == kBF16);           // raw codes as fp16 denormals (decode form 5; bf16 activations converted per wave)
     {
         size_t lds_w = 0;
         const int ww = (a2 || !a1) ? skinny1w_waves(p0, &lds_w, a2) : 0;     // (form 3's group-factored dequant keeps skinny1p_kernel)

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_forward_close, f32_to_torch, synth_gptq, torch_to_f32
+from helpers import NORM_TOL_BF16_EXACT, assert_forward_close, f32_to_torch, synth_gptq, torch_to_f32
 from oracle import gptq_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -37,8 +37,9 @@ def _tiled(ops, qweight, qzeros, scales, gs, sdt="fp16"):
                                     (11008, 4096, 128), (4096, 512, 4096)])
 @pytest.mark.parametrize("act,sdt", [("fp16", "fp16"), ("bf16", "bf16"), ("fp16", "bf16")])
 def test_plain_op_every_form_vs_oracle(ops, form, K, N, gs, act, sdt):
-    if act == "bf16" and not FORMS[form]:
-        pytest.skip("bf16 activations keep the reference's per-weight rounding: the exact-arithmetic forms are outside the bf16 gate (8e-3)")
+    if act == "bf16" and form in (1, 2, 3):
+        pytest.skip("forms 1 / 2 / 3 exist for fp16 activations only (bf16: form 4 = bit-faithful default, form 5 = exact arithmetic through the f16 matrix pipe)")
+    nt = NORM_TOL_BF16_EXACT if (act == "bf16" and form == 5) else None
     qweight, qzeros, scales, g_idx = synth_gptq(500 + K // 128 + N // 16 + gs, 4, K, N, gs, scale_dtype=sdt)
     rng = np.random.RandomState(5)
     x = O.round_to(rng.randn(1, K).astype(np.float32) * 0.5, act)
@@ -52,8 +53,8 @@ def test_plain_op_every_form_vs_oracle(ops, form, K, N, gs, act, sdt):
         torch.cuda.synchronize()
     finally:
         ops.set_decode_form(-1)
-    assert_forward_close(torch_to_f32(out)[None], ref, act, tag=("decode op", form), strict_atol=FORMS[form])
-    assert_forward_close(torch_to_f32(gen), ref, act, tag=("gemm M=1", form), strict_atol=FORMS[form])
+    assert_forward_close(torch_to_f32(out)[None], ref, act, tag=("decode op", form), strict_atol=FORMS[form], norm_tol=nt)
+    assert_forward_close(torch_to_f32(gen), ref, act, tag=("gemm M=1", form), strict_atol=FORMS[form], norm_tol=nt)
     assert torch.equal(out, gen[0]), "the plugin path (gptqhip_gemm at M = 1) and the decode op must run the same form"
 
 
@@ -86,8 +87,9 @@ def test_bit_faithful_forms_agree_bit_for_bit(ops, form):
 def test_layer_ops_with_glue_every_form(ops, form, act, inter):
     """The four ops of a decoder layer the way the chain runs them (RMSNorm from producer statistics, residual + stats_out, paired
     SiLU*mul epilogue), reference-scale activations, every form against the oracle's composition of the same steps."""
-    if act == "bf16" and not FORMS[form]:
-        pytest.skip("bf16 activations keep the reference's per-weight rounding")
+    if act == "bf16" and form in (1, 2, 3):
+        pytest.skip("fp16-only forms")
+    nt = NORM_TOL_BF16_EXACT if (act == "bf16" and form == 5) else None
     gs, hidden = 128, 4096
     rng = np.random.RandomState(31)
     h = O.round_to(rng.randn(hidden).astype(np.float32) * 0.5, act)
@@ -104,7 +106,7 @@ def test_layer_ops_with_glue_every_form(ops, form, act, inter):
                                residual=f32_to_torch(h, act, DEV), stats_out=stats)
         h1_np = torch_to_f32(h1)
         y_o = O.forward_gptq(a_in[None], qw_o, qz_o, sc_o, gi_o, 4, None, act, "fp16")
-        assert_forward_close(h1_np[None], O.residual_add_ref(h[None], y_o, act), act, tag=("residual+stats", form), strict_atol=strict)
+        assert_forward_close(h1_np[None], O.residual_add_ref(h[None], y_o, act), act, tag=("residual+stats", form), strict_atol=strict, norm_tol=nt)
         assert np.allclose(stats.cpu().numpy(), (h1_np.astype(np.float64) ** 2).reshape(-1, 16).sum(axis=1), rtol=1e-5)
         # gate_up-like: a = silu(g) * u, g|u = rmsnorm(h1) @ Wgu, columns interleaved in blocks of 8; statistics in (and, separately, none)
         qweight, qzeros, scales, g_idx = synth_gptq(41, 4, hidden, 2 * inter, gs)
@@ -120,7 +122,7 @@ def test_layer_ops_with_glue_every_form(ops, form, act, inter):
             ops.decode_linear(h1, qwi_t, meta_i, None, hidden, 2 * inter, gs, 4, sci.dtype, out=a_dev, in_glue=ops.GLUE_RMSNORM,
                               norm_weight=f32_to_torch(w, act, DEV), eps=1e-5, out_glue=ops.OUT_SILU_MUL_PAIRED, stats_in=st_in)
             assert_forward_close(torch_to_f32(a_dev)[None, :inter], a_ref[None], act, tag=("rmsnorm + paired silu", form, st_in is not None),
-                                 strict_atol=strict)
+                                 strict_atol=strict, norm_tol=nt)
         torch.cuda.synchronize()
     finally:
         ops.set_decode_form(-1)
@@ -227,3 +229,35 @@ def test_raw_code_form_adversarial_inputs(ops, case):
     err, err_ref = np.abs(out - y_exact).max() / scale, np.abs(y_ref - y_exact).max() / scale
     assert err <= max(err_ref * 1.05, 2.0 ** -11) + 1e-7, (case, err, err_ref)       # no further from exact arithmetic than the reference (or one fp16 rounding)
     assert np.abs(out - y_ref).max() / np.abs(y_ref).max() <= 1e-3, case              # north_star's bar against the reference itself
+
+
+@pytest.mark.parametrize("K,N,sdt", [(4096, 4096, "bf16"), (14336, 4096, "bf16"), (4096, 6144, "fp16")])
+@pytest.mark.parametrize("xscale", [0.5, 3000.0, 1e-3])
+def test_bf16_raw_code_form_vs_exact_arithmetic(ops, K, N, sdt, xscale):
+    """Form 5 on bf16 activations: the wave converts its bf16 x pieces to fp16 exactly (divided by a power of two taken from its largest |x|) and
+    runs the raw-code path of the f16 matrix pipe; the output is the bf16 rounding of the exact sum.  Against float64 arithmetic on the integer
+    codes it is no further away than the reference chain (TorchLinear: every weight rounded to bf16 first), at ordinary, large (beyond fp16's
+    range without the power of two) and tiny activation scales; against the reference itself it stays inside the reference's own element-wise gates."""
+    gs = 128
+    qweight, qzeros, scales, g_idx = synth_gptq(611 + K // 128 + N // 16, 4, K, N, gs, scale_dtype=sdt)
+    rng = np.random.RandomState(29)
+    x = O.round_to(rng.randn(1, K).astype(np.float32) * xscale, "bf16")
+    if xscale > 100:
+        x[0, 7] = O.round_to(np.float32(2.0e5), "bf16")          # one outlier far beyond fp16's 65504
+    codes = O.unpack_rows(qweight, 4).astype(np.int64)
+    zeros = O.unpack_cols(qzeros, 4).astype(np.int64)
+    g = O.normalize_g_idx(g_idx, scales.shape[0])
+    y_exact = x.astype(np.float64) @ (np.asarray(scales, np.float64)[g] * (codes - zeros[g]).astype(np.float64))
+    y_ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, 4, None, "bf16", sdt)
+    qw_t, meta, sc = _tiled(ops, qweight, qzeros, scales, gs, sdt)
+    ops.set_decode_form(5)
+    try:
+        out = torch_to_f32(ops.decode_linear(f32_to_torch(x[0], "bf16", DEV), qw_t, meta, None, K, N, gs, 4, sc.dtype))[None]
+        torch.cuda.synchronize()
+    finally:
+        ops.set_decode_form(-1)
+    assert np.isfinite(out).all()
+    scale = np.abs(y_exact).max()
+    err, err_ref = np.abs(out - y_exact).max() / scale, np.abs(y_ref.astype(np.float64) - y_exact).max() / scale
+    assert err <= max(err_ref * 1.05, 2.0 ** -8) + 1e-7, (err, err_ref)      # one bf16 rounding of the exact sum, never worse than the reference chain
+    assert_forward_close(out, y_ref, "bf16", tag=("bf16 form 5", K, N, sdt, xscale), norm_tol=NORM_TOL_BF16_EXACT)
