@@ -546,7 +546,7 @@ def main():
         launch_us = ev_ms * 1e3 / (args.steps * n_launch)   # average launch duration incl. whatever the ops do not overlap
         bytes_per_launch = step_bytes / n_launch
         achieved = bytes_per_launch / (launch_us * 1e-6) / 1e9
-        kernel = {"chain": "gptqhip::skinny1_kernel<ACT,SCL,D=4,GLUE,ALG> (decode op, preload form, glue fused; ALG=2 raw 4-bit codes as fp16 denormals for fp16 x fp16, ALG=0 per-weight rounding for bf16)",
+        kernel = {"chain": "gptqhip::skinny1_kernel<ACT,SCL,D=4,GLUE,ALG> (decode op, preload form, glue fused; ALG=2 raw 4-bit codes as fp16 denormals on the f16 matrix pipe -- bf16 activations converted to fp16 per wave, exactly; ALG=0 = the reference's per-weight rounding, GPTQHIP_DECODE_BITFAITHFUL=1)",
                   "modules": "gptqhip::skinny1_kernel<ACT,SCL,D=4,GLUE=0,ALG>"}[mode]
         out = {
             "metric": "llama3_8b_gptq_int4_g128_decode_linear_stack_tokens_per_s",
@@ -561,7 +561,7 @@ def main():
                                    "SiLU*mul, residual adds fused into the ops; attention stand-in = q), M=1, random packed weights",
                        "parallelism": f"replicas x{world}", "mode": mode,
                        # include/gptqhip.h gptqhip_set_decode_form: the process default of this dtype (GPTQHIP_DECODE_BITFAITHFUL=1 -> 4)
-                       "decode_form": (4 if (dtype != torch.float16 or os.environ.get("GPTQHIP_DECODE_BITFAITHFUL", "0") not in ("", "0")) else 5),
+                       "decode_form": (4 if os.environ.get("GPTQHIP_DECODE_BITFAITHFUL", "0") not in ("", "0") else 5),
                        "loader_path": "mode=chain is what gptqmodel_post_init yields on HF Llama-family layers by itself since round 6 "
                                       "(utils.hf_llama.auto_fuse; the reference's own post_init through integration/gptqmodel_overlay/utils/model.patch); "
                                       "mode=modules is the GPTQHIP_AUTO_FUSE=0 path: plugin forward() per linear + torch glue kernels",

@@ -411,9 +411,9 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
             del g, st
         except Exception as e:  # noqa: BLE001
             res.append({"config": "C2", "mode": other, "error": str(e)[:300]})
-    # the same chain with the reference's per-weight rounding kept (decode form 4 = what GPTQHIP_DECODE_BITFAITHFUL=1 selects; the bf16
-    # default): the price of bit-faithfulness next to the fp16 default's raw-code dequant (form 5)
-    if dtype == torch.float16 and mode == "chain":
+    # the same chain with the reference's per-weight rounding kept (decode form 4 = what GPTQHIP_DECODE_BITFAITHFUL=1 selects): the price of
+    # bit-faithfulness next to the default's raw-code dequant (form 5; fp16 and bf16 activations)
+    if mode == "chain":
         try:
             from gptqmodel_amd import ops as _ops
             _ops.set_decode_form(4)

@@ -42,19 +42,17 @@ static const EnvTuning& env_tuning() {
     return e;
 }
 // batch-1 decode form (include/gptqhip.h gptqhip_set_decode_form).  Process default: 5 (preload + raw codes as fp16 denormals) for fp16 activations
-// with fp16 scales, 4 (preload, the reference's per-weight rounding) for bf16 activations or scales -- the exact-arithmetic forms are outside the bf16
-// gate (8e-3) -- and 4 for everything when GPTQHIP_DECODE_BITFAITHFUL=1 is in the environment.
+// with fp16 scales and for bf16 activations (converted to fp16 per wave, exactly); 4 (preload, the reference's per-weight rounding) for fp16 activations
+// with bf16 scales, and for everything when GPTQHIP_DECODE_BITFAITHFUL=1 is in the environment.
 static int decode_form_for(int act_dtype, int scale_dtype) {
     static const int bitfaithful = env_int("GPTQHIP_DECODE_BITFAITHFUL");
     const bool exact_ok = act_dtype == GPTQHIP_FP16 && scale_dtype == GPTQHIP_FP16;   // the exact-arithmetic forms exist for fp16 x fp16 only
     const bool raw_ok = exact_ok || act_dtype == GPTQHIP_BF16;                        // ... the raw-code form also for bf16 activations (any scale dtype)
-    static const int bf16_exact = env_int("GPTQHIP_DECODE_BF16_EXACT");               // opt-in: bf16 activations take form 5 by default
     if (t_decode_form >= 0) {
         if (t_decode_form == 5) return raw_ok ? 5 : 4;
         return (t_decode_form == 1 && !exact_ok) ? 4 : t_decode_form;
     }
-    if (bitfaithful) return 4;
-    return exact_ok ? 5 : ((bf16_exact && raw_ok) ? 5 : 4);
+    return (bitfaithful || !raw_ok) ? 4 : 5;
 }
 #define g_force_split (t_force_split ? t_force_split : env_tuning().split)
 #define g_force_kernel (t_force_kernel ? t_force_kernel : env_tuning().kernel)

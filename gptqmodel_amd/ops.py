@@ -453,7 +453,7 @@ def set_tuning(force_split_k: int = 0, force_kernel: int = 0, force_waves: int =
 
 def set_decode_form(form: int = -1) -> None:
     """Batch-1 decode form for the calling thread (include/gptqhip.h gptqhip_set_decode_form documents all six): 5 = preload kernel + raw codes
-    as fp16 denormals (the fp16 default), 3 = preload + group-factored dequant, 4 = preload + the reference's per-weight rounding (the bf16
-    default; bit-faithful), 0 / 2 = the rounds 1-5 kernel (bit-faithful / group-factored), 1 = the LDS-DMA stream kernel (opt-in, slower),
+    as fp16 denormals (the default for fp16 and bf16 activations), 3 = preload + group-factored dequant, 4 = preload + the reference's per-weight
+    rounding (bit-faithful; the default for fp16 activations with bf16 scales), 0 / 2 = the rounds 1-5 kernel (bit-faithful / group-factored), 1 = the LDS-DMA stream kernel (opt-in, slower),
     -1 = the process default (GPTQHIP_DECODE_BITFAITHFUL=1 in the environment makes that 4 for every dtype)."""
     _lib.check(_lib.load().gptqhip_set_decode_form(form), "gptqhip_set_decode_form")

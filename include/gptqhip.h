@@ -319,7 +319,7 @@ int gptqhip_set_tuning(int force_split_k, int force_kernel, int force_waves);
  * 128-row chunk, no in-kernel act-order permutation; everything else keeps skinny_kernel).  All forms compute the reference's
  * y = x @ (s * (q - z)) (TorchLinear._forward_eager, torch.py:326-347); they differ in the kernel structure and in whether every weight is
  * rounded to the scales' dtype BEFORE the contraction like the reference does (torch.py:716-717):
- *   5  DEFAULT for fp16 activations with fp16 scales.  skinny1_kernel ("preload": a wave parks the glued x pieces and the group constants of
+ *   5  DEFAULT for fp16 activations with fp16 scales and for bf16 activations (any scale dtype).  skinny1_kernel ("preload": a wave parks the glued x pieces and the group constants of
  *      all its chunks in LDS up front, so the ring carries ONE VMEM instruction per 1 KiB chunk) + RAW CODES: the 4-bit codes enter the MFMA
  *      as they are -- (w & 0x000F000F) is a pair of fp16 denormals q * 2^-24, (w & 0x00F000F0) a pair q * 2^-20; the matrix pipe takes fp16
  *      denormals at face value (tests/dev/mfma_denorm_probe.hip) -- one AND per two weights, no zero-point subtraction:
@@ -328,10 +328,17 @@ int gptqhip_set_tuning(int force_split_k, int force_kernel, int force_waves);
  *      reference's expression up to fp32 accumulation; it differs from the reference's own output only by the reference's per-weight
  *      rounding fp16(s (q - z)) (2^-12 relative, random): inside north_star's 1e-3 bar on every golden and no further from float64
  *      arithmetic than the reference chain (tests/test_gpu_decode_forms.py), NOT bit-identical to forms 0 / 4.  +5 % over form 3.
+ *      bf16 activations: the f16 matrix pipe is the one that takes the codes as denormals (bf16 denormals times x underflow fp32), so a wave
+ *      converts its (glued) bf16 x pieces to fp16 -- exactly: 8 significant bits -- after dividing them by a power of two taken from its own
+ *      largest |x| (no fp16 overflow whatever the input), and multiplies the power of two back in through the chunk constants; the output is
+ *      the bf16 rounding of the exact sum.  Against the reference (every weight rounded to bf16 first) single outputs sit one bf16 ulp per
+ *      rounding step away: inside the reference's own element-wise gates (tests/test_torch_kernel_accuracy.py:111-125: allclose against
+ *      EXACT fp32 arithmetic, atol 3e-2 / rtol 1e-2; tests/kernels/test_gptq.py:229-266, 353-360: isclose rtol 0.15 / atol 0.008).
+ *      +16 % over form 4 on the bf16 chain (878 -> 1015 tokens/s), 0.96 of fp16.
  *   3  skinny1_kernel + GROUP-FACTORED dequant (the fp16 default until form 5): the exact integers (q - z) go into the MFMA as fp16 pairs
  *      (magic-number route, 9 VALU per packed word) and the group's scale multiplies the fp32 partial sum once per chunk,
  *      y = sum_g s_g * (sum_{k in g} x_k (q_k - z_g)).  +6 % over form 4.
- *   4  DEFAULT for bf16 activations or bf16 scales, and for everything when GPTQHIP_DECODE_BITFAITHFUL=1 is in the environment: skinny1_kernel
+ *   4  DEFAULT for fp16 activations with bf16 scales, and for everything when GPTQHIP_DECODE_BITFAITHFUL=1 is in the environment: skinny1_kernel
  *      with the reference's per-weight rounding kept (same bits as form 0 up to the fp32 summation order).  +6 % over form 0.
  *   0  skinny_kernel, per-weight rounding (the rounds 1-5 kernel).
  *   2  skinny_kernel + group-factored dequant (fp16 x fp16).

@@ -46,6 +46,16 @@ NORM_TOL_BF16_EXACT = 2.0 ** -6
 REF_KERNEL_RTOL, REF_KERNEL_ATOL = 0.15, {"fp16": 0.004, "bf16": 0.008}     # test_gptq.py: isclose(rtol=0.15, atol=<per backend: Marlin / ExllamaV2 values>)
 
 
+def decode_norm_tol(act: str, bits: int = 4):
+    """Norm-wise bar of a batch-1 call (gptqhip_gemm at M = 1, gptqhip_decode_linear at M = 1) under the process-default decode form: 4-bit codes
+    take the exact-arithmetic form 5 (fp16: 1e-3 as everywhere; bf16 activations: one bf16 ulp per rounding step, NORM_TOL_BF16_EXACT);
+    GPTQHIP_DECODE_BITFAITHFUL=1 and 8-bit codes keep the reference's rounding chain and the plain bars."""
+    import os
+    if act == "bf16" and bits == 4 and os.environ.get("GPTQHIP_DECODE_BITFAITHFUL", "0") in ("", "0"):
+        return NORM_TOL_BF16_EXACT
+    return NORM_TOL[act]
+
+
 def assert_forward_close(got: np.ndarray, ref: np.ndarray, act: str, tag=None, strict_atol: bool = False, norm_tol: float = None):
     """Both gates on a rounded forward output: (1) the norm-wise relative error of the output (north_star), and
     (2) the reference's own ELEMENT-WISE assertion with its atol/rtol.

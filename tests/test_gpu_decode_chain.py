@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_forward_close, f32_to_torch, rel_err, synth_gptq, torch_to_bits, torch_to_f32
+from helpers import assert_forward_close, decode_norm_tol, f32_to_torch, rel_err, synth_gptq, torch_to_bits, torch_to_f32
 from oracle import gptq_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -38,10 +38,10 @@ def test_decode_op_plain_vs_oracle(ops, K, N, act, bits):
     out = ops.decode_linear(f32_to_torch(x[0], act, DEV), qw_t, meta, f32_to_torch(bias, act, DEV), K, N, gs, bits, sc.dtype)
     torch.cuda.synchronize()
     ref = O.forward_gptq(x, qweight, qzeros, scales, g_idx, bits, bias, act, "fp16")
-    assert_forward_close(torch_to_f32(out)[None], ref, act)
+    assert_forward_close(torch_to_f32(out)[None], ref, act, norm_tol=decode_norm_tol(act, bits))
     # and against the general kernel of the product path at M = 1 (same rounding chain, different accumulation order)
     gen = ops.gemm(f32_to_torch(x, act, DEV), qw_t, meta, f32_to_torch(bias, act, DEV), None, N, gs, bits, sc.dtype)
-    assert_forward_close(torch_to_f32(out)[None], torch_to_f32(gen), act)
+    assert_forward_close(torch_to_f32(out)[None], torch_to_f32(gen), act, norm_tol=decode_norm_tol(act, bits))
 
 
 @pytest.mark.parametrize("act", ["fp16", "bf16"])
@@ -59,7 +59,7 @@ def test_decode_op_fused_glue_vs_hf_semantics(ops, act):
                            in_glue=ops.GLUE_RMSNORM, norm_weight=f32_to_torch(w, act, DEV), eps=1e-5)
     xn = O.rmsnorm_ref(h, w, 1e-5, act)
     gu_ref = O.forward_gptq(xn[None], qweight, qzeros, scales, g_idx, 4, None, act, "fp16")
-    assert_forward_close(torch_to_f32(gu)[None], gu_ref, act, tag="rmsnorm")
+    assert_forward_close(torch_to_f32(gu)[None], gu_ref, act, tag="rmsnorm", norm_tol=decode_norm_tol(act))
     # (b) h2 = h + (silu(gate) * up) @ Wdown   -- fed with the DEVICE's gate|up so only this op is under test
     qweight2, qzeros2, scales2, g_idx2 = synth_gptq(42, 4, inter, hidden, gs)
     qw2, meta2, sc2 = _tiled(ops, qweight2, qzeros2, scales2, gs, 4)
@@ -70,7 +70,7 @@ def test_decode_op_fused_glue_vs_hf_semantics(ops, act):
     a = O.silu_mul_ref(gu_np[:inter], gu_np[inter:], act)
     y = O.forward_gptq(a[None], qweight2, qzeros2, scales2, g_idx2, 4, bias, act, "fp16")
     h2_ref = O.residual_add_ref(h[None], y, act)
-    assert_forward_close(torch_to_f32(h2)[None], h2_ref, act, tag="silu_mul+residual")
+    assert_forward_close(torch_to_f32(h2)[None], h2_ref, act, tag="silu_mul+residual", norm_tol=decode_norm_tol(act))
     # (c) the same two ops the way the decode chain runs them: the producer of h hands over the per-tile sums of h^2
     #     (stats_out -> stats_in), gate|up columns interleaved in blocks of 8 with the SiLU*mul in the producer's epilogue
     qw_o, qz_o, sc_o, gi_o = synth_gptq(43, 4, hidden, hidden, gs)
@@ -81,7 +81,7 @@ def test_decode_op_fused_glue_vs_hf_semantics(ops, act):
                            residual=f32_to_torch(h, act, DEV), stats_out=stats)
     h1_np = torch_to_f32(h1)
     y_o = O.forward_gptq(a_in[None], qw_o, qz_o, sc_o, gi_o, 4, None, act, "fp16")
-    assert_forward_close(h1_np[None], O.residual_add_ref(h[None], y_o, act), act, tag="residual+stats")
+    assert_forward_close(h1_np[None], O.residual_add_ref(h[None], y_o, act), act, tag="residual+stats", norm_tol=decode_norm_tol(act))
     want_stats = (h1_np.astype(np.float64) ** 2).reshape(-1, 16).sum(axis=1)
     assert np.allclose(stats.cpu().numpy(), want_stats, rtol=1e-5), "stats_out must be the per-tile sums of out^2"
     gate_cols, up_cols = np.arange(inter), inter + np.arange(inter)
@@ -97,7 +97,7 @@ def test_decode_op_fused_glue_vs_hf_semantics(ops, act):
     xn1 = O.rmsnorm_ref(h1_np, w, 1e-5, act)
     gu1 = O.forward_gptq(xn1[None], qweight, qzeros, scales, g_idx, 4, None, act, "fp16")[0]
     a_ref = O.silu_mul_ref(gu1[:inter], gu1[inter:], act)
-    assert_forward_close(torch_to_f32(a_dev)[None, :inter], a_ref[None], act, tag="stats_in rmsnorm + paired silu*mul")
+    assert_forward_close(torch_to_f32(a_dev)[None, :inter], a_ref[None], act, tag="stats_in rmsnorm + paired silu*mul", norm_tol=decode_norm_tol(act))
 
 
 @pytest.mark.parametrize("act", ["fp16", "bf16"])
@@ -126,7 +126,7 @@ def test_decode_op_act_order_in_kernel_perm_with_glue(ops, act):
         y = O.forward_gptq(xn[None], qweight, qzeros, scales, g_idx, bits, None, act, "fp16")
         ref = O.residual_add_ref(res[None], y, act)
         got = torch_to_f32(out)
-        assert_forward_close(got[None], ref, act, tag=(K, N, with_stats))
+        assert_forward_close(got[None], ref, act, tag=(K, N, with_stats), norm_tol=decode_norm_tol(act))
         assert np.allclose(st_out.cpu().numpy(), (got.astype(np.float64) ** 2).reshape(-1, 16).sum(axis=1), rtol=1e-5)
         # plain (no glue) with the permutation == the plugin path's batch-1 kernel
         plain = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, None, K, N, gs, bits, sc.dtype, perm=perm)
@@ -372,7 +372,7 @@ def test_decode_op_glue_variants_ragged_n_bias(ops, act, bits, sdt):
     y = O.forward_gptq(xn[None], qweight, qzeros, scales, g_idx, bits, bias, act, sdt)
     ref = O.residual_add_ref(res[None], y, act)
     got = torch_to_f32(out)
-    assert_forward_close(got[None], ref, act)
+    assert_forward_close(got[None], ref, act, norm_tol=decode_norm_tol(act, bits))
     pad = np.zeros(len(stats) * 16, dtype=np.float64)
     pad[:N] = got.astype(np.float64) ** 2
     assert np.allclose(stats.cpu().numpy(), pad.reshape(-1, 16).sum(axis=1), rtol=1e-5)

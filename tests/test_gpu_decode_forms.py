@@ -243,7 +243,7 @@ def test_bf16_raw_code_form_vs_exact_arithmetic(ops, K, N, sdt, xscale):
     rng = np.random.RandomState(29)
     x = O.round_to(rng.randn(1, K).astype(np.float32) * xscale, "bf16")
     if xscale > 100:
-        x[0, 7] = O.round_to(np.float32(2.0e5), "bf16")          # one outlier far beyond fp16's 65504
+        x[0, 7] = float(O.round_to(np.array([2.0e5], np.float32), "bf16")[0])          # one outlier far beyond fp16's 65504
     codes = O.unpack_rows(qweight, 4).astype(np.int64)
     zeros = O.unpack_cols(qzeros, 4).astype(np.int64)
     g = O.normalize_g_idx(g_idx, scales.shape[0])
