@@ -442,16 +442,16 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
         del g
     except Exception as e:  # noqa: BLE001
         res.append({"config": "C2", "mode": "independent launches", "error": str(e)[:300]})
-    # opt-in exact-arithmetic dequant (GPTQHIP_GEMM_EXACT_BF16; bf16 activations only): NOT the default and not the headline -- it
-    # skips the reference's per-weight rounding (up to 2 output ulps away from its chain)
+    # the rounds 2-5 exact-arithmetic flag (GPTQHIP_GEMM_EXACT_BF16; bf16 activations only: 128 + q offsets on the bf16 matrix pipe inside the
+    # rounds 1-5 kernel).  Superseded by decode form 5, which bf16 activations take by default since round 6; kept as a legacy flag
     if dtype == torch.bfloat16:
         try:
             from gptqmodel_amd.utils.decode_chain import DecodeStep as _DSx
             st = _DSx(layers, cfg["hidden"], cfg["q"], dtype, exact=True)
             st.x_in.copy_((torch.randn(cfg["hidden"], device=dev, generator=gen) * 0.5).to(dtype))
             ms, g = time_graph(st.run, stream, 100, 10)
-            res.append(decode_entry("C2", "bf16 decode chain with the OPT-IN exact-arithmetic dequant (GPTQHIP_GEMM_EXACT_BF16; leaves the "
-                                    "reference's per-weight rounding chain -- not the default, not the headline)", cfg, ms, n_launch,
+            res.append(decode_entry("C2", "bf16 decode chain with the LEGACY exact-arithmetic flag of rounds 2-5 (GPTQHIP_GEMM_EXACT_BF16: the older "
+                                    "kernel; the default -- decode form 5 -- is the faster exact form)", cfg, ms, n_launch,
                                     extra={"mode": "chain, exact-arithmetic opt-in", "id": "c2_decode_exact_optin"}))
             del g, st
         except Exception as e:  # noqa: BLE001
