@@ -554,6 +554,15 @@ def extra_configs(args, cfg, layers, dtype, dev, gen, stream, make_step, mode, m
         res.append(decode_entry("C3", "Llama-3-8B GPTQ int4 g128 desc_act=True batch=1 decode, decode chain (permutation applied in the "
                                 "kernel on the glued input row)", cfg, ms, n_launch, extra={"id": "c3_decode_actorder"}))
         del g, st, act_layers
+        # ... and the way a LOADED model runs it: utils/hf_llama folds down_proj's permutation into gate|up's column order at load time
+        # (fold_act_order_into_producers: exact), so down_proj takes the plain kernel; with random weights that is a down_proj without g_idx
+        fold_layers = build_stack(cfg, lambda k, n: make_gptq(k, n, gs, dev, gen, dtype, desc_act=(k != cfg["inter"])), dev, gen, dtype)
+        st = _DS(fold_layers, cfg["hidden"], cfg["q"], dtype)
+        st.x_in.copy_((torch.randn(cfg["hidden"], device=dev, generator=gen) * 0.5).to(dtype))
+        ms, g = time_graph(st.run, stream, 100, 10)
+        res.append(decode_entry("C3", "the same with down_proj's permutation folded into gate|up's columns (what utils/hf_llama does at load time)",
+                                cfg, ms, n_launch, extra={"id": "c3_decode_actorder_folded"}))
+        del g, st, fold_layers
     except Exception as e:  # noqa: BLE001
         res.append({"config": "C3", "error": str(e)[:300]})
     torch.cuda.empty_cache()
