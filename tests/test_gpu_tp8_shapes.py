@@ -5,6 +5,8 @@ the decode op and gptqhip_gemm, incl. the unrounded fp32 partial sums a row-para
     gate|up column shard 8192 -> 2 x 3584 = 7168, interleaved   (fused RMSNorm in, paired SiLU*mul out)
     down_proj row shard  3584 -> 8192                           (OUT_PARTIAL_F32; 3584 = 28 x 128)
 VERDICT r3 item 2c: none of these shapes had run anywhere (every earlier multi-process test was TP = 2)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -72,6 +74,10 @@ def test_tp8_column_shards_through_the_decode_op(ops, act, M):
         assert_forward_close(torch_to_f32(out).reshape(ref.shape), ref, act, tag=(name, M, act))
 
 
+# (GPTQHIP_DECODE_BITFAITHFUL=1 in the environment: every batch-1 call keeps the reference's per-weight rounding -- no exact form to expect)
+EXACT_DEFAULT = os.environ.get("GPTQHIP_DECODE_BITFAITHFUL", "0") in ("", "0")
+
+
 def _assert_partial_f32(got, x, qweight, qzeros, scales, g_idx, act, exact_form, tag):
     """fp32 partial sums of a K-shard against the oracle's float64 product.  Bit-faithful forms: <= 1e-4 against the reference's ROUNDED
     weights (only the summation order differs).  The group-factored default of fp16 batch-1 calls multiplies the UNROUNDED s * (q - z):
@@ -112,7 +118,7 @@ def test_tp8_row_shards_partial_f32_through_the_decode_op(ops, act, M):
                 ops.set_decode_form(-1)
             assert out.dtype == torch.float32
             _assert_partial_f32(torch_to_f32(out).reshape(M, N), x, qweight, qzeros, scales, g_idx, act,
-                                form == -1 and ((act == "fp16" and M <= 4) or (act == "bf16" and M == 1)), (name, M, act, form))
+                                EXACT_DEFAULT and form == -1 and ((act == "fp16" and M <= 4) or (act == "bf16" and M == 1)), (name, M, act, form))
 
 
 @pytest.mark.gpu
@@ -131,7 +137,7 @@ def test_tp8_shards_through_gptqhip_gemm(ops, M):
         torch.cuda.synchronize()
         got = torch_to_f32(out)[rows]
         if partial:
-            _assert_partial_f32(got, x[rows], qweight, qzeros, scales, g_idx, "fp16", M == 1, (name, M))
+            _assert_partial_f32(got, x[rows], qweight, qzeros, scales, g_idx, "fp16", EXACT_DEFAULT and M == 1, (name, M))
         else:
             assert_forward_close(got, O.forward_gptq(x[rows], qweight, qzeros, scales, g_idx, 4, None, "fp16", "fp16"), "fp16", tag=(name, M))
 
@@ -160,5 +166,5 @@ def test_short_k_shards_through_the_decode_op(ops, K, M):
     torch.cuda.synchronize()
     xn = np.stack([O.rmsnorm_ref(h[m], w, 1e-5, act) for m in range(M)])
     assert_forward_close(torch_to_f32(out).reshape(M, N), O.forward_gptq(xn, qweight, qzeros, scales, g_idx, 4, bias, act, "fp16"), act, tag=(K, M))
-    _assert_partial_f32(torch_to_f32(part).reshape(M, N), h, qweight, qzeros, scales, g_idx, act, M == 1, (K, M))
+    _assert_partial_f32(torch_to_f32(part).reshape(M, N), h, qweight, qzeros, scales, g_idx, act, EXACT_DEFAULT and M == 1, (K, M))
     assert torch.equal(plain.reshape(M, N), gen)
