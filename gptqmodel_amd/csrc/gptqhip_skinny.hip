@@ -1477,7 +1477,9 @@ __global__ __launch_bounds__(1024) void skinny1_kernel(SkinnyParams p) {
 // and its 16 outputs leave through finish_outputs on wave (tile index % W) after ONE block barrier (reduction rows double-buffered by
 // tile parity).  No residual / bias / cross-block split here: the layers that have them (o_proj, down_proj) have one tile per CU.
 // ------------------------------------------------------------------------------------------------
-template <int ACT, int SCL, int GLUE, int ALG, int D = 4>
+// PERM (act-order checkpoints, like skinny1_kernel's): the block stages the GLUED x row in LDS once (natural order, one barrier), every wave gathers
+// the eight elements per lane of each of its D chunks from there by their indices -- once per block, the tile loop is unchanged.
+template <int ACT, int SCL, int GLUE, int ALG, int D = 4, bool PERM = false>
 __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
     static_assert(D == 4 || D == 8, "ring depth = chunks per wave and tile");
     constexpr int NQ = D / 4;                       // 16-byte preload instructions per wave (four chunks each)
@@ -1519,16 +1521,35 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
     }
     u4_t xq[NQ], gq[NQ];
     uint32_t mq[NQ];
+    u4_t pq[PERM ? NQ : 1][2];         // PERM: perm[k'] of the lane's eight rows of each chunk
+    u4_t xr[2], gr[2];                 // PERM: this thread's 16-byte pieces of the x row / norm weight (staged once per block)
+    uint16_t* const xbuf = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(lds) + W * kSlot + 96 + (size_t)(nb > 0 ? nb : 2) * 16 * 256 + 64);
+    const int n16 = p.K / 8;
     int tile = blockIdx.x;
     const char* mrow[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int ck_lane = wave + (4 * q + rq) * W;
-        xq[q] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.x) + (size_t)ck_lane * 256 + c * 16);
-        gq[q] = u4_t{0u, 0u, 0u, 0u};
-        if constexpr (GLUE == kGlueRmsNorm) gq[q] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (size_t)ck_lane * 256 + c * 16);
+        if constexpr (PERM) {
+            const u4_t* pp = reinterpret_cast<const u4_t*>(p.perm + (size_t)ck_lane * 128 + c * 8);
+            pq[q][0] = pp[0];
+            pq[q][1] = pp[1];
+        } else {
+            xq[q] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.x) + (size_t)ck_lane * 256 + c * 16);
+            gq[q] = u4_t{0u, 0u, 0u, 0u};
+            if constexpr (GLUE == kGlueRmsNorm) gq[q] = *reinterpret_cast<const u4_t*>(reinterpret_cast<const char*>(p.glue_b) + (size_t)ck_lane * 256 + c * 16);
+        }
         mrow[q] = reinterpret_cast<const char*>(p.meta) + (size_t)tile * tile_m + ((size_t)(ck_lane >> p.cpg_shift) << 6) + c4;
         mq[q] = *reinterpret_cast<const uint32_t*>(mrow[q]);
+    }
+    if constexpr (PERM) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = (int)threadIdx.x + i * (int)blockDim.x;
+            xr[i] = reinterpret_cast<const u4_t*>(p.x)[idx < n16 ? idx : 0];
+            gr[i] = u4_t{0u, 0u, 0u, 0u};
+            if constexpr (GLUE == kGlueRmsNorm) gr[i] = reinterpret_cast<const u4_t*>(p.glue_b)[idx < n16 ? idx : 0];
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     const char* wsrc = reinterpret_cast<const char*>(p.qw) + (size_t)tile * tile_w + (size_t)wave * 1024 + lane16;
@@ -1564,10 +1585,42 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
             __syncthreads();
             inv = scratch[0];
         }
+        if constexpr (!PERM) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) xq[q][j] = glue_pair<ACT>(xq[q][j], gq[q][j], inv, GLUE);
+        }
+        }
+    }
+    if constexpr (PERM) {
+        // (the launcher sends RMSNorm ops here only with producer statistics: the in-block reduction above reads the waves' natural pieces)
+        auto glued = [&](const u4_t& xv, const u4_t& gv) __attribute__((always_inline)) {
+            u4_t r = xv;
+            if constexpr (GLUE == kGlueRmsNorm) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] = glue_pair<ACT>(xv[j], gv[j], inv, GLUE);
+            }
+            return r;
+        };
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = (int)threadIdx.x + i * (int)blockDim.x;
+            if (idx < n16) reinterpret_cast<u4_t*>(xbuf)[idx] = glued(xr[i], gr[i]);
+        }
+        for (int idx = (int)threadIdx.x + 2 * (int)blockDim.x; idx < n16; idx += (int)blockDim.x) {   // (rows longer than 32 B x threads: rare)
+            u4_t gv = {0u, 0u, 0u, 0u};
+            if constexpr (GLUE == kGlueRmsNorm) gv = reinterpret_cast<const u4_t*>(p.glue_b)[idx];
+            reinterpret_cast<u4_t*>(xbuf)[idx] = glued(reinterpret_cast<const u4_t*>(p.x)[idx], gv);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t i0 = pq[q][j >> 1][(j & 1) * 2], i1 = pq[q][j >> 1][(j & 1) * 2 + 1];
+                xq[q][j] = (uint32_t)xbuf[i0] | ((uint32_t)xbuf[i1] << 16);
+            }
         }
     }
     float sx[NQ];      // RAW: Sx of chunk wave + (4 q + rq) W (the same for every tile)
@@ -1934,9 +1987,11 @@ static int skinny1p_depth() {   // dev A/B switch: GPTQHIP_SK1P_D8=1 runs chunks
 static int skinny1p_grid(const SkinnyParams& p, const SkinnyPlan& pl) {
     static const bool off = [] { const char* v = getenv("GPTQHIP_NO_PERSIST"); return v && *v && *v != '0'; }();
     const int tiles = ceil_div(p.N, kTileN), cus = 256;
-    if (off || p.splits != 1 || p.residual != nullptr || p.bias != nullptr || p.out_f32 || p.perm != nullptr) return 0;
+    if (off || p.splits != 1 || p.residual != nullptr || p.bias != nullptr || p.out_f32) return 0;
     if (tiles < 2 * cus || tiles % cus != 0 || p.N % kTileN != 0) return 0;
     const int d = skinny1p_depth();
+    // act-order: the staged x row shares the default dynamic LDS with the slots; RMSNorm ops need producer statistics there
+    if (p.perm != nullptr && (d != 4 || (size_t)p.K * 2 > 24 * 1024 || (p.in_glue == kGlueRmsNorm && p.stats_in == nullptr))) return 0;
     if (p.chunks % d != 0 || p.chunks / d < 4 || p.chunks / d > 16) return 0;
     return cus;
 }
@@ -1986,10 +2041,14 @@ static int launch_skinny1(const SkinnyParams& p0, const SkinnyPlan& pl, int alg,
         static const bool force_barrier = [] { const char* v = getenv("GPTQHIP_SK1P_NOBARRIER"); return !(v && *v && *v != '0'); }();
         const int tpb = ceil_div(ceil_div(p.N, kTileN), pg);
         const size_t lds_nb = (size_t)waves * d * (a2 ? 512 : 384) + 96 + (size_t)tpb * 16 * 256 + 64;
-        p.nb_tiles = (!force_barrier && tpb <= 16 && lds_nb <= 64 * 1024) ? tpb : 0;
-        const size_t lds_bytes = p.nb_tiles > 0 ? lds_nb : (size_t)waves * d * (a2 ? 512 : 384) + 96 + 2 * 16 * 256 + 64;
+        p.nb_tiles = (!force_barrier && tpb <= 16 && lds_nb + (perm ? (size_t)p.K * 2 : 0) <= 64 * 1024) ? tpb : 0;
+        const size_t lds_bytes = (p.nb_tiles > 0 ? lds_nb : (size_t)waves * d * (a2 ? 512 : 384) + 96 + 2 * 16 * 256 + 64) + (perm ? (size_t)p.K * 2 : 0);
 #define GPTQHIP_L1P(G_, A_, D_) hipLaunchKernelGGL((skinny1p_kernel<ACT, SCL, G_, A_, D_>), grid, block, lds_bytes, stream, p)
-        if (a2 && d == 4) {
+#define GPTQHIP_L1PP(G_, A_) hipLaunchKernelGGL((skinny1p_kernel<ACT, SCL, G_, A_, 4, true>), grid, block, lds_bytes, stream, p)
+        if (perm) {      // (d == 4 here: skinny1p_grid)
+            if (p.in_glue == kGlueRmsNorm) { if (a2) GPTQHIP_L1PP(kGlueRmsNorm, 2); else GPTQHIP_L1PP(kGlueRmsNorm, 0); }
+            else { if (a2) GPTQHIP_L1PP(kGlueNone, 2); else GPTQHIP_L1PP(kGlueNone, 0); }
+        } else if (a2 && d == 4) {
             if (p.in_glue == kGlueRmsNorm) GPTQHIP_L1P(kGlueRmsNorm, 2, 4); else GPTQHIP_L1P(kGlueNone, 2, 4);
         } else if (a2 && d == 8) {
             if (p.in_glue == kGlueRmsNorm) GPTQHIP_L1P(kGlueRmsNorm, 2, 8); else GPTQHIP_L1P(kGlueNone, 2, 8);
@@ -2001,6 +2060,7 @@ static int launch_skinny1(const SkinnyParams& p0, const SkinnyPlan& pl, int alg,
             else { if (a1) GPTQHIP_L1P(kGlueNone, 1, 4); else GPTQHIP_L1P(kGlueNone, 0, 4); }
         }
 #undef GPTQHIP_L1P
+#undef GPTQHIP_L1PP
         *served = true;
         return check_hip(hipGetLastError(), "skinny1p_kernel launch");
     }

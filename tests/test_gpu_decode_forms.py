@@ -261,3 +261,33 @@ def test_bf16_raw_code_form_vs_exact_arithmetic(ops, K, N, sdt, xscale):
     err, err_ref = np.abs(out - y_exact).max() / scale, np.abs(y_ref.astype(np.float64) - y_exact).max() / scale
     assert err <= max(err_ref * 1.05, 2.0 ** -8) + 1e-7, (err, err_ref)      # one bf16 rounding of the exact sum, never worse than the reference chain
     assert_forward_close(out, y_ref, "bf16", tag=("bf16 form 5", K, N, sdt, xscale), norm_tol=NORM_TOL_BF16_EXACT)
+
+
+@pytest.mark.parametrize("form", [4, 5])
+@pytest.mark.parametrize("act", ["fp16", "bf16"])
+@pytest.mark.parametrize("glue", ["rmsnorm+stats", "none"])
+def test_persistent_tile_variant_with_act_order(ops, form, act, glue):
+    """desc_act=True checkpoints on a many-tile layer (8192 columns = two tiles per CU): skinny1p_kernel stages the glued x row once per block and
+    every wave gathers its chunks' elements by the permutation (RMSNorm with producer statistics, or no glue) -- against the oracle with g_idx."""
+    K, N, gs = 4096, 8192, 128
+    qweight, qzeros, scales, g_idx = synth_gptq(733, 4, K, N, gs, desc_act=True)
+    perm = torch.from_numpy(np.argsort(g_idx, kind="stable").astype(np.int32)).to(DEV)
+    sc = f32_to_torch(scales, "fp16", DEV)
+    qw_t, meta = ops.repack_tiled(torch.from_numpy(qweight).to(DEV), torch.from_numpy(qzeros).to(DEV), sc, perm, gs, 4)
+    rng = np.random.RandomState(19)
+    h = O.round_to(rng.randn(K).astype(np.float32) * 1.5, act)
+    w = O.round_to(1.0 + rng.randn(K).astype(np.float32) * 0.1, act)
+    kw, x_ref = {}, h
+    if glue != "none":
+        st_in = torch.from_numpy((h.astype(np.float64) ** 2).reshape(-1, 16).sum(axis=1).astype(np.float32)).to(DEV)
+        kw = dict(in_glue=ops.GLUE_RMSNORM, norm_weight=f32_to_torch(w, act, DEV), eps=1e-5, stats_in=st_in)
+        x_ref = O.rmsnorm_ref(h, w, 1e-5, act)
+    ref = O.forward_gptq(x_ref[None], qweight, qzeros, scales, g_idx, 4, None, act, "fp16")
+    ops.set_decode_form(form)
+    try:
+        out = ops.decode_linear(f32_to_torch(h, act, DEV), qw_t, meta, None, K, N, gs, 4, sc.dtype, perm=perm, **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_decode_form(-1)
+    nt = NORM_TOL_BF16_EXACT if (act == "bf16" and form == 5) else None
+    assert_forward_close(torch_to_f32(out)[None], ref, act, tag=("persistent + act-order", form, act, glue), strict_atol=FORMS[form], norm_tol=nt)
