@@ -400,7 +400,14 @@ int gptqhip_plan_describe(int M, int K, int N, int group_size, int bits, int has
         const SkinnyPlan pl1 = plan_skinny(1, K, N, group_size, g_force_split, g_skinny_waves, true);
         fused_perm = pl1.regular && pl1.gpc == 1 && pl1.depth == 4 && (size_t)K * 2 <= kInKernelPermMaxRowBytes;
     }
-    const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_skinny_waves, fused_perm, bits, 1);
+    // batch 1, 4-bit: the geometry of the process-default decode form for fp16 activations (the preload forms plan without 2-deep rings, the
+    // raw-code form runs q|k|v-shaped layers with four waves: plan_skinny's prefer_deep)
+    int deep = 0;
+    if (mc == 1 && bits == 4 && !fused_perm) {
+        const int form = decode_form_for(GPTQHIP_FP16, GPTQHIP_FP16);
+        deep = form == 5 ? 2 : ((form == 3 || form == 4) ? 1 : 0);
+    }
+    const SkinnyPlan pl = plan_skinny(mc, K, N, group_size, g_force_split, g_skinny_waves, fused_perm, bits, 1, deep);
     snprintf(buf, (size_t)buf_len, "skinny launches=%d mt=%d nt=%d waves=%d depth=%d regular=%d splits=%d gather=%d", ceil_div(M, rows), pl.mt,
              pl.nt, pl.waves, pl.depth, pl.regular, pl.splits, has_perm && !fused_perm ? 1 : 0);
     return GPTQHIP_OK;
