@@ -31,6 +31,9 @@
 #ifndef GPTQHIP_ABLATE   // dev-only timing ablations (tests/dev/ablate.sh); the product build never defines it
 #define GPTQHIP_ABLATE 0
 #endif
+#ifndef GPTQHIP_SK1P_XREG
+#define GPTQHIP_SK1P_XREG 0
+#endif
 #ifndef GPTQHIP_OUT_WRITE_THROUGH   // dev A/B (see finish_outputs): write-through output stores measured SLOWER (o 4.19 -> 4.37, down 7.87 -> 7.98 us)
 #define GPTQHIP_OUT_WRITE_THROUGH 0
 #endif
@@ -1656,10 +1659,25 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
     uint32_t magic_hi = 0x54005400u;
     asm volatile("" : "+v"(magic_hi));
     float acc = 0.f;
+#if GPTQHIP_SK1P_XREG   // dev A/B (-DGPTQHIP_SK1P_XREG=1): the wave's x fragments (the same for every tile of the block) kept in registers instead of re-read
+                        // from LDS per chunk: gate_up 12.58 -> 12.43 us (same box, two rounds), but 64 more registers put the instantiation at the
+                        // 128-VGPR cap of a 1024-thread launch bound with 12 bytes of scratch per lane: not adopted for 0.3 % of a token
+    u4_t xreg[D][4];
+    if constexpr (RAW) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xreg[d][i] = xs[d * 16 + rq * 4 + i];
+    }
+#endif
     auto compute = [&](const u4_t& wv, int li, const uint32_t* mcur) __attribute__((always_inline)) {
         if constexpr (RAW) {
             const float2 ab = reinterpret_cast<const float2*>(mcur)[li * 16 + c];
+#if GPTQHIP_SK1P_XREG
+            const u4_t* xr = xreg[li];
+#else
             const u4_t* xr = xs + li * 16 + rq * 4;
+#endif
             const f4_t zero4 = {0.f, 0.f, 0.f, 0.f};
             f4_t glo = zero4, ghi = zero4;
 #pragma unroll
