@@ -1790,213 +1790,6 @@ __global__ __launch_bounds__(1024) void skinny1p_kernel(SkinnyParams p) {
     if (nb > 0 && wave == (ti - 1) % W) combine(ti - 1, tile - (int)gridDim.x);
 }
 
-// ------------------------------------------------------------------------------------------------
-// The preload form on layers with MANY column tiles per CU (the fused gate_up: 1792 tiles = 7 per CU), "wave per tile": instead of W waves
-// splitting one tile's K range (a block barrier + an LDS reduction + a one-wave epilogue per tile, the other waves idle through it), every
-// WAVE owns whole tiles -- wave w of block b takes tiles b + grid * w, then + grid * W, ... -- and runs the full K range of a tile
-// through an 8-deep ring by itself: no reduction, no barrier after the prologue, a tile's 32 KiB read as one sequential stream, the epilogue
-// (rounding, paired SiLU * mul, store) by the wave that owns the tile while the others keep streaming.  The glued x row is parked ONCE per
-// block (all waves share it: one barrier), the tile's constants are parked in the wave's private LDS rows.  ALG = 2: raw codes as fp16
-// denormals (see skinny1_kernel); ALG = 0: the reference's per-weight rounding.  Same restrictions as skinny1p_kernel (no residual / bias /
-// cross-block split / permutation) + statistics from the producer when the input glue is RMSNorm.
-// ------------------------------------------------------------------------------------------------
-template <int ACT, int SCL, int GLUE, int ALG>
-__global__ __launch_bounds__(1024) void skinny1w_kernel(SkinnyParams p) {
-    constexpr int D = 8;
-    constexpr int kMaxNM = 16;                      // constants instructions per tile and lane (four chunks each): K <= 8192
-    constexpr bool RAW = ALG == 2 && ACT == kFP16 && SCL == kFP16;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int W = blockDim.x >> 6;
-    const int c = lane & 15, rq = lane >> 4;
-    const int tiles = (p.N + kTileN - 1) / kTileN;
-    const int chunks = p.chunks, nm = chunks >> 2, rounds = chunks / D;
-    // LDS: [glued x row: K * 2 B][Sx per chunk][per-wave constants: chunks * 16 * (8 | 4) B]
-    u4_t* const xs = reinterpret_cast<u4_t*>(lds);
-    float* const sxs = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + (size_t)p.K * 2);
-    const int cbytes = chunks * 16 * (RAW ? 8 : 4);
-    char* const cb = reinterpret_cast<char*>(lds) + (size_t)p.K * 2 + chunks * 4 + wave * cbytes;
-    const DequantConsts dk = make_dequant_consts<4>();
-    const uint32_t lane16 = (uint32_t)lane * 16u, c4 = (uint32_t)c * 4u;
-    const size_t tile_w = (size_t)chunks * 1024, tile_m = (size_t)p.G * 64;
-    const int tstride = (int)gridDim.x * W;
-    int tile = blockIdx.x + wave * (int)gridDim.x;
-    const bool have_tile = tile < tiles;
-    const int tile0 = have_tile ? tile : 0;
-
-    // everything that does not depend on the block's barrier goes out first: statistics, the first tile's constants, the first ring round
-    f4_t sv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    if constexpr (GLUE == kGlueRmsNorm) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.stats_in), 0, p.stats_n * 4, 0x00020000);
-        sv[0] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, 0, 0));
-        if (p.stats_n > 256) sv[1] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, 1024, 0));
-    }
-    const int n16 = p.K / 8;
-    u4_t xr[2], gr[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = (int)threadIdx.x + i * (int)blockDim.x;
-        xr[i] = reinterpret_cast<const u4_t*>(p.x)[idx < n16 ? idx : 0];
-        gr[i] = u4_t{0u, 0u, 0u, 0u};
-        if constexpr (GLUE == kGlueRmsNorm) gr[i] = reinterpret_cast<const u4_t*>(p.glue_b)[idx < n16 ? idx : 0];
-    }
-    uint32_t mq[kMaxNM];
-    auto load_meta = [&](int t) __attribute__((always_inline)) {
-        const char* mb = reinterpret_cast<const char*>(p.meta) + (size_t)t * tile_m + c4;
-#pragma unroll
-        for (int i = 0; i < kMaxNM; ++i)
-            if (i < nm) mq[i] = *reinterpret_cast<const uint32_t*>(mb + ((size_t)((4 * i + rq) >> p.cpg_shift) << 6));
-    };
-    load_meta(tile0);
-    __builtin_amdgcn_sched_barrier(0);
-    const char* wt = reinterpret_cast<const char*>(p.qw) + (size_t)tile0 * tile_w + lane16;
-    u4_t st[D];
-    if (have_tile) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) st[d] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wt + d * 1024));
-    }
-
-    float inv = 1.f;
-    if constexpr (GLUE == kGlueRmsNorm) {
-        const float ssum = wave64_sum(((sv[0][0] + sv[0][1]) + (sv[0][2] + sv[0][3])) + ((sv[1][0] + sv[1][1]) + (sv[1][2] + sv[1][3])));
-        inv = rsqrtf(ssum / (float)p.K + p.eps);
-    }
-    // the glued x row into LDS, once per block.  Thread t holds 16-byte piece pi = t (+ blockDim, ...): chunk pi >> 4, piece pi & 15 == c.
-    auto park_x = [&](int pi, const u4_t& xv, const u4_t& gv) __attribute__((always_inline)) {
-        u4_t g = xv;
-        if constexpr (GLUE == kGlueRmsNorm) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = glue_pair<ACT>(xv[j], gv[j], inv, GLUE);
-        }
-        if constexpr (RAW) {
-            const int li = pi >> 4, j = c >> 2;
-            char* base = reinterpret_cast<char*>(xs) + li * 256 + (c & 3) * 64 + (j >> 1) * 32 + (j & 1) * 8;
-            *reinterpret_cast<u2_t*>(base) = u2_t{g[0], g[2]};
-            *reinterpret_cast<u2_t*>(base + 16) = u2_t{g[1], g[3]};
-            const h2_t ones = as_h2(0x3C003C00u);
-            float s8 = __builtin_amdgcn_fdot2(as_h2(g[0]), ones, 0.f, false);
-            s8 = __builtin_amdgcn_fdot2(as_h2(g[1]), ones, s8, false);
-            s8 = __builtin_amdgcn_fdot2(as_h2(g[2]), ones, s8, false);
-            s8 = __builtin_amdgcn_fdot2(as_h2(g[3]), ones, s8, false);
-            s8 = row16_sum(s8);           // (a 16-lane row holds the 16 pieces of ONE chunk: n16 and blockDim are multiples of 16)
-            if (c == 0) sxs[li] = s8;
-        } else {
-            xs[pi] = g;
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = (int)threadIdx.x + i * (int)blockDim.x;
-        if (idx < n16) park_x(idx, xr[i], gr[i]);
-    }
-    for (int idx = (int)threadIdx.x + 2 * (int)blockDim.x; idx < n16; idx += (int)blockDim.x) {   // (rows longer than 32 B x threads: rare)
-        u4_t gv = {0u, 0u, 0u, 0u};
-        if constexpr (GLUE == kGlueRmsNorm) gv = reinterpret_cast<const u4_t*>(p.glue_b)[idx];
-        park_x(idx, reinterpret_cast<const u4_t*>(p.x)[idx], gv);
-    }
-    __syncthreads();
-    if (!have_tile) return;      // (no barrier below this line)
-
-    float acc = 0.f;
-    // a tile's constants: raw meta words in registers (requested a tile ahead) -> this wave's LDS rows, + the zero-point term (RAW)
-    auto park_consts = [&]() __attribute__((always_inline)) {
-        float tsum = 0.f;
-#pragma unroll
-        for (int i = 0; i < kMaxNM; ++i) {
-            if (i < nm) {
-                const int li = 4 * i + rq;
-                if constexpr (RAW) {
-                    const float sc = bits16_to_f32<SCL>((uint16_t)(mq[i] & 0xffffu));
-                    const float z = (float)((mq[i] >> 16) & 0xFu);
-                    reinterpret_cast<float2*>(cb)[li * 16 + c] = float2{sc * 16777216.f, sc * 1048576.f};
-                    tsum = __builtin_fmaf(-(sc * z), sxs[li], tsum);
-                } else {
-                    reinterpret_cast<uint32_t*>(cb)[li * 16 + c] = mq[i];
-                }
-            }
-        }
-        if constexpr (RAW) {
-            tsum += __shfl_xor(tsum, 16, 64);
-            tsum += __shfl_xor(tsum, 32, 64);
-            acc = tsum;
-        }
-    };
-    auto compute = [&](const u4_t& wv, int li) __attribute__((always_inline)) {
-        if constexpr (RAW) {
-            const float2 ab = reinterpret_cast<const float2*>(cb)[li * 16 + c];
-            const u4_t* xq4 = xs + li * 16 + rq * 4;
-            const f4_t zero4 = {0.f, 0.f, 0.f, 0.f};
-            f4_t glo = zero4, ghi = zero4;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t w0 = wv[2 * h], w1 = wv[2 * h + 1], w0s = w0 >> 8, w1s = w1 >> 8;
-                const u4_t blo = {w0 & dk.lo, w0s & dk.lo, w1 & dk.lo, w1s & dk.lo};
-                const u4_t bhi = {w0 & dk.hi, w0s & dk.hi, w1 & dk.hi, w1s & dk.hi};
-                glo = mfma16<ACT>(xq4[2 * h], blo, glo);
-                ghi = mfma16<ACT>(xq4[2 * h + 1], bhi, ghi);
-            }
-            acc = __builtin_fmaf(ab.x, glo[0], acc);
-            acc = __builtin_fmaf(ab.y, ghi[0], acc);
-        } else {
-            const ColConst cc = expand_meta<4, SCL>(reinterpret_cast<const uint32_t*>(cb)[li * 16 + c]);
-            const u4_t* xa = xs + li * 16 + rq;
-            f4_t g = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) g = mfma16<ACT>(xa[4 * j], dequant_word4<ACT, SCL>(wv[j], cc, dk), g);
-            acc += g[0];
-        }
-    };
-    // One tile: MORE = another tile of this wave follows (its first ring round is requested UNCONDITIONALLY behind the last round's stages, its
-    // constants behind the first round; the last tile runs the drain instantiation -- no loads past the end).
-    auto do_tile = [&](auto more_c) __attribute__((always_inline)) {
-        constexpr bool MORE = decltype(more_c)::value;
-        park_consts();
-        if constexpr (MORE) load_meta(tile + tstride);
-        for (int r = 0; r + 1 < rounds; ++r) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                compute(st[d], r * D + d);
-                st[d] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wt + (size_t)((r + 1) * D + d) * 1024));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        const char* wn = wt + (size_t)tstride * tile_w;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            compute(st[d], (rounds - 1) * D + d);
-            if constexpr (MORE) st[d] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(wn + d * 1024));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const int n = tile * kTileN + c;
-        finish_outputs<ACT>(p, acc, rq == 0 && n < p.N, 4 * rq, n, tile, 0, 0, lane, 0u, nullptr);
-        acc = 0.f;
-        wt = wn;
-        tile += tstride;
-    };
-    while (tile + tstride < tiles) do_tile(std::true_type{});
-    do_tile(std::false_type{});
-}
-
-// waves per block of the wave-per-tile variant; 0: not applicable
-static int skinny1w_waves(const SkinnyParams& p, size_t* lds_bytes, bool raw) {
-    // OPT-IN (GPTQHIP_WAVETILE=1): measured SLOWER than skinny1p_kernel on the 8B gate_up -- 13.5 vs 12.45 us fp16, 18.1 vs 15.4 us bf16
-    // (profiles/r06_decode_forms.txt): seven tile-owning waves do not divide over four SIMDs (2 / 2 / 2 / 1) and a lone wave's instruction stream,
-    // not HBM, paces its tile; eight waves sharing a tile stay balanced.  Kept as the record of that experiment (parity-tested).
-    static const bool off = [] { const char* v = getenv("GPTQHIP_WAVETILE"); return !(v && *v && *v != '0'); }();
-    const int tiles = ceil_div(p.N, kTileN), cus = 256;
-    if (off || p.M != 1 || p.splits != 1 || p.residual != nullptr || p.bias != nullptr || p.out_f32 || p.perm != nullptr) return 0;
-    if (p.in_glue == kGlueRmsNorm && p.stats_in == nullptr) return 0;
-    if (tiles < 4 * cus || p.N % kTileN != 0 || p.cpg_shift < 0) return 0;
-    if (p.chunks % 8 != 0 || p.chunks > 64 || p.K % 128 != 0) return 0;
-    int waves = ceil_div(tiles, cus);
-    if (waves > 16) waves = 16;
-    const size_t need = (size_t)p.K * 2 + (size_t)p.chunks * 4 + (size_t)waves * p.chunks * 16 * (raw ? 8 : 4);
-    if (need > 150 * 1024) return 0;
-    *lds_bytes = need;
-    return waves;
-}
-
 // tiles per block of the persistent variant; 0: not applicable
 static int skinny1p_depth() {   // dev A/B switch: GPTQHIP_SK1P_D8=1 runs chunks / 8 waves with an 8-deep ring
     static const int d = [] { const char* v = getenv("GPTQHIP_SK1P_D8"); return (v && *v && *v != '0') ? 8 : 4; }();
@@ -2029,27 +1822,8 @@ static int launch_skinny1(const SkinnyParams& p0, const SkinnyPlan& pl, int alg,
     SkinnyParams p = p0;
     const bool a1 = alg != 0 && ACT == kFP16 && SCL == kFP16;   // (bf16 scales: the reference rounds W to bf16 -- 2^-9 per weight -- keep its chain)
     const bool a2 = alg == 2 && (a1 || ACT == kBF16);           // raw codes as fp16 denormals (decode form 5; bf16 activations converted per wave)
-    {
-        size_t lds_w = 0;
-        const int ww = (a2 || !a1) ? skinny1w_waves(p0, &lds_w, a2) : 0;     // (form 3's group-factored dequant keeps skinny1p_kernel)
-        if (ww > 0) {
-            const int tiles = ceil_div(p.N, kTileN);
-            const dim3 grid(tiles / ww >= 256 ? 256 : ceil_div(tiles, ww)), block(64 * ww);
-            auto go = [&](auto kern) {
-                static bool attr_done = false;
-                if (!attr_done && lds_w > 64 * 1024) {
-                    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                    if (e != hipSuccess) return check_hip(e, "skinny1w_kernel: hipFuncSetAttribute");
-                    attr_done = true;
-                }
-                hipLaunchKernelGGL(kern, grid, block, lds_w, stream, p);
-                return check_hip(hipGetLastError(), "skinny1w_kernel launch");
-            };
-            *served = true;
-            if (p.in_glue == kGlueRmsNorm) return a2 ? go(skinny1w_kernel<ACT, SCL, kGlueRmsNorm, 2>) : go(skinny1w_kernel<ACT, SCL, kGlueRmsNorm, 0>);
-            return a2 ? go(skinny1w_kernel<ACT, SCL, kGlueNone, 2>) : go(skinny1w_kernel<ACT, SCL, kGlueNone, 0>);
-        }
-    }
+    // (a wave-per-tile kernel for many-tile layers -- every wave owning whole tiles, no barrier / reduction per tile -- was built, parity-tested and measured
+    // slower than skinny1p_kernel, with and without register spills: gate_up 13.5-13.6 vs 12.5-12.7 us; commits b4141bd..this one's parent, profiles/r06_decode_forms.txt)
     if (const int pg = skinny1p_grid(p0, pl)) {
         const int d = skinny1p_depth();
         const int waves = p.chunks / d;

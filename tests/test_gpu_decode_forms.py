@@ -83,7 +83,7 @@ def test_bit_faithful_forms_agree_bit_for_bit(ops, form):
 
 @pytest.mark.parametrize("form", sorted(FORMS))
 @pytest.mark.parametrize("act", ["fp16", "bf16"])
-@pytest.mark.parametrize("inter", [1024, 8192])      # 8192: 1024 column tiles = four per CU -> skinny1p_kernel (GPTQHIP_WAVETILE=1: the wave-per-tile kernel, forms 4 / 5)
+@pytest.mark.parametrize("inter", [1024, 8192])      # 8192: 1024 column tiles = four per CU -> skinny1p_kernel
 def test_layer_ops_with_glue_every_form(ops, form, act, inter):
     """The four ops of a decoder layer the way the chain runs them (RMSNorm from producer statistics, residual + stats_out, paired
     SiLU*mul epilogue), reference-scale activations, every form against the oracle's composition of the same steps."""
@@ -172,8 +172,7 @@ def test_group_factored_default_is_no_further_from_exact_arithmetic_than_the_ref
 @pytest.mark.parametrize("N", [8192, 16384, 17600])
 def test_persistent_tile_variant_every_preload_form(ops, form, glue, N):
     """skinny1p_kernel (layers with >= 2 column tiles per CU, no bias / residual: the fused gate_up) -- 8192 columns = 512 tiles = two per block;
-    16384 / 17600 columns = 1024 / 1100 tiles: with GPTQHIP_WAVETILE=1 in the environment the opt-in wave-per-tile kernel where it applies
-    (forms 4 / 5 with producer statistics or no glue; this test passes no statistics, so the RMSNorm cases stay on skinny1p_kernel)."""
+    16384 columns = 1024 tiles = four per block; 17600 columns = 1100 tiles, not a multiple of the CU count: one tile per block (skinny1_kernel)."""
     K, gs, act = 4096, 128, "fp16"
     qweight, qzeros, scales, g_idx = synth_gptq(91, 4, K, N, gs)
     rng = np.random.RandomState(17)
